@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — particle-updates/s of the per-scan particle-filter update (render + propagate + score + weight
+statistics + resample) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one synthetic scan: H2D of the packed scan points, raster kernel,
+propagate kernel (device counter-based RNG), scoring kernel over this rank's particles, weight statistics,
+order-exact prefix, resample + state gather (and, for N > 1, the scan broadcast and the weight/state all-gathers over
+RCCL).  Map, sampling table and particles are resident in HBM before the timed region.  Workload at N = 1 is
+BASELINE.json configs[1] ("c2": 100k-pt scan, 6 classes, 256x256 polar render, 4000x4000 map, 100k particles);
+for N > 1 every GPU holds the same number of particles (weak scaling; N = 8 with --particles-per-gpu 125000 is
+configs[2]).
+
+One JSON line on stdout (rank 0).  `roofline` prices the scoring kernel against HBM bandwidth with the ALGORITHMIC
+bytes of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update): particles sharing map cells are served by
+L1/L2/Infinity Cache, so the fraction can exceed 1 — the HBM traffic measured with rocprofv3 --pmc is reported
+beside it (`traffic`, from profiles/score_traffic.json when present).  `cpu_baseline` times the CPU oracle
+(oracle/oracle.cpp, OpenMP over particles like the reference's parallel for_each) on a bounded sample of the same
+workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--particles-per-gpu", type=int, default=0, help="default: the config's particle count")
+    ap.add_argument("--locality-every", type=int, default=1, help="recompute the cache-locality order every k steps (0 = off)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="particles in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))   # a 1-GPU box's CPU share is 16
+
+
+def cpu_baseline(sc, cfg, n_sample, threads):
+    """The oracle's full update (score + statistics + O(N) resample) on a strided sample of the particle set."""
+    import numpy as np
+    from oracle import c_oracle as oracle
+
+    oracle.build()
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, cfg.map_resolution)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, cfg.map_resolution)
+    fp = oracle.make_params(cfg.ncls)
+    st = np.ascontiguousarray(sc.states[:: max(1, len(sc.states) // n_sample)][:n_sample]).copy()
+    t0 = time.perf_counter()
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    last = oracle.propagate(st, 1.0, 0.0, 0.01, True, fp, oracle.Rng(1))
+    raw = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, fp, st, nthreads=threads)
+    w, _, _ = oracle.update_weights(raw, last)
+    idx = oracle.resample_prefix(w, len(st), 0.5)
+    oracle.gather_states(st, idx)
+    dt = time.perf_counter() - t0
+    return {"value": len(st) / dt, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{len(st)} of the {len(sc.states)} particles of the same scene (strided), full step incl. "
+                      f"O(N) resample, {dt:.1f} s on {threads} OpenMP threads"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    import top_down_renderer_amd as pkg
+    from top_down_renderer_amd import synth
+    from top_down_renderer_amd.kernels import HipKernels
+
+    k = HipKernels()
+    cfg = synth.CONFIGS[a.config]
+    per_gpu = a.particles_per_gpu or cfg.n_particles
+    n_global = per_gpu * world
+    sc = synth.make_scene(cfg, n_particles=n_global)   # same seed on every rank -> identical scene
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    f = pkg.ParticleFilter(n_global, m, pkg.FilterParams(fixed_scale=1.0), seed=1, group=group, kernels=k,
+                           parity_rng=False, locality_every=a.locality_every, init_particles=False)
+    f.set_states(sc.states)
+    nl = f.n_local
+    st0 = f.st[:, :nl].clone()
+    pts_host = torch.from_numpy(sc.pts).pin_memory()
+
+    def step():
+        # every step scores the SAME particle distribution (90 % Gaussian about the true pose + 10 %
+        # uniform): the resampled set of the previous step is replaced by the initial one (a 2.8 MB device copy),
+        # otherwise the filter converges within a few steps and later steps measure an easier, cache-friendlier case
+        f.st[:, :nl].copy_(st0)
+        f.num_particles_ = n_global
+        # only rank 0 "receives" the scan; the others get the rasterised scan by broadcast inside update()
+        if rank == 0:
+            pts = pts_host.to(k.device, non_blocking=True)
+            r.renderSemanticTopDown(pts, cfg.res, cfg.ang_res)
+            scan = r.last_scan()
+        else:
+            scan = ("pk", k.empty((cfg.nr * cfg.nb * k.lib.tdr_rec_floats(cfg.ncls),)))
+        f.propagate((1.0, 0.0), 0.01)
+        f.update(scan, None, cfg.res)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    import ctypes as C
+    k.lib.tdr_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = C.c_double(0), C.c_int64(0)
+    k.lib.tdr_profile_score_ms(C.byref(tot_ms), C.byref(launches))
+    k.lib.tdr_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=k.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        P = cfg.nb * cfg.nr
+        b_pu = P * (4 * cfg.ncls + 1) + 64
+        n_local = per_gpu
+        avg_ms = tot_ms.value / max(1, launches.value)
+        achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "score_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("config") == cfg.name:
+                    traffic = tj["hbm_bytes_per_particle"] * n_local
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "particle-updates/sec (render+score+resample)",
+            "value": n_global * a.steps / dt,
+            "unit": "particle-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.n_pts}-pt scan, {cfg.ncls} classes, {cfg.nb}x{cfg.nr} polar "
+                                   f"render, {cfg.map_size}x{cfg.map_size} map",
+                       "particles_per_gpu": per_gpu, "particles_total": n_global,
+                       "particle_distribution": "90% Gaussian (30 px, 10 deg) about the true pose + 10% uniform",
+                       "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "kernel": "score_polar_kernel", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": launches.value,
+                         "algorithmic_bytes_per_launch": b_pu * n_local},
+        }
+        if not a.no_cpu and a.cpu_sample != 0 and world == 1:
+            ns = a.cpu_sample if a.cpu_sample > 0 else max(256, int(800 * host_threads() * 1.64e6 / b_pu))
+            out["cpu_baseline"] = cpu_baseline(sc, cfg, min(ns, n_global), host_threads())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/* tdr.h — C ABI of libtdr_hip.so: the MI355X (gfx950) implementation of top_down_renderer's per-scan
+ * particle-filter update (scan raster -> per-particle map gather + class-wise score -> weight statistics ->
+ * systematic resample, plus propagate).
+ *
+ * The reference (KumarRobotics/top_down_renderer) has no FFI layer: its boundary is the public C++ surface of
+ * library target `top_down_render` (CMakeLists.txt:145-165).  Every entry point below names the reference method
+ * (file:line, relative to the reference root) whose work it performs; include/top_down_render/ *.h rebuilds the
+ * reference's class names on top of these calls.
+ *
+ * Conventions
+ *  - plain C, no torch / Eigen / PCL types; every function returns an int status (TDR_OK == 0), never throws;
+ *  - "tdr_k_*" entry points are stateless launchers: every pointer is a DEVICE pointer unless the name says
+ *    `_host`, `stream` is a hipStream_t (NULL = default stream), nothing is allocated, nothing synchronises;
+ *  - images follow the reference's Eigen::ArrayXXf layout: column-major float32, element (i,j) at i + rows*j,
+ *    one image per class, images of one scan contiguous: [ncls][rows*cols];
+ *  - particle state on the device is a structure of arrays `float st[TDR_ST_FIELDS][cap]` (plane stride `cap`),
+ *    planes in the field order of the reference's `State` (include/top_down_render/state_particle.h:9-17),
+ *    have_init stored as 0.0f / 1.0f;
+ *  - no CPU fallback exists: without a HIP device every launcher fails with TDR_ERR_HIP.
+ */
+#ifndef TDR_H_
+#define TDR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDR_OK 0
+#define TDR_ERR_ARG (-1)      /* bad shape / null pointer / unsupported size (message in tdr_last_error) */
+#define TDR_ERR_HIP (-2)      /* HIP runtime error (message in tdr_last_error) */
+#define TDR_ERR_NOMEM (-3)
+
+#define TDR_MAX_CLASSES 15
+#define TDR_ST_FIELDS 7       /* init_x_px, init_y_px, dx_m, dy_m, theta, scale, have_init */
+enum { TDR_ST_INIT_X = 0, TDR_ST_INIT_Y = 1, TDR_ST_DX = 2, TDR_ST_DY = 3, TDR_ST_THETA = 4, TDR_ST_SCALE = 5,
+       TDR_ST_HAVE_INIT = 6 };
+
+/* Same bytes as the reference's `State` (state_particle.h:9-17): 6 floats + bool, sizeof == 28. */
+typedef struct tdr_state {
+  float init_x_px, init_y_px, dx_m, dy_m, theta, scale;
+  uint8_t have_init;
+  uint8_t pad_[3];
+} tdr_state;
+
+/* POD mirror of the reference's `FilterParams` (state_particle.h:19-38). */
+typedef struct tdr_filter_params {
+  float pos_cov, theta_cov, regularization;
+  float init_pos_px_x, init_pos_px_y, init_pos_px_cov;
+  float init_pos_m_x, init_pos_m_y, init_pos_deg_theta, init_pos_deg_cov;
+  int32_t force_on_map;
+  float fixed_scale, scale_log_min, scale_log_max;
+  int32_t num_classes;
+  float class_weights[16];
+} tdr_filter_params;
+
+/* Geometry of the device-resident map produced by tdr_k_pack_map. */
+typedef struct tdr_map_desc {
+  const float* rec;     /* [(rows*cols)+1][rec_floats]: per cell {dist_0..dist_{ncls-1}, 0.., known}; last record = out of bounds */
+  int32_t ncls, rows, cols, rec_floats;   /* rec_floats = 4*ceil((ncls+1)/4) */
+  float resolution;     /* TopDownMap::Params::resolution (top_down_map.h:61) */
+} tdr_map_desc;
+
+const char* tdr_last_error(void);
+int tdr_version(void);
+int tdr_device_count(void);
+/* floats per map / scan record for `ncls` classes */
+int tdr_rec_floats(int ncls);
+
+/* ---- map (storage of TopDownMap, include/top_down_render/top_down_map.h:77-79) ------------------------------ */
+/* Interleaves the reference's per-class column-major distance maps `class_maps_` ([ncls][rows*cols], element (r,c)
+ * at r + rows*c) and the unknown mask `class_mask_` (u8, 1 = unknown) into cell records (tdr_map_desc.rec).
+ * rec_out must hold (rows*cols + 1) * tdr_rec_floats(ncls) floats. */
+int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
+                   void* stream);
+
+/* TopDownMapPolar::samplePtsPolar (src/top_down_map_polar.cpp:7-19, via TopDownMap::samplePts
+ * src/top_down_map.cpp:367-389): fills the HOST table tab[nb*nr][2] = {cos(theta_i)*r_j, sin(theta_i)*r_j}. */
+int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float* tab_out);
+
+/* ---- scan raster -------------------------------------------------------------------------------------------- */
+/* ScanRendererPolar::renderSemanticTopDown (src/scan_renderer_polar.cpp:83-109).
+ * pts: n points, `stride` floats apart (pcl::PointXYZI: stride 8, ioff 4; packed xyzi: stride 4, ioff 3);
+ * lut256: flatten_lut_ (int32[256], -1 = ignore).  Outputs (either may be NULL):
+ *   img_out  [ncls][nb*nr]   the reference's images (zero-filled, counts as float);
+ *   pk_out   [nr][nb][rf]    the same counts interleaved per bin, slot rf-1 = sum over classes (scoring input). */
+int tdr_k_raster_polar(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
+                       const int32_t* lut256, int ncls, int nb, int nr, float* img_out, float* pk_out, void* stream);
+/* ScanRenderer::renderSemanticTopDown (src/scan_renderer.cpp:55-78); img_out [ncls][rows*cols]. */
+int tdr_k_raster_cart(const float* pts, int stride, int ioff, int64_t n, float res, const int32_t* lut256, int ncls,
+                      int rows, int cols, float* img_out, float* pk_out, void* stream);
+/* Builds pk_out from caller-supplied images (ParticleFilter::update is handed images, particle_filter.cpp:94-95). */
+int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, void* stream);
+
+/* ---- scoring: StateParticle::computeWeight for all particles (src/state_particle.cpp:157-219 =
+ *      TopDownMapPolar::getLocalMap src/top_down_map_polar.cpp:21-53 + getCostForRot src/state_particle.cpp:112-155,
+ *      driven by ParticleFilter::update src/particle_filter.cpp:104-105) ------------------------------------- */
+/* workspace floats needed by tdr_k_score_polar for n particles */
+size_t tdr_score_workspace_floats(int ncls, int nr, int64_t n);
+/* Scores particles [0,n) of st (plane stride cap) against the packed scan at each particle's own theta; writes raw
+ * weights raw_w[n] (NaN = "too much unknown", 0 = gated by force_on_map / scale range, state_particle.cpp:163-176).
+ * perm (optional, int32[n]): processing order (a permutation of 0..n-1, e.g. from tdr_k_locality_order) for cache
+ * locality; results are independent of it.  tab: DEVICE copy of the table from tdr_polar_table_host. */
+int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
+                      const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
+                      float* raw_w, float* workspace, void* stream);
+/* The 40-rotation initialisation search of state_particle.cpp:195-206 for the particles of st whose have_init is 0
+ * (and that are not gated): overwrites their raw_w, sets their theta to the best rotation and have_init to 1.
+ * Call after tdr_k_score_polar while such particles may exist; a no-op on the device when there are none
+ * (the launches are trimmed by a device-side count, nothing synchronises with the host). */
+int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
+                           const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, float* raw_w,
+                           float* workspace, void* stream);
+
+/* ---- StateParticle::propagate for all particles (src/state_particle.cpp:57-78 via particle_filter.cpp:86-92) -- */
+/* z4: optional DEVICE array [n][4] of standard normals {theta, dx, dy, scale} in the reference's consumption
+ * order (parity mode, from tdr_propagate_normals_host); NULL = counter-based device RNG keyed by (seed, step). */
+int tdr_k_propagate(float* st, int64_t cap, int64_t n, float* last_dist, float tx, float ty, float omega,
+                    int scale_freeze, float pos_cov, float theta_cov, const float* z4, uint64_t seed, uint64_t step,
+                    int64_t index_base, void* stream);
+/* The shared std::mt19937 of the reference (particle_filter.h:52): host-side handle, explicit seed. */
+void* tdr_rng_create(uint32_t seed);
+void tdr_rng_destroy(void* rng);
+float tdr_rng_uniform_host(void* rng);                      /* particle_filter.cpp:172-173 */
+int tdr_propagate_normals_host(void* rng, int64_t n, int scale_freeze, float* z4_out);
+/* ParticleFilter::initializeParticles particle loop (src/particle_filter.cpp:57-71) with the StateParticle
+ * constructor (src/state_particle.cpp:3-49): host-side, serial mt19937 draws with on-road rejection.
+ * class_maps: HOST copy of class_maps_ (column-major [ncls][rows*cols]); out must hold max_num+16 states. */
+int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int rows, int cols, float resolution,
+                            const tdr_filter_params* fp, int max_num, tdr_state* out, int64_t* n_out);
+
+/* ---- ParticleFilter::update, weight statistics (src/particle_filter.cpp:107-147) ---------------------------- */
+/* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, 8 floats):
+ * {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}. */
+int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out, float* info_out,
+                         void* stream);
+
+/* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
+/* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum. */
+int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream);
+/* idx_out[i - i_begin] = first j with prefix_j > (float(i)+shift)/n_new, else n-1, for i in [i_begin, i_end). */
+int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, int64_t i_begin, int64_t i_end,
+                   int32_t* idx_out, void* stream);
+/* new_particles_[i]->setState(particles_[j]->state()) (:184): dst[f][i] = src[f][idx[i]].
+ * src_shard == 0: src is a plain [7][src_cap] SoA.  src_shard > 0: src is the all-gathered [rank][7][src_shard]
+ * buffer of a sharded filter and idx holds global particle indices (rank*src_shard + local). */
+int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, const int32_t* idx, int64_t n_new,
+                        float* dst, int64_t dst_cap, void* stream);
+
+/* ---- per-step consumers (src/particle_filter.cpp:191-236, 325-334, 343-357) --------------------------------- */
+/* out (device, 24 floats): mean[4] (meanLikelihood), cov[16] row-major about ref (computeMeanCov when
+ * about_max < 0, computeCov about particle `about_max` otherwise), geo-mean scale, 3 spare. */
+int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, int64_t about_max, float* out, void* stream);
+int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, void* stream);   /* freezeScale :350-352 */
+int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream);      /* updateMap :325-334 */
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+/* While enabled, every launch of the scoring kernel is bracketed by HIP events on its launch stream;
+ * tdr_profile_score_ms synchronises on them, returns the summed duration and the launch count, and resets. */
+int tdr_profile_enable(int on);
+int tdr_profile_score_ms(double* total_ms, int64_t* launches);
+
+/* ---- layout helpers ------------------------------------------------------------------------------------------ */
+int tdr_k_states_aos_to_soa(const tdr_state* aos, int64_t n, float* st, int64_t cap, void* stream);
+int tdr_k_states_soa_to_aos(const float* st, int64_t cap, int64_t n, tdr_state* aos, void* stream);
+/* Locality order: perm_out = particle indices grouped by the 4x4 px map tile of their centre (row-major tiles).
+ * keys_tmp: int32[tdr_locality_tmp_ints(n, map_rows, map_cols)] scratch. */
+size_t tdr_locality_tmp_ints(int64_t n, int map_rows, int map_cols);
+int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols, int32_t* perm_out,
+                         int32_t* keys_tmp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDR_H_ */

@@ -1,0 +1,96 @@
+"""ctypes binding of libtdr_hip.so (include/tdr.h).  There is no CPU fallback: if the library is missing or no HIP
+device is present, the product path raises."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libtdr_hip.so")
+
+TDR_ST_FIELDS = 7
+TDR_MAX_CLASSES = 15
+
+
+class FilterParamsC(C.Structure):
+    _fields_ = [
+        ("pos_cov", C.c_float), ("theta_cov", C.c_float), ("regularization", C.c_float),
+        ("init_pos_px_x", C.c_float), ("init_pos_px_y", C.c_float), ("init_pos_px_cov", C.c_float),
+        ("init_pos_m_x", C.c_float), ("init_pos_m_y", C.c_float),
+        ("init_pos_deg_theta", C.c_float), ("init_pos_deg_cov", C.c_float),
+        ("force_on_map", C.c_int32),
+        ("fixed_scale", C.c_float), ("scale_log_min", C.c_float), ("scale_log_max", C.c_float),
+        ("num_classes", C.c_int32),
+        ("class_weights", C.c_float * 16),
+    ]
+
+
+class MapDescC(C.Structure):
+    _fields_ = [("rec", C.c_void_p), ("ncls", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("rec_floats", C.c_int32), ("resolution", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/tdr.h declares
+_vp, _i, _i64, _f, _u64, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_uint32
+SIGNATURES = {
+    "tdr_last_error": (C.c_char_p, []),
+    "tdr_version": (_i, []),
+    "tdr_device_count": (_i, []),
+    "tdr_rec_floats": (_i, [_i]),
+    "tdr_k_pack_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "tdr_polar_table_host": (_i, [_i, _i, _f, _f, _vp]),
+    "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tdr_k_pack_scan": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i64]),
+    "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
+                               _vp, _vp, _vp, _vp]),
+    "tdr_k_score_polar_init": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64,
+                                    _i64, _vp, _vp, _vp]),
+    "tdr_k_propagate": (_i, [_vp, _i64, _i64, _vp, _f, _f, _f, _i, _f, _f, _vp, _u64, _u64, _i64, _vp]),
+    "tdr_rng_create": (_vp, [_u32]),
+    "tdr_rng_destroy": (None, [_vp]),
+    "tdr_rng_uniform_host": (_f, [_vp]),
+    "tdr_propagate_normals_host": (_i, [_vp, _i64, _i, _vp]),
+    "tdr_k_update_weights": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "tdr_k_prefix": (_i, [_vp, _i64, _vp, _vp]),
+    "tdr_k_resample": (_i, [_vp, _i64, _i64, _f, _i64, _i64, _vp, _vp]),
+    "tdr_k_gather_states": (_i, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "tdr_init_particles_host": (_i, [_vp, _vp, _i, _i, _i, _f, C.POINTER(FilterParamsC), _i, _vp, C.POINTER(C.c_int64)]),
+    "tdr_k_mean_cov": (_i, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tdr_k_set_scale": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "tdr_k_shift_init": (_i, [_vp, _i64, _i64, _f, _f, _vp]),
+    "tdr_k_states_aos_to_soa": (_i, [_vp, _i64, _vp, _i64, _vp]),
+    "tdr_k_states_soa_to_aos": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "tdr_profile_enable": (_i, [_i]),
+    "tdr_profile_score_ms": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tdr_locality_tmp_ints": (C.c_size_t, [_i64, _i, _i]),
+    "tdr_k_locality_order": (_i, [_vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class TdrError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libtdr_hip.so and binds every entry point; raises TdrError if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise TdrError(
+            f"{SO_PATH} is missing: build the HIP extension first (python -m top_down_renderer_amd.build, or "
+            "__graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise TdrError(f"libtdr_hip error {rc}: {load().tdr_last_error().decode()}")

@@ -1,0 +1,1295 @@
+// tdr_kernels.hip — hand-written HIP kernels for gfx950 (MI355X) + the stateless C-ABI launchers of include/tdr.h.
+//
+// Compile with -ffp-contract=off: every float expression that decides a bin / cell index must round exactly like
+// the reference's x86-64 code (no FMA contraction); FMAs are spelled out (__builtin_fmaf) where they are wanted.
+//
+// Kernel map (reference loop nest -> kernel), see DESIGN.md:
+//   K0 pack_map_kernel        class_maps_/class_mask_ (top_down_map.h:77-79)          -> interleaved cell records
+//   K1 raster_kernel          scan_renderer_polar.cpp:93-108 / scan_renderer.cpp:65-77 -> LDS-tile bin counters
+//   K2 score_polar_kernel     top_down_map_polar.cpp:28-52 + state_particle.cpp:132-143 (lane = particle)
+//      score_finalize_kernel  state_particle.cpp:117-120,136-139,154,161-176,212
+//   K3 propagate_kernel       state_particle.cpp:57-78
+//   K4 update_weights_kernel  particle_filter.cpp:107-147
+//   K5 prefix_kernel / resample_kernel / gather_states_kernel   particle_filter.cpp:172-185
+//   K6 mean_cov_kernel        particle_filter.cpp:191-236, 343-357
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "tdr.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(TDR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define LAUNCH_CHECK(name)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ != hipSuccess) return fail(TDR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* tdr_last_error(void) { return g_err; }
+extern "C" int tdr_version(void) { return 100; }
+extern "C" int tdr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int tdr_rec_floats(int ncls) { return 4 * ((ncls + 1 + 3) / 4); }
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// K0: map packing.  One thread per cell (row-major output r*cols + c); input is the reference's column-major layout.
+__global__ void pack_map_kernel(const float* __restrict__ maps, const uint8_t* __restrict__ mask, int ncls, int rows,
+                                int cols, int rf, float* __restrict__ rec) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t ncell = (int64_t)rows * cols;
+  if (idx > ncell) return;
+  float* o = rec + idx * rf;
+  if (idx == ncell) {  // the out-of-bounds record: distances 0 (top_down_map_polar.cpp:39), unknown (:51)
+    for (int k = 0; k < rf; k++) o[k] = 0.f;
+    return;
+  }
+  int r = (int)(idx / cols), c = (int)(idx % cols);
+  int64_t src = (int64_t)r + (int64_t)rows * c;
+  for (int k = 0; k < rf; k++) o[k] = 0.f;
+  for (int k = 0; k < ncls; k++) o[k] = maps[(int64_t)k * ncell + src];
+  o[rf - 1] = 1.f - (float)mask[src];  // `1 - mask.cast<float>()` (state_particle.cpp:199,209)
+}
+
+extern "C" int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
+                              float* rec_out, void* stream) {
+  if (!class_maps || !class_mask || !rec_out) return fail(TDR_ERR_ARG, "pack_map: null pointer");
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "pack_map: bad shape");
+  int rf = tdr_rec_floats(ncls);
+  int64_t ncell = (int64_t)rows * cols;
+  if ((ncell + 1) * rf * 4 > (int64_t)0xFFFFFFF0ll) return fail(TDR_ERR_ARG, "pack_map: map exceeds 4 GiB of records");
+  hipLaunchKernelGGL(pack_map_kernel, dim3((unsigned)cdiv(ncell + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     class_maps, class_mask, ncls, rows, cols, rf, rec_out);
+  LAUNCH_CHECK("pack_map");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host: polar sampling table (top_down_map.cpp:367-389 + top_down_map_polar.cpp:7-19).  glibc cosf/sinf, like the
+// reference's host code; the table is an input of the scoring kernel.
+static inline float linspaced_f(int i, int n, float low, float high) {
+  int size1 = (n == 1) ? 1 : n - 1;
+  float step = (n == 1) ? 0.0f : (high - low) / (float)(n - 1);
+  if (fabsf(high) < fabsf(low)) return (i == 0) ? low : (high - (float)(size1 - i) * step);
+  return (i == size1) ? high : (low + (float)i * step);
+}
+extern "C" int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float* tab) {
+  if (nb < 1 || nr < 1 || !tab) return fail(TDR_ERR_ARG, "polar_table: bad arguments");
+  // samplePts(0, 0, pts, cols=nr, rows=nb, res=1): row0 = L_nb[i], row1 = L_nr[j]; identity rotation
+  float lo_r = (float)((double)(-1.f * (float)(nb - 1)) / 2.), hi_r = (float)((double)(1.f * (float)(nb - 1)) / 2.);
+  float lo_c = (float)((double)(-1.f * (float)(nr - 1)) / 2.), hi_c = (float)((double)(1.f * (float)(nr - 1)) / 2.);
+  float c = cosf(0.f), s = sinf(0.f);
+  float inv_res = (float)(1. / (double)resolution);
+  float first = 0.f;
+  for (int j = 0; j < nr; j++) {
+    for (int i = 0; i < nb; i++) {
+      float p0 = linspaced_f(i, nb, lo_r, hi_r), p1 = linspaced_f(j, nr, lo_c, hi_c);
+      float a = c * p0 + (-s) * p1 + 0.f;
+      float r = s * p0 + c * p1 + 0.f;
+      if (i == 0 && j == 0) first = r;
+      r = r + (-first);
+      a = a * ang_res;
+      r = r * inv_res;
+      size_t k = (size_t)i + (size_t)nb * j;
+      tab[2 * k] = cosf(a) * r;
+      tab[2 * k + 1] = sinf(a) * r;
+    }
+  }
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1: scan raster.  Each workgroup owns a tile of `cpt` image columns (range bins) x all rows x all classes as u32
+// counters in LDS, streams every point with coalesced loads and keeps those that fall into its tile.  Integer LDS
+// atomics -> exact, order-independent counts; plain coalesced stores out (the tile is written whole, zeros
+// included, so no memset pass is needed).
+struct RasterArgs {
+  const float* pts;
+  int stride, ioff;
+  int64_t n;
+  float res, ang_res;
+  const int32_t* lut;
+  int ncls, rows, cols, rf, cpt, polar;
+  float* img;
+  float* pk;
+};
+
+__device__ __forceinline__ bool raster_bin(const RasterArgs& a, float x, float y, int& row, int& col) {
+  if (x == 0.f && y == 0.f) return false;
+  if (a.polar) {
+    float theta = atan2f(x, y);
+    float r = sqrtf(x * x + y * y);
+    row = (int)(roundf(theta / a.ang_res) + (float)(a.rows / 2));
+    col = (int)roundf(r / a.res);
+  } else {
+    col = (int)(roundf(x / a.res) + (float)(a.cols / 2));
+    row = (int)(roundf(y / a.res) + (float)(a.rows / 2));
+  }
+  return row >= 0 && row < a.rows && col >= 0 && col < a.cols;
+}
+
+__global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
+  extern __shared__ unsigned int cnt[];  // [cpt][ncls][rows]
+  const int col0 = blockIdx.x * a.cpt;
+  const int ncol = min(a.cpt, a.cols - col0);
+  const int tile = ncol * a.ncls * a.rows;
+  for (int t = threadIdx.x; t < tile; t += blockDim.x) cnt[t] = 0;
+  __shared__ int lut_s[256];
+  if (threadIdx.x < 256) lut_s[threadIdx.x] = a.lut[threadIdx.x];
+  __syncthreads();
+  for (int64_t k = threadIdx.x; k < a.n; k += blockDim.x) {
+    const float* p = a.pts + k * a.stride;
+    float x, y, cf;
+    if (a.stride == 4 && a.ioff == 3) {
+      float4 v = *reinterpret_cast<const float4*>(p);
+      x = v.x; y = v.y; cf = v.w;
+    } else {
+      x = p[0]; y = p[1]; cf = p[a.ioff];
+    }
+    int row, col;
+    if (!raster_bin(a, x, y, row, col)) continue;
+    col -= col0;
+    if (col < 0 || col >= ncol) continue;
+    int pc = (int)cf;
+    if (pc < 0 || pc > 255) continue;
+    int c = lut_s[pc];
+    if (c < 0 || c >= a.ncls) continue;
+    atomicAdd(&cnt[(col * a.ncls + c) * a.rows + row], 1u);
+  }
+  __syncthreads();
+  const int64_t P = (int64_t)a.rows * a.cols;
+  if (a.img) {
+    for (int t = threadIdx.x; t < tile; t += blockDim.x) {
+      int row = t % a.rows, cc = t / a.rows;
+      int c = cc % a.ncls, col = cc / a.ncls;
+      a.img[(int64_t)c * P + row + (int64_t)a.rows * (col0 + col)] = (float)cnt[t];
+    }
+  }
+  if (a.pk) {
+    const int bins = ncol * a.rows;
+    for (int t = threadIdx.x; t < bins; t += blockDim.x) {
+      int row = t % a.rows, col = t / a.rows;
+      float* o = a.pk + ((int64_t)(col0 + col) * a.rows + row) * a.rf;
+      unsigned int tot = 0;
+      for (int c = 0; c < a.ncls; c++) {
+        unsigned int v = cnt[(col * a.ncls + c) * a.rows + row];
+        o[c] = (float)v;
+        tot += v;
+      }
+      for (int c = a.ncls; c < a.rf - 1; c++) o[c] = 0.f;
+      o[a.rf - 1] = (float)tot;
+    }
+  }
+}
+
+static int launch_raster(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
+                         const int32_t* lut, int ncls, int rows, int cols, int polar, float* img, float* pk,
+                         void* stream) {
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "raster: bad image shape");
+  if (n < 0 || (n > 0 && !pts) || !lut) return fail(TDR_ERR_ARG, "raster: null points / lut");
+  if (stride < 3 || ioff < 0 || ioff >= stride) return fail(TDR_ERR_ARG, "raster: bad point stride / offset");
+  if (!(res > 0.f) || (polar && !(ang_res > 0.f))) return fail(TDR_ERR_ARG, "raster: resolution must be > 0");
+  int64_t per_col = (int64_t)ncls * rows * 4;
+  if (per_col > 64 * 1024) return fail(TDR_ERR_ARG, "raster: ncls*rows too large for one LDS tile");
+  RasterArgs a;
+  a.pts = pts; a.stride = stride; a.ioff = ioff; a.n = n; a.res = res; a.ang_res = ang_res; a.lut = lut;
+  a.ncls = ncls; a.rows = rows; a.cols = cols; a.rf = tdr_rec_floats(ncls); a.polar = polar; a.img = img; a.pk = pk;
+  a.cpt = (int)std::max<int64_t>(1, (64 * 1024) / per_col);
+  a.cpt = std::min(a.cpt, cols);
+  // enough workgroups to spread over the chip when the image is small
+  while (a.cpt > 1 && cdiv(cols, a.cpt) < 32) a.cpt = (a.cpt + 1) / 2;
+  size_t lds = (size_t)a.cpt * per_col;
+  hipLaunchKernelGGL(raster_kernel, dim3((unsigned)cdiv(cols, a.cpt)), dim3(1024), lds, (hipStream_t)stream, a);
+  LAUNCH_CHECK("raster");
+  return TDR_OK;
+}
+
+extern "C" int tdr_k_raster_polar(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
+                                  const int32_t* lut256, int ncls, int nb, int nr, float* img_out, float* pk_out,
+                                  void* stream) {
+  return launch_raster(pts, stride, ioff, n, res, ang_res, lut256, ncls, nb, nr, 1, img_out, pk_out, stream);
+}
+extern "C" int tdr_k_raster_cart(const float* pts, int stride, int ioff, int64_t n, float res, const int32_t* lut256,
+                                 int ncls, int rows, int cols, float* img_out, float* pk_out, void* stream) {
+  return launch_raster(pts, stride, ioff, n, res, 1.f, lut256, ncls, rows, cols, 0, img_out, pk_out, stream);
+}
+
+__global__ void pack_scan_kernel(const float* __restrict__ img, int ncls, int rows, int cols, int rf,
+                                 float* __restrict__ pk) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t P = (int64_t)rows * cols;
+  if (t >= P) return;
+  float* o = pk + t * rf;  // t = row + rows*col == (col*rows + row)
+  float tot = 0.f;
+  for (int c = 0; c < ncls; c++) {
+    float v = img[(int64_t)c * P + t];
+    o[c] = v;
+    tot += v;
+  }
+  for (int c = ncls; c < rf - 1; c++) o[c] = 0.f;
+  o[rf - 1] = tot;
+}
+extern "C" int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, void* stream) {
+  if (!img || !pk_out || ncls < 1 || ncls > TDR_MAX_CLASSES || nb < 1 || nr < 1)
+    return fail(TDR_ERR_ARG, "pack_scan: bad arguments");
+  int64_t P = (int64_t)nb * nr;
+  hipLaunchKernelGGL(pack_scan_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, img, ncls, nb,
+                     nr, tdr_rec_floats(ncls), pk_out);
+  LAUNCH_CHECK("pack_scan");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2: scoring.  lane = particle, 64 particles per wave, 4 waves per workgroup; grid.y = chunk of range rings.
+// All lanes of a wave visit the same window sample (i,j) at the same time, so their map reads fall on neighbouring
+// cells when the particles are neighbours (tdr_k_locality_order) and coalesce in L1/L2 instead of being 64
+// unrelated gathers; the rotation enters only as a per-lane row offset into the ring of scan records held in LDS.
+struct ScoreArgs {
+  const float* rec;     // map cell records
+  int rows, cols;       // map
+  float resolution;
+  const float* tab;     // [P][2]
+  const float* scan_pk; // [nr][nb][rf]
+  int nb, nr;
+  float res;
+  const float* st;      // [7][cap]
+  int64_t cap, n;
+  const int32_t* order; // slot -> particle (NULL = identity)
+  const int32_t* count; // optional device count limiting the active slots (init search)
+  int use_theta_override;
+  float theta_override;
+  int rpc, nchunks;     // rings per chunk
+  int64_t npad;         // slots padded to a multiple of 64
+  float* part;          // [nchunks][rf+1][npad]
+};
+
+__device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
+  // state_particle.cpp:124-128
+  int s = (int)round((double)(rot * (float)nb / 2) / M_PI);
+  s %= nb;
+  if (s < 0) s += nb;
+  return s;
+}
+
+template <int NV4, int U>
+__global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
+  constexpr int RF = 4 * NV4;
+  extern __shared__ float4 ring[];  // [nb][NV4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const int64_t nact = a.count ? (int64_t)*a.count : a.n;
+  if ((int64_t)blockIdx.x * 256 >= nact) return;  // whole workgroup idle (uniform)
+  const bool valid = slot < nact;
+  int64_t p = valid ? (a.order ? (int64_t)a.order[slot] : slot) : 0;
+  if (nact == 0) return;
+  if (!valid) p = a.order ? (int64_t)a.order[0] : 0;
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];  // :162
+  const float off0 = cy / a.resolution;  // top_down_map_polar.cpp:29
+  const float off1 = cx / a.resolution;  // :30
+  const float theta = a.use_theta_override ? a.theta_override : a.st[TDR_ST_THETA * a.cap + p];
+  const int shift = rot_shift_dev(theta, a.nb);
+
+  const int j0 = blockIdx.y * a.rpc, j1 = min(a.nr, j0 + a.rpc);
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const unsigned oob = (unsigned)a.rows * (unsigned)a.cols;
+
+  float acc2[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
+  float known2 = 0.f;
+
+  for (int j = j0; j < j1; j++) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nb * NV4; t += 256) ring[t] = scan4[(int64_t)j * a.nb * NV4 + t];
+    __syncthreads();
+    float acc[RF];
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[k] = 0.f;
+    float known = 0.f;
+    int arow = shift;  // scan row paired with window row i is (i + shift) mod nb
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    int i = 0;
+    // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together,
+    // then the FMAs — the wave keeps 2*U*NV4 16-byte loads outstanding instead of waiting per sample.
+    for (; i + U <= a.nb; i += U) {
+      unsigned boff[U];
+      int ar[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float2 t = trow[i + u];
+        float p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
+        float p1 = (t.y * scale) * a.res;
+        p0 = p0 + off0;
+        p1 = p1 + off1;
+        const int ri = (int)roundf(p0), ci = (int)roundf(p1);  // :31
+        const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+        const unsigned cell = inb ? (unsigned)ri * (unsigned)a.cols + (unsigned)ci : oob;
+        boff[u] = cell * (unsigned)(RF * 4);  // < 4 GiB, checked by tdr_k_pack_map
+        ar[u] = arow;
+        arow = (arow + 1 == a.nb) ? 0 : arow + 1;
+      }
+      float4 m[U][NV4], s[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) s[u][v] = ring[ar[u] * NV4 + v];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[u][v].x, acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[u][v].y, acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[u][v].z, acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[u][v].w, acc[4 * v + 3]);
+        }
+        known += m[u][NV4 - 1].w;
+      }
+    }
+    for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
+      const float2 t = trow[i];
+      float p0 = (t.x * scale) * a.res;
+      float p1 = (t.y * scale) * a.res;
+      p0 = p0 + off0;
+      p1 = p1 + off1;
+      const int ri = (int)roundf(p0), ci = (int)roundf(p1);
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      const unsigned cell = inb ? (unsigned)ri * (unsigned)a.cols + (unsigned)ci : oob;
+      const unsigned bo = cell * (unsigned)(RF * 4);
+#pragma unroll
+      for (int v = 0; v < NV4; v++) {
+        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+        const float4 s = ring[arow * NV4 + v];
+        acc[4 * v + 0] = __builtin_fmaf(s.x, m.x, acc[4 * v + 0]);
+        acc[4 * v + 1] = __builtin_fmaf(s.y, m.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = __builtin_fmaf(s.z, m.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = __builtin_fmaf(s.w, m.w, acc[4 * v + 3]);
+        if (v == NV4 - 1) known += m.w;
+      }
+      arow = (arow + 1 == a.nb) ? 0 : arow + 1;
+    }
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
+    known2 += known;
+  }
+  if (slot < a.npad) {
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
+    o[(int64_t)RF * a.npad] = known2;
+  }
+}
+
+// Gates of state_particle.cpp:163-176.  scale_lo / scale_hi = pow(10, scale_log_min/max) evaluated on the host
+// (glibc pow, like the reference).
+struct GateArgs {
+  int force_on_map, scale_unknown;
+  float width, height;  // map size * resolution (state_particle.cpp:11,46-47)
+  double scale_lo, scale_hi;
+};
+static GateArgs make_gate(const tdr_filter_params* fp, const tdr_map_desc* map) {
+  GateArgs g;
+  g.force_on_map = fp->force_on_map;
+  g.scale_unknown = fp->fixed_scale < 0;
+  g.width = (float)map->cols * map->resolution;
+  g.height = (float)map->rows * map->resolution;
+  g.scale_lo = std::pow(10, fp->scale_log_min);
+  g.scale_hi = std::pow(10, fp->scale_log_max);
+  return g;
+}
+__device__ __forceinline__ bool particle_gated(const GateArgs& g, float cx, float cy, float scale) {
+  if (g.force_on_map) {
+    if (cx < 0 || cy < 0 || cx > g.width || cy > g.height) return true;  // :163-168
+  }
+  if (g.scale_unknown) {
+    if ((double)scale < g.scale_lo || (double)scale > g.scale_hi) return true;  // :169-176
+  }
+  return false;
+}
+
+struct FinalizeArgs {
+  const float* part;
+  int rf, nchunks;
+  int64_t npad, n, cap;
+  const int32_t* order;
+  const int32_t* count;
+  float* st;
+  tdr_filter_params fp;
+  GateArgs gate;
+  int64_t P;
+  int ncls;
+  int mode;             // 0: write raw weight; 1: init-search accumulate (best cost / theta)
+  int first;            // mode 1: first rotation (initialise best)
+  float theta_override;
+  float* raw_w;
+  float* best_cost;
+  float* best_theta;
+};
+
+__global__ void score_finalize_kernel(FinalizeArgs a) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nact = a.count ? (int64_t)*a.count : a.n;
+  if (slot >= nact) return;
+  const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  if (a.mode == 0 && particle_gated(a.gate, cx, cy, scale)) {
+    a.raw_w[p] = 0.f;
+    return;
+  }
+  // known fraction gate (state_particle.cpp:117-120); counts are exact integers in float
+  double known = 0;
+  for (int c = 0; c < a.nchunks; c++) known += (double)a.part[((int64_t)c * (a.rf + 1) + a.rf) * a.npad + slot];
+  float cost;
+  if ((float)known / (float)a.P < 0.5) {
+    cost = __builtin_nanf("");
+  } else {
+    cost = 0.f;
+    for (int k = 0; k < a.ncls; k++) {
+      double dot = 0;
+      for (int c = 0; c < a.nchunks; c++) dot += (double)a.part[((int64_t)c * (a.rf + 1) + k) * a.npad + slot];
+      cost = (float)((double)cost + (double)(float)dot * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
+    }
+    double norm = 0;
+    for (int c = 0; c < a.nchunks; c++) norm += (double)a.part[((int64_t)c * (a.rf + 1) + a.rf - 1) * a.npad + slot];
+    cost = cost / (float)norm;  // :154
+  }
+  if (a.mode == 0) {
+    a.raw_w[p] = (float)(1. / (double)(cost + a.fp.regularization));  // :212
+  } else {
+    float best = a.first ? 3.402823466e+38f : a.best_cost[slot];
+    float bt = a.first ? 0.f : a.best_theta[slot];
+    if (cost < best) { best = cost; bt = a.theta_override; }  // :200-203 (NaN never wins)
+    a.best_cost[slot] = best;
+    a.best_theta[slot] = bt;
+  }
+}
+
+// un-initialised, un-gated particles -> compact list (order irrelevant for the results)
+__global__ void init_list_kernel(const float* __restrict__ st, int64_t cap, int64_t n, GateArgs gate,
+                                 int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  if (st[TDR_ST_HAVE_INIT * cap + p] != 0.f) return;
+  const float scale = st[TDR_ST_SCALE * cap + p];
+  const float cx = st[TDR_ST_DX * cap + p] * scale + st[TDR_ST_INIT_X * cap + p];
+  const float cy = st[TDR_ST_DY * cap + p] * scale + st[TDR_ST_INIT_Y * cap + p];
+  if (particle_gated(gate, cx, cy, scale)) return;
+  int k = atomicAdd(count, 1);
+  list[k] = (int32_t)p;
+}
+
+__global__ void init_finish_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+                                   const float* __restrict__ best_cost, const float* __restrict__ best_theta,
+                                   float regularization, float* __restrict__ st, int64_t cap,
+                                   float* __restrict__ raw_w) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (int64_t)*count) return;
+  const int64_t p = list[slot];
+  st[TDR_ST_THETA * cap + p] = best_theta[slot];       // state_particle.cpp:205
+  st[TDR_ST_HAVE_INIT * cap + p] = 1.f;                // :206
+  raw_w[p] = (float)(1. / (double)(best_cost[slot] + regularization));  // :212
+}
+
+static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks) {
+  int64_t nbatches = cdiv(std::max<int64_t>(n, 1), 64);
+  int64_t want = std::max<int64_t>(1, cdiv(16384, nbatches));  // aim for >= 16k waves in flight
+  nchunks = (int)std::min<int64_t>(nr, want);
+  rpc = (int)cdiv(nr, nchunks);
+  nchunks = (int)cdiv(nr, rpc);
+}
+
+extern "C" size_t tdr_score_workspace_floats(int ncls, int nr, int64_t n) {
+  int rpc, nchunks;
+  choose_chunks(n, nr, rpc, nchunks);
+  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  int rf = tdr_rec_floats(ncls);
+  // partials + best_cost + best_theta + list + count(64)
+  return (size_t)((int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64);
+}
+
+#ifndef TDR_SCORE_U
+#define TDR_SCORE_U 4
+#endif
+// Optional in-library timing of the dominant kernel (bench.py's roofline figure): HIP events recorded on the launch
+// stream right around score_polar_kernel, read back after the timed region.
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+struct ScoreProfScope {
+  hipStream_t s;
+  hipEvent_t stop = nullptr;
+  explicit ScoreProfScope(hipStream_t s_) : s(s_) {
+    if (!g_prof_on) return;
+    if (g_prof_used == g_prof_events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      g_prof_events.emplace_back(a, b);
+    }
+    auto& ev = g_prof_events[g_prof_used++];
+    (void)hipEventRecord(ev.first, s);
+    stop = ev.second;
+  }
+  ~ScoreProfScope() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
+extern "C" int tdr_profile_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof_used = 0;
+  return TDR_OK;
+}
+extern "C" int tdr_profile_score_ms(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return fail(TDR_ERR_ARG, "profile_score_ms: null pointer");
+  double tot = 0;
+  for (size_t i = 0; i < g_prof_used; i++) {
+    HIP_TRY(hipEventSynchronize(g_prof_events[i].second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)g_prof_used;
+  g_prof_used = 0;
+  return TDR_OK;
+}
+
+static int launch_score(const ScoreArgs& a, int rf, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
+  size_t lds = (size_t)a.nb * rf * 4;
+  ScoreProfScope prof(s);
+  switch (rf / 4) {
+    case 1: hipLaunchKernelGGL((score_polar_kernel<1, TDR_SCORE_U>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U>), grid, block, lds, s, a); break;
+    case 3: hipLaunchKernelGGL((score_polar_kernel<3, TDR_SCORE_U>), grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((score_polar_kernel<4, TDR_SCORE_U>), grid, block, lds, s, a); break;
+    default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
+  }
+  LAUNCH_CHECK("score_polar");
+  return TDR_OK;
+}
+
+extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
+                                 float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
+                                 const int32_t* perm, float* raw_w, float* workspace, void* stream) {
+  if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score: n=%lld exceeds capacity %lld", (long long)n, (long long)cap);
+  if (n == 0) return TDR_OK;
+  if (nb < 1 || nr < 1) return fail(TDR_ERR_ARG, "score: bad image shape");
+  if (map->ncls < 1 || map->ncls > TDR_MAX_CLASSES || fp->num_classes != map->ncls)
+    return fail(TDR_ERR_ARG, "score: class count mismatch (map %d, params %d)", map->ncls, fp->num_classes);
+  const int rf = tdr_rec_floats(map->ncls);
+  if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score: map record size %d != %d", map->rec_floats, rf);
+  if ((size_t)nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score: nb too large for the LDS scan ring");
+  if (!(map->resolution > 0.f)) return fail(TDR_ERR_ARG, "score: map resolution must be > 0");
+  hipStream_t s = (hipStream_t)stream;
+
+  ScoreArgs a;
+  a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
+  a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
+  a.use_theta_override = 0; a.theta_override = 0.f;
+  choose_chunks(n, nr, a.rpc, a.nchunks);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  int rc = launch_score(a, rf, s);
+  if (rc) return rc;
+
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
+  f.gate = make_gate(fp, map);
+  f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
+  f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  LAUNCH_CHECK("score_finalize");
+  return TDR_OK;
+}
+
+// The 40-rotation initialisation search (state_particle.cpp:195-206) for particles with have_init == 0.
+// Runs the scoring kernel once per candidate rotation on the compacted list of such particles; grids are sized for
+// n and trimmed on the device by the list length, so nothing synchronises with the host.
+extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
+                                      float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
+                                      float* raw_w, float* workspace, void* stream) {
+  if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score_init: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_init: n exceeds capacity");
+  if (n == 0) return TDR_OK;
+  if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_init: class count mismatch");
+  const int rf = tdr_rec_floats(map->ncls);
+  if ((size_t)nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score_init: nb too large for the LDS scan ring");
+  hipStream_t s = (hipStream_t)stream;
+  ScoreArgs a;
+  a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
+  a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
+  a.st = st; a.cap = cap; a.n = n;
+  choose_chunks(n, nr, a.rpc, a.nchunks);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  float* best_cost = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;
+  float* best_theta = best_cost + a.npad;
+  int32_t* list = reinterpret_cast<int32_t*>(best_theta + a.npad);
+  int32_t* count = list + a.npad;
+  a.order = list; a.count = count; a.use_theta_override = 1;
+  const GateArgs gate = make_gate(fp, map);
+  HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(init_list_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)st, cap, n, gate,
+                     list, count);
+  LAUNCH_CHECK("init_list");
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = list; f.count = count; f.st = st; f.fp = *fp; f.gate = gate;
+  f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 1; f.raw_w = raw_w; f.best_cost = best_cost;
+  f.best_theta = best_theta;
+  bool first = true;
+  for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {  // state_particle.cpp:197 (float t, double increment)
+    a.theta_override = t;
+    int rc = launch_score(a, rf, s);
+    if (rc) return rc;
+    f.first = first ? 1 : 0;
+    f.theta_override = t;
+    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+    LAUNCH_CHECK("score_finalize(init)");
+    first = false;
+  }
+  hipLaunchKernelGGL(init_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const int32_t*)list,
+                     (const int32_t*)count, (const float*)best_cost, (const float*)best_theta, fp->regularization, st,
+                     cap, raw_w);
+  LAUNCH_CHECK("init_finish");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K3: propagate (state_particle.cpp:57-78).  z*sigma+mu spelled without contraction like libstdc++'s
+// normal_distribution (`__ret * stddev + mean`).
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+__device__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void propagate_kernel(float* __restrict__ st, int64_t cap, int64_t n, float* __restrict__ last_dist,
+                                 float tx, float ty, float omega, int scale_freeze, float pos_cov, float theta_cov,
+                                 const float* __restrict__ z4, uint64_t seed, uint64_t step, int64_t index_base) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float z[4];
+  if (z4) {
+    z[0] = z4[4 * p]; z[1] = z4[4 * p + 1]; z[2] = z4[4 * p + 2]; z[3] = z4[4 * p + 3];
+  } else {
+    uint64_t gi = (uint64_t)(index_base + p);
+    uint32_t c[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // Box-Muller on (0,1] uniforms
+    float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    z[0] = r0 * cosf(6.283185307f * u1); z[1] = r0 * sinf(6.283185307f * u1);
+    z[2] = r1 * cosf(6.283185307f * u3); z[3] = r1 * sinf(6.283185307f * u3);
+  }
+  float theta = st[TDR_ST_THETA * cap + p];
+  float dx = st[TDR_ST_DX * cap + p], dy = st[TDR_ST_DY * cap + p];
+  // Rotation2D<float>(theta) * trans; sin/cos evaluated in double and rounded (glibc's sinf/cosf are correctly
+  // rounded in practice, the device float versions are not)
+  const float c = (float)cos((double)theta), s = (float)sin((double)theta);
+  const float gx = c * tx + (-s) * ty;
+  const float gy = s * tx + c * ty;
+  const float lx = dx, ly = dy;
+  dx += gx;
+  dy += gy;
+  const float dist = sqrtf(gx * gx + gy * gy);
+  const float sd_pos = pos_cov * dist, sd_th = theta_cov * dist;
+  theta += (z[0] * sd_th + 0.f) + omega;
+  dx += z[1] * sd_pos + 0.f;
+  dy += z[2] * sd_pos + 0.f;
+  if (!scale_freeze) {
+    const float sd_s = (float)fmin(2. / (double)dist, 0.02);
+    float scale = st[TDR_ST_SCALE * cap + p];
+    scale *= z[3] * sd_s + 1.f;
+    st[TDR_ST_SCALE * cap + p] = scale;
+  }
+  st[TDR_ST_THETA * cap + p] = theta;
+  st[TDR_ST_DX * cap + p] = dx;
+  st[TDR_ST_DY * cap + p] = dy;
+  const float mx = lx - dx, my = ly - dy;
+  last_dist[p] = sqrtf(mx * mx + my * my);
+}
+
+extern "C" int tdr_k_propagate(float* st, int64_t cap, int64_t n, float* last_dist, float tx, float ty, float omega,
+                               int scale_freeze, float pos_cov, float theta_cov, const float* z4, uint64_t seed,
+                               uint64_t step, int64_t index_base, void* stream) {
+  if (!st || !last_dist) return fail(TDR_ERR_ARG, "propagate: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "propagate: n exceeds capacity");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(propagate_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
+                     last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4, seed, step, index_base);
+  LAUNCH_CHECK("propagate");
+  return TDR_OK;
+}
+
+// host RNG: the reference's shared std::mt19937 + libstdc++ distributions (particle_filter.h:52, state_particle.cpp:64-73)
+extern "C" void* tdr_rng_create(uint32_t seed) { return new std::mt19937(seed); }
+extern "C" void tdr_rng_destroy(void* rng) { delete (std::mt19937*)rng; }
+extern "C" float tdr_rng_uniform_host(void* rng) {
+  std::uniform_real_distribution<float> d(0., 1.);
+  return d(*(std::mt19937*)rng);
+}
+extern "C" int tdr_propagate_normals_host(void* rng, int64_t n, int scale_freeze, float* z4) {
+  if (!rng || !z4 || n < 0) return fail(TDR_ERR_ARG, "propagate_normals: bad arguments");
+  std::mt19937& gen = *(std::mt19937*)rng;
+  for (int64_t p = 0; p < n; p++) {
+    // fresh distribution objects per call and per use, like state_particle.cpp:64-65,72
+    std::normal_distribution<float> disp{0, 1}, th{0, 1};
+    z4[4 * p + 0] = th(gen);
+    z4[4 * p + 1] = disp(gen);
+    z4[4 * p + 2] = disp(gen);
+    if (!scale_freeze) {
+      std::normal_distribution<float> sc{0, 1};
+      z4[4 * p + 3] = sc(gen);
+    } else {
+      z4[4 * p + 3] = 0.f;
+    }
+  }
+  return TDR_OK;
+}
+
+// Host: particle initialisation.  Serial draws from the shared mt19937 with data-dependent rejection, exactly the
+// consumption order of StateParticle::StateParticle (state_particle.cpp:3-49) inside
+// ParticleFilter::initializeParticles (particle_filter.cpp:57-71) — including the draws the reference burns on the
+// prototype particle and on its second buffer.  class_maps: HOST copy, the reference's column-major layout.
+static bool on_road_host(const float* maps, int ncls, int rows, int cols, float resolution, int px, int py) {
+  // TopDownMap::getClassesAtPoint (top_down_map.cpp:159-170) tested for class 1 (state_particle.cpp:29)
+  const int c0 = (int)((float)px / resolution), c1 = (int)((float)py / resolution);
+  if (ncls < 2) return false;
+  if (!(c0 < cols && c1 < rows && c0 >= 0 && c1 >= 0)) return false;
+  return maps[(size_t)1 * rows * cols + c1 + (size_t)rows * c0] < 1;
+}
+static tdr_state draw_particle(std::mt19937& gen, const float* maps, int ncls, int rows, int cols, float resolution,
+                               const tdr_filter_params* fp) {
+  std::uniform_real_distribution<float> uniform_dist(0., 1.);
+  std::normal_distribution<float> normal_dist(0., 1.);
+  tdr_state st;
+  std::memset(&st, 0, sizeof(st));
+  const float map_w = (float)cols * resolution, map_h = (float)rows * resolution;
+  if (fp->fixed_scale < 0) st.scale = (float)std::pow(10, ((double)uniform_dist(gen) - 0.5) * 2);  // :15
+  else st.scale = fp->fixed_scale;                                                                // :17
+  while (true) {
+    if (fp->init_pos_px_x > 0) {  // :21-23
+      st.init_x_px = std::min(std::max(normal_dist(gen) * fp->init_pos_px_cov + fp->init_pos_px_x, 0.f), map_w);
+      st.init_y_px = std::min(std::max(normal_dist(gen) * fp->init_pos_px_cov + fp->init_pos_px_y, 0.f), map_h);
+    } else {                      // :25-26
+      st.init_x_px = uniform_dist(gen) * map_w;
+      st.init_y_px = uniform_dist(gen) * map_h;
+    }
+    if (on_road_host(maps, ncls, rows, cols, resolution, (int)st.init_x_px, (int)st.init_y_px)) break;  // :28-31
+  }
+  if (fp->init_pos_deg_theta != std::numeric_limits<float>::infinity()) {
+    st.theta = normal_dist(gen) * fp->init_pos_deg_cov + fp->init_pos_deg_theta;  // :35
+    st.theta = (float)((double)st.theta * (M_PI / 180));                          // :37
+    st.have_init = 1;
+  } else {
+    st.theta = 0;
+    st.have_init = 0;
+  }
+  return st;
+}
+extern "C" int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int rows, int cols,
+                                       float resolution, const tdr_filter_params* fp, int max_num, tdr_state* out,
+                                       int64_t* n_out) {
+  if (!rng || !class_maps || !fp || !out || !n_out || max_num < 0) return fail(TDR_ERR_ARG, "init_particles: bad arguments");
+  if (ncls < 2) return fail(TDR_ERR_ARG, "init_particles: class 1 (road) is required for the on-road test");
+  std::mt19937& gen = *(std::mt19937*)rng;
+  bool any_road = false;
+  for (size_t k = 0; k < (size_t)rows * cols && !any_road; k++) any_road = class_maps[(size_t)rows * cols + k] < 1;
+  if (!any_road) return fail(TDR_ERR_ARG, "init_particles: the map has no road cell, rejection sampling cannot end");
+  const size_t num_at_scale = (fp->fixed_scale < 0) ? 10 : 1;  // particle_filter.cpp:20-25
+  int64_t count = 0;
+  for (int i = 0; i < (int)((size_t)max_num / num_at_scale); i++) {                          // :57
+    const tdr_state proto = draw_particle(gen, class_maps, ncls, rows, cols, resolution, fp);  // :58
+    for (float scale = 0; scale < 1; scale += 1. / num_at_scale) {                            // :59
+      tdr_state part = draw_particle(gen, class_maps, ncls, rows, cols, resolution, fp);       // :60
+      if (fp->fixed_scale < 0) {
+        part = proto;                                                                        // :62
+        part.scale = (float)std::pow(10., (double)scale);                                    // :63
+      }
+      if (count < max_num + 16) out[count] = part;
+      count++;
+      (void)draw_particle(gen, class_maps, ncls, rows, cols, resolution, fp);                 // :68 second buffer
+    }
+  }
+  *n_out = count;
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4: weight statistics (particle_filter.cpp:107-147).  One 1024-thread workgroup; sums in double with a fixed
+// strided/tree order, so the result depends only on (raw_w, last_dist, n) — identical on every rank that holds the
+// all-gathered weights.
+__device__ double block_sum_d(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) t += sh[w];
+  return t;
+}
+__device__ long long block_sum_ll(long long v, long long* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  long long t = 0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void update_weights_kernel(const float* __restrict__ raw,
+                                                             const float* __restrict__ last_dist, int64_t n,
+                                                             float* __restrict__ w, float* __restrict__ info) {
+  __shared__ double shd[16];
+  __shared__ long long shl[16];
+  __shared__ float sh_best[16];
+  __shared__ long long sh_besti[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // :108-116
+  double s = 0;
+  long long cnt = 0;
+  for (int64_t i = tid; i < n; i += nt) {
+    float v = raw[i];
+    if (!isnan(v)) { s += (double)v; cnt++; }
+  }
+  const float sum = (float)block_sum_d(s, shd);
+  const long long num_valid = block_sum_ll(cnt, shl);
+  const float mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
+  // :118-126
+  double bs = 0;
+  long long cu = 0;
+  for (int64_t i = tid; i < n; i += nt) {
+    float v = raw[i];
+    if (!isnan(v) && v < mean) {
+      double d = (double)(v - mean);
+      bs += d * d;
+      cu++;
+    }
+  }
+  const float bsum = (float)block_sum_d(bs, shd);
+  const long long num_under = block_sum_ll(cu, shl);
+  const float bottom = sqrtf(bsum / (float)num_under);
+  const bool fallback = (sum == 0.f || num_under < 1);  // :129
+  const float fill = mean - bottom;                      // :133
+  double s1 = 0;
+  for (int64_t i = tid; i < n; i += nt) {
+    float v = raw[i];
+    v = fallback ? 1.f : (isnan(v) ? fill : v);
+    w[i] = v;
+    s1 += (double)v;
+  }
+  const float fs1 = (float)block_sum_d(s1, shd);
+  const float invn_den = (float)n;
+  double s2 = 0;
+  for (int64_t i = tid; i < n; i += nt) {  // :135, :138-141
+    float v = w[i] / fs1;
+    float d = fminf(last_dist[i] * 5.f, 1.f);
+    v = d * v + (1.f - d) / invn_den;
+    w[i] = v;
+    s2 += (double)v;
+  }
+  const float fs2 = (float)block_sum_d(s2, shd);
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffll;
+  for (int64_t i = tid; i < n; i += nt) {  // :142, :145-147 (first maximum)
+    float v = w[i] / fs2;
+    w[i] = v;
+    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_down(best, o, 64);
+    long long oi = __shfl_down(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { sh_best[tid >> 6] = best; sh_besti[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < (nt >> 6); k++)
+      if (sh_best[k] > best || (sh_best[k] == best && sh_besti[k] < besti)) { best = sh_best[k]; besti = sh_besti[k]; }
+    if (besti == 0x7fffffffffffffffll) besti = 0;
+    info[0] = __int_as_float((int)besti);
+    info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = fallback ? 1.f : 0.f;
+    info[5] = (float)num_valid; info[6] = (float)num_under; info[7] = 0.f;
+  }
+}
+
+extern "C" int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out,
+                                    float* info_out, void* stream) {
+  if (!raw_w || !last_dist || !w_out || !info_out) return fail(TDR_ERR_ARG, "update_weights: null pointer");
+  if (n < 1) return fail(TDR_ERR_ARG, "update_weights: n must be >= 1");
+  hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, raw_w, last_dist, n, w_out,
+                     info_out);
+  LAUNCH_CHECK("update_weights");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5: resample.  The running sum of particle_filter.cpp:179 is a serial float32 chain: reproduced by one wave that
+// loads 64 weights at a time (coalesced) and adds them in index order; every lane carries the same running value,
+// lane k stops after element k so it ends up holding prefix_k.  The running maximum makes "first j with
+// prefix_j > sample" searchable even when weights are negative (NaN fill, :133).
+__global__ __launch_bounds__(64) void prefix_kernel(const float* __restrict__ w, int64_t n,
+                                                    float* __restrict__ runmax) {
+  const int lane = threadIdx.x;
+  float run = 0.f, mx = -INFINITY;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    const float wv = (i < n) ? w[i] : 0.f;
+    float mine = run;
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+      const float x = __shfl(wv, k, 64);
+      run = run + x;
+      if (lane == k) mine = run;
+    }
+    // inclusive running max across lanes (exact: max is associative), seeded with the carry
+    float m = mine;
+    if (m != m) m = -INFINITY;  // NaN never exceeds a threshold
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      float t = __shfl_up(m, o, 64);
+      if (lane >= o) m = fmaxf(m, t);
+    }
+    m = fmaxf(m, mx);
+    if (i < n) runmax[i] = m;
+    mx = __shfl(m, 63, 64);
+    // lanes beyond n added zeros: run is unchanged by them only if x + 0 == x, true for finite and inf
+  }
+}
+
+extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream) {
+  if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
+  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  LAUNCH_CHECK("prefix");
+  return TDR_OK;
+}
+
+__global__ void resample_kernel(const float* __restrict__ runmax, int64_t n, int64_t n_new, float shift,
+                                int64_t i_begin, int64_t i_end, int32_t* __restrict__ idx) {
+  const int64_t i = i_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i_end) return;
+  const float sample = ((float)i + shift) / (float)n_new;  // particle_filter.cpp:176
+  int64_t lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (runmax[mid] > sample) hi = mid; else lo = mid + 1;
+  }
+  idx[i - i_begin] = (int32_t)lo;
+}
+
+extern "C" int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, int64_t i_begin,
+                              int64_t i_end, int32_t* idx_out, void* stream) {
+  if (!runmax || !idx_out) return fail(TDR_ERR_ARG, "resample: null pointer");
+  if (n < 1 || n_new < 1 || i_begin < 0 || i_end > n_new || i_begin > i_end)
+    return fail(TDR_ERR_ARG, "resample: bad range");
+  if (i_begin == i_end) return TDR_OK;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)cdiv(i_end - i_begin, 256)), dim3(256), 0, (hipStream_t)stream,
+                     runmax, n, n_new, shift, i_begin, i_end, idx_out);
+  LAUNCH_CHECK("resample");
+  return TDR_OK;
+}
+
+__global__ void gather_states_kernel(const float* __restrict__ src, int64_t src_cap, int64_t src_shard,
+                                     const int32_t* __restrict__ idx, int64_t n_new, float* __restrict__ dst,
+                                     int64_t dst_cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int64_t j = idx[i];
+  if (src_shard > 0) {  // all-gathered source: [rank][field][src_shard], global particle j = rank*src_shard + local
+    const int64_t r = j / src_shard, l = j - r * src_shard;
+#pragma unroll
+    for (int f = 0; f < TDR_ST_FIELDS; f++) dst[f * dst_cap + i] = src[(r * TDR_ST_FIELDS + f) * src_shard + l];
+  } else {
+#pragma unroll
+    for (int f = 0; f < TDR_ST_FIELDS; f++) dst[f * dst_cap + i] = src[f * src_cap + j];
+  }
+}
+
+extern "C" int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, const int32_t* idx,
+                                   int64_t n_new, float* dst, int64_t dst_cap, void* stream) {
+  if (!src || !idx || !dst) return fail(TDR_ERR_ARG, "gather_states: null pointer");
+  if (n_new < 0 || dst_cap < n_new || src_shard < 0) return fail(TDR_ERR_ARG, "gather_states: n_new exceeds capacity");
+  if (n_new == 0) return TDR_OK;
+  hipLaunchKernelGGL(gather_states_kernel, dim3((unsigned)cdiv(n_new, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_cap, src_shard, idx, n_new, dst, dst_cap);
+  LAUNCH_CHECK("gather_states");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K6: pose statistics (particle_filter.cpp:191-236) + geometric-mean scale (:343-357).  Double accumulation.
+__global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
+                                                       int64_t about_max, float* __restrict__ out) {
+  __shared__ double shd[16];
+  __shared__ float ref[4];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int64_t p = tid; p < n; p += nt) {
+    const float sc = st[TDR_ST_SCALE * cap + p];
+    const float x = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];  // mlState, state_particle.cpp:98-102
+    const float y = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+    const float th = st[TDR_ST_THETA * cap + p];
+    acc[0] += x; acc[1] += y; acc[2] += th; acc[3] += sc;
+    acc[4] += cos((double)th); acc[5] += sin((double)th);
+    acc[6] += log((double)sc);
+  }
+  double tot[7];
+  for (int k = 0; k < 7; k++) tot[k] = block_sum_d(acc[k], shd);
+  if (tid == 0) {
+    const float fn = (float)n;
+    float mean[4];
+    mean[0] = (float)tot[0] / fn; mean[1] = (float)tot[1] / fn; mean[3] = (float)tot[3] / fn;
+    mean[2] = atan2f((float)tot[5] / fn, (float)tot[4] / fn);  // :202
+    for (int k = 0; k < 4; k++) out[k] = mean[k];
+    out[20] = (float)exp(tot[6] / (double)n);  // freezeScale geo-mean
+    out[21] = out[22] = out[23] = 0.f;
+    if (about_max >= 0) {
+      const int64_t q = about_max;
+      const float sc = st[TDR_ST_SCALE * cap + q];
+      ref[0] = st[TDR_ST_DX * cap + q] * sc + st[TDR_ST_INIT_X * cap + q];
+      ref[1] = st[TDR_ST_DY * cap + q] * sc + st[TDR_ST_INIT_Y * cap + q];
+      ref[2] = st[TDR_ST_THETA * cap + q];
+      ref[3] = sc;
+    } else {
+      for (int k = 0; k < 4; k++) ref[k] = mean[k];
+    }
+  }
+  __syncthreads();
+  double c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t p = tid; p < n; p += nt) {
+    const float sc = st[TDR_ST_SCALE * cap + p];
+    float d[4];
+    d[0] = (st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p]) - ref[0];
+    d[1] = (st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p]) - ref[1];
+    d[2] = st[TDR_ST_THETA * cap + p] - ref[2];
+    d[3] = sc - ref[3];
+    while (d[2] > M_PI) d[2] = (float)((double)d[2] - 2 * M_PI);    // :215
+    while (d[2] < -M_PI) d[2] = (float)((double)d[2] + 2 * M_PI);   // :216
+    int k = 0;
+    for (int a = 0; a < 4; a++)
+      for (int b = a; b < 4; b++) c[k++] += (double)(d[a] * d[b]);
+  }
+  double ct[10];
+  for (int k = 0; k < 10; k++) ct[k] = block_sum_d(c[k], shd);
+  if (tid == 0) {
+    int k = 0;
+    for (int a = 0; a < 4; a++)
+      for (int b = a; b < 4; b++) {
+        float v = (float)ct[k++] / (float)(n - 1);  // :219
+        out[4 + 4 * a + b] = v;
+        out[4 + 4 * b + a] = v;
+      }
+  }
+}
+
+extern "C" int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, int64_t about_max, float* out, void* stream) {
+  if (!st || !out || n < 1 || cap < n || about_max >= n) return fail(TDR_ERR_ARG, "mean_cov: bad arguments");
+  hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, st, cap, n, about_max, out);
+  LAUNCH_CHECK("mean_cov");
+  return TDR_OK;
+}
+
+__global__ void set_scale_kernel(float* __restrict__ st, int64_t cap, int64_t n, const float* __restrict__ scale) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) st[TDR_ST_SCALE * cap + p] = *scale;
+}
+extern "C" int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, void* stream) {
+  if (!st || !scale_dev || n < 0 || cap < n) return fail(TDR_ERR_ARG, "set_scale: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(set_scale_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
+                     scale_dev);
+  LAUNCH_CHECK("set_scale");
+  return TDR_OK;
+}
+
+__global__ void shift_init_kernel(float* __restrict__ st, int64_t cap, int64_t n, float dx, float dy) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    st[TDR_ST_INIT_X * cap + p] += dx;
+    st[TDR_ST_INIT_Y * cap + p] += dy;
+  }
+}
+extern "C" int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream) {
+  if (!st || n < 0 || cap < n) return fail(TDR_ERR_ARG, "shift_init: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(shift_init_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
+                     dx, dy);
+  LAUNCH_CHECK("shift_init");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// layout helpers
+__global__ void aos_to_soa_kernel(const tdr_state* __restrict__ aos, int64_t n, float* __restrict__ st, int64_t cap) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const tdr_state s = aos[p];
+  st[TDR_ST_INIT_X * cap + p] = s.init_x_px;
+  st[TDR_ST_INIT_Y * cap + p] = s.init_y_px;
+  st[TDR_ST_DX * cap + p] = s.dx_m;
+  st[TDR_ST_DY * cap + p] = s.dy_m;
+  st[TDR_ST_THETA * cap + p] = s.theta;
+  st[TDR_ST_SCALE * cap + p] = s.scale;
+  st[TDR_ST_HAVE_INIT * cap + p] = s.have_init ? 1.f : 0.f;
+}
+__global__ void soa_to_aos_kernel(const float* __restrict__ st, int64_t cap, int64_t n, tdr_state* __restrict__ aos) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  tdr_state s;
+  s.init_x_px = st[TDR_ST_INIT_X * cap + p];
+  s.init_y_px = st[TDR_ST_INIT_Y * cap + p];
+  s.dx_m = st[TDR_ST_DX * cap + p];
+  s.dy_m = st[TDR_ST_DY * cap + p];
+  s.theta = st[TDR_ST_THETA * cap + p];
+  s.scale = st[TDR_ST_SCALE * cap + p];
+  s.have_init = st[TDR_ST_HAVE_INIT * cap + p] != 0.f;
+  s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
+  aos[p] = s;
+}
+extern "C" int tdr_k_states_aos_to_soa(const tdr_state* aos, int64_t n, float* st, int64_t cap, void* stream) {
+  if (!aos || !st || n < 0 || cap < n) return fail(TDR_ERR_ARG, "aos_to_soa: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, aos, n, st,
+                     cap);
+  LAUNCH_CHECK("aos_to_soa");
+  return TDR_OK;
+}
+extern "C" int tdr_k_states_soa_to_aos(const float* st, int64_t cap, int64_t n, tdr_state* aos, void* stream) {
+  if (!aos || !st || n < 0 || cap < n) return fail(TDR_ERR_ARG, "soa_to_aos: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(soa_to_aos_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
+                     aos);
+  LAUNCH_CHECK("soa_to_aos");
+  return TDR_OK;
+}
+
+// Locality order: counting sort of the particles by the TILE x TILE px map tile of their centre (row-major tile
+// id; off-map centres clamp to the border tiles).  keys_tmp[0..n) keeps the keys, the histogram lives behind it.
+#define TDR_TILE 4
+__global__ void loc_key_kernel(const float* __restrict__ st, int64_t cap, int64_t n, int trows, int tcols,
+                               int32_t* __restrict__ keys, int32_t* __restrict__ hist) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float sc = st[TDR_ST_SCALE * cap + p];
+  const float cx = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
+  const float cy = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+  int tx = (int)fminf(fmaxf(cx * (1.f / TDR_TILE), 0.f), (float)(tcols - 1));
+  int ty = (int)fminf(fmaxf(cy * (1.f / TDR_TILE), 0.f), (float)(trows - 1));
+  if (!(cx == cx)) tx = 0;
+  if (!(cy == cy)) ty = 0;
+  const int key = ty * tcols + tx;
+  keys[p] = key;
+  atomicAdd(&hist[key], 1);
+}
+// exclusive scan of hist[0..m) in place, single workgroup
+__global__ __launch_bounds__(1024) void loc_scan_kernel(int32_t* __restrict__ hist, int64_t m) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < m; base += 1024) {
+    const int64_t i = base + tid;
+    const int32_t v = (i < m) ? hist[i] : 0;
+    int32_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      int32_t t = __shfl_up(x, o, 64);
+      if (lane >= o) x += t;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int k = 0; k < wave; k++) woff += wsum[k];
+    const int32_t c = carry;
+    if (i < m) hist[i] = c + woff + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = c + woff + x;
+    __syncthreads();
+  }
+}
+__global__ void loc_scatter_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ hist,
+                                   int32_t* __restrict__ perm) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int pos = atomicAdd(&hist[keys[p]], 1);
+  perm[pos] = (int32_t)p;
+}
+
+extern "C" size_t tdr_locality_tmp_ints(int64_t n, int map_rows, int map_cols) {
+  int64_t trows = cdiv(map_rows, TDR_TILE), tcols = cdiv(map_cols, TDR_TILE);
+  return (size_t)(n + trows * tcols + 64);
+}
+
+extern "C" int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols,
+                                    int32_t* perm_out, int32_t* keys_tmp, void* stream) {
+  if (!st || !perm_out || !keys_tmp || n < 0 || cap < n || map_rows < 1 || map_cols < 1)
+    return fail(TDR_ERR_ARG, "locality_order: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int trows = (int)cdiv(map_rows, TDR_TILE), tcols = (int)cdiv(map_cols, TDR_TILE);
+  const int64_t m = (int64_t)trows * tcols;
+  int32_t* hist = keys_tmp + n;
+  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(int32_t) * m, s));
+  hipLaunchKernelGGL(loc_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, st, cap, n, trows, tcols, keys_tmp,
+                     hist);
+  LAUNCH_CHECK("loc_key");
+  hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, s, hist, m);
+  LAUNCH_CHECK("loc_scan");
+  hipLaunchKernelGGL(loc_scatter_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const int32_t*)keys_tmp, n,
+                     hist, perm_out);
+  LAUNCH_CHECK("loc_scatter");
+  return TDR_OK;
+}

@@ -1,0 +1,185 @@
+"""HipKernels: the one product implementation of the kernel interface the host classes use — thin wrappers that
+hand torch-owned device memory and the current HIP stream to the stateless launchers of libtdr_hip.so
+(include/tdr.h).  PyTorch is plumbing here (device memory, streams); every computation is a hand-written HIP kernel.
+
+There is deliberately no CPU implementation in the product: constructing HipKernels without the built extension or
+without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FilterParamsC, MapDescC, check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class DeviceMap:
+    """Device-resident interleaved map (tdr_map_desc) + the polar sampling table."""
+
+    def __init__(self, rec, ncls, rows, cols, resolution):
+        self.rec, self.ncls, self.rows, self.cols, self.resolution = rec, ncls, rows, cols, float(resolution)
+        self.rec_floats = _lib.load().tdr_rec_floats(ncls)
+        self.desc = MapDescC(rec.data_ptr(), ncls, rows, cols, self.rec_floats, self.resolution)
+        self.tab = None       # device (P,2) f32
+        self.tab_host = None  # numpy (P,2) f32
+        self.nb = self.nr = 0
+        self.ang_res = 0.0
+
+
+class HipKernels:
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available() or self.lib.tdr_device_count() < 1:
+            raise _lib.TdrError("no HIP device visible: the MI355X path cannot run (there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ws = None
+
+    # ---- plumbing -------------------------------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, array):
+        return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # ---- map ------------------------------------------------------------------------------------------------
+    def make_map(self, class_maps, class_mask, resolution):
+        """class_maps (ncls,H,W) f32 indexed [cls,row,col]; class_mask (H,W) u8.  Uploaded in the reference's
+        column-major per-class layout and interleaved on the device by tdr_k_pack_map."""
+        ncls, H, W = class_maps.shape
+        maps_cm = self.to_device(np.ascontiguousarray(np.transpose(class_maps, (0, 2, 1)), np.float32))
+        mask_cm = self.to_device(np.ascontiguousarray(class_mask.T, np.uint8))
+        rf = self.lib.tdr_rec_floats(ncls)
+        rec = self.empty(((H * W + 1) * rf,))
+        check(self.lib.tdr_k_pack_map(_ptr(maps_cm), _ptr(mask_cm), ncls, H, W, _ptr(rec), self.stream()))
+        self.synchronize()
+        del maps_cm, mask_cm
+        return DeviceMap(rec, ncls, H, W, resolution)
+
+    def set_polar_table(self, m, nb, nr, ang_res):
+        tab = np.empty((nb * nr, 2), np.float32)
+        check(self.lib.tdr_polar_table_host(nb, nr, C.c_float(ang_res), C.c_float(m.resolution),
+                                            tab.ctypes.data_as(C.c_void_p)))
+        m.tab_host, m.tab, m.nb, m.nr, m.ang_res = tab, self.to_device(tab), nb, nr, float(ang_res)
+
+    # ---- raster ---------------------------------------------------------------------------------------------
+    def raster_polar(self, pts, n, stride, ioff, res, ang_res, lut, ncls, nb, nr, want_img=True):
+        img = self.empty((ncls, nb * nr)) if want_img else None
+        pk = self.empty((nr * nb * self.lib.tdr_rec_floats(ncls),))
+        check(self.lib.tdr_k_raster_polar(_ptr(pts), stride, ioff, n, C.c_float(res), C.c_float(ang_res), _ptr(lut),
+                                          ncls, nb, nr, _ptr(img), _ptr(pk), self.stream()))
+        return img, pk
+
+    def raster_cart(self, pts, n, stride, ioff, res, lut, ncls, rows, cols, want_img=True):
+        img = self.empty((ncls, rows * cols)) if want_img else None
+        pk = self.empty((rows * cols * self.lib.tdr_rec_floats(ncls),))
+        check(self.lib.tdr_k_raster_cart(_ptr(pts), stride, ioff, n, C.c_float(res), _ptr(lut), ncls, rows, cols,
+                                         _ptr(img), _ptr(pk), self.stream()))
+        return img, pk
+
+    def pack_scan(self, img, ncls, nb, nr):
+        pk = self.empty((nr * nb * self.lib.tdr_rec_floats(ncls),))
+        check(self.lib.tdr_k_pack_scan(_ptr(img), ncls, nb, nr, _ptr(pk), self.stream()))
+        return pk
+
+    # ---- filter ---------------------------------------------------------------------------------------------
+    def _workspace(self, ncls, nr, n):
+        need = int(self.lib.tdr_score_workspace_floats(ncls, nr, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.empty((need,))
+        return self._ws
+
+    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False):
+        ws = self._workspace(m.ncls, m.nr, n)
+        cap = st.shape[1]
+        check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
+                                         C.byref(fp), _ptr(st), cap, n, _ptr(perm), _ptr(raw_w), _ptr(ws),
+                                         self.stream()))
+        if init_search:
+            check(self.lib.tdr_k_score_polar_init(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr,
+                                                  C.c_float(res), C.byref(fp), _ptr(st), cap, n, _ptr(raw_w),
+                                                  _ptr(ws), self.stream()))
+
+    def propagate(self, st, n, last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4=None, seed=0, step=0,
+                  index_base=0):
+        check(self.lib.tdr_k_propagate(_ptr(st), st.shape[1], n, _ptr(last_dist), C.c_float(tx), C.c_float(ty),
+                                       C.c_float(omega), int(scale_freeze), C.c_float(pos_cov), C.c_float(theta_cov),
+                                       _ptr(z4), seed, step, index_base, self.stream()))
+
+    def update_weights(self, raw_w, last_dist, n, w_out, info):
+        check(self.lib.tdr_k_update_weights(_ptr(raw_w), _ptr(last_dist), n, _ptr(w_out), _ptr(info), self.stream()))
+
+    def prefix(self, w, n, runmax):
+        check(self.lib.tdr_k_prefix(_ptr(w), n, _ptr(runmax), self.stream()))
+
+    def resample(self, runmax, n, n_new, shift, i_begin, i_end, idx):
+        check(self.lib.tdr_k_resample(_ptr(runmax), n, n_new, C.c_float(shift), i_begin, i_end, _ptr(idx),
+                                      self.stream()))
+
+    def gather_states(self, src, idx, n_new, dst, src_shard=0):
+        src_cap = src.shape[1] if src.dim() == 2 else 0
+        check(self.lib.tdr_k_gather_states(_ptr(src), src_cap, src_shard, _ptr(idx), n_new, _ptr(dst), dst.shape[1],
+                                           self.stream()))
+
+    def mean_cov(self, st, n, about_max=-1):
+        out = self.empty((24,))
+        check(self.lib.tdr_k_mean_cov(_ptr(st), st.shape[1], n, about_max, _ptr(out), self.stream()))
+        return out
+
+    def set_scale(self, st, n, scale_dev):
+        check(self.lib.tdr_k_set_scale(_ptr(st), st.shape[1], n, _ptr(scale_dev), self.stream()))
+
+    def shift_init(self, st, n, dx, dy):
+        check(self.lib.tdr_k_shift_init(_ptr(st), st.shape[1], n, C.c_float(dx), C.c_float(dy), self.stream()))
+
+    def locality_order(self, st, n, rows, cols, perm):
+        need = int(self.lib.tdr_locality_tmp_ints(n, rows, cols))
+        tmp = self.empty((need,), torch.int32)
+        check(self.lib.tdr_k_locality_order(_ptr(st), st.shape[1], n, rows, cols, _ptr(perm), _ptr(tmp),
+                                            self.stream()))
+
+    def states_to_device(self, states_aos, st, n):
+        """states_aos: numpy structured array with the reference's 28-byte State layout."""
+        raw = self.to_device(np.ascontiguousarray(states_aos).view(np.uint8).reshape(-1))
+        check(self.lib.tdr_k_states_aos_to_soa(_ptr(raw), n, _ptr(st), st.shape[1], self.stream()))
+        self.synchronize()
+
+    def states_to_host(self, st, n, dtype):
+        raw = self.empty((n * 28,), torch.uint8)
+        check(self.lib.tdr_k_states_soa_to_aos(_ptr(st), st.shape[1], n, _ptr(raw), self.stream()))
+        return raw.cpu().numpy().view(dtype).reshape(-1).copy()
+
+    # ---- host RNG (the reference's shared std::mt19937) -------------------------------------------------------
+    def rng_create(self, seed):
+        return C.c_void_p(self.lib.tdr_rng_create(C.c_uint32(seed & 0xFFFFFFFF)))
+
+    def rng_uniform(self, rng):
+        return float(self.lib.tdr_rng_uniform_host(rng))
+
+    def init_particles(self, rng, maps_cm_host, ncls, rows, cols, resolution, fp, max_num, dtype):
+        out = np.zeros(max_num + 16, dtype)
+        n = C.c_int64(0)
+        check(self.lib.tdr_init_particles_host(rng, maps_cm_host.ctypes.data_as(C.c_void_p), ncls, rows, cols,
+                                               C.c_float(resolution), C.byref(fp), max_num,
+                                               out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out[: min(n.value, max_num + 16)].copy()
+
+    def propagate_normals(self, rng, n, scale_freeze):
+        z = np.empty((n, 4), np.float32)
+        check(self.lib.tdr_propagate_normals_host(rng, n, int(scale_freeze), z.ctypes.data_as(C.c_void_p)))
+        return z

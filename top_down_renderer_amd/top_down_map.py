@@ -1,0 +1,127 @@
+"""TopDownMap / TopDownMapPolar — host-side mirrors of the reference classes (include/top_down_render/top_down_map.h:52-102,
+top_down_map_polar.h:6-22) holding the map on the device for the HIP kernels.
+
+Map content is taken in the form the reference's load-time code produces (src/top_down_map.cpp:289-326): per-class
+truncated distance maps + unknown mask.  Loading SVG/PNG maps and the on-disk caches is load-time work outside the
+per-scan path.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Params:
+    """TopDownMap::Params (top_down_map.h:54-62), minus the load-time colour LUT."""
+    map_path: str = ""
+    flatten_lut: list = field(default_factory=list)
+    num_classes: int = 0
+    exclusive_classes: list = field(default_factory=list)
+    resolution: float = 1.0
+    out_of_bounds_const: float = 5.0   # read but unused by the reference: every OOB write is a literal 0
+
+
+class TopDownMap:
+    def __init__(self, params, class_maps=None, class_mask=None, kernels=None):
+        """class_maps: (ncls, H, W) float32 indexed [cls, row(y), col(x)]; class_mask: (H, W) uint8, 1 = unknown."""
+        if kernels is None:
+            from .kernels import HipKernels
+            kernels = HipKernels()   # raises without the built extension / a GPU: no CPU fallback
+        self.k = kernels
+        self.params_ = params
+        self.map_center_ = (0, 0)
+        self.have_map_ = False
+        self.dev = None
+        if class_maps is not None:
+            self._load(class_maps, class_mask)
+
+    def _load(self, class_maps, class_mask):
+        class_maps = np.ascontiguousarray(class_maps, np.float32)
+        class_mask = np.ascontiguousarray(class_mask, np.uint8)
+        ncls, H, W = class_maps.shape
+        if self.params_.num_classes and self.params_.num_classes != ncls:
+            raise ValueError("num_classes does not match the class maps")
+        self.params_.num_classes = ncls
+        self.rows, self.cols = H, W
+        # host copy in the reference's column-major layout (class_maps_): needed by getClassesAtPoint / particle init
+        self.maps_cm_host = np.ascontiguousarray(np.transpose(class_maps, (0, 2, 1)))
+        self.dev = self.k.make_map(class_maps, class_mask, self.params_.resolution)
+        self.have_map_ = True
+
+    # top_down_map.cpp:146-157 with the distance transform already applied
+    def updateMap(self, class_maps, class_mask, map_center):
+        self.map_center_ = (int(map_center[0]), int(map_center[1]))
+        old = self.dev
+        self._load(class_maps, class_mask)
+        if old is not None and getattr(old, "nb", 0):
+            self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
+
+    # top_down_map.cpp:159-175
+    def getClassesAtPoint(self, center):
+        cx, cy = center
+        res = np.float32(self.params_.resolution)
+        if not (isinstance(cx, (int, np.integer)) and isinstance(cy, (int, np.integer))):
+            # Vector2f overload (:172-175) converts to an index and then calls the Vector2i overload
+            cx, cy = int(np.float32(cx) / res), int(np.float32(cy) / res)
+        c0, c1 = int(np.float32(cx) / res), int(np.float32(cy) / res)   # :160
+        out = []
+        for cls in range(self.params_.num_classes):
+            if 0 <= c0 < self.cols and 0 <= c1 < self.rows and self.maps_cm_host[cls, c0, c1] < 1:
+                out.append(cls)
+        return out
+
+    def numClasses(self):
+        return self.params_.num_classes
+
+    def size(self):
+        return (self.cols, self.rows)
+
+    def mapCenter(self):
+        return self.map_center_
+
+    def resolution(self):
+        return self.params_.resolution
+
+    def haveMap(self):
+        return self.have_map_
+
+
+class TopDownMapPolar(TopDownMap):
+    def __init__(self, params, class_maps=None, class_mask=None, kernels=None):
+        super().__init__(params, class_maps, class_mask, kernels)
+        if self.have_map_:
+            self.samplePtsPolar((100, 50), np.float32(2 * np.pi / 100))   # top_down_map_polar.cpp:3-5
+
+    def samplePtsPolar(self, shape, ang_res):
+        """top_down_map_polar.cpp:7-19; shape = (theta bins, range bins)."""
+        self.k.set_polar_table(self.dev, int(shape[0]), int(shape[1]), float(ang_res))
+
+    @property
+    def nb(self):
+        return self.dev.nb
+
+    @property
+    def nr(self):
+        return self.dev.nr
+
+    def scan_handle(self, scan):
+        """Accepts what ParticleFilter::update is handed in the reference (a list of per-class column-major nb x nr
+        images) or an (ncls, nb*nr) array / device tensor, or an already packed device scan; returns the packed
+        device scan the scoring kernel reads."""
+        ncls, nb, nr = self.numClasses(), self.nb, self.nr
+        if isinstance(scan, tuple) and scan[0] == "pk":
+            return scan[1]
+        if isinstance(scan, (list, tuple)):
+            if len(scan) < ncls:
+                raise ValueError("fewer scan images than map classes")
+            scan = np.stack([np.asarray(s, np.float32).reshape(nb, nr, order="A").ravel(order="F") for s in scan[:ncls]])
+        if isinstance(scan, np.ndarray):
+            if scan.shape != (ncls, nb * nr):
+                raise ValueError(f"scan shape {scan.shape} != {(ncls, nb * nr)}")
+            scan = self.k.to_device(np.ascontiguousarray(scan, np.float32))
+        if isinstance(scan, torch.Tensor):
+            if tuple(scan.shape) != (ncls, nb * nr):
+                raise ValueError(f"scan shape {tuple(scan.shape)} != {(ncls, nb * nr)}")
+            return self.k.pack_scan(scan.contiguous(), ncls, nb, nr)
+        raise TypeError("unsupported scan type")
