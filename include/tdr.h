@@ -58,7 +58,8 @@ typedef struct tdr_filter_params {
 
 /* Geometry of the device-resident map produced by tdr_k_pack_map. */
 typedef struct tdr_map_desc {
-  const float* rec;     /* [(rows*cols)+1][rec_floats]: per cell {dist_0..dist_{ncls-1}, 0.., known}; last record = out of bounds */
+  const float* rec;     /* [(rows+2)*(cols+2)][rec_floats], row-major over the map plus a one-cell guard ring of zero
+                           records; per cell {dist_0..dist_{ncls-1}, 0.., [known,] known} (see tdr_k_pack_map) */
   int32_t ncls, rows, cols, rec_floats;   /* rec_floats = 4*ceil((ncls+1)/4) */
   float resolution;     /* TopDownMap::Params::resolution (top_down_map.h:61) */
 } tdr_map_desc;
@@ -72,7 +73,8 @@ int tdr_rec_floats(int ncls);
 /* ---- map (storage of TopDownMap, include/top_down_render/top_down_map.h:77-79) ------------------------------ */
 /* Interleaves the reference's per-class column-major distance maps `class_maps_` ([ncls][rows*cols], element (r,c)
  * at r + rows*c) and the unknown mask `class_mask_` (u8, 1 = unknown) into cell records (tdr_map_desc.rec).
- * rec_out must hold (rows*cols + 1) * tdr_rec_floats(ncls) floats. */
+ * rec_out must hold tdr_map_rec_floats_total(ncls, rows, cols) floats. */
+size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
 int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
                    void* stream);
 
@@ -98,21 +100,24 @@ int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, v
  *      TopDownMapPolar::getLocalMap src/top_down_map_polar.cpp:21-53 + getCostForRot src/state_particle.cpp:112-155,
  *      driven by ParticleFilter::update src/particle_filter.cpp:104-105) ------------------------------------- */
 /* workspace floats needed by tdr_k_score_polar for n particles */
-size_t tdr_score_workspace_floats(int ncls, int nr, int64_t n);
+size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n);
 /* Scores particles [0,n) of st (plane stride cap) against the packed scan at each particle's own theta; writes raw
  * weights raw_w[n] (NaN = "too much unknown", 0 = gated by force_on_map / scale range, state_particle.cpp:163-176).
  * perm (optional, int32[n]): processing order (a permutation of 0..n-1, e.g. from tdr_k_locality_order) for cache
- * locality; results are independent of it.  tab: DEVICE copy of the table from tdr_polar_table_host. */
+ * locality; results are independent of it.  tab: DEVICE copy of the table from tdr_polar_table_host.
+ * uniform_scale: > 0 is the caller's promise that every particle's scale equals it (fixed or frozen scale,
+ * particle_filter.cpp:24,343-357): the sample offsets (tab*scale)*res are then evaluated once per call instead of
+ * once per particle and sample — same float operations, same results; <= 0 reads each particle's own scale. */
 int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
                       const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                      float* raw_w, float* workspace, void* stream);
+                      float uniform_scale, float* raw_w, float* workspace, void* stream);
 /* The 40-rotation initialisation search of state_particle.cpp:195-206 for the particles of st whose have_init is 0
  * (and that are not gated): overwrites their raw_w, sets their theta to the best rotation and have_init to 1.
  * Call after tdr_k_score_polar while such particles may exist; a no-op on the device when there are none
  * (the launches are trimmed by a device-side count, nothing synchronises with the host). */
 int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
-                           const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, float* raw_w,
-                           float* workspace, void* stream);
+                           const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, float uniform_scale,
+                           float* raw_w, float* workspace, void* stream);
 
 /* ---- StateParticle::propagate for all particles (src/state_particle.cpp:57-78 via particle_filter.cpp:86-92) -- */
 /* z4: optional DEVICE array [n][4] of standard normals {theta, dx, dy, scale} in the reference's consumption
@@ -161,6 +166,8 @@ int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void
  * tdr_profile_score_ms synchronises on them, returns the summed duration and the launch count, and resets. */
 int tdr_profile_enable(int on);
 int tdr_profile_score_ms(double* total_ms, int64_t* launches);
+/* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
+int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------------------------------------------ */
 int tdr_k_states_aos_to_soa(const tdr_state* aos, int64_t n, float* st, int64_t cap, void* stream);

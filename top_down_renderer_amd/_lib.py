@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_PKG, "libtdr_hip.so")
+SO_PATH = os.environ.get("TDR_LIB_PATH") or os.path.join(_PKG, "libtdr_hip.so")   # override: tuning variants only
 
 TDR_ST_FIELDS = 7
 TDR_MAX_CLASSES = 15
@@ -35,16 +35,18 @@ SIGNATURES = {
     "tdr_version": (_i, []),
     "tdr_device_count": (_i, []),
     "tdr_rec_floats": (_i, [_i]),
+    "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_k_selftest_round": (_i, [_vp, _i64, _f, _vp, _vp]),
     "tdr_k_pack_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "tdr_polar_table_host": (_i, [_i, _i, _f, _f, _vp]),
     "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_k_pack_scan": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i64]),
+    "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
-                               _vp, _vp, _vp, _vp]),
+                               _vp, _f, _vp, _vp, _vp]),
     "tdr_k_score_polar_init": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64,
-                                    _i64, _vp, _vp, _vp]),
+                                    _i64, _f, _vp, _vp, _vp]),
     "tdr_k_propagate": (_i, [_vp, _i64, _i64, _vp, _f, _f, _f, _i, _f, _f, _vp, _u64, _u64, _i64, _vp]),
     "tdr_rng_create": (_vp, [_u32]),
     "tdr_rng_destroy": (None, [_vp]),

@@ -23,7 +23,17 @@
 #include <utility>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "tdr.h"
+
+// tuning knobs (compile-time)
+#ifndef TDR_SCORE_U
+#define TDR_SCORE_U 4          // samples whose loads are kept in flight together in the scoring loop
+#endif
+#ifndef TDR_RPI_FIX_BELOW_HALF
+#define TDR_RPI_FIX_BELOW_HALF 1  // patch v_cvt_rpi_i32_f32 at the largest float below 0.5 (see round_half_away_clamped)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // error plumbing
@@ -58,32 +68,44 @@ extern "C" int tdr_rec_floats(int ncls) { return 4 * ((ncls + 1 + 3) / 4); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K0: map packing.  One thread per cell (row-major output r*cols + c); input is the reference's column-major layout.
+// K0: map packing.  Output is row-major over a GUARDED grid of (rows+2) x (cols+2) cell records: one ring of
+// all-zero records around the map, so that a sample coordinate clamped to [-1, rows] x [-1, cols] always addresses a
+// valid record and "out of bounds" needs no branch or select in the scoring loop — the guard record is exactly what
+// the reference returns there: distance 0 (top_down_map_polar.cpp:39) and unknown (:51).
+// Record slots: [0,ncls) distances, rf-1 = known (1 - mask); when a spare slot exists (ncls+2 <= rf) slot rf-2 also
+// holds `known`, paired with a constant 1 in the scan record, so the known-cell count rides on the packed FMAs.
+__host__ __device__ inline bool tdr_has_kslot(int ncls, int rf) { return ncls + 2 <= rf; }
+
 __global__ void pack_map_kernel(const float* __restrict__ maps, const uint8_t* __restrict__ mask, int ncls, int rows,
                                 int cols, int rf, float* __restrict__ rec) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t ncell = (int64_t)rows * cols;
-  if (idx > ncell) return;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gcols = cols + 2, gcell = (int64_t)(rows + 2) * gcols;
+  if (idx >= gcell) return;
   float* o = rec + idx * rf;
-  if (idx == ncell) {  // the out-of-bounds record: distances 0 (top_down_map_polar.cpp:39), unknown (:51)
-    for (int k = 0; k < rf; k++) o[k] = 0.f;
-    return;
-  }
-  int r = (int)(idx / cols), c = (int)(idx % cols);
-  int64_t src = (int64_t)r + (int64_t)rows * c;
   for (int k = 0; k < rf; k++) o[k] = 0.f;
+  const int r = (int)(idx / gcols) - 1, c = (int)(idx % gcols) - 1;
+  if (r < 0 || r >= rows || c < 0 || c >= cols) return;  // guard record
+  const int64_t ncell = (int64_t)rows * cols;
+  const int64_t src = (int64_t)r + (int64_t)rows * c;    // the reference's column-major layout
   for (int k = 0; k < ncls; k++) o[k] = maps[(int64_t)k * ncell + src];
-  o[rf - 1] = 1.f - (float)mask[src];  // `1 - mask.cast<float>()` (state_particle.cpp:199,209)
+  const float known = 1.f - (float)mask[src];            // `1 - mask.cast<float>()` (state_particle.cpp:199,209)
+  o[rf - 1] = known;
+  if (tdr_has_kslot(ncls, rf)) o[rf - 2] = known;
+}
+
+extern "C" size_t tdr_map_rec_floats_total(int ncls, int rows, int cols) {
+  return (size_t)(rows + 2) * (size_t)(cols + 2) * (size_t)tdr_rec_floats(ncls);
 }
 
 extern "C" int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
                               float* rec_out, void* stream) {
   if (!class_maps || !class_mask || !rec_out) return fail(TDR_ERR_ARG, "pack_map: null pointer");
   if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "pack_map: bad shape");
+  if (rows > 8000000 || cols > 8000000) return fail(TDR_ERR_ARG, "pack_map: map side exceeds 2^23");
   int rf = tdr_rec_floats(ncls);
-  int64_t ncell = (int64_t)rows * cols;
-  if ((ncell + 1) * rf * 4 > (int64_t)0xFFFFFFF0ll) return fail(TDR_ERR_ARG, "pack_map: map exceeds 4 GiB of records");
-  hipLaunchKernelGGL(pack_map_kernel, dim3((unsigned)cdiv(ncell + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+  int64_t gcell = (int64_t)(rows + 2) * (cols + 2);
+  if (gcell * rf * 4 > (int64_t)0xFFFFFFF0ll) return fail(TDR_ERR_ARG, "pack_map: map exceeds 4 GiB of records");
+  hipLaunchKernelGGL(pack_map_kernel, dim3((unsigned)cdiv(gcell, 256)), dim3(256), 0, (hipStream_t)stream,
                      class_maps, class_mask, ncls, rows, cols, rf, rec_out);
   LAUNCH_CHECK("pack_map");
   return TDR_OK;
@@ -202,6 +224,7 @@ __global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
         tot += v;
       }
       for (int c = a.ncls; c < a.rf - 1; c++) o[c] = 0.f;
+      if (tdr_has_kslot(a.ncls, a.rf)) o[a.rf - 2] = 1.f;
       o[a.rf - 1] = (float)tot;
     }
   }
@@ -252,6 +275,7 @@ __global__ void pack_scan_kernel(const float* __restrict__ img, int ncls, int ro
     tot += v;
   }
   for (int c = ncls; c < rf - 1; c++) o[c] = 0.f;
+  if (tdr_has_kslot(ncls, rf)) o[rf - 2] = 1.f;
   o[rf - 1] = tot;
 }
 extern "C" int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, void* stream) {
@@ -274,6 +298,7 @@ struct ScoreArgs {
   int rows, cols;       // map
   float resolution;
   const float* tab;     // [P][2]
+  const float* utab;    // [P][2] (tab*scale)*res when all particles share one scale, else NULL
   const float* scan_pk; // [nr][nb][rf]
   int nb, nr;
   float res;
@@ -296,67 +321,92 @@ __device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
   return s;
 }
 
-template <int NV4, int U>
+// roundf (half away from zero) of a coordinate already clamped to [-1, limit], as an int, in two VALU ops:
+//     roundf(x) == floor(fl(x + (0.5 - 2^-25)))   for every float x in [-1, 2^23]
+// (the float addition's own rounding lands exact .5 ties on the next integer and everything below them under it;
+// checked exhaustively on the CPU over [-1, 8] and on the GPU by tests/test_gpu_parity.py).  The generic expansion
+// of roundf costs seven.
+__device__ __forceinline__ int round_half_away_clamped(float x) {
+  const float y = x + 0.49999997f;
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  return r;
+}
+
+template <int NV4, int U, bool KSLOT, bool USCALE>
 __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
-  extern __shared__ float4 ring[];  // [nb][NV4]
+  extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]: row r and r+nb hold scan row r (no wrap arithmetic)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if ((int64_t)blockIdx.x * 256 >= nact) return;  // whole workgroup idle (uniform)
   const bool valid = slot < nact;
-  int64_t p = valid ? (a.order ? (int64_t)a.order[slot] : slot) : 0;
-  if (nact == 0) return;
-  if (!valid) p = a.order ? (int64_t)a.order[0] : 0;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
   const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];  // :162
   const float off0 = cy / a.resolution;  // top_down_map_polar.cpp:29
   const float off1 = cx / a.resolution;  // :30
   const float theta = a.use_theta_override ? a.theta_override : a.st[TDR_ST_THETA * a.cap + p];
-  const int shift = rot_shift_dev(theta, a.nb);
+  const int shift = rot_shift_dev(theta, a.nb);  // scan row paired with window row i is (i + shift) mod nb
 
   const int j0 = blockIdx.y * a.rpc, j1 = min(a.nr, j0 + a.rpc);
+  const int rowstride = (a.cols + 2) * (RF * 4);            // bytes per guarded map row
+  const int kbase = (a.cols + 3) * (RF * 4);                // byte offset of cell (0,0)
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
-  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(a.tab);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
   const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
-  const unsigned oob = (unsigned)a.rows * (unsigned)a.cols;
+  const int nb2 = 2 * a.nb;
 
   float acc2[RF];
 #pragma unroll
   for (int k = 0; k < RF; k++) acc2[k] = 0.f;
   float known2 = 0.f;
 
+  // USCALE: every particle has the same scale, so (tab*scale)*res was evaluated once per step into a.utab and is
+  // wave-uniform here; otherwise it is evaluated per lane.  Identical float operations either way.
+  auto cell_offset = [&](float2 t) -> unsigned {
+    float p0, p1;
+    if constexpr (USCALE) {
+      p0 = t.x;
+      p1 = t.y;
+    } else {
+      p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
+      p1 = (t.y * scale) * a.res;
+    }
+    p0 = p0 + off0;
+    p1 = p1 + off1;
+    // clamp into the guard ring, then round like `pts.round().cast<int>()` (:31)
+    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+    return (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase));  // v_mad_i32_i24 + v_lshl_add
+  };
+
   for (int j = j0; j < j1; j++) {
     __syncthreads();
-    for (int t = threadIdx.x; t < a.nb * NV4; t += 256) ring[t] = scan4[(int64_t)j * a.nb * NV4 + t];
+    for (int t = threadIdx.x; t < a.nb * NV4; t += 256) {
+      const float4 v = scan4[(int64_t)j * a.nb * NV4 + t];
+      const int row = t / NV4, pl = t - row * NV4;
+      ring[pl * nb2 + row] = v;
+      ring[pl * nb2 + row + a.nb] = v;
+    }
     __syncthreads();
     float acc[RF];
 #pragma unroll
     for (int k = 0; k < RF; k++) acc[k] = 0.f;
     float known = 0.f;
-    int arow = shift;  // scan row paired with window row i is (i + shift) mod nb
     const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* rl = ring + shift;
     int i = 0;
     // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together,
     // then the FMAs — the wave keeps 2*U*NV4 16-byte loads outstanding instead of waiting per sample.
     for (; i + U <= a.nb; i += U) {
       unsigned boff[U];
-      int ar[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const float2 t = trow[i + u];
-        float p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
-        float p1 = (t.y * scale) * a.res;
-        p0 = p0 + off0;
-        p1 = p1 + off1;
-        const int ri = (int)roundf(p0), ci = (int)roundf(p1);  // :31
-        const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
-        const unsigned cell = inb ? (unsigned)ri * (unsigned)a.cols + (unsigned)ci : oob;
-        boff[u] = cell * (unsigned)(RF * 4);  // < 4 GiB, checked by tdr_k_pack_map
-        ar[u] = arow;
-        arow = (arow + 1 == a.nb) ? 0 : arow + 1;
-      }
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(trow[i + u]);
       float4 m[U][NV4], s[U][NV4];
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -365,7 +415,7 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int v = 0; v < NV4; v++) s[u][v] = ring[ar[u] * NV4 + v];
+        for (int v = 0; v < NV4; v++) s[u][v] = rl[v * nb2 + i + u];
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
@@ -375,30 +425,21 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
           acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[u][v].z, acc[4 * v + 2]);
           acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[u][v].w, acc[4 * v + 3]);
         }
-        known += m[u][NV4 - 1].w;
+        if (!KSLOT) known += m[u][NV4 - 1].w;
       }
     }
     for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
-      const float2 t = trow[i];
-      float p0 = (t.x * scale) * a.res;
-      float p1 = (t.y * scale) * a.res;
-      p0 = p0 + off0;
-      p1 = p1 + off1;
-      const int ri = (int)roundf(p0), ci = (int)roundf(p1);
-      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
-      const unsigned cell = inb ? (unsigned)ri * (unsigned)a.cols + (unsigned)ci : oob;
-      const unsigned bo = cell * (unsigned)(RF * 4);
+      const unsigned bo = cell_offset(trow[i]);
 #pragma unroll
       for (int v = 0; v < NV4; v++) {
         const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
-        const float4 s = ring[arow * NV4 + v];
+        const float4 s = rl[v * nb2 + i];
         acc[4 * v + 0] = __builtin_fmaf(s.x, m.x, acc[4 * v + 0]);
         acc[4 * v + 1] = __builtin_fmaf(s.y, m.y, acc[4 * v + 1]);
         acc[4 * v + 2] = __builtin_fmaf(s.z, m.z, acc[4 * v + 2]);
         acc[4 * v + 3] = __builtin_fmaf(s.w, m.w, acc[4 * v + 3]);
-        if (v == NV4 - 1) known += m.w;
+        if (!KSLOT && v == NV4 - 1) known += m.w;
       }
-      arow = (arow + 1 == a.nb) ? 0 : arow + 1;
     }
 #pragma unroll
     for (int k = 0; k < RF; k++) acc2[k] += acc[k];
@@ -408,7 +449,7 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
     float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
 #pragma unroll
     for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
-    o[(int64_t)RF * a.npad] = known2;
+    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
   }
 }
 
@@ -532,18 +573,34 @@ static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks) {
   nchunks = (int)cdiv(nr, rpc);
 }
 
-extern "C" size_t tdr_score_workspace_floats(int ncls, int nr, int64_t n) {
+__global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float scale, float res,
+                            float* __restrict__ utab) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n2) utab[k] = (tab[k] * scale) * res;  // `ang_sample_pts_*scale*res` (top_down_map_polar.cpp:28)
+}
+
+extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n) {
   int rpc, nchunks;
   choose_chunks(n, nr, rpc, nchunks);
   int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   int rf = tdr_rec_floats(ncls);
-  // partials + best_cost + best_theta + list + count(64)
-  return (size_t)((int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64);
+  // partials + best_cost + best_theta + list + count(64) + uniform-scale table
+  return (size_t)((int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64 + 2 * (int64_t)nb * nr);
+}
+static float* ws_utab(float* workspace, int rf, int nchunks, int64_t npad) {
+  return workspace + (int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64;
+}
+static int fill_utab(ScoreArgs& a, float* workspace, int rf, float uniform_scale, hipStream_t s) {
+  a.utab = nullptr;
+  if (!(uniform_scale > 0.f)) return TDR_OK;
+  float* ut = ws_utab(workspace, rf, a.nchunks, a.npad);
+  const int64_t n2 = 2 * (int64_t)a.nb * a.nr;
+  hipLaunchKernelGGL(utab_kernel, dim3((unsigned)cdiv(n2, 256)), dim3(256), 0, s, a.tab, n2, uniform_scale, a.res, ut);
+  LAUNCH_CHECK("utab");
+  a.utab = ut;
+  return TDR_OK;
 }
 
-#ifndef TDR_SCORE_U
-#define TDR_SCORE_U 4
-#endif
 // Optional in-library timing of the dominant kernel (bench.py's roofline figure): HIP events recorded on the launch
 // stream right around score_polar_kernel, read back after the timed region.
 static bool g_prof_on = false;
@@ -587,24 +644,33 @@ extern "C" int tdr_profile_score_ms(double* total_ms, int64_t* launches) {
   return TDR_OK;
 }
 
-static int launch_score(const ScoreArgs& a, int rf, hipStream_t s) {
+static int launch_score(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
-  size_t lds = (size_t)a.nb * rf * 4;
+  size_t lds = (size_t)2 * a.nb * rf * 4;
+  const bool ks = tdr_has_kslot(ncls, rf);
   ScoreProfScope prof(s);
+  const bool us = a.utab != nullptr;
+#define TDR_LAUNCH_SCORE(NV4)                                                                                   \
+  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true>), grid, block, lds, s, a);   \
+  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false>), grid, block, lds, s, a);   \
+  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true>), grid, block, lds, s, a);   \
+  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false>), grid, block, lds, s, a);
   switch (rf / 4) {
-    case 1: hipLaunchKernelGGL((score_polar_kernel<1, TDR_SCORE_U>), grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U>), grid, block, lds, s, a); break;
-    case 3: hipLaunchKernelGGL((score_polar_kernel<3, TDR_SCORE_U>), grid, block, lds, s, a); break;
-    case 4: hipLaunchKernelGGL((score_polar_kernel<4, TDR_SCORE_U>), grid, block, lds, s, a); break;
+    case 1: TDR_LAUNCH_SCORE(1) break;
+    case 2: TDR_LAUNCH_SCORE(2) break;
+    case 3: TDR_LAUNCH_SCORE(3) break;
+    case 4: TDR_LAUNCH_SCORE(4) break;
     default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
   }
+#undef TDR_LAUNCH_SCORE
   LAUNCH_CHECK("score_polar");
   return TDR_OK;
 }
 
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                  float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                 const int32_t* perm, float* raw_w, float* workspace, void* stream) {
+                                 const int32_t* perm, float uniform_scale, float* raw_w, float* workspace,
+                                 void* stream) {
   if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score: null pointer");
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score: n=%lld exceeds capacity %lld", (long long)n, (long long)cap);
@@ -614,7 +680,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     return fail(TDR_ERR_ARG, "score: class count mismatch (map %d, params %d)", map->ncls, fp->num_classes);
   const int rf = tdr_rec_floats(map->ncls);
   if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score: map record size %d != %d", map->rec_floats, rf);
-  if ((size_t)nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score: nb too large for the LDS scan ring");
+  if ((size_t)2 * nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score: nb too large for the LDS scan ring");
   if (!(map->resolution > 0.f)) return fail(TDR_ERR_ARG, "score: map resolution must be > 0");
   hipStream_t s = (hipStream_t)stream;
 
@@ -626,7 +692,9 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   choose_chunks(n, nr, a.rpc, a.nchunks);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
-  int rc = launch_score(a, rf, s);
+  int rc = fill_utab(a, workspace, rf, uniform_scale, s);
+  if (rc) return rc;
+  rc = launch_score(a, rf, map->ncls, s);
   if (rc) return rc;
 
   FinalizeArgs f;
@@ -645,14 +713,14 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
 // n and trimmed on the device by the list length, so nothing synchronises with the host.
 extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                       float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                      float* raw_w, float* workspace, void* stream) {
+                                      float uniform_scale, float* raw_w, float* workspace, void* stream) {
   if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score_init: null pointer");
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_init: n exceeds capacity");
   if (n == 0) return TDR_OK;
   if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_init: class count mismatch");
   const int rf = tdr_rec_floats(map->ncls);
-  if ((size_t)nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score_init: nb too large for the LDS scan ring");
+  if ((size_t)2 * nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score_init: nb too large for the LDS scan ring");
   hipStream_t s = (hipStream_t)stream;
   ScoreArgs a;
   a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
@@ -666,6 +734,8 @@ extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab,
   int32_t* list = reinterpret_cast<int32_t*>(best_theta + a.npad);
   int32_t* count = list + a.npad;
   a.order = list; a.count = count; a.use_theta_override = 1;
+  int rcu = fill_utab(a, workspace, rf, uniform_scale, s);
+  if (rcu) return rcu;
   const GateArgs gate = make_gate(fp, map);
   HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(init_list_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)st, cap, n, gate,
@@ -679,7 +749,7 @@ extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab,
   bool first = true;
   for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {  // state_particle.cpp:197 (float t, double increment)
     a.theta_override = t;
-    int rc = launch_score(a, rf, s);
+    int rc = launch_score(a, rf, map->ncls, s);
     if (rc) return rc;
     f.first = first ? 1 : 0;
     f.theta_override = t;
@@ -981,32 +1051,62 @@ extern "C" int tdr_k_update_weights(const float* raw_w, const float* last_dist, 
 // loads 64 weights at a time (coalesced) and adds them in index order; every lane carries the same running value,
 // lane k stops after element k so it ends up holding prefix_k.  The running maximum makes "first j with
 // prefix_j > sample" searchable even when weights are negative (NaN fill, :133).
+#define TDR_PFX_BLOCK 4096  // elements staged in LDS per pass (64 per lane)
 __global__ __launch_bounds__(64) void prefix_kernel(const float* __restrict__ w, int64_t n,
                                                     float* __restrict__ runmax) {
+  __shared__ float4 buf4[TDR_PFX_BLOCK / 4];
+  float* buf = reinterpret_cast<float*>(buf4);
   const int lane = threadIdx.x;
-  float run = 0.f, mx = -INFINITY;
-  for (int64_t base = 0; base < n; base += 64) {
-    const int64_t i = base + lane;
-    const float wv = (i < n) ? w[i] : 0.f;
-    float mine = run;
-#pragma unroll
-    for (int k = 0; k < 64; k++) {
-      const float x = __shfl(wv, k, 64);
-      run = run + x;
-      if (lane == k) mine = run;
+  float run = 0.f;        // the serial chain lives in lane 0
+  float carry_max = -INFINITY;
+  for (int64_t base = 0; base < n; base += TDR_PFX_BLOCK) {
+    const int cnt = (int)min((int64_t)TDR_PFX_BLOCK, n - base);
+    // coalesced stage-in (pad with zeros: x + 0 == x)
+    for (int t = lane; t < TDR_PFX_BLOCK; t += 64) buf[t] = (t < cnt) ? w[base + t] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const int q4 = (cnt + 3) / 4;
+#pragma unroll 4
+      for (int q = 0; q < q4; q++) {
+        float4 v = buf4[q];
+        run = run + v.x; v.x = run;   // particle_filter.cpp:179, one float add per weight, index order
+        run = run + v.y; v.y = run;
+        run = run + v.z; v.z = run;
+        run = run + v.w; v.w = run;
+        buf4[q] = v;
+      }
     }
-    // inclusive running max across lanes (exact: max is associative), seeded with the carry
-    float m = mine;
-    if (m != m) m = -INFINITY;  // NaN never exceeds a threshold
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // running maximum of the block's prefix values (max is associative: any order is exact)
+    float m = -INFINITY;
+    float loc[64];
+#pragma unroll
+    for (int t = 0; t < 64; t++) {
+      float x = buf[lane * 64 + t];
+      if (x != x) x = -INFINITY;  // a NaN prefix never exceeds a threshold (`running_sum > sample` is false)
+      m = fmaxf(m, x);
+      loc[t] = m;
+    }
+    float incl = m;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      float t = __shfl_up(m, o, 64);
-      if (lane >= o) m = fmaxf(m, t);
+      float t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl = fmaxf(incl, t);
     }
-    m = fmaxf(m, mx);
-    if (i < n) runmax[i] = m;
-    mx = __shfl(m, 63, 64);
-    // lanes beyond n added zeros: run is unchanged by them only if x + 0 == x, true for finite and inf
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -INFINITY;
+    excl = fmaxf(excl, carry_max);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 64; t++) buf[lane * 64 + t] = fmaxf(loc[t], excl);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < cnt; t += 64) runmax[base + t] = buf[t];
+    carry_max = fmaxf(__shfl(incl, 63, 64), carry_max);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1171,6 +1271,20 @@ extern "C" int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, flo
   return TDR_OK;
 }
 
+// Self-test hook: the scoring loop's coordinate rounding applied to caller-supplied floats (clamped to [-1, limit]
+// like the loop does), so the GPU tests can compare it with roundf over whole float ranges.
+__global__ void selftest_round_kernel(const float* __restrict__ x, int64_t n, float limit, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = round_half_away_clamped(__builtin_amdgcn_fmed3f(x[i], -1.f, limit));
+}
+extern "C" int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream) {
+  if (!x || !out || n < 1) return fail(TDR_ERR_ARG, "selftest_round: bad arguments");
+  hipLaunchKernelGGL(selftest_round_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, limit,
+                     out);
+  LAUNCH_CHECK("selftest_round");
+  return TDR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // layout helpers
 __global__ void aos_to_soa_kernel(const tdr_state* __restrict__ aos, int64_t n, float* __restrict__ st, int64_t cap) {
@@ -1216,80 +1330,65 @@ extern "C" int tdr_k_states_soa_to_aos(const float* st, int64_t cap, int64_t n, 
   return TDR_OK;
 }
 
-// Locality order: counting sort of the particles by the TILE x TILE px map tile of their centre (row-major tile
-// id; off-map centres clamp to the border tiles).  keys_tmp[0..n) keeps the keys, the histogram lives behind it.
-#define TDR_TILE 4
-__global__ void loc_key_kernel(const float* __restrict__ st, int64_t cap, int64_t n, int trows, int tcols,
-                               int32_t* __restrict__ keys, int32_t* __restrict__ hist) {
+// Locality order: particles sorted by the Morton (Z-order) code of their centre at half-pixel granularity, so that
+// the 64 particles of a wave — and the 4 lanes of each TA quad — read the same or neighbouring map cells.
+// The key kernel is ours; the sort itself is rocPRIM's device radix sort (a utility, not a hot op).
+__device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__global__ void loc_key_kernel(const float* __restrict__ st, int64_t cap, int64_t n, float xmax, float ymax,
+                               uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const float sc = st[TDR_ST_SCALE * cap + p];
-  const float cx = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
-  const float cy = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
-  int tx = (int)fminf(fmaxf(cx * (1.f / TDR_TILE), 0.f), (float)(tcols - 1));
-  int ty = (int)fminf(fmaxf(cy * (1.f / TDR_TILE), 0.f), (float)(trows - 1));
-  if (!(cx == cx)) tx = 0;
-  if (!(cy == cy)) ty = 0;
-  const int key = ty * tcols + tx;
-  keys[p] = key;
-  atomicAdd(&hist[key], 1);
+  float cx = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
+  float cy = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+  if (!(cx == cx)) cx = 0.f;
+  if (!(cy == cy)) cy = 0.f;
+  const uint32_t hx = (uint32_t)fminf(fmaxf(cx * 2.f, 0.f), xmax);
+  const uint32_t hy = (uint32_t)fminf(fmaxf(cy * 2.f, 0.f), ymax);
+  keys[p] = spread_bits16(hx) | (spread_bits16(hy) << 1);
+  vals[p] = (int32_t)p;
 }
-// exclusive scan of hist[0..m) in place, single workgroup
-__global__ __launch_bounds__(1024) void loc_scan_kernel(int32_t* __restrict__ hist, int64_t m) {
-  __shared__ int32_t wsum[16];
-  __shared__ int32_t carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < m; base += 1024) {
-    const int64_t i = base + tid;
-    const int32_t v = (i < m) ? hist[i] : 0;
-    int32_t x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      int32_t t = __shfl_up(x, o, 64);
-      if (lane >= o) x += t;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    int32_t woff = 0;
-    for (int k = 0; k < wave; k++) woff += wsum[k];
-    const int32_t c = carry;
-    if (i < m) hist[i] = c + woff + x - v;
-    __syncthreads();
-    if (tid == 1023) carry = c + woff + x;
-    __syncthreads();
-  }
-}
-__global__ void loc_scatter_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ hist,
-                                   int32_t* __restrict__ perm) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int pos = atomicAdd(&hist[keys[p]], 1);
-  perm[pos] = (int32_t)p;
+
+static size_t radix_tmp_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  int32_t* v = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, 32u, (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) bytes = (size_t)(n + 4096) * 16;  // no device to ask: a generous bound
+  return bytes;
 }
 
 extern "C" size_t tdr_locality_tmp_ints(int64_t n, int map_rows, int map_cols) {
-  int64_t trows = cdiv(map_rows, TDR_TILE), tcols = cdiv(map_cols, TDR_TILE);
-  return (size_t)(n + trows * tcols + 64);
+  (void)map_rows; (void)map_cols;
+  if (n < 1) n = 1;
+  return (size_t)(3 * n + 64) + (radix_tmp_bytes(n) + 3) / 4 + 64;
 }
 
 extern "C" int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols,
                                     int32_t* perm_out, int32_t* keys_tmp, void* stream) {
   if (!st || !perm_out || !keys_tmp || n < 0 || cap < n || map_rows < 1 || map_cols < 1)
     return fail(TDR_ERR_ARG, "locality_order: bad arguments");
+  if (map_rows > 32767 || map_cols > 32767) return fail(TDR_ERR_ARG, "locality_order: map larger than 32767 px");
   if (n == 0) return TDR_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int trows = (int)cdiv(map_rows, TDR_TILE), tcols = (int)cdiv(map_cols, TDR_TILE);
-  const int64_t m = (int64_t)trows * tcols;
-  int32_t* hist = keys_tmp + n;
-  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(int32_t) * m, s));
-  hipLaunchKernelGGL(loc_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, st, cap, n, trows, tcols, keys_tmp,
-                     hist);
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(keys_tmp);
+  uint32_t* keys_out = keys_in + n;
+  int32_t* vals_in = keys_tmp + 2 * n;
+  void* tmp = keys_tmp + 3 * n + 64 - ((3 * n) % 64);  // keep the sort's scratch 256-byte aligned
+  size_t tmp_bytes = radix_tmp_bytes(n);
+  hipLaunchKernelGGL(loc_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, st, cap, n,
+                     (float)(2 * map_cols - 1), (float)(2 * map_rows - 1), keys_in, vals_in);
   LAUNCH_CHECK("loc_key");
-  hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, s, hist, m);
-  LAUNCH_CHECK("loc_scan");
-  hipLaunchKernelGGL(loc_scatter_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const int32_t*)keys_tmp, n,
-                     hist, perm_out);
-  LAUNCH_CHECK("loc_scatter");
+  unsigned bits = 2;
+  while ((1u << (bits / 2)) < (unsigned)(2 * std::max(map_rows, map_cols)) && bits < 32) bits += 2;
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm_out, (size_t)n, 0u, bits, s,
+                                    false));
   return TDR_OK;
 }

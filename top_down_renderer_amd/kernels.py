@@ -64,8 +64,7 @@ class HipKernels:
         ncls, H, W = class_maps.shape
         maps_cm = self.to_device(np.ascontiguousarray(np.transpose(class_maps, (0, 2, 1)), np.float32))
         mask_cm = self.to_device(np.ascontiguousarray(class_mask.T, np.uint8))
-        rf = self.lib.tdr_rec_floats(ncls)
-        rec = self.empty(((H * W + 1) * rf,))
+        rec = self.empty((int(self.lib.tdr_map_rec_floats_total(ncls, H, W)),))
         check(self.lib.tdr_k_pack_map(_ptr(maps_cm), _ptr(mask_cm), ncls, H, W, _ptr(rec), self.stream()))
         self.synchronize()
         del maps_cm, mask_cm
@@ -98,22 +97,22 @@ class HipKernels:
         return pk
 
     # ---- filter ---------------------------------------------------------------------------------------------
-    def _workspace(self, ncls, nr, n):
-        need = int(self.lib.tdr_score_workspace_floats(ncls, nr, n))
+    def _workspace(self, ncls, nb, nr, n):
+        need = int(self.lib.tdr_score_workspace_floats(ncls, nb, nr, n))
         if self._ws is None or self._ws.numel() < need:
             self._ws = self.empty((need,))
         return self._ws
 
-    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False):
-        ws = self._workspace(m.ncls, m.nr, n)
+    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0):
+        ws = self._workspace(m.ncls, m.nb, m.nr, n)
         cap = st.shape[1]
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
-                                         C.byref(fp), _ptr(st), cap, n, _ptr(perm), _ptr(raw_w), _ptr(ws),
-                                         self.stream()))
+                                         C.byref(fp), _ptr(st), cap, n, _ptr(perm), C.c_float(uniform_scale),
+                                         _ptr(raw_w), _ptr(ws), self.stream()))
         if init_search:
             check(self.lib.tdr_k_score_polar_init(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr,
-                                                  C.c_float(res), C.byref(fp), _ptr(st), cap, n, _ptr(raw_w),
-                                                  _ptr(ws), self.stream()))
+                                                  C.c_float(res), C.byref(fp), _ptr(st), cap, n,
+                                                  C.c_float(uniform_scale), _ptr(raw_w), _ptr(ws), self.stream()))
 
     def propagate(self, st, n, last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4=None, seed=0, step=0,
                   index_base=0):

@@ -115,6 +115,7 @@ class ParticleFilter:
         self.gen_ = self.k.rng_create(seed)
         self.step_ = 0
         self._maybe_uninit = True
+        self._uniform_scale = 0.0
         self._ml_state = None
         self._alloc()
         if map.haveMap():
@@ -157,6 +158,9 @@ class ParticleFilter:
         self.k.states_to_device(mine, self.st, nl)
         self._maybe_uninit = bool((states["have_init"] == 0).any())
         self.scale_frozen_ = self.scale_frozen_ or self.params_.fixed_scale > 0
+        # all scales equal AND frozen (propagate leaves them alone): the scoring kernel may hoist (tab*scale)*res
+        sc = np.unique(states["scale"]) if n else np.zeros(0, np.float32)
+        self._uniform_scale = float(sc[0]) if (self.scale_frozen_ and len(sc) == 1 and sc[0] > 0) else 0.0
         self.perm = None
 
     def get_states(self):
@@ -226,7 +230,8 @@ class ParticleFilter:
                 self.perm = k.zeros((self.cap_local,), torch.int32)
             k.locality_order(self.st, nl, m.rows, m.cols, self.perm)
         k.score(m.dev, scan_pk, float(res), self.fp_c, self.st, nl, self.raw_w,
-                perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit)
+                perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
+                uniform_scale=self._uniform_scale)
         # the init search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay
         # un-initialised, and gates exist only with force_on_map or an unknown scale
         if not (self.params_.force_on_map or self.params_.fixed_scale < 0):
@@ -328,6 +333,7 @@ class ParticleFilter:
             out = self.k.mean_cov(st, n, -1)
             self.k.set_scale(self.st, self.n_local, out[20:21])
             self.scale_frozen_ = True
+            self._uniform_scale = float(out[20].item())
 
     def isScaleFrozen(self):
         return self.scale_frozen_
