@@ -4,7 +4,7 @@
  *
  * The reference (KumarRobotics/top_down_renderer) has no FFI layer: its boundary is the public C++ surface of
  * library target `top_down_render` (CMakeLists.txt:145-165).  Every entry point below names the reference method
- * (file:line, relative to the reference root) whose work it performs; include/top_down_render/ *.h rebuilds the
+ * (file:line, relative to the reference root) whose work it performs; the headers under include/top_down_render/ rebuild the
  * reference's class names on top of these calls.
  *
  * Conventions
@@ -155,9 +155,10 @@ int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, co
                         float* dst, int64_t dst_cap, void* stream);
 
 /* ---- per-step consumers (src/particle_filter.cpp:191-236, 325-334, 343-357) --------------------------------- */
-/* out (device, 24 floats): mean[4] (meanLikelihood), cov[16] row-major about ref (computeMeanCov when
- * about_max < 0, computeCov about particle `about_max` otherwise), geo-mean scale, 3 spare. */
-int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, int64_t about_max, float* out, void* stream);
+/* out (device, 24 floats): mean[4] (meanLikelihood :191-203), cov[16] row-major about the mean (computeMeanCov,
+ * about == NULL) or about the 4 device floats `about` (computeCov about the max-likelihood mlState :226-236),
+ * geometric-mean scale (freezeScale :345-348), 3 spare. */
+int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, const float* about, float* out, void* stream);
 int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, void* stream);   /* freezeScale :350-352 */
 int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream);      /* updateMap :325-334 */
 
@@ -177,6 +178,59 @@ int tdr_k_states_soa_to_aos(const float* st, int64_t cap, int64_t n, tdr_state* 
 size_t tdr_locality_tmp_ints(int64_t n, int map_rows, int map_cols);
 int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols, int32_t* perm_out,
                          int32_t* keys_tmp, void* stream);
+
+/* =================================================================================================================
+ * Handle layer: C++ host code (csrc/tdr_host.cpp) that owns the device memory and sequences the kernels above the way
+ * the reference's classes sequence their loops.  HOST pointers in and out; one handle per reference object; one caller
+ * thread per handle.  This is what the headers under include/top_down_render/ (the reference's class surface) are
+ * written against.
+ * ================================================================================================================= */
+typedef struct tdr_map tdr_map;            /* TopDownMapPolar   (top_down_map_polar.h:6-22)  */
+typedef struct tdr_renderer tdr_renderer;  /* ScanRenderer[Polar] (scan_renderer_polar.h:15-22) */
+typedef struct tdr_filter tdr_filter;      /* ParticleFilter    (particle_filter.h:22-73)    */
+
+int tdr_map_create(tdr_map** out);
+void tdr_map_destroy(tdr_map* m);
+/* class_maps_/class_mask_ as computeDists leaves them (top_down_map.cpp:289-326), column-major HOST arrays; also the
+ * map side of TopDownMap::updateMap (:146-157).  center = map_center_. */
+int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
+                float resolution, int center_x, int center_y);
+int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res);                 /* top_down_map_polar.cpp:7-19 */
+int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map);
+int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
+
+int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out);              /* scan_renderer.cpp:3-5 */
+void tdr_renderer_destroy(tdr_renderer* r);
+/* renderSemanticTopDown: polar != 0 -> scan_renderer_polar.cpp:83-109 (rows = theta bins, cols = range bins),
+ * else scan_renderer.cpp:55-78.  imgs_out: HOST [ncls][rows*cols] column-major, or NULL to keep the render on the
+ * device for tdr_filter_update. */
+int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride, int ioff, int64_t n, float res,
+                        float ang_res, int ncls, int rows, int cols, float* imgs_out);
+
+int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_filter** out);
+void tdr_filter_destroy(tdr_filter* f);
+/* parity_rng: propagate consumes host std::mt19937 normals in the reference's order (default 1); 0 = device RNG.
+ * locality_every: > 0 processes particles in Morton order of their map position (default 1; results unchanged). */
+int tdr_filter_configure(tdr_filter* f, int parity_rng, int locality_every);
+int tdr_filter_initialize_particles(tdr_filter* f);                                      /* particle_filter.cpp:19-84 */
+int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n);
+int tdr_filter_get_states(tdr_filter* f, tdr_state* out, int64_t n);
+int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega);                /* particle_filter.cpp:86-92 */
+/* particle_filter.cpp:94-189.  scan_imgs: HOST [ncls][nb*nr] images or NULL (= renderer's last render, no host round
+ * trip); n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
+int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target);
+int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n);
+int tdr_filter_get_resample_indices(tdr_filter* f, int32_t* out, int64_t n);
+/* about_max == 0: meanLikelihood + computeMeanCov (:191-220); != 0: maxLikelihood + computeCov (:222-236). */
+int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[16]);
+int tdr_filter_freeze_scale(tdr_filter* f);                                              /* :343-357 */
+int tdr_filter_is_scale_frozen(const tdr_filter* f);
+float tdr_filter_scale(tdr_filter* f);                                                   /* :359-367 */
+int64_t tdr_filter_num_particles(const tdr_filter* f);                                   /* :369-371 */
+int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
+                          float resolution, int center_x, int center_y);                 /* :320-341 */
+/* internal: lets tdr_host.cpp report through tdr_last_error() */
+int tdr_set_error(int code, const char* msg);
 
 #ifdef __cplusplus
 }

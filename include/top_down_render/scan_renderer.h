@@ -1,0 +1,57 @@
+// ScanRenderer — the reference's class surface (include/top_down_render/scan_renderer.h:14-23 in the reference)
+// over the MI355X raster kernel (tdr_renderer, include/tdr.h).  Same constructor and method signatures, same
+// ownership rule (the caller sizes the images, the call zero-fills and writes them in place), same silent early
+// return on an empty image list.
+#ifndef SCAN_RENDERER_H_
+#define SCAN_RENDERER_H_
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tdr.h"
+#include "top_down_render/tdr_compat.h"
+
+typedef pcl::PointXYZI PointType;
+
+class ScanRenderer {
+ public:
+  explicit ScanRenderer(const Eigen::VectorXi& flatten_lut) {  // src/scan_renderer.cpp:3-5
+    if (flatten_lut.size() != 256) throw std::invalid_argument("flatten_lut must have 256 entries");
+    int32_t lut[256];
+    for (int i = 0; i < 256; i++) lut[i] = flatten_lut[i];
+    if (tdr_renderer_create(lut, &r_) != TDR_OK) throw std::runtime_error(std::string("ScanRenderer: ") + tdr_last_error());
+  }
+  virtual ~ScanRenderer() { tdr_renderer_destroy(r_); }
+  ScanRenderer(const ScanRenderer&) = delete;
+  ScanRenderer& operator=(const ScanRenderer&) = delete;
+
+  // src/scan_renderer.cpp:55-78
+  void renderSemanticTopDown(const pcl::PointCloud<pcl::PointXYZI>::ConstPtr& cloud, float res,
+                             std::vector<Eigen::ArrayXXf>& imgs) {
+    render(0, cloud, res, 1.f, imgs);
+  }
+  // src/scan_renderer.cpp:7-53: disabled at the reference's call site (src/top_down_render.cpp:540) and unused by the
+  // score (src/state_particle.cpp:145-152); zero-fills like the reference's first lines and returns.
+  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr&, float, std::vector<Eigen::ArrayXXf>& imgs) {
+    for (auto& im : imgs) im.setZero();
+  }
+  const tdr_renderer* handle() const { return r_; }  // device-resident last render, for ParticleFilter::update
+
+ protected:
+  void render(int polar, const pcl::PointCloud<pcl::PointXYZI>::ConstPtr& cloud, float res, float ang_res,
+              std::vector<Eigen::ArrayXXf>& imgs) {
+    if (imgs.size() < 1) return;
+    const int rows = (int)imgs[0].rows(), cols = (int)imgs[0].cols(), ncls = (int)imgs.size();
+    const size_t P = (size_t)rows * cols;
+    std::vector<float> buf(P * ncls);
+    const float* pts = cloud && !cloud->points.empty() ? reinterpret_cast<const float*>(cloud->points.data()) : nullptr;
+    const int64_t n = cloud ? (int64_t)cloud->points.size() : 0;
+    if (tdr_renderer_render(r_, polar, pts, 8, 4, n, res, ang_res, ncls, rows, cols, buf.data()) != TDR_OK)
+      throw std::runtime_error(std::string("renderSemanticTopDown: ") + tdr_last_error());
+    for (int c = 0; c < ncls; c++) std::memcpy(imgs[c].data(), buf.data() + P * c, P * sizeof(float));
+  }
+  tdr_renderer* r_ = nullptr;
+};
+
+#endif  // SCAN_RENDERER_H_

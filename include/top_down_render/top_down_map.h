@@ -1,0 +1,79 @@
+// TopDownMap — reference surface: include/top_down_render/top_down_map.h:52-102.  Holds the per-class truncated
+// distance maps + unknown mask on the GPU (tdr_map, include/tdr.h).  The reference builds these at load time from an
+// SVG / PNG / cache file (src/top_down_map.cpp:9-64, OpenCV + nanosvg): that ingest is outside the per-scan path
+// (SURVEY §8f N1), so here the distance maps are handed over with setDistanceMaps() in the same layout as the
+// reference's class_maps_ / class_mask_ members.
+#ifndef TOP_DOWN_MAP_H_
+#define TOP_DOWN_MAP_H_
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tdr.h"
+#include "top_down_render/tdr_compat.h"
+
+class TopDownMap {
+ public:
+  struct Params {  // top_down_map.h:54-62 (color_lut belongs to the load-time ingest)
+    std::string map_path = "";
+    std::vector<int> flatten_lut;
+    int num_classes = 0;
+    std::vector<int> exclusive_classes;
+    float resolution = 1;
+    float out_of_bounds_const = 5;  // unused by the reference too: every out-of-bounds write is a literal 0
+  };
+  explicit TopDownMap(const Params& params) : params_(params) {
+    if (tdr_map_create(&m_) != TDR_OK) throw std::runtime_error(std::string("TopDownMap: ") + tdr_last_error());
+  }
+  virtual ~TopDownMap() { tdr_map_destroy(m_); }
+  TopDownMap(const TopDownMap&) = delete;
+  TopDownMap& operator=(const TopDownMap&) = delete;
+
+  // class_maps_[c] (rows = height/resolution, cols = width/resolution, column-major) and class_mask_ (1 = unknown),
+  // as computeDists leaves them (src/top_down_map.cpp:289-326).  Also the map side of updateMap (:146-157).
+  void setDistanceMaps(const std::vector<Eigen::ArrayXXf>& class_maps, const Eigen::ArrayXXc& class_mask,
+                       const Eigen::Vector2i& map_center = Eigen::Vector2i(0, 0)) {
+    if (class_maps.empty()) return;
+    const int rows = (int)class_maps[0].rows(), cols = (int)class_maps[0].cols(), ncls = (int)class_maps.size();
+    std::vector<float> buf((size_t)rows * cols * ncls);
+    for (int c = 0; c < ncls; c++)
+      std::memcpy(buf.data() + (size_t)c * rows * cols, class_maps[c].data(), (size_t)rows * cols * sizeof(float));
+    if (tdr_map_set(m_, buf.data(), class_mask.data(), ncls, rows, cols, params_.resolution, map_center[0],
+                    map_center[1]) != TDR_OK)
+      throw std::runtime_error(std::string("TopDownMap::setDistanceMaps: ") + tdr_last_error());
+    params_.num_classes = ncls;
+    map_center_ = map_center;
+  }
+  void getClassesAtPoint(const Eigen::Vector2i& center_ind, std::vector<int>& classes) {  // top_down_map.cpp:159-170
+    classes.clear();
+    uint32_t bits = 0;
+    if (tdr_map_classes_at_point(m_, center_ind[0], center_ind[1], &bits) != TDR_OK) return;
+    for (int c = 0; c < params_.num_classes; c++)
+      if (bits & (1u << c)) classes.push_back(c);
+  }
+  void getClassesAtPoint(const Eigen::Vector2f& center, std::vector<int>& classes) {      // :172-175
+    getClassesAtPoint(Eigen::Vector2i((int)(center[0] / params_.resolution), (int)(center[1] / params_.resolution)), classes);
+  }
+  Eigen::Vector2i size() const {
+    int rows = 0, cols = 0;
+    tdr_map_info(m_, nullptr, &rows, &cols, nullptr, nullptr);
+    return Eigen::Vector2i(cols, rows);
+  }
+  Eigen::Vector2i mapCenter() const { return map_center_; }
+  int numClasses() const { return params_.num_classes; }
+  float resolution() const { return params_.resolution; }
+  bool haveMap() const {
+    int have = 0;
+    tdr_map_info(m_, nullptr, nullptr, nullptr, nullptr, &have);
+    return have != 0;
+  }
+  tdr_map* handle() const { return m_; }
+
+ protected:
+  Params params_;
+  Eigen::Vector2i map_center_;
+  tdr_map* m_ = nullptr;
+};
+
+#endif  // TOP_DOWN_MAP_H_

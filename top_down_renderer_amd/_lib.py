@@ -57,13 +57,40 @@ SIGNATURES = {
     "tdr_k_resample": (_i, [_vp, _i64, _i64, _f, _i64, _i64, _vp, _vp]),
     "tdr_k_gather_states": (_i, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tdr_init_particles_host": (_i, [_vp, _vp, _i, _i, _i, _f, C.POINTER(FilterParamsC), _i, _vp, C.POINTER(C.c_int64)]),
-    "tdr_k_mean_cov": (_i, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tdr_k_mean_cov": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "tdr_k_set_scale": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_k_shift_init": (_i, [_vp, _i64, _i64, _f, _f, _vp]),
     "tdr_k_states_aos_to_soa": (_i, [_vp, _i64, _vp, _i64, _vp]),
     "tdr_k_states_soa_to_aos": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_profile_enable": (_i, [_i]),
     "tdr_profile_score_ms": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    # handle layer (csrc/tdr_host.cpp)
+    "tdr_map_create": (_i, [C.POINTER(_vp)]),
+    "tdr_map_destroy": (None, [_vp]),
+    "tdr_map_set": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i]),
+    "tdr_map_sample_pts_polar": (_i, [_vp, _i, _i, _f]),
+    "tdr_map_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
+    "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),
+    "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
+    "tdr_renderer_destroy": (None, [_vp]),
+    "tdr_renderer_render": (_i, [_vp, _i, _vp, _i, _i, _i64, _f, _f, _i, _i, _i, _vp]),
+    "tdr_filter_create": (_i, [_vp, _i, C.POINTER(FilterParamsC), _u32, C.POINTER(_vp)]),
+    "tdr_filter_destroy": (None, [_vp]),
+    "tdr_filter_configure": (_i, [_vp, _i, _i]),
+    "tdr_filter_initialize_particles": (_i, [_vp]),
+    "tdr_filter_set_states": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_get_states": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_propagate": (_i, [_vp, _f, _f, _f]),
+    "tdr_filter_update": (_i, [_vp, _vp, _vp, _f, _i64]),
+    "tdr_filter_get_weights": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_get_resample_indices": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_mean_cov": (_i, [_vp, _i, _vp, _vp]),
+    "tdr_filter_freeze_scale": (_i, [_vp]),
+    "tdr_filter_is_scale_frozen": (_i, [_vp]),
+    "tdr_filter_scale": (_f, [_vp]),
+    "tdr_filter_num_particles": (_i64, [_vp]),
+    "tdr_filter_update_map": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i]),
+    "tdr_set_error": (_i, [_i, C.c_char_p]),
     "tdr_locality_tmp_ints": (C.c_size_t, [_i64, _i, _i]),
     "tdr_k_locality_order": (_i, [_vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),
 }

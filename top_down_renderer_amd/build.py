@@ -6,7 +6,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = [os.path.join(PKG, "csrc", "tdr_kernels.hip")]
+SRC = [os.path.join(PKG, "csrc", "tdr_kernels.hip"), os.path.join(PKG, "csrc", "tdr_host.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 
@@ -32,7 +32,7 @@ def needs_build():
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-o", OUT] + SRC
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-o", OUT, "-x", "hip"] + SRC
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

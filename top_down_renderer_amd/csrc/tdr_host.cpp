@@ -1,0 +1,484 @@
+// tdr_host.cpp — the handle layer of the C ABI (include/tdr.h, "tdr_map_* / tdr_renderer_* / tdr_filter_*"):
+// C++ host code that owns device memory and sequences the hand-written HIP kernels (tdr_kernels.hip) exactly the way
+// the reference's classes sequence their Eigen loops.  One handle = one reference object:
+//     tdr_map       TopDownMapPolar   (include/top_down_render/top_down_map_polar.h:6-22)
+//     tdr_renderer  ScanRendererPolar (include/top_down_render/scan_renderer_polar.h:15-22)
+//     tdr_filter    ParticleFilter    (include/top_down_render/particle_filter.h:22-73)
+// Single GPU, one caller thread per handle (the reference calls everything from the ROS spinner thread).
+// No CPU fallback: every entry point fails with TDR_ERR_HIP when no device is present.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "tdr.h"
+
+extern "C" int tdr_set_error(int code, const char* msg);  // tdr_kernels.hip
+
+namespace {
+
+int failh(int code, const char* fmt, ...) {
+  char buf[400];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return tdr_set_error(code, buf);
+}
+#define HTRY(expr)                                                                        \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return failh(TDR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define TTRY(expr)            \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != TDR_OK) return rc_; \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int resize(size_t count) {
+    if (count <= n) return TDR_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) return failh(TDR_ERR_NOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    n = count;
+    return TDR_OK;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+}  // namespace
+
+struct tdr_map {
+  DevBuf<float> rec;
+  DevBuf<float> tab;
+  std::vector<float> maps_host;  // class_maps_ (column-major), kept for getClassesAtPoint / particle initialisation
+  tdr_map_desc desc{};
+  int nb = 0, nr = 0;
+  float ang_res = 0;
+  int center_x = 0, center_y = 0;
+  bool have_map = false;
+};
+
+struct tdr_renderer {
+  DevBuf<int32_t> lut;
+  DevBuf<float> pts, img, pk;
+  int ncls = 0, rows = 0, cols = 0;  // shape of the last render
+  bool have_scan = false;
+};
+
+struct tdr_filter {
+  tdr_map* map = nullptr;
+  tdr_filter_params fp{};
+  int64_t n_max = 0, n = 0;
+  DevBuf<float> st, st_new, last_dist, raw_w, w, runmax, info, ws, z4, scan_img, scan_pk, stats;
+  DevBuf<int32_t> idx, perm, loc_tmp;
+  DevBuf<tdr_state> aos;
+  void* rng = nullptr;
+  uint64_t seed = 0, step = 0;
+  bool scale_frozen = false, maybe_uninit = true, parity_rng = true;
+  int locality_every = 1;
+  float uniform_scale = 0.f;
+  tdr_state ml_state{};
+  hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+// ---- TopDownMap(Polar) ------------------------------------------------------------------------------------------------
+int tdr_map_create(tdr_map** out) {
+  if (!out) return failh(TDR_ERR_ARG, "map_create: null out");
+  if (tdr_device_count() < 1) return failh(TDR_ERR_HIP, "map_create: no HIP device (there is no CPU fallback)");
+  *out = new tdr_map();
+  return TDR_OK;
+}
+void tdr_map_destroy(tdr_map* m) { delete m; }
+
+// Storage of class_maps_ / class_mask_ (top_down_map.h:77-79) in the form computeDists leaves them
+// (top_down_map.cpp:289-326); also the body of TopDownMap::updateMap once the distance transform is done (:146-157).
+int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
+                float resolution, int center_x, int center_y) {
+  if (!m || !class_maps || !class_mask) return failh(TDR_ERR_ARG, "map_set: null pointer");
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1 || !(resolution > 0))
+    return failh(TDR_ERR_ARG, "map_set: bad shape / resolution");
+  const size_t ncell = (size_t)rows * cols;
+  DevBuf<float> d_maps;
+  DevBuf<uint8_t> d_mask;
+  TTRY(d_maps.resize(ncell * ncls));
+  TTRY(d_mask.resize(ncell));
+  HTRY(hipMemcpy(d_maps.p, class_maps, ncell * ncls * sizeof(float), hipMemcpyHostToDevice));
+  HTRY(hipMemcpy(d_mask.p, class_mask, ncell, hipMemcpyHostToDevice));
+  TTRY(m->rec.resize(tdr_map_rec_floats_total(ncls, rows, cols)));
+  TTRY(tdr_k_pack_map(d_maps.p, d_mask.p, ncls, rows, cols, m->rec.p, nullptr));
+  HTRY(hipDeviceSynchronize());
+  m->maps_host.assign(class_maps, class_maps + ncell * ncls);
+  m->desc.rec = m->rec.p;
+  m->desc.ncls = ncls;
+  m->desc.rows = rows;
+  m->desc.cols = cols;
+  m->desc.rec_floats = tdr_rec_floats(ncls);
+  m->desc.resolution = resolution;
+  m->center_x = center_x;
+  m->center_y = center_y;
+  m->have_map = true;
+  if (m->nb > 0) return tdr_map_sample_pts_polar(m, m->nb, m->nr, m->ang_res);
+  return TDR_OK;
+}
+
+// TopDownMapPolar::samplePtsPolar (top_down_map_polar.cpp:7-19)
+int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res) {
+  if (!m || nb < 1 || nr < 1) return failh(TDR_ERR_ARG, "sample_pts_polar: bad arguments");
+  m->nb = nb;
+  m->nr = nr;
+  m->ang_res = ang_res;
+  if (!m->have_map) return TDR_OK;  // table needs params_.resolution; built when the map arrives
+  std::vector<float> tab((size_t)2 * nb * nr);
+  TTRY(tdr_polar_table_host(nb, nr, ang_res, m->desc.resolution, tab.data()));
+  TTRY(m->tab.resize(tab.size()));
+  HTRY(hipMemcpy(m->tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  return TDR_OK;
+}
+
+int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map) {
+  if (!m) return failh(TDR_ERR_ARG, "map_info: null map");
+  if (ncls) *ncls = m->desc.ncls;
+  if (rows) *rows = m->desc.rows;
+  if (cols) *cols = m->desc.cols;
+  if (resolution) *resolution = m->desc.resolution;
+  if (have_map) *have_map = m->have_map ? 1 : 0;
+  return TDR_OK;
+}
+
+// TopDownMap::getClassesAtPoint(Vector2i) (top_down_map.cpp:159-170): bit c set = class c present (< 1 px away)
+int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits) {
+  if (!m || !class_bits || !m->have_map) return failh(TDR_ERR_ARG, "classes_at_point: no map");
+  const int rows = m->desc.rows, cols = m->desc.cols;
+  const int c0 = (int)((float)px / m->desc.resolution), c1 = (int)((float)py / m->desc.resolution);
+  uint32_t bits = 0;
+  if (c0 < cols && c1 < rows && c0 >= 0 && c1 >= 0)
+    for (int c = 0; c < m->desc.ncls; c++)
+      if (m->maps_host[(size_t)c * rows * cols + c1 + (size_t)rows * c0] < 1) bits |= 1u << c;
+  *class_bits = bits;
+  return TDR_OK;
+}
+
+// ---- ScanRenderer(Polar) ------------------------------------------------------------------------------------------------
+int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out) {
+  if (!flatten_lut256 || !out) return failh(TDR_ERR_ARG, "renderer_create: null pointer");
+  if (tdr_device_count() < 1) return failh(TDR_ERR_HIP, "renderer_create: no HIP device (there is no CPU fallback)");
+  tdr_renderer* r = new tdr_renderer();
+  int rc = r->lut.resize(256);
+  if (rc == TDR_OK && hipMemcpy(r->lut.p, flatten_lut256, 256 * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+    rc = failh(TDR_ERR_HIP, "renderer_create: lut upload failed");
+  if (rc != TDR_OK) {
+    delete r;
+    return rc;
+  }
+  *out = r;
+  return TDR_OK;
+}
+void tdr_renderer_destroy(tdr_renderer* r) { delete r; }
+
+// renderSemanticTopDown (scan_renderer_polar.cpp:83-109 when polar != 0, scan_renderer.cpp:55-78 otherwise).
+// pts: HOST points; imgs_out: HOST [ncls][rows*cols] column-major images, written in place (may be NULL: the render
+// then only stays on the device for tdr_filter_update).
+int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride, int ioff, int64_t n, float res,
+                        float ang_res, int ncls, int rows, int cols, float* imgs_out) {
+  if (!r) return failh(TDR_ERR_ARG, "render: null renderer");
+  if (n < 0 || (n > 0 && !pts)) return failh(TDR_ERR_ARG, "render: null points");
+  if (ncls < 1 || rows < 1 || cols < 1) return TDR_OK;  // `if (imgs.size() < 1) return;` (:85)
+  const size_t P = (size_t)rows * cols;
+  TTRY(r->pts.resize((size_t)std::max<int64_t>(n, 1) * stride));
+  TTRY(r->img.resize(P * ncls));
+  TTRY(r->pk.resize(P * tdr_rec_floats(ncls)));
+  if (n > 0) HTRY(hipMemcpy(r->pts.p, pts, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
+  if (polar)
+    TTRY(tdr_k_raster_polar(r->pts.p, stride, ioff, n, res, ang_res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p, nullptr));
+  else
+    TTRY(tdr_k_raster_cart(r->pts.p, stride, ioff, n, res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p, nullptr));
+  if (imgs_out) HTRY(hipMemcpy(imgs_out, r->img.p, P * ncls * sizeof(float), hipMemcpyDeviceToHost));
+  else HTRY(hipDeviceSynchronize());
+  r->ncls = ncls;
+  r->rows = rows;
+  r->cols = cols;
+  r->have_scan = true;
+  return TDR_OK;
+}
+
+// ---- ParticleFilter ------------------------------------------------------------------------------------------------------
+int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_filter** out) {
+  if (!map || !fp || !out || n_max < 1) return failh(TDR_ERR_ARG, "filter_create: bad arguments");
+  tdr_filter* f = new tdr_filter();
+  f->map = map;
+  f->fp = *fp;
+  f->n_max = n_max;
+  f->seed = seed;
+  f->rng = tdr_rng_create(seed);  // explicit seed instead of std::random_device (particle_filter.cpp:4-5)
+  int rc = TDR_OK;
+  const size_t cap = (size_t)n_max;
+  if (rc == TDR_OK) rc = f->st.resize(TDR_ST_FIELDS * cap);
+  if (rc == TDR_OK) rc = f->st_new.resize(TDR_ST_FIELDS * cap);
+  if (rc == TDR_OK) rc = f->last_dist.resize(cap);
+  if (rc == TDR_OK) rc = f->raw_w.resize(cap);
+  if (rc == TDR_OK) rc = f->w.resize(cap);
+  if (rc == TDR_OK) rc = f->runmax.resize(cap);
+  if (rc == TDR_OK) rc = f->idx.resize(cap);
+  if (rc == TDR_OK) rc = f->perm.resize(cap);
+  if (rc == TDR_OK) rc = f->info.resize(8);
+  if (rc == TDR_OK) rc = f->stats.resize(24);
+  if (rc == TDR_OK) rc = f->aos.resize(cap);
+  if (rc == TDR_OK) rc = f->z4.resize(4 * cap);
+  if (rc == TDR_OK && hipMemset(f->last_dist.p, 0, cap * sizeof(float)) != hipSuccess) rc = failh(TDR_ERR_HIP, "memset");
+  if (rc != TDR_OK) {
+    tdr_filter_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return TDR_OK;
+}
+void tdr_filter_destroy(tdr_filter* f) {
+  if (!f) return;
+  if (f->rng) tdr_rng_destroy(f->rng);
+  delete f;
+}
+
+int tdr_filter_configure(tdr_filter* f, int parity_rng, int locality_every) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_configure: null filter");
+  f->parity_rng = parity_rng != 0;
+  f->locality_every = locality_every;
+  return TDR_OK;
+}
+
+static void note_uniform_scale(tdr_filter* f, const tdr_state* s, int64_t n) {
+  f->uniform_scale = 0.f;
+  if (!f->scale_frozen || n < 1 || !(s[0].scale > 0)) return;
+  for (int64_t i = 1; i < n; i++)
+    if (s[i].scale != s[0].scale) return;
+  f->uniform_scale = s[0].scale;
+}
+
+int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n) {
+  if (!f || (n > 0 && !states) || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_set_states: bad arguments");
+  if (n > 0) {
+    HTRY(hipMemcpy(f->aos.p, states, (size_t)n * sizeof(tdr_state), hipMemcpyHostToDevice));
+    TTRY(tdr_k_states_aos_to_soa(f->aos.p, n, f->st.p, f->n_max, f->stream));
+    HTRY(hipDeviceSynchronize());
+  }
+  f->n = n;
+  f->maybe_uninit = false;
+  for (int64_t i = 0; i < n; i++) f->maybe_uninit |= states[i].have_init == 0;
+  if (f->fp.fixed_scale > 0) f->scale_frozen = true;
+  note_uniform_scale(f, states, n);
+  return TDR_OK;
+}
+
+int tdr_filter_get_states(tdr_filter* f, tdr_state* out, int64_t n) {
+  if (!f || !out || n < 0 || n > f->n) return failh(TDR_ERR_ARG, "filter_get_states: bad arguments");
+  if (n == 0) return TDR_OK;
+  TTRY(tdr_k_states_soa_to_aos(f->st.p, f->n_max, n, f->aos.p, f->stream));
+  HTRY(hipMemcpy(out, f->aos.p, (size_t)n * sizeof(tdr_state), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
+// ParticleFilter::initializeParticles (particle_filter.cpp:19-84)
+int tdr_filter_initialize_particles(tdr_filter* f) {
+  if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "initialize_particles: no map");
+  tdr_map* m = f->map;
+  tdr_filter_params& p = f->fp;
+  if (p.fixed_scale >= 0) f->scale_frozen = true;  // :23-25
+  const float inf = std::numeric_limits<float>::infinity();
+  if (f->scale_frozen && p.init_pos_m_x != inf) {   // :27-53
+    p.init_pos_px_x = (p.init_pos_m_x * p.fixed_scale) + (float)m->center_x;
+    p.init_pos_px_y = (p.init_pos_m_y * p.fixed_scale) + (float)m->center_y;
+    if (p.init_pos_px_x < 0 || p.init_pos_px_x >= (float)m->desc.cols || p.init_pos_px_y < 0 ||
+        p.init_pos_px_y >= (float)m->desc.rows)
+      return TDR_OK;  // "No map received for input loc"
+    bool good = false;
+    for (int dx = -4; dx <= 4 && !good; dx++)
+      for (int dy = -4; dy <= 4 && !good; dy++) {
+        uint32_t bits = 0;
+        TTRY(tdr_map_classes_at_point(m, (int)(p.init_pos_px_x + dx), (int)(p.init_pos_px_y + dy), &bits));
+        good = (bits & 2u) != 0;
+      }
+    if (!good) return TDR_OK;  // "No road in map at init location"
+  }
+  std::vector<tdr_state> states((size_t)f->n_max + 16);
+  int64_t n = 0;
+  TTRY(tdr_init_particles_host(f->rng, m->maps_host.data(), m->desc.ncls, m->desc.rows, m->desc.cols,
+                               m->desc.resolution, &p, (int)f->n_max, states.data(), &n));
+  n = std::min<int64_t>(n, f->n_max);
+  return tdr_filter_set_states(f, states.data(), n);
+}
+
+// ParticleFilter::propagate (particle_filter.cpp:86-92)
+int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_propagate: null filter");
+  if (f->n == 0) return TDR_OK;
+  const float* z = nullptr;
+  if (f->parity_rng) {
+    std::vector<float> zh((size_t)4 * f->n);
+    TTRY(tdr_propagate_normals_host(f->rng, f->n, f->scale_frozen ? 1 : 0, zh.data()));
+    HTRY(hipMemcpyAsync(f->z4.p, zh.data(), zh.size() * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HTRY(hipStreamSynchronize(f->stream));
+    z = f->z4.p;
+  }
+  return tdr_k_propagate(f->st.p, f->n_max, f->n, f->last_dist.p, tx, ty, omega, f->scale_frozen ? 1 : 0,
+                         f->fp.pos_cov, f->fp.theta_cov, z, f->seed, f->step, 0, f->stream);
+}
+
+// ParticleFilter::update (particle_filter.cpp:94-189).  scan_imgs: HOST [ncls][nb*nr] column-major images, or NULL to
+// score against `renderer`'s last render without a host round trip.  n_target < 0 keeps the particle count
+// (the adaptive count of :151-157 is an explicit input; the reference feeds it from an OpenCV EM thread).
+int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target) {
+  if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_update: no map");
+  if (f->n == 0) return TDR_OK;  // :96-99
+  tdr_map* m = f->map;
+  if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "filter_update: samplePtsPolar was never called");
+  f->fp.num_classes = m->desc.ncls;
+  const int ncls = m->desc.ncls, nb = m->nb, nr = m->nr;
+  const size_t P = (size_t)nb * nr;
+  const float* pk = nullptr;
+  if (scan_imgs) {
+    TTRY(f->scan_img.resize(P * ncls));
+    TTRY(f->scan_pk.resize(P * tdr_rec_floats(ncls)));
+    HTRY(hipMemcpyAsync(f->scan_img.p, scan_imgs, P * ncls * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    TTRY(tdr_k_pack_scan(f->scan_img.p, ncls, nb, nr, f->scan_pk.p, f->stream));
+    pk = f->scan_pk.p;
+  } else {
+    if (!renderer || !renderer->have_scan) return failh(TDR_ERR_ARG, "filter_update: no scan");
+    if (renderer->ncls != ncls || renderer->rows != nb || renderer->cols != nr)
+      return failh(TDR_ERR_ARG, "filter_update: render shape %dx%dx%d does not match the map's %dx%dx%d",
+                   renderer->ncls, renderer->rows, renderer->cols, ncls, nb, nr);
+    pk = renderer->pk.p;
+  }
+  const int64_t n = f->n;
+  const int32_t* perm = nullptr;
+  if (f->locality_every > 0) {
+    TTRY(f->loc_tmp.resize(tdr_locality_tmp_ints(n, m->desc.rows, m->desc.cols)));
+    TTRY(tdr_k_locality_order(f->st.p, f->n_max, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
+    perm = f->perm.p;
+  }
+  TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n)));
+  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->n_max, n, perm, f->uniform_scale,
+                         f->raw_w.p, f->ws.p, f->stream));
+  if (f->maybe_uninit) {
+    TTRY(tdr_k_score_polar_init(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->n_max, n, f->uniform_scale,
+                                f->raw_w.p, f->ws.p, f->stream));
+    if (!(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
+  }
+  TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
+  int64_t n_new = n;
+  if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));
+  const float shift = tdr_rng_uniform_host(f->rng);  // :172-173
+  TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->stream));
+  TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, 0, n_new, f->idx.p, f->stream));
+  TTRY(tdr_k_gather_states(f->st.p, f->n_max, 0, f->idx.p, n_new, f->st_new.p, f->n_max, f->stream));
+  // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state
+  float info[8];
+  HTRY(hipMemcpyAsync(info, f->info.p, sizeof(info), hipMemcpyDeviceToHost, f->stream));
+  HTRY(hipStreamSynchronize(f->stream));
+  int32_t best;
+  std::memcpy(&best, &info[0], 4);
+  float mlf[TDR_ST_FIELDS];
+  for (int k = 0; k < TDR_ST_FIELDS; k++)
+    HTRY(hipMemcpy(&mlf[k], f->st.p + (size_t)k * f->n_max + best, sizeof(float), hipMemcpyDeviceToHost));
+  f->ml_state = tdr_state{mlf[0], mlf[1], mlf[2], mlf[3], mlf[4], mlf[5], (uint8_t)(mlf[6] != 0.f), {0, 0, 0}};
+  std::swap(f->st.p, f->st_new.p);  // :187
+  f->n = n_new;
+  f->step++;
+  return TDR_OK;
+}
+
+int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n) {
+  if (!f || !out || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_get_weights: bad arguments");
+  HTRY(hipMemcpy(out, f->w.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+int tdr_filter_get_resample_indices(tdr_filter* f, int32_t* out, int64_t n) {
+  if (!f || !out || n < 0 || n > f->n) return failh(TDR_ERR_ARG, "filter_get_resample_indices: bad arguments");
+  HTRY(hipMemcpy(out, f->idx.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
+static void ml_of(const tdr_state& s, float out[4]) {  // StateParticle::mlState (state_particle.cpp:98-102)
+  out[0] = s.dx_m * s.scale + s.init_x_px;
+  out[1] = s.dy_m * s.scale + s.init_y_px;
+  out[2] = s.theta;
+  out[3] = s.scale;
+}
+
+// meanLikelihood + computeMeanCov (particle_filter.cpp:191-220); about_max != 0: maxLikelihood + computeCov (:222-236)
+int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[16]) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_mean_cov: null filter");
+  if (cov) std::memset(cov, 0, 16 * sizeof(float));
+  if (state) std::memset(state, 0, 4 * sizeof(float));
+  if (f->n < 1) return TDR_OK;  // :207-209
+  float out[24];
+  if (!about_max) {
+    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, nullptr, f->stats.p, f->stream));
+    HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
+    if (state) std::memcpy(state, out, 4 * sizeof(float));
+  } else {
+    float ref[4];
+    ml_of(f->ml_state, ref);
+    DevBuf<float> dref;
+    TTRY(dref.resize(4));
+    HTRY(hipMemcpy(dref.p, ref, sizeof(ref), hipMemcpyHostToDevice));
+    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, dref.p, f->stats.p, f->stream));
+    HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
+    if (state) std::memcpy(state, ref, sizeof(ref));
+  }
+  if (cov) std::memcpy(cov, out + 4, 16 * sizeof(float));
+  return TDR_OK;
+}
+
+// freezeScale (particle_filter.cpp:343-357)
+int tdr_filter_freeze_scale(tdr_filter* f) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_freeze_scale: null filter");
+  if (f->scale_frozen || f->n < 1) return TDR_OK;
+  TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, nullptr, f->stats.p, f->stream));
+  TTRY(tdr_k_set_scale(f->st.p, f->n_max, f->n, f->stats.p + 20, f->stream));
+  float gm = 0;
+  HTRY(hipMemcpy(&gm, f->stats.p + 20, sizeof(float), hipMemcpyDeviceToHost));
+  f->scale_frozen = true;
+  f->uniform_scale = gm;
+  return TDR_OK;
+}
+int tdr_filter_is_scale_frozen(const tdr_filter* f) { return f && f->scale_frozen; }
+// scale() (particle_filter.cpp:359-367)
+float tdr_filter_scale(tdr_filter* f) {
+  if (!f) return -1.f;
+  if (f->fp.fixed_scale > 0) return f->fp.fixed_scale;
+  if (f->scale_frozen && f->n > 0) {
+    float s = -1.f;
+    if (hipMemcpy(&s, f->st.p + (size_t)TDR_ST_SCALE * f->n_max, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    return s;
+  }
+  return -1.f;
+}
+int64_t tdr_filter_num_particles(const tdr_filter* f) { return f ? f->n : 0; }
+
+// ParticleFilter::updateMap (particle_filter.cpp:320-341), with the map already in distance-map form
+int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
+                          float resolution, int center_x, int center_y) {
+  if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map: null filter");
+  const int ox = f->map->center_x, oy = f->map->center_y;
+  TTRY(tdr_map_set(f->map, class_maps, class_mask, ncls, rows, cols, resolution, center_x, center_y));
+  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->n_max, f->n, (float)(center_x - ox), (float)(center_y - oy), f->stream);
+  return tdr_filter_initialize_particles(f);  // :337-340
+}
+
+}  // extern "C"

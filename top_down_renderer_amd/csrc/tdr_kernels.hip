@@ -57,6 +57,7 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* tdr_last_error(void) { return g_err; }
+extern "C" int tdr_set_error(int code, const char* msg) { return fail(code, "%s", msg ? msg : ""); }
 extern "C" int tdr_version(void) { return 100; }
 extern "C" int tdr_device_count(void) {
   int n = 0;
@@ -1172,7 +1173,7 @@ extern "C" int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t sr
 // ------------------------------------------------------------------------------------------------------------------
 // K6: pose statistics (particle_filter.cpp:191-236) + geometric-mean scale (:343-357).  Double accumulation.
 __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
-                                                       int64_t about_max, float* __restrict__ out) {
+                                                       const float* __restrict__ about, float* __restrict__ out) {
   __shared__ double shd[16];
   __shared__ float ref[4];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -1196,13 +1197,8 @@ __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict_
     for (int k = 0; k < 4; k++) out[k] = mean[k];
     out[20] = (float)exp(tot[6] / (double)n);  // freezeScale geo-mean
     out[21] = out[22] = out[23] = 0.f;
-    if (about_max >= 0) {
-      const int64_t q = about_max;
-      const float sc = st[TDR_ST_SCALE * cap + q];
-      ref[0] = st[TDR_ST_DX * cap + q] * sc + st[TDR_ST_INIT_X * cap + q];
-      ref[1] = st[TDR_ST_DY * cap + q] * sc + st[TDR_ST_INIT_Y * cap + q];
-      ref[2] = st[TDR_ST_THETA * cap + q];
-      ref[3] = sc;
+    if (about) {  // computeCov: about the max-likelihood particle's mlState (particle_filter.cpp:226-236)
+      for (int k = 0; k < 4; k++) ref[k] = about[k];
     } else {
       for (int k = 0; k < 4; k++) ref[k] = mean[k];
     }
@@ -1235,9 +1231,9 @@ __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict_
   }
 }
 
-extern "C" int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, int64_t about_max, float* out, void* stream) {
-  if (!st || !out || n < 1 || cap < n || about_max >= n) return fail(TDR_ERR_ARG, "mean_cov: bad arguments");
-  hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, st, cap, n, about_max, out);
+extern "C" int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, const float* about, float* out, void* stream) {
+  if (!st || !out || n < 1 || cap < n) return fail(TDR_ERR_ARG, "mean_cov: bad arguments");
+  hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, st, cap, n, about, out);
   LAUNCH_CHECK("mean_cov");
   return TDR_OK;
 }

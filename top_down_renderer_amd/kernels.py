@@ -135,9 +135,10 @@ class HipKernels:
         check(self.lib.tdr_k_gather_states(_ptr(src), src_cap, src_shard, _ptr(idx), n_new, _ptr(dst), dst.shape[1],
                                            self.stream()))
 
-    def mean_cov(self, st, n, about_max=-1):
+    def mean_cov(self, st, n, about=None):
+        """about: optional device tensor of 4 floats (computeCov about that mlState); None = about the mean."""
         out = self.empty((24,))
-        check(self.lib.tdr_k_mean_cov(_ptr(st), st.shape[1], n, about_max, _ptr(out), self.stream()))
+        check(self.lib.tdr_k_mean_cov(_ptr(st), st.shape[1], n, _ptr(about), _ptr(out), self.stream()))
         return out
 
     def set_scale(self, st, n, scale_dev):

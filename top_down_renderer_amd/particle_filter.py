@@ -168,10 +168,10 @@ class ParticleFilter:
         return self.k.states_to_host(self.st, self.n_local, STATE_DTYPE)
 
     def weights(self):
-        return self.weights_[: self._n_weights].cpu().numpy()
+        return self.weights_[: self._n_weights].cpu().numpy().copy()
 
     def raw_weights(self):
-        return self.raw_w[: self._n_raw].cpu().numpy()
+        return self.raw_w[: self._n_raw].cpu().numpy().copy()
 
     # ---- particle_filter.cpp:19-84 ----------------------------------------------------------------------------------
     def initializeParticles(self):
@@ -291,7 +291,7 @@ class ParticleFilter:
 
     def resample_indices(self):
         """Global source index of every particle of this rank's shard after the last update (for parity tests)."""
-        return self.idx[: self.n_local].cpu().numpy()
+        return self.idx[: self.n_local].cpu().numpy().copy()
 
     def _argmax(self):
         return int(self.info[:1].cpu().view(torch.int32).item())
@@ -308,13 +308,13 @@ class ParticleFilter:
 
     def meanLikelihood(self):
         st, n, _ = self._global_states()
-        return self.k.mean_cov(st, n, -1)[:4].cpu().numpy()
+        return self.k.mean_cov(st, n)[:4].cpu().numpy().copy()
 
     def computeMeanCov(self):
         if self.num_particles_ < 1:
             return np.zeros((4, 4), np.float32)
         st, n, _ = self._global_states()
-        return self.k.mean_cov(st, n, -1)[4:20].cpu().numpy().reshape(4, 4)
+        return self.k.mean_cov(st, n)[4:20].cpu().numpy().reshape(4, 4).copy()
 
     def maxLikelihood(self):
         st_all, nl, st_old = self._ml_src
@@ -327,10 +327,16 @@ class ParticleFilter:
         sc = np.float32(s[5])
         return np.asarray([np.float32(s[2] * sc + s[0]), np.float32(s[3] * sc + s[1]), s[4], sc], np.float32)
 
+    def computeCov(self):
+        """particle_filter.cpp:226-236: covariance about the max-likelihood particle."""
+        st, n, _ = self._global_states()
+        ref = self.k.to_device(self.maxLikelihood())
+        return self.k.mean_cov(st, n, about=ref)[4:20].cpu().numpy().reshape(4, 4).copy()
+
     def freezeScale(self):
         if not self.scale_frozen_:
             st, n, _ = self._global_states()
-            out = self.k.mean_cov(st, n, -1)
+            out = self.k.mean_cov(st, n)
             self.k.set_scale(self.st, self.n_local, out[20:21])
             self.scale_frozen_ = True
             self._uniform_scale = float(out[20].item())
