@@ -137,14 +137,19 @@ int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int ro
                             const tdr_filter_params* fp, int max_num, tdr_state* out, int64_t* n_out);
 
 /* ---- ParticleFilter::update, weight statistics (src/particle_filter.cpp:107-147) ---------------------------- */
-/* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, 8 floats):
- * {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}. */
+/* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, TDR_UW_INFO_FLOATS floats: the first 8
+ * are {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}, the rest is scratch for
+ * the multi-workgroup reductions).  The result is a pure function of (raw_w, last_dist, n). */
+#define TDR_UW_INFO_FLOATS 8192
 int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out, float* info_out,
                          void* stream);
 
 /* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
 /* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum. */
 int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream);
+/* Same, choosing the implementation: mode 0 = one wave adding in index order, 1 = the exact parallel kernel (integer
+ * increments per binade, see tdr_kernels.hip); both give identical bits.  prefix_out (optional, mode 1) = raw sums. */
+int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out, void* stream);
 /* idx_out[i - i_begin] = first j with prefix_j > (float(i)+shift)/n_new, else n-1, for i in [i_begin, i_end). */
 int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, int64_t i_begin, int64_t i_end,
                    int32_t* idx_out, void* stream);

@@ -293,7 +293,7 @@ def test_update_weights_vs_oracle(tdr, oracle, g):
     for raw, ld in cases:
         n = len(raw)
         w = k.zeros((n,))
-        info = k.zeros((8,))
+        info = k.zeros((8192,))
         k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
         ref, best, stats = oracle.update_weights(raw, ld)
         got = w.cpu().numpy()
@@ -319,6 +319,91 @@ def test_resample_bit_exact(tdr, oracle, g):
         ref = oracle.resample_prefix(w, n_new, shift)
         assert np.array_equal(idx.cpu().numpy(), ref)
     assert np.array_equal(oracle.resample_literal(g["upd_weights"], 32, 0.37), g["resample_idx_32"])
+
+
+def _prefix_cases():
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    cases = {}
+    for n in (1, 7, 1000, 100_000):
+        w = rng.random(n).astype(f32) ** 3
+        cases[f"random^3 n={n}"] = (w / w.sum()).astype(f32)
+    cases["uniform 1/N"] = np.full(100_000, f32(1e-5))
+    cases["power of two"] = np.full(65_536, f32(2.0 ** -16))
+    cases["ties forced"] = np.tile(np.asarray([1.0, 2.0 ** -24, 2.0 ** -24, 3 * 2.0 ** -25], f32), 5000)
+    cases["half-ulp spam"] = np.concatenate([[f32(1.0)], np.full(20_000, f32(2.0 ** -24))])
+    cases["zeros then data"] = np.concatenate([np.zeros(9000, f32), rng.random(5000).astype(f32) * f32(1e-4),
+                                               np.zeros(100, f32)])
+    cases["negatives"] = ((rng.random(20_000).astype(f32) - f32(0.2)) * f32(1e-4)).astype(f32)
+    cases["nan-fill negative"] = np.where(rng.random(60_000) < 0.1, f32(-3e-6), rng.random(60_000).astype(f32) * 4e-5).astype(f32)
+    cases["wide dynamic range"] = (10.0 ** rng.uniform(-12, -2, 50_000)).astype(f32)
+    cases["subnormals"] = (rng.random(3000) * 1e-41).astype(f32)
+    cases["big then small"] = np.concatenate([[f32(1e30)], rng.random(3000).astype(f32)])
+    cases["nan inside"] = np.concatenate([rng.random(9000).astype(f32), [f32(np.nan)], rng.random(300).astype(f32)])
+    cases["inf inside"] = np.concatenate([rng.random(9000).astype(f32), [f32(np.inf)], rng.random(300).astype(f32)])
+    w = rng.random(1_000_000).astype(f32) ** 4
+    cases["1M random^4"] = (w / w.sum()).astype(f32)
+    return cases
+
+
+def test_exact_parallel_prefix_is_the_serial_float_chain(tdr):
+    """tdr_k_prefix_mode: the parallel kernel (integer increments per binade) and the one-wave serial kernel must both
+    reproduce `running_sum += weights_[j]` (particle_filter.cpp:179) bit for bit, including rounding ties, zero runs,
+    negative weights, NaN/inf and binade crossings."""
+    pkg, k = tdr
+    import ctypes as C
+    for name, w in _prefix_cases().items():
+        n = len(w)
+        with np.errstate(over="ignore", invalid="ignore"):
+            ref = np.cumsum(w, dtype=np.float32)                      # sequential float32 accumulation
+            refmax = np.maximum.accumulate(np.where(np.isnan(ref), -np.inf, ref)).astype(np.float32)
+        wd = k.to_device(w)
+        for mode in (0, 1):
+            rm, pf = k.zeros((n,)), k.zeros((n,))
+            assert k.lib.tdr_k_prefix_mode(C.c_void_p(wd.data_ptr()), n, mode, C.c_void_p(rm.data_ptr()),
+                                           C.c_void_p(pf.data_ptr()) if mode else None, k.stream()) == 0
+            assert np.array_equal(rm.cpu().numpy(), refmax), (name, mode)
+            if mode:
+                assert np.array_equal(pf.cpu().numpy(), ref, equal_nan=True), name
+        rm = k.zeros((n,))
+        k.prefix(wd, n, rm)                                           # the dispatching entry point
+        assert np.array_equal(rm.cpu().numpy(), refmax), name
+
+
+def test_update_weights_large_n_multi_workgroup(tdr, oracle):
+    pkg, k = tdr
+    rng = np.random.default_rng(8)
+    n = 300_000
+    raw = (rng.random(n).astype(np.float32) * 6 + 0.5)
+    raw[rng.random(n) < 0.03] = np.nan
+    raw[rng.random(n) < 0.01] = 0.0
+    ld = rng.random(n).astype(np.float32) * 0.4
+    w, info = k.zeros((n,)), k.zeros((8192,))
+    k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
+    ref, best, stats = oracle.update_weights(raw, ld)
+    got = w.cpu().numpy()
+    # Valid particles: only the normalisation sums differ (Eigen's order is unspecified anyway).  NaN-filled particles
+    # carry mean - bottom_stddev, which the reference accumulates in a 150k-term serial FLOAT chain
+    # (particle_filter.cpp:118-126) whose own rounding error is ~sqrt(n)*2^-24 = 3e-5; the GPU accumulates in double.
+    valid = ~np.isnan(raw)
+    assert np.allclose(got[valid], ref[valid], rtol=3e-6, atol=0)
+    assert np.allclose(got[~valid], ref[~valid], rtol=2e-4, atol=0)
+    assert int(info[:1].cpu().view(__import__("torch").int32).item()) == best
+    # `sum`/`mean` are serial float chains in the reference too (:108-117): ~1e-5 of their own rounding at n = 300k
+    assert np.allclose(info[1:3].cpu().numpy(), stats[:2], rtol=5e-5)
+    assert np.allclose(info[3:4].cpu().numpy(), stats[2:3], rtol=2e-4)
+    exact_sum = raw[valid].astype(np.float64).sum()
+    assert abs(float(info[1].item()) - exact_sum) <= abs(float(stats[0]) - exact_sum) + 0.5   # closer to exact
+    exact_bottom = np.sqrt(((raw[valid & (raw < stats[1])].astype(np.float64) - float(stats[1])) ** 2).mean())
+    assert abs(float(info[3].item()) - exact_bottom) <= abs(float(stats[2]) - exact_bottom) + 1e-7  # closer to exact
+    # determinism: same inputs, same bits
+    w2, info2 = k.zeros((n,)), k.zeros((8192,))
+    k.update_weights(k.to_device(raw), k.to_device(ld), n, w2, info2)
+    assert np.array_equal(got, w2.cpu().numpy())
+    # all-NaN at large n: all-ones fallback
+    w3 = k.zeros((n,))
+    k.update_weights(k.to_device(np.full(n, np.nan, np.float32)), k.to_device(ld), n, w3, info2)
+    assert np.allclose(w3.cpu().numpy(), 1.0 / n, rtol=1e-5)
 
 
 def test_gather_states_and_aos_roundtrip(tdr, g):

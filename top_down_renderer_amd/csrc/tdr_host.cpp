@@ -237,7 +237,7 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
   if (rc == TDR_OK) rc = f->runmax.resize(cap);
   if (rc == TDR_OK) rc = f->idx.resize(cap);
   if (rc == TDR_OK) rc = f->perm.resize(cap);
-  if (rc == TDR_OK) rc = f->info.resize(8);
+  if (rc == TDR_OK) rc = f->info.resize(TDR_UW_INFO_FLOATS);
   if (rc == TDR_OK) rc = f->stats.resize(24);
   if (rc == TDR_OK) rc = f->aos.resize(cap);
   if (rc == TDR_OK) rc = f->z4.resize(4 * cap);

@@ -1037,24 +1037,213 @@ __global__ __launch_bounds__(1024) void update_weights_kernel(const float* __res
   }
 }
 
+// Multi-workgroup form of the same statistics for large n: five grid-wide passes, each workgroup reducing its own
+// contiguous chunk in a fixed order and every workgroup re-reducing the G per-workgroup partials in index order, so
+// the result is again a pure function of (raw_w, last_dist, n) — identical on every rank — without grid barriers.
+// Scratch lives behind the 8 info floats (TDR_UW_INFO_FLOATS in total).
+#define UW_G 256
+struct UwScratch {
+  double a[UW_G];
+  double b[UW_G];
+};
+__device__ __forceinline__ void uw_chunk(int64_t n, int64_t& lo, int64_t& hi) {
+  const int64_t per = (n + UW_G - 1) / UW_G;
+  lo = (int64_t)blockIdx.x * per;
+  hi = lo + per < n ? lo + per : n;
+  if (lo > n) lo = n;
+}
+// Sum of the UW_G per-workgroup partials in index order (same order in every workgroup -> same value everywhere).
+// Staged through LDS so the dependent additions do not each wait on a global load.
+__device__ double uw_total(const double* part) {
+  __shared__ double stage[UW_G];
+  __shared__ double result;
+  __syncthreads();
+  for (int g = threadIdx.x; g < UW_G; g += blockDim.x) stage[g] = part[g];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int g = 0; g < UW_G; g++) t += stage[g];
+    result = t;
+  }
+  __syncthreads();
+  return result;
+}
+// pass 1: sum / count of the valid raw weights (:108-116)
+__global__ __launch_bounds__(256) void uw_pass1(const float* __restrict__ raw, int64_t n, UwScratch* s1) {
+  __shared__ double shd[4];
+  __shared__ long long shl[4];
+  int64_t lo, hi;
+  uw_chunk(n, lo, hi);
+  double s = 0;
+  long long c = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = raw[i];
+    if (!isnan(v)) { s += (double)v; c++; }
+  }
+  const double ts = block_sum_d(s, shd);
+  const long long tc = block_sum_ll(c, shl);
+  if (threadIdx.x == 0) { s1->a[blockIdx.x] = ts; s1->b[blockIdx.x] = (double)tc; }
+}
+// pass 2: squared deviations of the weights below the mean (:118-125)
+__global__ __launch_bounds__(256) void uw_pass2(const float* __restrict__ raw, int64_t n, const UwScratch* s1,
+                                                UwScratch* s2) {
+  __shared__ double shd[4];
+  __shared__ long long shl[4];
+  const float sum = (float)uw_total(s1->a);
+  const float mean = sum / (float)(long long)uw_total(s1->b);
+  int64_t lo, hi;
+  uw_chunk(n, lo, hi);
+  double bs = 0;
+  long long cu = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = raw[i];
+    if (!isnan(v) && v < mean) {
+      const double d = (double)(v - mean);
+      bs += d * d;
+      cu++;
+    }
+  }
+  const double tb = block_sum_d(bs, shd);
+  const long long tc = block_sum_ll(cu, shl);
+  if (threadIdx.x == 0) { s2->a[blockIdx.x] = tb; s2->b[blockIdx.x] = (double)tc; }
+}
+// pass 3: NaN fill / all-ones fallback (:129-134) and the first normalisation sum
+__global__ __launch_bounds__(256) void uw_pass3(const float* __restrict__ raw, int64_t n, const UwScratch* s1,
+                                                const UwScratch* s2, UwScratch* s3, float* __restrict__ w) {
+  __shared__ double shd[4];
+  const float sum = (float)uw_total(s1->a);
+  const float mean = sum / (float)(long long)uw_total(s1->b);
+  const long long num_under = (long long)uw_total(s2->b);
+  const float bottom = sqrtf((float)uw_total(s2->a) / (float)num_under);
+  const bool fallback = (sum == 0.f || num_under < 1);
+  const float fill = mean - bottom;
+  int64_t lo, hi;
+  uw_chunk(n, lo, hi);
+  double acc = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    float v = raw[i];
+    v = fallback ? 1.f : (isnan(v) ? fill : v);
+    w[i] = v;
+    acc += (double)v;
+  }
+  const double t = block_sum_d(acc, shd);
+  if (threadIdx.x == 0) s3->a[blockIdx.x] = t;
+}
+// pass 4: normalise (:135), motion regularisation (:138-141), second normalisation sum
+__global__ __launch_bounds__(256) void uw_pass4(const float* __restrict__ last_dist, int64_t n, const UwScratch* s3,
+                                                UwScratch* s4, float* __restrict__ w) {
+  __shared__ double shd[4];
+  const float fs1 = (float)uw_total(s3->a);
+  const float fn = (float)n;
+  int64_t lo, hi;
+  uw_chunk(n, lo, hi);
+  double acc = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    float v = w[i] / fs1;
+    const float d = fminf(last_dist[i] * 5.f, 1.f);
+    v = d * v + (1.f - d) / fn;
+    w[i] = v;
+    acc += (double)v;
+  }
+  const double t = block_sum_d(acc, shd);
+  if (threadIdx.x == 0) s4->a[blockIdx.x] = t;
+}
+// pass 5: final normalisation (:142) and per-workgroup first maximum (:145-147)
+__global__ __launch_bounds__(256) void uw_pass5(int64_t n, const UwScratch* s4, UwScratch* s5, float* __restrict__ w) {
+  __shared__ float sb[4];
+  __shared__ long long si[4];
+  const float fs2 = (float)uw_total(s4->a);
+  int64_t lo, hi;
+  uw_chunk(n, lo, hi);
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffll;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = w[i] / fs2;
+    w[i] = v;
+    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_down(best, o, 64);
+    const long long oi = __shfl_down(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; k++)
+      if (sb[k] > best || (sb[k] == best && si[k] < besti)) { best = sb[k]; besti = si[k]; }
+    s5->a[blockIdx.x] = (double)best;
+    s5->b[blockIdx.x] = (double)besti;  // exact: indices < 2^53
+  }
+}
+__global__ __launch_bounds__(256) void uw_pass6(int64_t n, const UwScratch* s1, const UwScratch* s2,
+                                                const UwScratch* s5, float* info) {
+  __shared__ float sb[UW_G];
+  __shared__ long long si[UW_G];
+  for (int g = threadIdx.x; g < UW_G; g += blockDim.x) { sb[g] = (float)s5->a[g]; si[g] = (long long)s5->b[g]; }
+  const float sum = (float)uw_total(s1->a);
+  const long long nv = (long long)uw_total(s1->b), nu = (long long)uw_total(s2->b);
+  const float mean = sum / (float)nv;
+  const float bottom = sqrtf((float)uw_total(s2->a) / (float)nu);
+  if (threadIdx.x != 0) return;
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffll;
+  for (int g = 0; g < UW_G; g++)
+    if (sb[g] > best || (sb[g] == best && si[g] < besti)) { best = sb[g]; besti = si[g]; }
+  if (besti == 0x7fffffffffffffffll) besti = 0;
+  info[0] = __int_as_float((int)besti);
+  info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = (sum == 0.f || nu < 1) ? 1.f : 0.f;
+  info[5] = (float)nv; info[6] = (float)nu; info[7] = 0.f;
+}
+
+#define TDR_UW_SINGLE_MAX_N 32768
 extern "C" int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out,
                                     float* info_out, void* stream) {
   if (!raw_w || !last_dist || !w_out || !info_out) return fail(TDR_ERR_ARG, "update_weights: null pointer");
   if (n < 1) return fail(TDR_ERR_ARG, "update_weights: n must be >= 1");
-  hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, raw_w, last_dist, n, w_out,
-                     info_out);
-  LAUNCH_CHECK("update_weights");
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= TDR_UW_SINGLE_MAX_N) {
+    hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(1024), 0, s, raw_w, last_dist, n, w_out, info_out);
+    LAUNCH_CHECK("update_weights");
+    return TDR_OK;
+  }
+  static_assert(8 * sizeof(float) + 5 * sizeof(UwScratch) + 64 <= TDR_UW_INFO_FLOATS * sizeof(float), "info scratch");
+  UwScratch* sc = reinterpret_cast<UwScratch*>(
+      (reinterpret_cast<uintptr_t>(info_out + 8) + 63) & ~(uintptr_t)63);
+  hipLaunchKernelGGL(uw_pass1, dim3(UW_G), dim3(256), 0, s, raw_w, n, sc + 0);
+  hipLaunchKernelGGL(uw_pass2, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwScratch*)(sc + 0), sc + 1);
+  hipLaunchKernelGGL(uw_pass3, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwScratch*)(sc + 0),
+                     (const UwScratch*)(sc + 1), sc + 2, w_out);
+  hipLaunchKernelGGL(uw_pass4, dim3(UW_G), dim3(256), 0, s, last_dist, n, (const UwScratch*)(sc + 2), sc + 3, w_out);
+  hipLaunchKernelGGL(uw_pass5, dim3(UW_G), dim3(256), 0, s, n, (const UwScratch*)(sc + 3), sc + 4, w_out);
+  hipLaunchKernelGGL(uw_pass6, dim3(1), dim3(256), 0, s, n, (const UwScratch*)(sc + 0), (const UwScratch*)(sc + 1),
+                     (const UwScratch*)(sc + 4), info_out);
+  LAUNCH_CHECK("update_weights(multi)");
   return TDR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K5: resample.  The running sum of particle_filter.cpp:179 is a serial float32 chain: reproduced by one wave that
-// loads 64 weights at a time (coalesced) and adds them in index order; every lane carries the same running value,
-// lane k stops after element k so it ends up holding prefix_k.  The running maximum makes "first j with
-// prefix_j > sample" searchable even when weights are negative (NaN fill, :133).
+// K5: resample.  The running sum of particle_filter.cpp:179 is a serial float32 chain,
+//     prefix_j = fl(prefix_{j-1} + w_j),
+// and "bit-exact resample indices" needs exactly these values.  Two kernels produce them:
+//
+//  * prefix_serial_kernel — one wave, lane 0 performs the additions in index order (weights staged through LDS).
+//    Simple, ~10 ns per element; kept as the reference implementation and for small n.
+//  * prefix_exact_kernel — the same values computed in parallel.  While the running sum r stays inside one binade
+//    [2^e, 2^(e+1)) it is an integer multiple R*u of u = 2^(e-23) and fl(r + w) = (R + q)*u, where q is w/u rounded
+//    to nearest — a pure integer increment that depends on r only when w/u ends in exactly .5 (tie to even: the parity
+//    of R + floor(w/u)).  So per tile of 4096 weights the workgroup (i) classifies every weight into an integer
+//    increment / tie / "needs a real float add" (NaN, inf, larger than the binade), (ii) prefix-sums the increments,
+//    (iii) resolves the (rare) ties in order on one thread, (iv) prefix-sums the tie corrections, (v) finds the first
+//    element at which the sum leaves the binade or a real add is needed, commits everything before it, performs that
+//    one addition in float arithmetic and restarts behind it in the new binade.  A running sum of 1 crosses ~24
+//    binades, so a million weights take a few hundred workgroup passes instead of a million dependent additions.
+//    tests/test_gpu_parity.py compares both kernels with the CPU chain bit for bit on random and adversarial inputs.
+//
+// The running maximum makes "first j with prefix_j > sample" searchable even when weights are negative (NaN fill, :133).
 #define TDR_PFX_BLOCK 4096  // elements staged in LDS per pass (64 per lane)
-__global__ __launch_bounds__(64) void prefix_kernel(const float* __restrict__ w, int64_t n,
-                                                    float* __restrict__ runmax) {
+__global__ __launch_bounds__(64) void prefix_serial_kernel(const float* __restrict__ w, int64_t n,
+                                                           float* __restrict__ runmax) {
   __shared__ float4 buf4[TDR_PFX_BLOCK / 4];
   float* buf = reinterpret_cast<float*>(buf4);
   const int lane = threadIdx.x;
@@ -1111,10 +1300,339 @@ __global__ __launch_bounds__(64) void prefix_kernel(const float* __restrict__ w,
   }
 }
 
+// ---- exact parallel prefix -------------------------------------------------------------------------------------------
+#define PFX_THREADS 1024
+#define PFX_K 8
+#define PFX_TILE (PFX_THREADS * PFX_K)
+#define PFX_TIE_CAP 2048   // ties resolved per pass; a (never observed) denser tile is simply cut at that tie
+#define PFX_HEAD 2048      // leading elements added one by one: the running sum crosses most of its binades here
+
+// inclusive block scan (sum) of one value per thread; `sh` holds one slot per wave
+template <class T>
+__device__ __forceinline__ T pfx_block_scan(T v, T* sh, T& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  __syncthreads();
+  if (lane == 63) sh[wave] = v;
+  __syncthreads();
+  T off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < PFX_THREADS / 64; k++) {
+    const T x = sh[k];
+    if (k < wave) off += x;
+    tot += x;
+  }
+  total = tot;
+  return v + off;
+}
+__device__ __forceinline__ float pfx_block_scan_max(float v, float* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v = fmaxf(v, t);
+  }
+  __syncthreads();
+  if (lane == 63) sh[wave] = v;
+  __syncthreads();
+  float off = -INFINITY;
+  for (int k = 0; k < wave; k++) off = fmaxf(off, sh[k]);
+  return fmaxf(v, off);
+}
+
+__global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* __restrict__ w, int64_t n,
+                                                                   float* __restrict__ runmax,
+                                                                   float* __restrict__ prefix_opt) {
+  __shared__ long long sh_ll[PFX_THREADS / 64];
+  __shared__ int sh_i[PFX_THREADS / 64];
+  __shared__ float sh_f[PFX_THREADS / 64];
+  __shared__ int tie_pos[PFX_TIE_CAP];         // local element index of every tie in order, weight sign in bit 31
+  __shared__ long long tie_sval[PFX_TIE_CAP];  // inclusive increment prefix at the tie
+  __shared__ signed char tie_corr[PFX_TIE_CAP];
+  __shared__ float head[PFX_HEAD];
+  __shared__ float last_val[PFX_THREADS], last_max[PFX_THREADS];
+  __shared__ int s_first_bad, s_first_cross, s_first_nz;
+  __shared__ float s_r, s_carry;
+  __shared__ long long s_base;
+  const int tid = threadIdx.x;
+  {  // head: plain serial additions by one thread out of LDS
+    const int hn = (int)min((long long)PFX_HEAD, (long long)n);
+    for (int t = tid; t < hn; t += PFX_THREADS) head[t] = w[t];
+    __syncthreads();
+    if (tid == 0) {
+      float run = 0.f, mx = -INFINITY;
+      for (int t = 0; t < hn; t++) {
+        run = run + head[t];  // particle_filter.cpp:179
+        if (prefix_opt) prefix_opt[t] = run;
+        if (run == run) mx = fmaxf(mx, run);
+        head[t] = mx;
+      }
+      s_r = run; s_carry = mx; s_base = hn;
+    }
+    __syncthreads();
+    for (int t = tid; t < hn; t += PFX_THREADS) runmax[t] = head[t];
+    __syncthreads();
+  }
+
+  while (true) {
+    const long long base = s_base;
+    if (base >= n) break;
+    const float r = s_r;
+    const float carry = s_carry;
+    const int cnt = (int)min((long long)PFX_TILE, (long long)n - base);
+    const unsigned rb = __float_as_uint(r);
+    const int re = (rb >> 23) & 0xFF;
+    float wv[PFX_K];
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      wv[k] = (li < cnt) ? w[base + li] : 0.f;
+    }
+    if (tid == 0) { s_first_bad = PFX_TILE; s_first_cross = PFX_TILE; s_first_nz = PFX_TILE; }
+    __syncthreads();  // also: everyone has read s_r / s_carry / s_base
+
+    if (r != r) {  // NaN running sum: every later prefix is NaN, the running maximum stays
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        const int li = tid * PFX_K + k;
+        if (li < cnt) {
+          runmax[base + li] = carry;
+          if (prefix_opt) prefix_opt[base + li] = r;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_base = base + cnt;
+      __syncthreads();
+      continue;
+    }
+    const bool r_zero = (rb & 0x7FFFFFFFu) == 0;
+    const bool r_slow = (rb >> 31) != 0 || re == 0 || re == 255;  // negative, zero / subnormal, inf: plain float steps
+    if (r_slow) {
+      int stop = 0;  // leading elements that leave r unchanged (r == +-0 only: skip the run of zero weights)
+      if (r_zero) {
+#pragma unroll
+        for (int k = 0; k < PFX_K; k++) {
+          const int li = tid * PFX_K + k;
+          if (li < cnt && (__float_as_uint(wv[k]) & 0x7FFFFFFFu) != 0) atomicMin(&s_first_nz, li);
+        }
+        __syncthreads();
+        stop = min(s_first_nz, cnt);
+      }
+      const float m0 = fmaxf(carry, r);
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        const int li = tid * PFX_K + k;
+        if (li < stop) {
+          runmax[base + li] = m0;
+          if (prefix_opt) prefix_opt[base + li] = r;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float nr = r, nc = stop > 0 ? m0 : carry;
+        long long nb = base + stop;
+        if (stop < cnt) {  // one real float addition (particle_filter.cpp:179)
+          nr = r + w[base + stop];
+          if (nr == nr) nc = fmaxf(nc, nr);
+          runmax[base + stop] = nc;
+          if (prefix_opt) prefix_opt[base + stop] = nr;
+          nb = base + stop + 1;
+        }
+        s_r = nr; s_carry = nc; s_base = nb;
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // ---- r is a positive normal float: r = R * 2^(e-23), R in [2^23, 2^24)
+    const int e = re - 127;
+    const long long R = (long long)((rb & 0x7FFFFFu) | 0x800000u);
+    long long inc[PFX_K];
+    bool tie[PFX_K], neg[PFX_K];
+    long long tsum = 0;
+    int ntie = 0;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      const unsigned b = __float_as_uint(wv[k]);
+      const int ew = (b >> 23) & 0xFF;
+      unsigned mw = b & 0x7FFFFFu;
+      const bool zero = (b & 0x7FFFFFFFu) == 0;
+      const int E = ew == 0 ? -126 : ew - 127;
+      if (ew != 0) mw |= 0x800000u;
+      const int sft = e - E;
+      const bool in = li < cnt;
+      const bool bad = in && ((ew == 255) || (sft < 0));  // NaN / inf / at least as large as the binade: real add
+      neg[k] = (b >> 31) != 0 && !zero;
+      const int sc = sft < 0 ? 0 : (sft > 26 ? 26 : sft);
+      const unsigned f = mw >> sc;
+      const unsigned rem = mw & ((1u << sc) - 1u);
+      const unsigned half = sc >= 1 ? (1u << (sc - 1)) : 0u;
+      const bool up = sc >= 1 && rem > half;
+      tie[k] = in && !bad && sc >= 1 && rem == half;
+      long long q = (long long)f + (up ? 1 : 0);  // |w|/u rounded to nearest (ties toward zero, patched below)
+      if (neg[k]) q = -q;
+      if (!in || bad) q = 0;
+      if (bad) atomicMin(&s_first_bad, li);
+      inc[k] = q;
+      tsum += q;
+      ntie += tie[k] ? 1 : 0;
+    }
+    long long tot_ll;
+    const long long sincl = pfx_block_scan<long long>(tsum, sh_ll, tot_ll);
+    long long S[PFX_K];  // inclusive prefix of the increments at this thread's elements
+    {
+      long long acc = sincl - tsum;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) { acc += inc[k]; S[k] = acc; }
+    }
+    // ---- ties, in element order: the even neighbour wins, which depends on everything before the tie
+    int tot_tie;
+    const int tincl = pfx_block_scan<int>(ntie, sh_i, tot_tie);
+    const int tfirst = tincl - ntie;
+    {
+      int pos = tfirst;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++)
+        if (tie[k]) {
+          if (pos < PFX_TIE_CAP) {
+            tie_pos[pos] = (tid * PFX_K + k) | (neg[k] ? (int)0x80000000 : 0);
+            tie_sval[pos] = S[k];
+          } else if (pos == PFX_TIE_CAP) {
+            atomicMin(&s_first_bad, tid * PFX_K + k);  // more ties than slots: cut the tile here
+          }
+          pos++;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && tot_tie > 0) {
+      long long c = 0;
+      const int fb = s_first_bad;
+      const int nt = min(tot_tie, PFX_TIE_CAP);
+      for (int t = 0; t < nt; t++) {
+        const int pk = tie_pos[t];
+        const int li = pk & 0x7FFFFFFF;
+        signed char corr = 0;
+        if (li < fb) {
+          const long long V = R + tie_sval[t] + c;  // mantissa if the tie is rounded toward zero
+          if (V & 1) corr = (pk < 0) ? -1 : 1;      // exact value is V +- 1/2: move to the even neighbour
+        }
+        tie_corr[t] = corr;
+        c += corr;
+      }
+    }
+    __syncthreads();
+    int csum = 0;
+    int corr[PFX_K];
+    {
+      int pos = tfirst;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        corr[k] = 0;
+        if (tie[k]) { corr[k] = pos < PFX_TIE_CAP ? tie_corr[pos] : 0; pos++; }
+        csum += corr[k];
+      }
+    }
+    int tot_c;
+    const int cincl = pfx_block_scan<int>(csum, sh_i, tot_c);
+    // ---- mantissas, first element that leaves the binade
+    long long state[PFX_K];
+    {
+      int cacc = cincl - csum;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        cacc += corr[k];
+        state[k] = R + S[k] + cacc;
+        const int li = tid * PFX_K + k;
+        if (li < cnt && (state[k] >= (1ll << 24) || state[k] < (1ll << 23))) atomicMin(&s_first_cross, li);
+      }
+    }
+    __syncthreads();
+    const int stop = min(min(s_first_bad, s_first_cross), cnt);
+    // ---- commit [0, stop): values and running maximum
+    float val[PFX_K], lm[PFX_K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      val[k] = __uint_as_float(((unsigned)re << 23) | ((unsigned)state[k] & 0x7FFFFFu));
+      if (li < stop) m = fmaxf(m, val[k]);
+      lm[k] = m;
+    }
+    const float mincl = pfx_block_scan_max(m, sh_f);
+    float mexcl = __shfl_up(mincl, 1, 64);
+    {  // exclusive maximum over the preceding threads
+      __syncthreads();
+      last_max[tid] = mincl;
+      __syncthreads();
+      mexcl = tid > 0 ? last_max[tid - 1] : -INFINITY;
+    }
+    const float mbase = fmaxf(carry, mexcl);
+    float lastv = r, lastm = carry;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      if (li < stop) {
+        const float rm = fmaxf(mbase, lm[k]);
+        runmax[base + li] = rm;
+        if (prefix_opt) prefix_opt[base + li] = val[k];
+        lastv = val[k];
+        lastm = rm;
+      }
+    }
+    __syncthreads();
+    last_val[tid] = lastv;   // value / running max at this thread's last committed element (if any)
+    last_max[tid] = lastm;
+    __syncthreads();
+    if (tid == 0) {
+      float pv = r, pm = carry;  // value / running max at element stop-1
+      if (stop > 0) {
+        const int ot = (stop - 1) / PFX_K;
+        pv = last_val[ot];
+        pm = last_max[ot];
+      }
+      long long nb = base + stop;
+      if (stop < cnt) {  // one real float addition, then a new binade
+        const float nr = pv + w[base + stop];
+        if (nr == nr) pm = fmaxf(pm, nr);
+        runmax[base + stop] = pm;
+        if (prefix_opt) prefix_opt[base + stop] = nr;
+        pv = nr;
+        nb = base + stop + 1;
+      }
+      s_r = pv; s_carry = pm; s_base = nb;
+    }
+    __syncthreads();
+  }
+}
+
+// n below this: the single-wave serial kernel is faster than the workgroup passes
+#define TDR_PFX_EXACT_MIN_N 16384
 extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
-  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  if (n < TDR_PFX_EXACT_MIN_N)
+    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  else
+    hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
+                       (float*)nullptr);
   LAUNCH_CHECK("prefix");
+  return TDR_OK;
+}
+// Test / diagnostic entry: mode 0 = serial kernel, 1 = exact parallel kernel; prefix_out (optional) receives the raw
+// running sums (only from mode 1).
+extern "C" int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out,
+                                 void* stream) {
+  if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix_mode: bad arguments");
+  if (mode == 0)
+    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  else
+    hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
+                       prefix_out);
+  LAUNCH_CHECK("prefix_mode");
   return TDR_OK;
 }
 
