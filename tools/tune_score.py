@@ -61,20 +61,20 @@ def main():
             "morton1px": np.argsort(morton(row, col), kind="stable"),
             "morton.5px": np.argsort(morton(np.clip(np.floor(cy * 2), 0, 8191).astype(np.int64), np.clip(np.floor(cx * 2), 0, 8191).astype(np.int64)), kind="stable"),
         }
-        for loc in ((False, True) if "quick" in sys.argv else (False, True, "rowmajor1px", "morton1px", "morton.5px")):
+        for loc in ((True,) if "sorted" in sys.argv else (False, True) if "quick" in sys.argv else (False, True, "rowmajor1px", "morton1px", "morton.5px")):
             if loc is True:
                 k.locality_order(st, n, m.rows, m.cols, perm)
             elif isinstance(loc, str):
                 perm.copy_(torch.from_numpy(host_perms[loc].astype(np.int32)))
             ts = []
-            for rep in range(4):
+            for rep in range(5):
                 k.lib.tdr_profile_enable(1)
                 k.score(m.dev, scan, cfg.res, fp, st, n, raw, perm=perm if loc else None, uniform_scale=USC)
                 tot, cnt = C.c_double(0), C.c_int64(0)
                 k.lib.tdr_profile_score_ms(C.byref(tot), C.byref(cnt))
                 ts.append(tot.value)
             k.lib.tdr_profile_enable(0)
-            print(f"{sname:14s} locality={str(loc):12s}  score kernel ms: " + " ".join(f"{t:7.2f}" for t in ts), flush=True)
+            print(f"{sname:14s} locality={str(loc):12s}  score kernel ms: " + " ".join(f"{t:7.2f}" for t in ts) + f"   min {min(ts):7.2f}", flush=True)
 
 
 if __name__ == "__main__":

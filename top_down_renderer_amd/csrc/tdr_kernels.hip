@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -31,8 +32,11 @@
 #ifndef TDR_SCORE_U
 #define TDR_SCORE_U 4          // samples whose loads are kept in flight together in the scoring loop
 #endif
-#ifndef TDR_RPI_FIX_BELOW_HALF
-#define TDR_RPI_FIX_BELOW_HALF 1  // patch v_cvt_rpi_i32_f32 at the largest float below 0.5 (see round_half_away_clamped)
+#ifndef TDR_XCD_SWIZZLE
+#define TDR_XCD_SWIZZLE 0
+#endif
+#ifndef TDR_OOB_ALIAS
+#define TDR_OOB_ALIAS 1      // all out-of-bounds samples read one guard record (A/B on MI355X: -11 % on config 2)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -339,9 +343,18 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
   extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]: row r and r+nb hold scan row r (no wrap arithmetic)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+#if TDR_XCD_SWIZZLE
+  // Workgroups are dealt round-robin over the 8 XCDs; remap so that each XCD (its own L2) gets a contiguous run of
+  // particle batches (Morton neighbours) instead of every 8th one.  Speed only: any mapping gives the same results.
+  const unsigned nbx = gridDim.x, per = (nbx + 7) / 8;
+  unsigned bx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (nbx % 8 != 0) bx = blockIdx.x;  // keep it a bijection
+#else
+  const unsigned bx = blockIdx.x;
+#endif
+  const int64_t slot = ((int64_t)bx * 4 + wave) * 64 + lane;
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
-  if ((int64_t)blockIdx.x * 256 >= nact) return;  // whole workgroup idle (uniform)
+  if ((int64_t)bx * 256 >= nact) return;  // whole workgroup idle (uniform)
   const bool valid = slot < nact;
   const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
@@ -383,7 +396,13 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
     p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
     p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
     const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+#if TDR_OOB_ALIAS
+    // every out-of-bounds sample reads the SAME guard record (always cache-resident) instead of a distinct one
+    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+    return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+#else
     return (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase));  // v_mad_i32_i24 + v_lshl_add
+#endif
   };
 
   for (int j = j0; j < j1; j++) {
@@ -566,9 +585,20 @@ __global__ void init_finish_kernel(const int32_t* __restrict__ list, const int32
   raw_w[p] = (float)(1. / (double)(best_cost[slot] + regularization));  // :212
 }
 
+static int64_t score_wave_target() {
+  static int64_t v = [] {
+    // tuning knob.  Many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms):
+    // workgroups of one ring chunk run together, so the concurrently touched part of the map is a thin annulus that
+    // L2 can hold, and the slow (scattered) batches no longer leave a long tail.
+    const char* e = getenv("TDR_SCORE_WAVES");
+    long t = e ? atol(e) : 0;
+    return (int64_t)(t > 0 ? t : 131072);
+  }();
+  return v;
+}
 static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks) {
   int64_t nbatches = cdiv(std::max<int64_t>(n, 1), 64);
-  int64_t want = std::max<int64_t>(1, cdiv(16384, nbatches));  // aim for >= 16k waves in flight
+  int64_t want = std::max<int64_t>(1, cdiv(score_wave_target(), nbatches));  // enough waves to fill the chip
   nchunks = (int)std::min<int64_t>(nr, want);
   rpc = (int)cdiv(nr, nchunks);
   nchunks = (int)cdiv(nr, rpc);
