@@ -119,6 +119,16 @@ int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const floa
                            const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, float uniform_scale,
                            float* raw_w, float* workspace, void* stream);
 
+/* Cartesian scoring (BASELINE config 4).  The reference's StateParticle only reaches the polar overloads
+ * (state_particle.h:61), so there is no reference function to match; the score is DEFINED as the window of
+ * TopDownMap::getLocalMap(center, rot = theta, res = res*scale) (src/top_down_map.cpp:429-459) scored by
+ * getCostForRot with shift 0 (src/state_particle.cpp:132-143), weight = 1/(cost + regularization), no gates.
+ * scan_pk: packed [cols][rows][rf] Cartesian render (tdr_k_raster_cart / tdr_k_pack_scan with nb=rows, nr=cols). */
+size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n);
+int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
+                     const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
+                     float* raw_w, float* workspace, void* stream);
+
 /* ---- StateParticle::propagate for all particles (src/state_particle.cpp:57-78 via particle_filter.cpp:86-92) -- */
 /* z4: optional DEVICE array [n][4] of standard normals {theta, dx, dy, scale} in the reference's consumption
  * order (parity mode, from tdr_propagate_normals_host); NULL = counter-based device RNG keyed by (seed, step). */

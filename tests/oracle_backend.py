@@ -72,6 +72,11 @@ class OracleMapStub:
     def haveMap(self):
         return True
 
+    polar = True
+
+    def window_shape(self):
+        return (self.dev.nb, self.dev.nr)
+
 
 class OracleKernels:
     name = "oracle-test-double"

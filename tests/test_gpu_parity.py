@@ -241,6 +241,40 @@ def test_score_non_unit_scale_and_resolution(tdr, oracle):
     _assert_weights(f.raw_weights(), ref)
 
 
+def test_score_cartesian_vs_oracle(tdr, oracle):
+    """BASELINE config 4's path at a small shape: Cartesian render (A2) + Cartesian window gather (A7) scored with
+    shift 0.  The reference has no Cartesian score function; both sides implement the definition in include/tdr.h."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("cart", 8000, 6, 50, 64, 700, 512, polar=False, seed=31, res=0.75)
+    sc = synth.make_scene(cfg)
+    rows, cols = cfg.nb, cfg.nr
+    st = sc.states.copy()
+    rng = np.random.default_rng(3)
+    st["scale"] = rng.uniform(0.8, 1.25, len(st)).astype(np.float32)
+    st["dx_m"] = rng.normal(0, 2, len(st)).astype(np.float32)
+    st["init_x_px"][:8] = np.asarray([-50, 5, 700, 695, 350, 350, 0.5, 699.5], np.float32)   # off / at the border
+    st["init_y_px"][:8] = np.asarray([350, 350, 350, 350, -40, 698, 0.5, 699.5], np.float32)
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
+    scan = oracle.raster_cart(sc.pts, cfg.res, sc.lut, cfg.ncls, rows, cols)
+    cw = [1.0, 0.5, 2.0, 1.5, 0.25, 1.0]
+    ref = oracle.compute_weights_cart(om, rows, cols, scan, cfg.res, oracle.make_params(cfg.ncls, class_weights=cw),
+                                      st.copy())
+    assert np.isnan(ref).any() and (~np.isnan(ref)).sum() > 400
+    m = pkg.TopDownMap(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.setWindow(rows, cols)
+    r = pkg.ScanRenderer(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, rows, cols)
+    r.renderSemanticTopDown(sc.pts, cfg.res)
+    assert np.array_equal(r.last_images().cpu().numpy(), scan)
+    for loc in (0, 1):
+        f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0, class_weights=cw), kernels=k,
+                               init_particles=False, locality_every=loc)
+        f.set_states(st)
+        f.update(r.last_scan(), None, cfg.res)
+        _assert_weights(f.raw_weights(), ref, rtol=2e-5)   # cos/sin of theta: last-ulp differences move a few samples
+
+
 # ---- A10 propagate ------------------------------------------------------------------------------------------------------
 def test_propagate_golden(tdr, g):
     pkg, k = tdr

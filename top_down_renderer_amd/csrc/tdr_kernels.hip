@@ -473,6 +473,136 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
   }
 }
 
+// K2c: Cartesian scoring (BASELINE config 4).  The reference's StateParticle never reaches the Cartesian
+// TopDownMap::getLocalMap, so the Cartesian score is DEFINED as: window sampled by getLocalMap
+// (src/top_down_map.cpp:429-459 via samplePts :367-389) at rot = theta, res = res*scale, scored by getCostForRot
+// with shift 0 (src/state_particle.cpp:132-143) (definition recorded in include/tdr.h:tdr_k_score_cart and DESIGN.md).
+// Same mapping as the polar kernel (lane = particle); the rotation now lives in the sampling, so the scan record of
+// sample (i,j) is the same for every lane and comes through the scalar cache instead of LDS.
+struct CartArgs {
+  const float* rec;
+  int map_rows, map_cols;
+  float resolution;
+  const float* scan_pk;  // [cols][rows][rf]
+  int rows, cols;        // window (image) shape
+  float res;
+  const float* st;
+  int64_t cap, n;
+  const int32_t* order;
+  int cpc, nchunks;      // window columns per chunk
+  int64_t npad;
+  float* part;
+};
+
+__device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
+  // Eigen LinSpaced<float>, |high| == |low| here, so never the flipped branch of linspaced_op_impl
+  return (i == size1) ? high : (low + (float)i * step);
+}
+
+template <int NV4, int U, bool KSLOT>
+__global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
+  constexpr int RF = 4 * NV4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  if ((int64_t)blockIdx.x * 256 >= a.n) return;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const float theta = a.st[TDR_ST_THETA * a.cap + p];
+  const float off0 = cy / a.resolution;  // samplePts(center/resolution, ...): x_vals += center[1] (top_down_map.cpp:387)
+  const float off1 = cx / a.resolution;  // y_vals += center[0] (:388)
+  const float resq = (a.res * scale) / a.resolution;  // res/params_.resolution (:434)
+  // glibc's cosf/sinf are correctly rounded in practice; the device float versions are not -> evaluate in double
+  const float c = (float)cos((double)theta), s = (float)sin((double)theta);
+  const float ns = -s;
+  const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
+  const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
+  const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
+  const float step_c = a.cols == 1 ? 0.f : (hi_c - lo_c) / (float)(a.cols - 1);
+  const int r1 = a.rows == 1 ? 1 : a.rows - 1, c1 = a.cols == 1 ? 1 : a.cols - 1;
+
+  const int j0 = blockIdx.y * a.cpc, j1 = min(a.cols, j0 + a.cpc);
+  const int rowstride = (a.map_cols + 2) * (RF * 4);
+  const int kbase = (a.map_cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+
+  float acc2[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
+  float known2 = 0.f;
+
+  for (int j = j0; j < j1; j++) {
+    const float xj = linspaced_dev(j, c1, lo_c, hi_c, step_c);
+    const float A = ns * xj, B = c * xj;  // rotm * pts (:383-385): q0 = c*y + (-s)*x, q1 = s*y + c*x
+    auto cell_offset = [&](int i) -> unsigned {
+      const float yi = linspaced_dev(i, r1, lo_r, hi_r, step_r);
+      float p0 = c * yi + A;
+      float p1 = s * yi + B;
+      p0 = p0 + off0;
+      p1 = p1 + off1;
+      p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);  // :437
+      const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
+      return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+    };
+    float acc[RF];
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[k] = 0.f;
+    float known = 0.f;
+    const float4* srow = scan4 + (int64_t)j * a.rows * NV4;  // wave-uniform: scalar loads
+    int i = 0;
+    for (; i + U <= a.rows; i += U) {
+      unsigned boff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(i + u);
+      float4 m[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          const float4 sv = srow[(i + u) * NV4 + v];
+          acc[4 * v + 0] = __builtin_fmaf(sv.x, m[u][v].x, acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(sv.y, m[u][v].y, acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(sv.z, m[u][v].z, acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(sv.w, m[u][v].w, acc[4 * v + 3]);
+        }
+        if (!KSLOT) known += m[u][NV4 - 1].w;
+      }
+    }
+    for (; i < a.rows; i++) {
+      const unsigned bo = cell_offset(i);
+#pragma unroll
+      for (int v = 0; v < NV4; v++) {
+        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+        const float4 sv = srow[i * NV4 + v];
+        acc[4 * v + 0] = __builtin_fmaf(sv.x, m.x, acc[4 * v + 0]);
+        acc[4 * v + 1] = __builtin_fmaf(sv.y, m.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = __builtin_fmaf(sv.z, m.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = __builtin_fmaf(sv.w, m.w, acc[4 * v + 3]);
+        if (!KSLOT && v == NV4 - 1) known += m.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
+    known2 += known;
+  }
+  if (slot < a.npad) {
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
+    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
+  }
+}
+
 // Gates of state_particle.cpp:163-176.  scale_lo / scale_hi = pow(10, scale_log_min/max) evaluated on the host
 // (glibc pow, like the reference).
 struct GateArgs {
@@ -792,6 +922,63 @@ extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab,
                      (const int32_t*)count, (const float*)best_cost, (const float*)best_theta, fp->regularization, st,
                      cap, raw_w);
   LAUNCH_CHECK("init_finish");
+  return TDR_OK;
+}
+
+extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n) {
+  (void)rows;
+  int cpc, nchunks;
+  choose_chunks(n, cols, cpc, nchunks);
+  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  return (size_t)((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64);
+}
+
+extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
+                                const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
+                                float* raw_w, float* workspace, void* stream) {
+  if (!map || !map->rec || !scan_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score_cart: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_cart: n exceeds capacity");
+  if (n == 0) return TDR_OK;
+  if (rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "score_cart: bad window shape");
+  if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_cart: class count mismatch");
+  const int rf = tdr_rec_floats(map->ncls);
+  if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score_cart: map record size mismatch");
+  hipStream_t s = (hipStream_t)stream;
+  CartArgs a;
+  a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.resolution = map->resolution;
+  a.scan_pk = scan_pk; a.rows = rows; a.cols = cols; a.res = res;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm;
+  choose_chunks(n, cols, a.cpc, a.nchunks);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
+  const bool ks = tdr_has_kslot(map->ncls, rf);
+  {
+    ScoreProfScope prof(s);
+#define TDR_LAUNCH_CART(NV4)                                                                        \
+  if (ks) hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, true>), grid, block, 0, s, a);    \
+  else hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, false>), grid, block, 0, s, a);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_CART(1) break;
+      case 2: TDR_LAUNCH_CART(2) break;
+      case 3: TDR_LAUNCH_CART(3) break;
+      case 4: TDR_LAUNCH_CART(4) break;
+      default: return fail(TDR_ERR_ARG, "score_cart: unsupported record size %d", rf);
+    }
+#undef TDR_LAUNCH_CART
+  }
+  LAUNCH_CHECK("score_cart");
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
+  f.gate = make_gate(fp, map);
+  f.gate.force_on_map = 0;   // the Cartesian definition has no gates (include/tdr.h)
+  f.gate.scale_unknown = 0;
+  f.P = (int64_t)rows * cols; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
+  f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  LAUNCH_CHECK("score_finalize(cart)");
   return TDR_OK;
 }
 

@@ -114,6 +114,14 @@ class HipKernels:
                                                   C.c_float(res), C.byref(fp), _ptr(st), cap, n,
                                                   C.c_float(uniform_scale), _ptr(raw_w), _ptr(ws), self.stream()))
 
+    def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None):
+        need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.empty((need,))
+        check(self.lib.tdr_k_score_cart(C.byref(m.desc), _ptr(scan_pk), rows, cols, C.c_float(res), C.byref(fp),
+                                        _ptr(st), st.shape[1], n, _ptr(perm), _ptr(raw_w), _ptr(self._ws),
+                                        self.stream()))
+
     def propagate(self, st, n, last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4=None, seed=0, step=0,
                   index_base=0):
         check(self.lib.tdr_k_propagate(_ptr(st), st.shape[1], n, _ptr(last_dist), C.c_float(tx), C.c_float(ty),

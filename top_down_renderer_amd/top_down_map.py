@@ -71,6 +71,38 @@ class TopDownMap:
                 out.append(cls)
         return out
 
+    # --- window (image) shape of the scan the filter scores against -------------------------------------------------
+    polar = False
+
+    def setWindow(self, rows, cols):
+        """Cartesian window shape (rows = y, cols = x) for the Cartesian score (BASELINE config 4)."""
+        self.win_rows, self.win_cols = int(rows), int(cols)
+
+    def window_shape(self):
+        return (self.win_rows, self.win_cols)
+
+    def scan_handle(self, scan):
+        """Accepts what ParticleFilter::update is handed in the reference (a list of per-class column-major images),
+        an (ncls, rows*cols) array / device tensor, or an already packed device scan; returns the packed device scan
+        the scoring kernel reads."""
+        ncls = self.numClasses()
+        nb, nr = self.window_shape()
+        if isinstance(scan, tuple) and scan[0] == "pk":
+            return scan[1]
+        if isinstance(scan, (list, tuple)):
+            if len(scan) < ncls:
+                raise ValueError("fewer scan images than map classes")
+            scan = np.stack([np.asarray(s, np.float32).reshape(nb, nr, order="A").ravel(order="F") for s in scan[:ncls]])
+        if isinstance(scan, np.ndarray):
+            if scan.shape != (ncls, nb * nr):
+                raise ValueError(f"scan shape {scan.shape} != {(ncls, nb * nr)}")
+            scan = self.k.to_device(np.ascontiguousarray(scan, np.float32))
+        if isinstance(scan, torch.Tensor):
+            if tuple(scan.shape) != (ncls, nb * nr):
+                raise ValueError(f"scan shape {tuple(scan.shape)} != {(ncls, nb * nr)}")
+            return self.k.pack_scan(scan.contiguous(), ncls, nb, nr)
+        raise TypeError("unsupported scan type")
+
     def numClasses(self):
         return self.params_.num_classes
 
@@ -97,6 +129,8 @@ class TopDownMapPolar(TopDownMap):
         """top_down_map_polar.cpp:7-19; shape = (theta bins, range bins)."""
         self.k.set_polar_table(self.dev, int(shape[0]), int(shape[1]), float(ang_res))
 
+    polar = True
+
     @property
     def nb(self):
         return self.dev.nb
@@ -105,23 +139,5 @@ class TopDownMapPolar(TopDownMap):
     def nr(self):
         return self.dev.nr
 
-    def scan_handle(self, scan):
-        """Accepts what ParticleFilter::update is handed in the reference (a list of per-class column-major nb x nr
-        images) or an (ncls, nb*nr) array / device tensor, or an already packed device scan; returns the packed
-        device scan the scoring kernel reads."""
-        ncls, nb, nr = self.numClasses(), self.nb, self.nr
-        if isinstance(scan, tuple) and scan[0] == "pk":
-            return scan[1]
-        if isinstance(scan, (list, tuple)):
-            if len(scan) < ncls:
-                raise ValueError("fewer scan images than map classes")
-            scan = np.stack([np.asarray(s, np.float32).reshape(nb, nr, order="A").ravel(order="F") for s in scan[:ncls]])
-        if isinstance(scan, np.ndarray):
-            if scan.shape != (ncls, nb * nr):
-                raise ValueError(f"scan shape {scan.shape} != {(ncls, nb * nr)}")
-            scan = self.k.to_device(np.ascontiguousarray(scan, np.float32))
-        if isinstance(scan, torch.Tensor):
-            if tuple(scan.shape) != (ncls, nb * nr):
-                raise ValueError(f"scan shape {tuple(scan.shape)} != {(ncls, nb * nr)}")
-            return self.k.pack_scan(scan.contiguous(), ncls, nb, nr)
-        raise TypeError("unsupported scan type")
+    def window_shape(self):
+        return (self.nb, self.nr)
