@@ -106,16 +106,41 @@ def main():
     per_gpu = a.particles_per_gpu or cfg.n_particles
     n_global = per_gpu * world
     sc = synth.make_scene(cfg, n_particles=n_global)   # same seed on every rank -> identical scene
-    m = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
-    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
-    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    if cfg.polar:
+        m = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
+        m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+        r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    else:   # BASELINE configs[3]: Cartesian render + Cartesian window score
+        m = pkg.TopDownMap(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
+        m.setWindow(cfg.nb, cfg.nr)
+        r = pkg.ScanRenderer(sc.lut, kernels=k)
     r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
     f = pkg.ParticleFilter(n_global, m, pkg.FilterParams(fixed_scale=1.0), seed=1, group=group, kernels=k,
                            parity_rng=False, locality_every=a.locality_every, init_particles=False)
     f.set_states(sc.states)
     nl = f.n_local
-    st0 = f.st[:, :nl].clone()
     pts_host = torch.from_numpy(sc.pts).pin_memory()
+
+    def render(pts):
+        if cfg.polar:
+            r.renderSemanticTopDown(pts, cfg.res, cfg.ang_res)
+        else:
+            r.renderSemanticTopDown(pts, cfg.res)
+
+    init_step_ms = None
+    if not cfg.have_init:
+        # BASELINE configs[4]: particles start without a heading; the FIRST update runs the 40-rotation search of
+        # src/state_particle.cpp:195-206.  It is a one-off: timed on its own, then the steady-state steps below start
+        # from the initialised set.
+        render(pts_host.to(k.device))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f.update(r.last_scan(), None, cfg.res)
+        torch.cuda.synchronize()
+        init_step_ms = (time.perf_counter() - t0) * 1e3
+        f.st, f.st_new = f.st_new, f.st     # keep the scored (now initialised) set, drop the resampled one
+        f.num_particles_ = n_global
+    st0 = f.st[:, :nl].clone()
 
     def step():
         # every step scores the SAME particle distribution (90 % Gaussian about the true pose + 10 %
@@ -125,8 +150,7 @@ def main():
         f.num_particles_ = n_global
         # only rank 0 "receives" the scan; the others get the rasterised scan by broadcast inside update()
         if rank == 0:
-            pts = pts_host.to(k.device, non_blocking=True)
-            r.renderSemanticTopDown(pts, cfg.res, cfg.ang_res)
+            render(pts_host.to(k.device, non_blocking=True))
             scan = r.last_scan()
         else:
             scan = ("pk", k.empty((cfg.nr * cfg.nb * k.lib.tdr_rec_floats(cfg.ncls),)))
@@ -159,6 +183,7 @@ def main():
     if rank == 0:
         P = cfg.nb * cfg.nr
         b_pu = P * (4 * cfg.ncls + 1) + 64
+        kname = "score_polar_kernel" if cfg.polar else "score_cart_kernel"
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -179,17 +204,21 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg.name}: {cfg.n_pts}-pt scan, {cfg.ncls} classes, {cfg.nb}x{cfg.nr} polar "
-                                   f"render, {cfg.map_size}x{cfg.map_size} map",
+            "config": {"workload": f"{cfg.name}: {cfg.n_pts}-pt scan, {cfg.ncls} classes, {cfg.nb}x{cfg.nr} "
+                                   f"{'polar' if cfg.polar else 'Cartesian'} render, {cfg.map_size}x{cfg.map_size} map",
                        "particles_per_gpu": per_gpu, "particles_total": n_global,
-                       "particle_distribution": "90% Gaussian (30 px, 10 deg) about the true pose + 10% uniform",
+                       "particle_distribution": ("90% Gaussian (30 px, 10 deg) about the true pose + 10% uniform"
+                                                 if cfg.have_init else "8 Gaussian clusters (40 px) on road cells"),
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "kernel": "score_polar_kernel", "achieved": achieved, "peak": 8000.0,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          "algorithmic_bytes_per_launch": b_pu * n_local},
         }
-        if not a.no_cpu and a.cpu_sample != 0 and world == 1:
+        if init_step_ms is not None:
+            out["config"]["init_search_first_step_ms"] = init_step_ms
+            out["config"]["init_search_particle_updates_per_s"] = n_global / (init_step_ms * 1e-3)
+        if not a.no_cpu and a.cpu_sample != 0 and world == 1 and cfg.polar:
             ns = a.cpu_sample if a.cpu_sample > 0 else max(256, int(800 * host_threads() * 1.64e6 / b_pu))
             out["cpu_baseline"] = cpu_baseline(sc, cfg, min(ns, n_global), host_threads())
         print(json.dumps(out), flush=True)
