@@ -107,17 +107,15 @@ size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n);
  * locality; results are independent of it.  tab: DEVICE copy of the table from tdr_polar_table_host.
  * uniform_scale: > 0 is the caller's promise that every particle's scale equals it (fixed or frozen scale,
  * particle_filter.cpp:24,343-357): the sample offsets (tab*scale)*res are then evaluated once per call instead of
- * once per particle and sample — same float operations, same results; <= 0 reads each particle's own scale. */
+ * once per particle and sample — same float operations, same results; <= 0 reads each particle's own scale.
+ * init_search != 0: particles whose have_init is 0 (and that are not gated) first run the 40-rotation search of
+ * state_particle.cpp:195-206 — one pass over their window scoring all candidate rotations — which sets their theta
+ * and have_init in st; they are then scored at that rotation like everyone else (all-NaN searches keep the
+ * reference's 1/(FLT_MAX + regularization)).  Batches without such particles exit immediately; nothing synchronises
+ * with the host.  Pass 0 when the caller knows every particle is initialised. */
 int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
                       const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                      float uniform_scale, float* raw_w, float* workspace, void* stream);
-/* The 40-rotation initialisation search of state_particle.cpp:195-206 for the particles of st whose have_init is 0
- * (and that are not gated): overwrites their raw_w, sets their theta to the best rotation and have_init to 1.
- * Call after tdr_k_score_polar while such particles may exist; a no-op on the device when there are none
- * (the launches are trimmed by a device-side count, nothing synchronises with the host). */
-int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
-                           const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, float uniform_scale,
-                           float* raw_w, float* workspace, void* stream);
+                      float uniform_scale, int init_search, float* raw_w, float* workspace, void* stream);
 
 /* Cartesian scoring (BASELINE config 4).  The reference's StateParticle only reaches the polar overloads
  * (state_particle.h:61), so there is no reference function to match; the score is DEFINED as the window of

@@ -373,12 +373,9 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
   }
   TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n)));
   TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->n_max, n, perm, f->uniform_scale,
-                         f->raw_w.p, f->ws.p, f->stream));
-  if (f->maybe_uninit) {
-    TTRY(tdr_k_score_polar_init(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->n_max, n, f->uniform_scale,
-                                f->raw_w.p, f->ws.p, f->stream));
-    if (!(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
-  }
+                         f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
+  // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised
+  if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
   TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
   int64_t n_new = n;
   if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));

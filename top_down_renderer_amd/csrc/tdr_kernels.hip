@@ -32,6 +32,9 @@
 #ifndef TDR_SCORE_U
 #define TDR_SCORE_U 4          // samples whose loads are kept in flight together in the scoring loop
 #endif
+#ifndef TDR_INIT_SCAN_LDS
+#define TDR_INIT_SCAN_LDS 1   // init search: candidates' scan records via LDS broadcast (1) or the scalar cache (0)
+#endif
 #ifndef TDR_XCD_SWIZZLE
 #define TDR_XCD_SWIZZLE 0
 #endif
@@ -689,30 +692,229 @@ __global__ void score_finalize_kernel(FinalizeArgs a) {
   }
 }
 
-// un-initialised, un-gated particles -> compact list (order irrelevant for the results)
-__global__ void init_list_kernel(const float* __restrict__ st, int64_t cap, int64_t n, GateArgs gate,
-                                 int32_t* __restrict__ list, int32_t* __restrict__ count) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  if (st[TDR_ST_HAVE_INIT * cap + p] != 0.f) return;
-  const float scale = st[TDR_ST_SCALE * cap + p];
-  const float cx = st[TDR_ST_DX * cap + p] * scale + st[TDR_ST_INIT_X * cap + p];
-  const float cy = st[TDR_ST_DY * cap + p] * scale + st[TDR_ST_INIT_Y * cap + p];
-  if (particle_gated(gate, cx, cy, scale)) return;
-  int k = atomicAdd(count, 1);
-  list[k] = (int32_t)p;
+// The 40-rotation initialisation search of state_particle.cpp:195-206 in ONE pass over the window: the candidate
+// rotations are the same for every particle, so for rotation t the scan row paired with window row i — (i + s_t) mod nb
+// — is the same for all lanes, and a map record gathered once is multiplied against all candidates' scan records
+// (the reference also gathers once and scores 40 times).  One workgroup = one batch of 64 particles; its 4 waves
+// split the candidates (INIT_TW each), gather the same records (the repeats hit L1), read the candidates' scan records
+// through the scalar cache (they are wave-uniform) and keep INIT_TW x rf accumulators per lane.  Sums run in float over the whole window, which is only used to pick the best rotation:
+// the weight itself is then produced by the regular scoring pass at that rotation.
+#ifndef INIT_TW
+#define INIT_TW 6          // candidate rotations per wave
+#endif
+#ifndef INIT_WAVES
+#define INIT_WAVES 8       // waves per workgroup, all on the same 64 particles (A/B on MI355X, 250k particles:
+#endif                     // 4x11 401 ms, 6x8 630 ms, 8x6 285 ms, 12x4 422 ms, 16x3 447 ms; scalar-cache scan reads 773 ms)
+#define INIT_MAXROT (INIT_WAVES * INIT_TW)
+struct InitArgs {
+  const float* rec;
+  int rows, cols;
+  float resolution;
+  const float* tab;
+  const float* utab;
+  const float* scan_pk;
+  int nb, nr;
+  float res;
+  const float* st;     // read-only here: results go to res_theta / res_flag (keeps every other load scalarisable)
+  int64_t cap, n;
+  const int32_t* order;
+  tdr_filter_params fp;
+  GateArgs gate;
+  int64_t P;
+  int ncls;
+  const int* nrot;
+  const int* shift;    // [nrot] device arrays (filled by init_rot_kernel)
+  const float* theta;
+  float* res_theta;  // [n] chosen rotation
+  float* res_flag;   // [n] 0 = untouched, 1 = initialised, 2 = initialised but every rotation scored NaN
+                     //     (weight 1/(FLT_MAX + reg), state_particle.cpp:193,212)
+};
+
+template <int NV4, bool KSLOT, bool USCALE>
+__global__ __launch_bounds__(64 * INIT_WAVES) void score_init_kernel(InitArgs a) {
+  constexpr int RF = 4 * NV4;
+  constexpr int U = 1;
+#if TDR_INIT_SCAN_LDS
+  extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]
+  const int nb2 = 2 * a.nb;
+#endif
+  __shared__ float x_cost[INIT_WAVES][64];
+  __shared__ int x_rot[INIT_WAVES][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
+  const int64_t slot = (int64_t)blockIdx.x * 64 + lane;   // all four waves work on the same 64 particles
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  // every wave of the workgroup looks at the same 64 particles, so this per-wave vote is the same in all of them
+  // (and, unlike __syncthreads_or, involves no LDS atomic that would stop the compiler from using scalar loads)
+  if (__ballot(want) == 0) return;  // nothing to initialise in this batch
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const int rowstride = (a.cols + 2) * (RF * 4);
+  const int kbase = (a.cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  int sh[INIT_TW];
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++) {
+    const int t = wave * INIT_TW + r;
+    sh[r] = t < nrot ? a.shift[t] : 0;
+  }
+  float acc[INIT_TW][RF];
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++)
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[r][k] = 0.f;
+  float known = 0.f;
+
+  auto cell_offset = [&](float2 t) -> unsigned {
+    float p0, p1;
+    if constexpr (USCALE) { p0 = t.x; p1 = t.y; }
+    else { p0 = (t.x * scale) * a.res; p1 = (t.y * scale) * a.res; }
+    p0 = p0 + off0;
+    p1 = p1 + off1;
+    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+    return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+  };
+
+  for (int j = 0; j < a.nr; j++) {
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* srow = scan4 + (int64_t)j * a.nb * NV4;  // ring j of the packed scan
+#if TDR_INIT_SCAN_LDS
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nb * NV4; t += 64 * INIT_WAVES) {
+      const float4 v = srow[t];
+      const int row = t / NV4, pl = t - row * NV4;
+      ring[pl * nb2 + row] = v;
+      ring[pl * nb2 + row + a.nb] = v;
+    }
+    __syncthreads();
+#endif
+    int i = 0;
+    for (; i + U <= a.nb; i += U) {
+      unsigned boff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(trow[i + u]);
+      float4 m[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (!KSLOT) known += m[u][NV4 - 1].w;
+#pragma unroll
+        for (int r = 0; r < INIT_TW; r++) {
+#pragma unroll
+          for (int v = 0; v < NV4; v++) {
+#if TDR_INIT_SCAN_LDS
+            const float4 sv = ring[v * nb2 + sh[r] + i + u];  // same address in every lane: LDS broadcast
+#else
+            int row = sh[r] + i + u;                    // wave-uniform: the record comes through the scalar cache
+            row -= row >= a.nb ? a.nb : 0;
+            const float4 sv = srow[row * NV4 + v];
+#endif
+            acc[r][4 * v + 0] = __builtin_fmaf(sv.x, m[u][v].x, acc[r][4 * v + 0]);
+            acc[r][4 * v + 1] = __builtin_fmaf(sv.y, m[u][v].y, acc[r][4 * v + 1]);
+            acc[r][4 * v + 2] = __builtin_fmaf(sv.z, m[u][v].z, acc[r][4 * v + 2]);
+            acc[r][4 * v + 3] = __builtin_fmaf(sv.w, m[u][v].w, acc[r][4 * v + 3]);
+          }
+        }
+      }
+    }
+    for (; i < a.nb; i++) {
+      const unsigned bo = cell_offset(trow[i]);
+      float4 m[NV4];
+#pragma unroll
+      for (int v = 0; v < NV4; v++) m[v] = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+      if (!KSLOT) known += m[NV4 - 1].w;
+#pragma unroll
+      for (int r = 0; r < INIT_TW; r++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+#if TDR_INIT_SCAN_LDS
+          const float4 sv = ring[v * nb2 + sh[r] + i];
+#else
+          int row = sh[r] + i;
+          row -= row >= a.nb ? a.nb : 0;
+          const float4 sv = srow[row * NV4 + v];
+#endif
+          acc[r][4 * v + 0] = __builtin_fmaf(sv.x, m[v].x, acc[r][4 * v + 0]);
+          acc[r][4 * v + 1] = __builtin_fmaf(sv.y, m[v].y, acc[r][4 * v + 1]);
+          acc[r][4 * v + 2] = __builtin_fmaf(sv.z, m[v].z, acc[r][4 * v + 2]);
+          acc[r][4 * v + 3] = __builtin_fmaf(sv.w, m[v].w, acc[r][4 * v + 3]);
+        }
+    }
+  }
+  // cost of each candidate (state_particle.cpp:117-120,136-139,154), best of this wave's candidates in order
+  const float kn = KSLOT ? acc[0][RF - 2] : known;
+  const bool unknown = (kn / (float)a.P) < 0.5;
+  float cw[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) cw[k] = k < 16 ? a.fp.class_weights[k < 16 ? k : 0] : 0.f;
+  float best = 3.402823466e+38f;
+  int best_t = -1;
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++) {
+    const int t = wave * INIT_TW + r;
+    float cost = 0.f;
+#pragma unroll
+    for (int k = 0; k < RF - 1; k++)   // constant indices only: a dynamic index would push the arguments to scratch
+      if (k < a.ncls) cost = (float)((double)cost + (double)acc[r][k] * 0.01 * (double)cw[k]);
+    cost = cost / acc[r][RF - 1];
+    if (unknown) cost = __builtin_nanf("");
+    if (t < nrot && cost < best) { best = cost; best_t = t; }  // :200-203 (NaN never wins)
+  }
+  x_cost[wave][lane] = best;
+  x_rot[wave][lane] = best_t;
+  __syncthreads();
+  if (wave == 0 && want) {
+    float b = 3.402823466e+38f;
+    int bt = -1;
+    for (int wv = 0; wv < INIT_WAVES; wv++)   // waves hold the candidates in loop order: strict '<' keeps the first minimum
+      if (x_cost[wv][lane] < b) { b = x_cost[wv][lane]; bt = x_rot[wv][lane]; }
+    a.res_theta[p] = bt >= 0 ? a.theta[bt] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bt < 0 ? 2.f : 1.f;
+  }
 }
 
-__global__ void init_finish_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count,
-                                   const float* __restrict__ best_cost, const float* __restrict__ best_theta,
-                                   float regularization, float* __restrict__ st, int64_t cap,
-                                   float* __restrict__ raw_w) {
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= (int64_t)*count) return;
-  const int64_t p = list[slot];
-  st[TDR_ST_THETA * cap + p] = best_theta[slot];       // state_particle.cpp:205
-  st[TDR_ST_HAVE_INIT * cap + p] = 1.f;                // :206
-  raw_w[p] = (float)(1. / (double)(best_cost[slot] + regularization));  // :212
+// candidate rotations of the search, generated exactly like the reference's loop (state_particle.cpp:197: float t,
+// double increment) together with their bin shifts (:124-128)
+__global__ void init_rot_kernel(int nb, int* __restrict__ shift, float* __restrict__ theta, int* __restrict__ nrot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int k = 0;
+  for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {
+    if (k >= INIT_MAXROT) break;
+    theta[k] = t;
+    shift[k] = rot_shift_dev(t, nb);
+    k++;
+  }
+  *nrot = k;
+}
+
+// state_.theta = best_theta; state_.have_init = true (state_particle.cpp:205-206)
+__global__ void init_apply_kernel(const float* __restrict__ res_theta, const float* __restrict__ res_flag, int64_t n,
+                                  float* __restrict__ st, int64_t cap) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && res_flag[p] != 0.f) {
+    st[TDR_ST_THETA * cap + p] = res_theta[p];
+    st[TDR_ST_HAVE_INIT * cap + p] = 1.f;
+  }
+}
+// particles whose init search found no valid rotation keep best_cost = FLT_MAX (:193) -> weight 1/(FLT_MAX + reg)
+__global__ void init_fixup_kernel(const float* __restrict__ res_flag, int64_t n, float regularization,
+                                  float* __restrict__ raw_w) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && res_flag[p] == 2.f) raw_w[p] = (float)(1. / (double)(3.402823466e+38f + regularization));
 }
 
 static int64_t score_wave_target() {
@@ -830,8 +1032,8 @@ static int launch_score(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
 
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                  float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                 const int32_t* perm, float uniform_scale, float* raw_w, float* workspace,
-                                 void* stream) {
+                                 const int32_t* perm, float uniform_scale, int init_search, float* raw_w,
+                                 float* workspace, void* stream) {
   if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score: null pointer");
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score: n=%lld exceeds capacity %lld", (long long)n, (long long)cap);
@@ -855,6 +1057,43 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   a.part = workspace;
   int rc = fill_utab(a, workspace, rf, uniform_scale, s);
   if (rc) return rc;
+  float* res_flag = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;  // npad floats
+  float* res_theta = res_flag + a.npad;                                // npad floats
+  if (init_search) {
+    // state_particle.cpp:195-206 first: it fixes theta / have_init of the un-initialised particles, the regular pass
+    // below then scores every particle at its (possibly just chosen) rotation
+    InitArgs ia;
+    ia.rec = a.rec; ia.rows = a.rows; ia.cols = a.cols; ia.resolution = a.resolution;
+    ia.tab = a.tab; ia.utab = a.utab; ia.scan_pk = a.scan_pk; ia.nb = nb; ia.nr = nr; ia.res = res;
+    ia.st = st; ia.cap = cap; ia.n = n; ia.order = perm; ia.fp = *fp; ia.gate = make_gate(fp, map);
+    ia.P = (int64_t)nb * nr; ia.ncls = map->ncls; ia.res_flag = res_flag; ia.res_theta = res_theta;
+    // rotation table lives behind the result arrays: [shift INIT_MAXROT][theta INIT_MAXROT][nrot]
+    int* d_shift = reinterpret_cast<int*>(res_theta + a.npad);
+    float* d_theta = reinterpret_cast<float*>(d_shift + INIT_MAXROT);
+    int* d_nrot = reinterpret_cast<int*>(d_theta + INIT_MAXROT);
+    hipLaunchKernelGGL(init_rot_kernel, dim3(1), dim3(64), 0, s, nb, d_shift, d_theta, d_nrot);
+    LAUNCH_CHECK("init_rot");
+    ia.shift = d_shift; ia.theta = d_theta; ia.nrot = d_nrot;
+    HIP_TRY(hipMemsetAsync(res_flag, 0, sizeof(float) * (size_t)n, s));
+    dim3 grid((unsigned)cdiv(n, 64)), block(64 * INIT_WAVES);
+    const size_t lds = TDR_INIT_SCAN_LDS ? (size_t)2 * nb * rf * 4 : 0;
+    const bool ks = tdr_has_kslot(map->ncls, rf), us = a.utab != nullptr;
+#define TDR_LAUNCH_INIT(NV4)                                                                                \
+  if (ks && us) hipLaunchKernelGGL((score_init_kernel<NV4, true, true>), grid, block, lds, s, ia);         \
+  else if (ks) hipLaunchKernelGGL((score_init_kernel<NV4, true, false>), grid, block, lds, s, ia);         \
+  else if (us) hipLaunchKernelGGL((score_init_kernel<NV4, false, true>), grid, block, lds, s, ia);         \
+  else hipLaunchKernelGGL((score_init_kernel<NV4, false, false>), grid, block, lds, s, ia);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_INIT(1) break;
+      case 2: TDR_LAUNCH_INIT(2) break;
+      default: return fail(TDR_ERR_ARG, "score: init search supports up to 7 classes (record of %d floats)", rf);
+    }
+#undef TDR_LAUNCH_INIT
+    LAUNCH_CHECK("score_init");
+    hipLaunchKernelGGL(init_apply_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_theta,
+                       (const float*)res_flag, n, st, cap);
+    LAUNCH_CHECK("init_apply");
+  }
   rc = launch_score(a, rf, map->ncls, s);
   if (rc) return rc;
 
@@ -866,62 +1105,11 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
   hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
   LAUNCH_CHECK("score_finalize");
-  return TDR_OK;
-}
-
-// The 40-rotation initialisation search (state_particle.cpp:195-206) for particles with have_init == 0.
-// Runs the scoring kernel once per candidate rotation on the compacted list of such particles; grids are sized for
-// n and trimmed on the device by the list length, so nothing synchronises with the host.
-extern "C" int tdr_k_score_polar_init(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
-                                      float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                      float uniform_scale, float* raw_w, float* workspace, void* stream) {
-  if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
-    return fail(TDR_ERR_ARG, "score_init: null pointer");
-  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_init: n exceeds capacity");
-  if (n == 0) return TDR_OK;
-  if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_init: class count mismatch");
-  const int rf = tdr_rec_floats(map->ncls);
-  if ((size_t)2 * nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score_init: nb too large for the LDS scan ring");
-  hipStream_t s = (hipStream_t)stream;
-  ScoreArgs a;
-  a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
-  a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
-  a.st = st; a.cap = cap; a.n = n;
-  choose_chunks(n, nr, a.rpc, a.nchunks);
-  a.npad = cdiv(n, 64) * 64;
-  a.part = workspace;
-  float* best_cost = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;
-  float* best_theta = best_cost + a.npad;
-  int32_t* list = reinterpret_cast<int32_t*>(best_theta + a.npad);
-  int32_t* count = list + a.npad;
-  a.order = list; a.count = count; a.use_theta_override = 1;
-  int rcu = fill_utab(a, workspace, rf, uniform_scale, s);
-  if (rcu) return rcu;
-  const GateArgs gate = make_gate(fp, map);
-  HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(init_list_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)st, cap, n, gate,
-                     list, count);
-  LAUNCH_CHECK("init_list");
-  FinalizeArgs f;
-  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
-  f.order = list; f.count = count; f.st = st; f.fp = *fp; f.gate = gate;
-  f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 1; f.raw_w = raw_w; f.best_cost = best_cost;
-  f.best_theta = best_theta;
-  bool first = true;
-  for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {  // state_particle.cpp:197 (float t, double increment)
-    a.theta_override = t;
-    int rc = launch_score(a, rf, map->ncls, s);
-    if (rc) return rc;
-    f.first = first ? 1 : 0;
-    f.theta_override = t;
-    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
-    LAUNCH_CHECK("score_finalize(init)");
-    first = false;
+  if (init_search) {
+    hipLaunchKernelGGL(init_fixup_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_flag, n,
+                       fp->regularization, raw_w);
+    LAUNCH_CHECK("init_fixup");
   }
-  hipLaunchKernelGGL(init_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const int32_t*)list,
-                     (const int32_t*)count, (const float*)best_cost, (const float*)best_theta, fp->regularization, st,
-                     cap, raw_w);
-  LAUNCH_CHECK("init_finish");
   return TDR_OK;
 }
 

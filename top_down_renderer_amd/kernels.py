@@ -108,11 +108,7 @@ class HipKernels:
         cap = st.shape[1]
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
                                          C.byref(fp), _ptr(st), cap, n, _ptr(perm), C.c_float(uniform_scale),
-                                         _ptr(raw_w), _ptr(ws), self.stream()))
-        if init_search:
-            check(self.lib.tdr_k_score_polar_init(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr,
-                                                  C.c_float(res), C.byref(fp), _ptr(st), cap, n,
-                                                  C.c_float(uniform_scale), _ptr(raw_w), _ptr(ws), self.stream()))
+                                         int(bool(init_search)), _ptr(raw_w), _ptr(ws), self.stream()))
 
     def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None):
         need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n))
