@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--locality-every", type=int, default=1, help="recompute the cache-locality order every k steps (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="particles in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
     return ap.parse_args()
 
 
@@ -89,12 +92,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     import top_down_renderer_amd as pkg
