@@ -78,6 +78,20 @@ size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
 int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
                    void* stream);
 
+/* Map ingest on the device: TopDownMap::loadCompressedRasterMap (src/top_down_map.cpp:116-144) +
+ * computeDists (:289-326) for a class-index image, the work of TopDownMap::updateMap (:146-157) when a new aerial
+ * map arrives.  label_img: DEVICE image, img_h x img_w, row-major u8 (cv::Mat CV_8UC1); flatten_lut: DEVICE int32
+ * [lut_size] raw label -> flattened class (params_.flatten_lut).  Writes the cell records of the
+ * rows = int(img_h/resolution), cols = int(img_w/resolution) map (tdr_map_ingest_shape) into rec_out
+ * (tdr_map_rec_floats_total floats).  The Euclidean distance transform is exact. */
+size_t tdr_map_ingest_workspace_bytes(int ncls, int rows, int cols);
+int tdr_map_ingest_shape(int img_h, int img_w, float resolution, int* rows, int* cols);
+int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut, int lut_size,
+                          int ncls, float resolution, float* rec_out, void* workspace, void* stream);
+/* Cell records back to the reference's layout: class_maps_out [ncls][rows*cols] column-major, class_mask_out u8. */
+int tdr_k_unpack_map(const float* rec, int ncls, int rows, int cols, float* class_maps_out, uint8_t* class_mask_out,
+                     void* stream);
+
 /* TopDownMapPolar::samplePtsPolar (src/top_down_map_polar.cpp:7-19, via TopDownMap::samplePts
  * src/top_down_map.cpp:367-389): fills the HOST table tab[nb*nr][2] = {cos(theta_i)*r_j, sin(theta_i)*r_j}. */
 int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float* tab_out);
@@ -208,6 +222,11 @@ void tdr_map_destroy(tdr_map* m);
  * map side of TopDownMap::updateMap (:146-157).  center = map_center_. */
 int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
                 float resolution, int center_x, int center_y);
+/* TopDownMap::updateMap(const cv::Mat&, map_center) (top_down_map.cpp:146-157) for a HOST class-index image
+ * (CV_8UC1 layout): loadCompressedRasterMap + the exact distance transform of computeDists run on the device.
+ * haveMap() turns true only if the map contains road (class 1), like :150-154. */
+int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut,
+                       int lut_size, int ncls, float resolution, int center_x, int center_y);
 int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res);                 /* top_down_map_polar.cpp:7-19 */
 int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map);
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
@@ -242,6 +261,9 @@ float tdr_filter_scale(tdr_filter* f);                                          
 int64_t tdr_filter_num_particles(const tdr_filter* f);                                   /* :369-371 */
 int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,
                           float resolution, int center_x, int center_y);                 /* :320-341 */
+int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int img_h, int img_w,
+                                 const int32_t* flatten_lut, int lut_size, int ncls, float resolution, int center_x,
+                                 int center_y);                                          /* :320-341, cv::Mat form */
 /* internal: lets tdr_host.cpp report through tdr_last_error() */
 int tdr_set_error(int code, const char* msg);
 

@@ -65,6 +65,20 @@ class ParticleFilter {
                                 map_center[1]), "updateMap");
   }
 
+  // updateMap (:320-341) for a class-index image in cv::Mat CV_8UC1 layout; the map's Params carry the flatten LUT
+  void updateMap(const uint8_t* label_img, int img_h, int img_w, const std::vector<int>& flatten_lut,
+                 const Eigen::Vector2i& map_center) {
+    std::vector<int32_t> lut(flatten_lut.begin(), flatten_lut.end());
+    check(tdr_filter_update_map_labels(f_, label_img, img_h, img_w, lut.data(), (int)lut.size(), map_->numClasses(),
+                                       map_->resolution(), map_center[0], map_center[1]), "updateMap");
+  }
+#ifdef CV_VERSION
+  void updateMap(const cv::Mat& map, const std::vector<int>& flatten_lut, const Eigen::Vector2i& map_center) {
+    cv::Mat m = map.isContinuous() ? map : map.clone();
+    updateMap(m.ptr<uint8_t>(), m.rows, m.cols, flatten_lut, map_center);
+  }
+#endif
+
   // --- beyond the reference's surface -------------------------------------------------------------------------------
   void setTargetCount(int n) { target_count_ = n; }  // explicit adaptive particle count; < 0 keeps N
   void configure(bool parity_rng, int locality_every) { check(tdr_filter_configure(f_, parity_rng, locality_every), "configure"); }

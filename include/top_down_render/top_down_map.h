@@ -45,6 +45,22 @@ class TopDownMap {
     params_.num_classes = ncls;
     map_center_ = map_center;
   }
+  // updateMap (src/top_down_map.cpp:146-157) for a class-index image in cv::Mat CV_8UC1 layout (row 0 = top):
+  // loadCompressedRasterMap + computeDists run on the GPU.  `flatten_lut` is Params::flatten_lut.
+  void updateMap(const uint8_t* label_img, int img_h, int img_w, const Eigen::Vector2i& map_center) {
+    std::vector<int32_t> lut(params_.flatten_lut.begin(), params_.flatten_lut.end());
+    if (lut.empty() || params_.num_classes < 1) throw std::invalid_argument("updateMap: Params::flatten_lut / num_classes not set");
+    if (tdr_map_set_labels(m_, label_img, img_h, img_w, lut.data(), (int)lut.size(), params_.num_classes,
+                           params_.resolution, map_center[0], map_center[1]) != TDR_OK)
+      throw std::runtime_error(std::string("TopDownMap::updateMap: ") + tdr_last_error());
+    map_center_ = map_center;
+  }
+#ifdef CV_VERSION
+  void updateMap(const cv::Mat& map, const Eigen::Vector2i& map_center) {  // the reference's signature
+    cv::Mat m = map.isContinuous() ? map : map.clone();
+    updateMap(m.ptr<uint8_t>(), m.rows, m.cols, map_center);
+  }
+#endif
   void getClassesAtPoint(const Eigen::Vector2i& center_ind, std::vector<int>& classes) {  // top_down_map.cpp:159-170
     classes.clear();
     uint32_t bits = 0;

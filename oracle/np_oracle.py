@@ -223,3 +223,54 @@ def resample(w, n_new, shift):
     samples = ((np.arange(n_new).astype(f32) + f32(shift)).astype(f32) / f32(n_new)).astype(f32)
     idx = np.searchsorted(runmax, samples, side="right")
     return np.minimum(idx, len(w) - 1).astype(np.int32)
+
+
+def load_compressed_raster_map(label_img, flatten_lut, ncls, resolution=1.0):
+    """TopDownMap::loadCompressedRasterMap + computeDists (src/top_down_map.cpp:116-144, 289-326) for a class-index
+    image laid out like a cv::Mat (row 0 = top).  Returns (class_maps (ncls, rows, cols) f32 indexed [cls, y, x],
+    class_mask (rows, cols) u8, 1 = unknown).  cv::distanceTransform(DIST_L2, DIST_MASK_PRECISE) is the exact
+    Euclidean distance transform: restated with scipy's exact EDT."""
+    from scipy.ndimage import distance_transform_edt
+
+    label_img = np.asarray(label_img, np.uint8)
+    img_h, img_w = label_img.shape
+    res = f32(resolution)
+    rows, cols = int(f32(img_h) / res), int(f32(img_w) / res)                      # :121-122
+    yi, xi = np.arange(rows), np.arange(cols)
+    iy = np.maximum((f32(img_h) - yi.astype(f32) * res - f32(1)).astype(f32).astype(np.int64), 0)   # :137
+    ix = np.minimum((xi.astype(f32) * res).astype(f32).astype(np.int64), img_w - 1)                 # :138
+    lab = label_img[iy[:, None], ix[None, :]].astype(np.int64)
+    lut = np.asarray(flatten_lut, np.int64)
+    cls = np.where(lab < len(lut), lut[np.minimum(lab, len(lut) - 1)], -1)
+    cls = np.where((cls >= 0) & (cls < ncls), cls, -1)                                              # :139
+    unknown = cls < 0                                                                               # :294-299
+    maps = np.empty((ncls, rows, cols), f32)
+    for c in range(ncls):
+        binary = cls != c                                                                           # 0 inside the class
+        if binary.all():
+            d = np.full((rows, cols), np.inf)
+        else:
+            d = distance_transform_edt(binary)
+        d = np.sqrt(np.round(d * d).astype(np.float64)).astype(f32)    # exact integer d^2 -> correctly rounded float sqrt
+        d = (d * res).astype(f32)                                                                   # :314
+        d = np.minimum(d, f32(50))                                                                  # :315
+        d[unknown] = 0                                                                              # :317
+        maps[c] = d
+    return maps, unknown.astype(np.uint8)
+
+
+def write_eig(path, array):
+    """write_binary (include/top_down_render/top_down_map.h:29-39): Index rows, Index cols (2 x int64), then the
+    column-major raw scalars.  `array` is indexed [row, col]."""
+    a = np.asarray(array)
+    with open(path, "wb") as f:
+        np.asarray([a.shape[0], a.shape[1]], np.int64).tofile(f)
+        np.asfortranarray(a).ravel(order="F").tofile(f)
+
+
+def read_eig(path, dtype):
+    """read_binary (top_down_map.h:41-50)."""
+    with open(path, "rb") as f:
+        rows, cols = np.fromfile(f, np.int64, 2)
+        data = np.fromfile(f, dtype, int(rows) * int(cols))
+    return data.reshape(int(cols), int(rows)).T.copy()

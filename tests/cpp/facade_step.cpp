@@ -32,13 +32,14 @@ int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 2; }
   const std::string dir = argv[1];
   try {
-    int ncls, rows, cols, nb, nr, npts, npart, use_device_scan;
+    int ncls, rows, cols, nb, nr, npts, npart, use_device_scan, labels_mode = 0;
     float res, ang_res, tx, ty, omega;
     unsigned seed;
     {
       std::ifstream meta(dir + "/meta.txt");
       meta >> ncls >> rows >> cols >> nb >> nr >> npts >> npart >> res >> ang_res >> seed >> tx >> ty >> omega >> use_device_scan;
       if (!meta) throw std::runtime_error("bad meta.txt");
+      meta >> labels_mode;  // optional: 1 = the map arrives as a class-index image (aerialMapCallback path)
     }
     auto maps = slurp<float>(dir + "/maps.bin");
     auto mask = slurp<uint8_t>(dir + "/mask.bin");
@@ -49,7 +50,13 @@ int main(int argc, char** argv) {
     TopDownMap::Params map_params;
     map_params.num_classes = ncls;
     map_params.resolution = 1;
+    for (int c = 0; c < ncls; c++) map_params.flatten_lut.push_back(c);
     TopDownMapPolar* map_ = new TopDownMapPolar(map_params);
+    if (labels_mode) {
+      // TopDownRender::aerialMapCallback -> updateMap(map_img, centre) (src/top_down_render.cpp:574-593)
+      auto labels = slurp<uint8_t>(dir + "/labels.bin");
+      map_->updateMap(labels.data(), rows, cols, Eigen::Vector2i(0, 0));
+    }
     std::vector<Eigen::ArrayXXf> class_maps;
     for (int c = 0; c < ncls; c++) {
       Eigen::ArrayXXf m(rows, cols);
@@ -58,7 +65,7 @@ int main(int argc, char** argv) {
     }
     Eigen::ArrayXXc class_mask(rows, cols);
     std::memcpy(class_mask.data(), mask.data(), (size_t)rows * cols);
-    map_->setDistanceMaps(class_maps, class_mask);
+    if (!labels_mode) map_->setDistanceMaps(class_maps, class_mask);
     map_->samplePtsPolar(Eigen::Vector2i(nb, nr), ang_res);
 
     FilterParams filter_params;

@@ -43,8 +43,8 @@ def test_facade_compiles_and_fails_loudly_without_gpu(facade_exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("device_scan", [0, 1])
-def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan):
+@pytest.mark.parametrize("device_scan,labels_mode", [(0, 0), (1, 0), (1, 1)])
+def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan, labels_mode):
     from top_down_renderer_amd import synth
     sc = synth.make_scene("c1", n_particles=2048)
     cfg = sc.cfg
@@ -52,7 +52,9 @@ def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan):
     seed, tx, ty, omega = 17, 1.0, 0.25, 0.01
     open(os.path.join(d, "meta.txt"), "w").write(
         f"{cfg.ncls} {cfg.map_size} {cfg.map_size} {cfg.nb} {cfg.nr} {len(sc.pts)} {len(sc.states)} {cfg.res} "
-        f"{float(cfg.ang_res)!r} {seed} {tx} {ty} {omega} {device_scan}\n")
+        f"{float(cfg.ang_res)!r} {seed} {tx} {ty} {omega} {device_scan} {labels_mode}\n")
+    # the same map as a class-index image (cv::Mat layout: row 0 = top), raw id 200 = unlabelled
+    np.where(sc.lab >= 0, sc.lab, 200).astype(np.uint8)[::-1].copy().tofile(os.path.join(d, "labels.bin"))
     np.ascontiguousarray(np.transpose(sc.class_maps, (0, 2, 1)), np.float32).tofile(os.path.join(d, "maps.bin"))
     np.ascontiguousarray(sc.class_mask.T, np.uint8).tofile(os.path.join(d, "mask.bin"))
     pcl = np.zeros((len(sc.pts), 8), np.float32)

@@ -38,6 +38,10 @@ SIGNATURES = {
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_selftest_round": (_i, [_vp, _i64, _f, _vp, _vp]),
     "tdr_k_pack_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "tdr_map_ingest_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "tdr_map_ingest_shape": (_i, [_i, _i, _f, C.POINTER(_i), C.POINTER(_i)]),
+    "tdr_k_map_from_labels": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "tdr_k_unpack_map": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_polar_table_host": (_i, [_i, _i, _f, _f, _vp]),
     "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -70,6 +74,8 @@ SIGNATURES = {
     "tdr_map_create": (_i, [C.POINTER(_vp)]),
     "tdr_map_destroy": (None, [_vp]),
     "tdr_map_set": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i]),
+    "tdr_map_set_labels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _i]),
+    "tdr_filter_update_map_labels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _i]),
     "tdr_map_sample_pts_polar": (_i, [_vp, _i, _i, _f]),
     "tdr_map_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
     "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),

@@ -138,6 +138,48 @@ int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, 
   return TDR_OK;
 }
 
+// TopDownMap::updateMap(const cv::Mat&, map_center) (top_down_map.cpp:146-157): loadCompressedRasterMap (:116-144) +
+// computeDists (:289-326) for a HOST class-index image (cv::Mat CV_8UC1 layout), all on the device.
+int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut,
+                       int lut_size, int ncls, float resolution, int center_x, int center_y) {
+  if (!m || !label_img || !flatten_lut) return failh(TDR_ERR_ARG, "map_set_labels: null pointer");
+  int rows = 0, cols = 0;
+  TTRY(tdr_map_ingest_shape(img_h, img_w, resolution, &rows, &cols));
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return failh(TDR_ERR_ARG, "map_set_labels: bad shape");
+  DevBuf<uint8_t> d_img, d_ws, d_mask;
+  DevBuf<int32_t> d_lut;
+  DevBuf<float> d_maps;
+  const size_t ncell = (size_t)rows * cols;
+  TTRY(d_img.resize((size_t)img_h * img_w));
+  TTRY(d_lut.resize((size_t)lut_size));
+  TTRY(d_ws.resize(tdr_map_ingest_workspace_bytes(ncls, rows, cols)));
+  HTRY(hipMemcpy(d_img.p, label_img, (size_t)img_h * img_w, hipMemcpyHostToDevice));
+  HTRY(hipMemcpy(d_lut.p, flatten_lut, (size_t)lut_size * sizeof(int32_t), hipMemcpyHostToDevice));
+  TTRY(m->rec.resize(tdr_map_rec_floats_total(ncls, rows, cols)));
+  TTRY(tdr_k_map_from_labels(d_img.p, img_h, img_w, d_lut.p, lut_size, ncls, resolution, m->rec.p, d_ws.p, nullptr));
+  // host copy of class_maps_ for getClassesAtPoint / particle initialisation
+  TTRY(d_maps.resize(ncell * ncls));
+  TTRY(d_mask.resize(ncell));
+  TTRY(tdr_k_unpack_map(m->rec.p, ncls, rows, cols, d_maps.p, d_mask.p, nullptr));
+  m->maps_host.resize(ncell * ncls);
+  HTRY(hipMemcpy(m->maps_host.data(), d_maps.p, ncell * ncls * sizeof(float), hipMemcpyDeviceToHost));
+  m->desc.rec = m->rec.p;
+  m->desc.ncls = ncls;
+  m->desc.rows = rows;
+  m->desc.cols = cols;
+  m->desc.rec_floats = tdr_rec_floats(ncls);
+  m->desc.resolution = resolution;
+  m->center_x = center_x;
+  m->center_y = center_y;
+  // `if (!class_maps_[1].isZero(0)) have_map_ = true; else "Received map with no road"` (:150-154)
+  bool road = false;
+  if (ncls > 1)
+    for (size_t k = 0; k < ncell && !road; k++) road = m->maps_host[ncell + k] != 0.f;
+  if (road) m->have_map = true;
+  if (m->nb > 0 && m->have_map) return tdr_map_sample_pts_polar(m, m->nb, m->nr, m->ang_res);
+  return TDR_OK;
+}
+
 // TopDownMapPolar::samplePtsPolar (top_down_map_polar.cpp:7-19)
 int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res) {
   if (!m || nb < 1 || nr < 1) return failh(TDR_ERR_ARG, "sample_pts_polar: bad arguments");
@@ -467,6 +509,18 @@ float tdr_filter_scale(tdr_filter* f) {
   return -1.f;
 }
 int64_t tdr_filter_num_particles(const tdr_filter* f) { return f ? f->n : 0; }
+
+// ParticleFilter::updateMap(const cv::Mat& map, map_center) (particle_filter.cpp:320-341) for a class-index image
+int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int img_h, int img_w,
+                                 const int32_t* flatten_lut, int lut_size, int ncls, float resolution, int center_x,
+                                 int center_y) {
+  if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map_labels: null filter");
+  const int ox = f->map->center_x, oy = f->map->center_y;
+  TTRY(tdr_map_set_labels(f->map, label_img, img_h, img_w, flatten_lut, lut_size, ncls, resolution, center_x, center_y));
+  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->n_max, f->n, (float)(center_x - ox), (float)(center_y - oy), f->stream);
+  if (f->map->have_map) return tdr_filter_initialize_particles(f);  // :337-340
+  return TDR_OK;
+}
 
 // ParticleFilter::updateMap (particle_filter.cpp:320-341), with the map already in distance-map form
 int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols,

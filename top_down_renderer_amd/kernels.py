@@ -70,6 +70,30 @@ class HipKernels:
         del maps_cm, mask_cm
         return DeviceMap(rec, ncls, H, W, resolution)
 
+    def make_map_from_labels(self, label_img, flatten_lut, ncls, resolution):
+        """label_img: (img_h, img_w) uint8 class-index image (cv::Mat layout, row 0 = top).  Runs
+        loadCompressedRasterMap + computeDists on the device (tdr_k_map_from_labels)."""
+        label_img = np.ascontiguousarray(label_img, np.uint8)
+        img_h, img_w = label_img.shape
+        rows, cols = C.c_int(0), C.c_int(0)
+        check(self.lib.tdr_map_ingest_shape(img_h, img_w, C.c_float(resolution), C.byref(rows), C.byref(cols)))
+        rows, cols = rows.value, cols.value
+        lut = np.ascontiguousarray(flatten_lut, np.int32).ravel()
+        img_d, lut_d = self.to_device(label_img), self.to_device(lut)
+        rec = self.empty((int(self.lib.tdr_map_rec_floats_total(ncls, rows, cols)),))
+        ws = self.empty((int(self.lib.tdr_map_ingest_workspace_bytes(ncls, rows, cols)),), torch.uint8)
+        check(self.lib.tdr_k_map_from_labels(_ptr(img_d), img_h, img_w, _ptr(lut_d), len(lut), ncls,
+                                             C.c_float(resolution), _ptr(rec), _ptr(ws), self.stream()))
+        self.synchronize()
+        return DeviceMap(rec, ncls, rows, cols, resolution)
+
+    def unpack_map(self, m):
+        """Device map -> the reference's host layout: class maps (ncls, cols, rows) i.e. column-major, mask (cols, rows)."""
+        maps = self.empty((m.ncls, m.cols, m.rows))
+        mask = self.empty((m.cols, m.rows), torch.uint8)
+        check(self.lib.tdr_k_unpack_map(_ptr(m.rec), m.ncls, m.rows, m.cols, _ptr(maps), _ptr(mask), self.stream()))
+        return maps.cpu().numpy(), mask.cpu().numpy()
+
     def set_polar_table(self, m, nb, nr, ang_res):
         tab = np.empty((nb * nr, 2), np.float32)
         check(self.lib.tdr_polar_table_host(nb, nr, C.c_float(ang_res), C.c_float(m.resolution),

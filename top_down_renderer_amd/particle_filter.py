@@ -359,10 +359,16 @@ class ParticleFilter:
     def numParticles(self):
         return self.num_particles_
 
-    def updateMap(self, class_maps, class_mask, map_center):
-        """particle_filter.cpp:320-341 with the map already in distance-map form (map ingest: SURVEY.md §8f N1)."""
+    def updateMap(self, class_maps, class_mask=None, map_center=(0, 0)):
+        """particle_filter.cpp:320-341.  updateMap(label_img, map_center) like the reference (class-index image, the
+        distance transform runs on the GPU), or updateMap(class_maps, class_mask, map_center) with ready distance maps."""
         old = self.map_.mapCenter()
-        self.map_.updateMap(class_maps, class_mask, map_center)
+        if class_mask is None or np.ndim(class_maps) == 2:
+            if class_mask is not None:
+                map_center = class_mask
+            self.map_.updateMap(class_maps, None, map_center)
+        else:
+            self.map_.updateMap(class_maps, class_mask, map_center)
         self.fp_c = self.params_.to_c(self.map_.numClasses())
         if self.num_particles_ > 0:
             self.k.shift_init(self.st, self.n_local, float(map_center[0] - old[0]), float(map_center[1] - old[1]))

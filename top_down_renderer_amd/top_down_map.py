@@ -49,11 +49,37 @@ class TopDownMap:
         self.dev = self.k.make_map(class_maps, class_mask, self.params_.resolution)
         self.have_map_ = True
 
-    # top_down_map.cpp:146-157 with the distance transform already applied
-    def updateMap(self, class_maps, class_mask, map_center):
+    # top_down_map.cpp:146-157
+    def updateMap(self, class_maps, class_mask=None, map_center=(0, 0)):
+        """updateMap(label_img, map_center) like the reference (a cv::Mat of class ids), or
+        updateMap(class_maps, class_mask, map_center) with distance maps computed elsewhere."""
+        if class_mask is None or np.ndim(class_maps) == 2:
+            if class_mask is not None and np.ndim(class_mask) == 1:
+                map_center = class_mask
+            return self.loadCompressedRasterMap(class_maps, map_center)
         self.map_center_ = (int(map_center[0]), int(map_center[1]))
         old = self.dev
         self._load(class_maps, class_mask)
+        if old is not None and getattr(old, "nb", 0):
+            self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
+
+    # top_down_map.cpp:116-144 + 289-326, and updateMap :146-157 for a class-index image (cv::Mat CV_8UC1)
+    def loadCompressedRasterMap(self, label_img, map_center=(0, 0)):
+        """label_img: (H, W) uint8 image of raw class ids, row 0 = top like a cv::Mat; params_.flatten_lut maps raw id
+        -> flattened class.  Class binary maps, the exact Euclidean distance transform, truncation at 50 and the
+        unknown mask are all computed on the GPU."""
+        p = self.params_
+        if not p.num_classes or not len(p.flatten_lut):
+            raise ValueError("Params.num_classes and Params.flatten_lut are needed to ingest a label image")
+        old = self.dev
+        self.dev = self.k.make_map_from_labels(label_img, p.flatten_lut, p.num_classes, p.resolution)
+        self.rows, self.cols = self.dev.rows, self.dev.cols
+        maps_cm, _ = self.k.unpack_map(self.dev)
+        self.maps_cm_host = maps_cm            # column-major host copy (class_maps_), for getClassesAtPoint / init
+        self.map_center_ = (int(map_center[0]), int(map_center[1]))
+        # `if (!class_maps_[1].isZero(0)) have_map_ = true` (:150): a map without any road is not usable
+        if p.num_classes > 1 and bool((self.maps_cm_host[1] != 0).any()):
+            self.have_map_ = True
         if old is not None and getattr(old, "nb", 0):
             self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
 
