@@ -196,6 +196,8 @@ int tdr_profile_enable(int on);
 int tdr_profile_score_ms(double* total_ms, int64_t* launches);
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
+/* Self-test hook: out[i] = the raster kernel's atan2f(y[i], x[i]) (bit-identical to glibc's atan2f). */
+int tdr_k_selftest_atan2(const float* y, const float* x, int64_t n, float* out, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------------------------------------------ */
 int tdr_k_states_aos_to_soa(const tdr_state* aos, int64_t n, float* st, int64_t cap, void* stream);

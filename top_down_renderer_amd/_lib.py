@@ -36,6 +36,7 @@ SIGNATURES = {
     "tdr_device_count": (_i, []),
     "tdr_rec_floats": (_i, [_i]),
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_k_selftest_atan2": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tdr_k_selftest_round": (_i, [_vp, _i64, _f, _vp, _vp]),
     "tdr_k_pack_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "tdr_map_ingest_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
