@@ -167,11 +167,17 @@ int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, 
                          void* stream);
 
 /* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
-/* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum. */
-int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream);
-/* Same, choosing the implementation: mode 0 = one wave adding in index order, 1 = the exact parallel kernel (integer
- * increments per binade, see tdr_kernels.hip); both give identical bits.  prefix_out (optional, mode 1) = raw sums. */
-int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out, void* stream);
+/* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum.
+ * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  With a workspace and n >= 32768 the chain
+ * is evaluated by many workgroups (per-chunk parity summaries, see tdr_kernels.hip); without one, by one workgroup.
+ * The bits written are the serial chain's either way. */
+int64_t tdr_prefix_workspace_bytes(int64_t n);
+int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream);
+/* Same, choosing the implementation: mode 0 = one wave adding in index order, 1 = the exact parallel kernel in one
+ * workgroup (integer increments per binade), 2 = the multi-workgroup scan (workspace required); all give identical
+ * bits.  prefix_out (optional, modes 1 and 2) = raw sums. */
+int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out, void* workspace,
+                      void* stream);
 /* idx_out[i - i_begin] = first j with prefix_j > (float(i)+shift)/n_new, else n-1, for i in [i_begin, i_end). */
 int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, int64_t i_begin, int64_t i_end,
                    int32_t* idx_out, void* stream);

@@ -407,12 +407,29 @@ def _prefix_cases():
     cases["inf inside"] = np.concatenate([rng.random(9000).astype(f32), [f32(np.inf)], rng.random(300).astype(f32)])
     w = rng.random(1_000_000).astype(f32) ** 4
     cases["1M random^4"] = (w / w.sum()).astype(f32)
+    # large inputs for the multi-workgroup scan: ties in bulk, stagnation, irregular weights deep inside, ragged tail
+    cases["300k dyadic ties"] = (rng.integers(0, 64, 300_001) * f32(2.0 ** -22)).astype(f32)
+    cases["half-ulp ties"] = np.concatenate([[f32(4096.0)], np.full(200_000, f32(2.0 ** -12), f32),  # exactly half an ulp
+                                             np.full(50_000, f32(2.0 ** -13), f32), rng.random(70_000).astype(f32)])
+    # the float chain stalls below 2 while the exact sum passes it: every later chunk is mispredicted
+    cases["stagnation"] = np.concatenate([[f32(1.9999)], np.full(400_000, f32(2.0 ** -25), f32),
+                                          rng.random(30_000).astype(f32) * f32(1e-3)])
+    w = (rng.random(500_003).astype(f32) / f32(250_000))
+    w[[70_000, 250_001]] = f32(-0.125)
+    w[400_000] = f32(3.0)
+    cases["500k negatives and a jump"] = w
+    w = (rng.random(262_144 + 5).astype(f32) / f32(131_072))
+    w[200_000] = f32(np.nan)
+    cases["262k nan inside"] = w
+    cases["2M uniform"] = np.full(2_000_000, f32(1.0 / 2_000_000), f32)
+    w = np.exp(rng.normal(0, 2.0, 800_000)).astype(f32)
+    cases["800k lognormal normalised"] = (w / w.sum(dtype=np.float64)).astype(f32)
     return cases
 
 
 def test_exact_parallel_prefix_is_the_serial_float_chain(tdr):
-    """tdr_k_prefix_mode: the parallel kernel (integer increments per binade) and the one-wave serial kernel must both
-    reproduce `running_sum += weights_[j]` (particle_filter.cpp:179) bit for bit, including rounding ties, zero runs,
+    """tdr_k_prefix_mode: the one-workgroup parallel kernel (integer increments per binade), the multi-workgroup scan
+    (per-chunk parity summaries) and the one-wave serial kernel must all reproduce `running_sum += weights_[j]` (particle_filter.cpp:179) bit for bit, including rounding ties, zero runs,
     negative weights, NaN/inf and binade crossings."""
     pkg, k = tdr
     import ctypes as C
@@ -422,10 +439,12 @@ def test_exact_parallel_prefix_is_the_serial_float_chain(tdr):
             ref = np.cumsum(w, dtype=np.float32)                      # sequential float32 accumulation
             refmax = np.maximum.accumulate(np.where(np.isnan(ref), -np.inf, ref)).astype(np.float32)
         wd = k.to_device(w)
-        for mode in (0, 1):
+        ws = k.prefix_workspace(n)
+        for mode in (0, 1, 2):
             rm, pf = k.zeros((n,)), k.zeros((n,))
             assert k.lib.tdr_k_prefix_mode(C.c_void_p(wd.data_ptr()), n, mode, C.c_void_p(rm.data_ptr()),
-                                           C.c_void_p(pf.data_ptr()) if mode else None, k.stream()) == 0
+                                           C.c_void_p(pf.data_ptr()) if mode else None,
+                                           C.c_void_p(ws.data_ptr()) if n else None, k.stream()) == 0
             assert np.array_equal(rm.cpu().numpy(), refmax), (name, mode)
             if mode:
                 assert np.array_equal(pf.cpu().numpy(), ref, equal_nan=True), name

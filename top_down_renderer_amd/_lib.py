@@ -59,8 +59,9 @@ SIGNATURES = {
     "tdr_rng_uniform_host": (_f, [_vp]),
     "tdr_propagate_normals_host": (_i, [_vp, _i64, _i, _vp]),
     "tdr_k_update_weights": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "tdr_k_prefix": (_i, [_vp, _i64, _vp, _vp]),
-    "tdr_k_prefix_mode": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "tdr_prefix_workspace_bytes": (_i64, [_i64]),
+    "tdr_k_prefix": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "tdr_k_prefix_mode": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "tdr_k_resample": (_i, [_vp, _i64, _i64, _f, _i64, _i64, _vp, _vp]),
     "tdr_k_gather_states": (_i, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tdr_init_particles_host": (_i, [_vp, _vp, _i, _i, _i, _f, C.POINTER(FilterParamsC), _i, _vp, C.POINTER(C.c_int64)]),

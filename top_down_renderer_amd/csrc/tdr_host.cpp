@@ -85,6 +85,7 @@ struct tdr_filter {
   tdr_filter_params fp{};
   int64_t n_max = 0, n = 0;
   DevBuf<float> st, st_new, last_dist, raw_w, w, runmax, info, ws, z4, scan_img, scan_pk, stats;
+  DevBuf<uint8_t> pfx_ws;  // chunk headers of the multi-workgroup running sum
   DevBuf<int32_t> idx, perm, loc_tmp;
   DevBuf<tdr_state> aos;
   void* rng = nullptr;
@@ -277,6 +278,7 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
   if (rc == TDR_OK) rc = f->raw_w.resize(cap);
   if (rc == TDR_OK) rc = f->w.resize(cap);
   if (rc == TDR_OK) rc = f->runmax.resize(cap);
+  if (rc == TDR_OK) rc = f->pfx_ws.resize((size_t)tdr_prefix_workspace_bytes((int64_t)cap));
   if (rc == TDR_OK) rc = f->idx.resize(cap);
   if (rc == TDR_OK) rc = f->perm.resize(cap);
   if (rc == TDR_OK) rc = f->info.resize(TDR_UW_INFO_FLOATS);
@@ -422,7 +424,7 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
   int64_t n_new = n;
   if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));
   const float shift = tdr_rng_uniform_host(f->rng);  // :172-173
-  TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->stream));
+  TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
   TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, 0, n_new, f->idx.p, f->stream));
   TTRY(tdr_k_gather_states(f->st.p, f->n_max, 0, f->idx.p, n_new, f->st_new.p, f->n_max, f->stream));
   // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state

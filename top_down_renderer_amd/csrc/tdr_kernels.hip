@@ -1968,9 +1968,13 @@ __device__ __forceinline__ float pfx_block_scan_max(float v, float* sh) {
   return fmaxf(v, off);
 }
 
-__global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* __restrict__ w, int64_t n,
-                                                                   float* __restrict__ runmax,
-                                                                   float* __restrict__ prefix_opt) {
+// The running sum carried through [lo, hi) in index order by the whole workgroup (PFX_THREADS threads): r_io / carry_io
+// are the (workgroup-uniform) running sum and running maximum before element lo on entry and after element hi-1 on
+// exit.  With lo == 0 the first PFX_HEAD elements are added one by one.
+__device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, long long lo, long long hi,
+                                             float* __restrict__ runmax, float* __restrict__ prefix_opt,
+                                             float& r_io, float& carry_io) {
+  const long long n = hi;
   __shared__ long long sh_ll[PFX_THREADS / 64];
   __shared__ int sh_i[PFX_THREADS / 64];
   __shared__ float sh_f[PFX_THREADS / 64];
@@ -1983,7 +1987,10 @@ __global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* 
   __shared__ float s_r, s_carry;
   __shared__ long long s_base;
   const int tid = threadIdx.x;
-  {  // head: plain serial additions by one thread out of LDS
+  __syncthreads();
+  if (tid == 0) { s_r = r_io; s_carry = carry_io; s_base = lo; }
+  __syncthreads();
+  if (lo == 0) {  // head: plain serial additions by one thread out of LDS
     const int hn = (int)min((long long)PFX_HEAD, (long long)n);
     for (int t = tid; t < hn; t += PFX_THREADS) head[t] = w[t];
     __syncthreads();
@@ -2232,28 +2239,332 @@ __global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* 
     }
     __syncthreads();
   }
+  r_io = s_r;
+  carry_io = s_carry;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* __restrict__ w, int64_t n,
+                                                                   float* __restrict__ runmax,
+                                                                   float* __restrict__ prefix_opt) {
+  float r = 0.f, carry = -INFINITY;
+  pfx_exact_range(w, 0, n, runmax, prefix_opt, r, carry);
+}
+
+// ---- exact parallel prefix over many workgroups ---------------------------------------------------------------------
+// Inside one binade (ulp u) the chain r <- fl(r + w) with w >= 0 is R <- R + a(R & 1): the increment of one element is
+// an integer that depends on the running mantissa only through its PARITY (round-half-even ties).  A run of elements is
+// therefore summarised by two integers (D0, D1) — its total increment entered with an even / odd mantissa — and
+// summaries compose associatively: (A then B)_p = A_p + B_{(p + A_p) & 1}.  That turns the chain into a scan:
+//   1. pfx_chunk_sum_kernel      — per chunk of PFXM_CHUNK weights: the sum in double
+//   2. pfx_chunk_summary_kernel  — per chunk: binade predicted from the double sum of everything before it; (D0, D1) in
+//                                  that binade, or "irregular" (NaN / inf / negative / weight above the binade)
+//   3. pfx_walk_kernel           — ONE workgroup walks the chunks in order with the exact running sum: a chunk whose
+//                                  prediction holds (same binade, R + D_p stays below 2^24) is a single integer add;
+//                                  any other chunk (the ~log2(n) binade crossings, irregular weights, the head) is
+//                                  processed on the spot by pfx_exact_range
+//   4. pfx_chunk_fill_kernel     — per accepted chunk: the same scan again, now with the exact starting mantissa,
+//                                  writes every element's running sum / running maximum
+// Every value written is the serial float32 chain's, whatever the prediction was: a wrong prediction only sends the
+// chunk down the slower path.
+#define PFXM_THREADS 256
+#define PFXM_K 16
+#define PFXM_CHUNK (PFXM_THREADS * PFXM_K)
+#define PFXM_SAT (1u << 30)
+struct PfxChunk {     // 32 bytes per chunk in the caller's workspace
+  double sum;         // 1: double sum of the chunk
+  int re;             // 2: predicted biased exponent of the running sum, or -1 = irregular
+  unsigned d0, d1;    // 2: total increment entered with an even / odd mantissa
+  float r0, carry0;   // 3: running sum / running maximum before the chunk's first element (accepted chunks)
+  int accepted;       // 3: 1 = pfx_chunk_fill_kernel writes this chunk's outputs
+};
+static_assert(sizeof(PfxChunk) == 32, "PfxChunk");
+
+struct PfxPair { unsigned a0, a1; };
+__device__ __forceinline__ unsigned pfx_sat(unsigned x) { return x > PFXM_SAT ? PFXM_SAT : x; }
+// first A, then B
+__device__ __forceinline__ PfxPair pfx_compose(PfxPair A, PfxPair B) {
+  PfxPair c;
+  c.a0 = pfx_sat(A.a0 + ((A.a0 & 1u) ? B.a1 : B.a0));
+  c.a1 = pfx_sat(A.a1 + ((A.a1 & 1u) ? B.a0 : B.a1));   // entered odd: the parity after A is (1 + A.a1) & 1
+  return c;
+}
+// One weight against the binade with exponent e (unbiased): f = floor(w/u) (+1 when the remainder exceeds one half),
+// tie = remainder exactly one half, bad = cannot be an integer increment (NaN, inf, negative, exponent above e).
+__device__ __forceinline__ void pfx_classify(float wv, int e, unsigned& f, bool& tie, bool& bad) {
+  const unsigned b = __float_as_uint(wv);
+  const int ew = (b >> 23) & 0xFF;
+  unsigned mw = b & 0x7FFFFFu;
+  const bool zero = (b & 0x7FFFFFFFu) == 0;
+  const int E = ew == 0 ? -126 : ew - 127;
+  if (ew != 0) mw |= 0x800000u;
+  const int sft = e - E;
+  bad = ew == 255 || sft < 0 || ((b >> 31) != 0 && !zero);
+  const int sc = sft < 0 ? 0 : (sft > 26 ? 26 : sft);
+  const unsigned q = mw >> sc;
+  const unsigned rem = mw & ((1u << sc) - 1u);
+  const unsigned half = sc >= 1 ? (1u << (sc - 1)) : 0u;
+  tie = sc >= 1 && rem == half;
+  f = q + ((sc >= 1 && rem > half) ? 1u : 0u);
+  if (bad) { f = 0; tie = false; }
+}
+__device__ __forceinline__ PfxPair pfx_element_pair(unsigned f, bool tie) {
+  PfxPair p;
+  p.a0 = f + (tie ? (f & 1u) : 0u);         // even mantissa + f + 1/2 -> the even neighbour
+  p.a1 = f + (tie ? ((f & 1u) ^ 1u) : 0u);
+  return p;
+}
+// inclusive scan of per-thread pairs over the workgroup (PFXM_THREADS threads); returns the EXCLUSIVE pair of this
+// thread and the workgroup total
+__device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh /*[PFXM_THREADS/64]*/, PfxPair& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    PfxPair t;
+    t.a0 = __shfl_up(v.a0, o, 64);
+    t.a1 = __shfl_up(v.a1, o, 64);
+    if (lane >= o) v = pfx_compose(t, v);
+  }
+  if (lane == 63) sh[wave] = v;
+  __syncthreads();
+  PfxPair pre = {0u, 0u}, tot = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < PFXM_THREADS / 64; k++) {
+    const PfxPair x = sh[k];
+    if (k < wave) pre = pfx_compose(pre, x);
+    tot = pfx_compose(tot, x);
+  }
+  total = tot;
+  PfxPair ex;
+  ex.a0 = __shfl_up(v.a0, 1, 64);
+  ex.a1 = __shfl_up(v.a1, 1, 64);
+  if (lane == 0) { ex.a0 = 0u; ex.a1 = 0u; }
+  return pfx_compose(pre, ex);
+}
+__device__ __forceinline__ void pfx_load_chunk(const float* __restrict__ w, long long lo, int cnt, float (&wv)[PFXM_K]) {
+  const int t0 = threadIdx.x * PFXM_K;
+  if (t0 + PFXM_K <= cnt && ((lo & 3) == 0)) {
+    const float4* p = reinterpret_cast<const float4*>(w + lo + t0);
+#pragma unroll
+    for (int k = 0; k < PFXM_K / 4; k++) {
+      const float4 v = p[k];
+      wv[4 * k] = v.x; wv[4 * k + 1] = v.y; wv[4 * k + 2] = v.z; wv[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PFXM_K; k++) wv[k] = (t0 + k < cnt) ? w[lo + t0 + k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_sum_kernel(const float* __restrict__ w, int64_t n,
+                                                                     PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXM_THREADS / 64];
+  const long long lo = (long long)blockIdx.x * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) acc += (double)wv[k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < PFXM_THREADS / 64; k++) t += shd[k];
+    ch[blockIdx.x].sum = t;
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const float* __restrict__ w, int64_t n,
+                                                                         PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXM_THREADS / 64];
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  __shared__ int s_bad;
+  const int c = blockIdx.x;
+  const long long lo = (long long)c * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  // predicted running sum before the chunk: the double sums of the chunks before it, in chunk order per thread
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < c; j += PFXM_THREADS) acc += ch[j].sum;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  double before = 0.0;
+  for (int k = 0; k < PFXM_THREADS / 64; k++) before += shd[k];
+  const float r_pred = (float)before, r_end = (float)(before + ch[c].sum);
+  const unsigned pb = __float_as_uint(r_pred), eb = __float_as_uint(r_end);
+  const int re = (pb >> 23) & 0xFF;
+  // a chunk that is predicted to start and end in one binade of a positive normal sum; everything else is irregular
+  const bool plausible = (pb >> 31) == 0 && re != 0 && re != 255 && (int)((eb >> 23) & 0xFF) == re && (eb >> 31) == 0;
+  if (!plausible) {   // uniform across the workgroup
+    if (threadIdx.x == 0) { ch[c].re = -1; ch[c].d0 = 0u; ch[c].d1 = 0u; }
+    return;
+  }
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  PfxPair mine = {0u, 0u};
+  bool anybad = false;
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    unsigned f; bool tie, bad;
+    pfx_classify(wv[k], re - 127, f, tie, bad);
+    anybad |= bad;
+    mine = pfx_compose(mine, pfx_element_pair(f, tie));
+  }
+  if (anybad) s_bad = 1;   // benign race: every writer stores 1; ordered by the barrier inside the scan
+  PfxPair total;
+  (void)pfx_pair_scan(mine, shp, total);
+  if (threadIdx.x == 0) {
+    const bool ok = s_bad == 0 && total.a0 < (1u << 24) && total.a1 < (1u << 24);
+    ch[c].re = ok ? re : -1;
+    ch[c].d0 = total.a0;
+    ch[c].d1 = total.a1;
+  }
+}
+
+__global__ __launch_bounds__(PFX_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
+                                                               PfxChunk* __restrict__ ch, int nch,
+                                                               float* __restrict__ runmax,
+                                                               float* __restrict__ prefix_opt) {
+  __shared__ int sm_re[PFX_THREADS];
+  __shared__ unsigned sm_d0[PFX_THREADS], sm_d1[PFX_THREADS];
+  float r = 0.f, carry = -INFINITY;   // workgroup-uniform
+  for (int cb = 0; cb < nch; cb += PFX_THREADS) {
+    __syncthreads();
+    if (cb + (int)threadIdx.x < nch) {
+      const PfxChunk x = ch[cb + threadIdx.x];
+      sm_re[threadIdx.x] = x.re; sm_d0[threadIdx.x] = x.d0; sm_d1[threadIdx.x] = x.d1;
+    }
+    __syncthreads();
+    const int ce = min(nch, cb + PFX_THREADS);
+    for (int c = cb; c < ce; c++) {
+      const unsigned rb = __float_as_uint(r);
+      const int re = (int)(rb >> 23);                   // sign bit included: a negative sum never matches
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      const unsigned D = (R & 1u) ? sm_d1[c - cb] : sm_d0[c - cb];
+      const bool fast = sm_re[c - cb] == re && R + D < (1u << 24);   // sm_re is in [1, 254] or -1
+      if (fast) {
+        if ((int)threadIdx.x == ((c - cb) & (PFX_THREADS - 1))) {
+          ch[c].r0 = r; ch[c].carry0 = carry; ch[c].accepted = 1;
+        }
+        r = __uint_as_float(((unsigned)re << 23) | ((R + D) & 0x7FFFFFu));
+        carry = fmaxf(carry, r);
+      } else {
+        if (threadIdx.x == 0) ch[c].accepted = 0;
+        const long long lo = (long long)c * PFXM_CHUNK;
+        const long long hi = min((long long)n, lo + PFXM_CHUNK);
+        pfx_exact_range(w, lo, hi, runmax, prefix_opt, r, carry);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const float* __restrict__ w, int64_t n,
+                                                                      const PfxChunk* __restrict__ ch,
+                                                                      float* __restrict__ runmax,
+                                                                      float* __restrict__ prefix_opt) {
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  const int c = blockIdx.x;
+  const PfxChunk hdr = ch[c];
+  if (!hdr.accepted) return;   // written by the walk
+  const long long lo = (long long)c * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  const unsigned rb = __float_as_uint(hdr.r0);
+  const unsigned re = rb >> 23;
+  const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  unsigned f[PFXM_K];
+  bool tie[PFXM_K];
+  PfxPair mine = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    bool bad;
+    pfx_classify(wv[k], (int)re - 127, f[k], tie[k], bad);
+    mine = pfx_compose(mine, pfx_element_pair(f[k], tie[k]));
+  }
+  PfxPair total;
+  const PfxPair ex = pfx_pair_scan(mine, shp, total);
+  unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);   // the exact mantissa before this thread's first element
+  const int t0 = threadIdx.x * PFXM_K;
+  float val[PFXM_K];
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    state += f[k] + (tie[k] ? ((state + f[k]) & 1u) : 0u);
+    val[k] = __uint_as_float((re << 23) | (state & 0x7FFFFFu));
+  }
+  const float carry = hdr.carry0;
+  if (t0 + PFXM_K <= cnt && ((lo & 3) == 0)) {
+    float4* o = reinterpret_cast<float4*>(runmax + lo + t0);
+#pragma unroll
+    for (int k = 0; k < PFXM_K / 4; k++)
+      o[k] = make_float4(fmaxf(carry, val[4 * k]), fmaxf(carry, val[4 * k + 1]), fmaxf(carry, val[4 * k + 2]),
+                         fmaxf(carry, val[4 * k + 3]));
+    if (prefix_opt) {
+      float4* q = reinterpret_cast<float4*>(prefix_opt + lo + t0);
+#pragma unroll
+      for (int k = 0; k < PFXM_K / 4; k++) q[k] = make_float4(val[4 * k], val[4 * k + 1], val[4 * k + 2], val[4 * k + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PFXM_K; k++)
+      if (t0 + k < cnt) {
+        runmax[lo + t0 + k] = fmaxf(carry, val[k]);
+        if (prefix_opt) prefix_opt[lo + t0 + k] = val[k];
+      }
+  }
 }
 
 // n below this: the single-wave serial kernel is faster than the workgroup passes
 #define TDR_PFX_EXACT_MIN_N 16384
-extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* stream) {
+// n from this on (and a workspace): the multi-workgroup scan
+#define TDR_PFX_MULTI_MIN_N 32768
+extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
+  return n < 1 ? 0 : (int64_t)sizeof(PfxChunk) * cdiv(n, (int64_t)PFXM_CHUNK);
+}
+static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* prefix_out, void* workspace,
+                        hipStream_t st) {
+  const int64_t nch64 = cdiv(n, (int64_t)PFXM_CHUNK);
+  if (nch64 > (1 << 24)) return fail(TDR_ERR_ARG, "prefix: n too large");
+  const int nch = (int)nch64;
+  PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
+  hipLaunchKernelGGL(pfx_chunk_sum_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
+  hipLaunchKernelGGL(pfx_chunk_summary_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
+  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFX_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out);
+  hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,
+                     runmax_out, prefix_out);
+  return TDR_OK;
+}
+extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
   if (n < TDR_PFX_EXACT_MIN_N)
     hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
-  else
+  else if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
+    const int rc = prefix_multi(w, n, runmax_out, nullptr, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  } else
     hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
                        (float*)nullptr);
   LAUNCH_CHECK("prefix");
   return TDR_OK;
 }
-// Test / diagnostic entry: mode 0 = serial kernel, 1 = exact parallel kernel; prefix_out (optional) receives the raw
-// running sums (only from mode 1).
+// Test / diagnostic entry: mode 0 = serial kernel, 1 = exact parallel kernel in one workgroup, 2 = the multi-workgroup
+// scan (needs a workspace of tdr_prefix_workspace_bytes(n)); prefix_out (optional, modes 1 and 2) receives the raw
+// running sums.
 extern "C" int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out,
-                                 void* stream) {
+                                 void* workspace, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix_mode: bad arguments");
+  if (mode == 2 && !workspace) return fail(TDR_ERR_ARG, "prefix_mode: mode 2 needs a workspace");
   if (mode == 0)
     hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
-  else
+  else if (mode == 2) {
+    const int rc = prefix_multi(w, n, runmax_out, prefix_out, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  } else
     hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
                        prefix_out);
   LAUNCH_CHECK("prefix_mode");

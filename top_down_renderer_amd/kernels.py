@@ -40,6 +40,7 @@ class HipKernels:
             raise _lib.TdrError("no HIP device visible: the MI355X path cannot run (there is no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ws = None
+        self._pws = None
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -151,8 +152,14 @@ class HipKernels:
     def update_weights(self, raw_w, last_dist, n, w_out, info):
         check(self.lib.tdr_k_update_weights(_ptr(raw_w), _ptr(last_dist), n, _ptr(w_out), _ptr(info), self.stream()))
 
+    def prefix_workspace(self, n):
+        need = int(self.lib.tdr_prefix_workspace_bytes(n))
+        if self._pws is None or self._pws.numel() < need:
+            self._pws = self.empty((need,), torch.uint8)
+        return self._pws
+
     def prefix(self, w, n, runmax):
-        check(self.lib.tdr_k_prefix(_ptr(w), n, _ptr(runmax), self.stream()))
+        check(self.lib.tdr_k_prefix(_ptr(w), n, _ptr(runmax), _ptr(self.prefix_workspace(n)), self.stream()))
 
     def resample(self, runmax, n, n_new, shift, i_begin, i_end, idx):
         check(self.lib.tdr_k_resample(_ptr(runmax), n, n_new, C.c_float(shift), i_begin, i_end, _ptr(idx),
