@@ -1931,8 +1931,17 @@ __global__ __launch_bounds__(64) void prefix_serial_kernel(const float* __restri
 #define PFX_TIE_CAP 2048   // ties resolved per pass; a (never observed) denser tile is simply cut at that tie
 #define PFX_HEAD 2048      // leading elements added one by one: the running sum crosses most of its binades here
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (~1 us each time); in the prefix kernels the threads exchange data through LDS alone — global memory is read-only
+// input (w, chunk headers of an earlier launch) or write-only output — so the store wait would be pure latency.
+__device__ __forceinline__ void pfx_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // inclusive block scan (sum) of one value per thread; `sh` holds one slot per wave
-template <class T>
+template <int NT, class T>
 __device__ __forceinline__ T pfx_block_scan(T v, T* sh, T& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1940,12 +1949,12 @@ __device__ __forceinline__ T pfx_block_scan(T v, T* sh, T& total) {
     T t = __shfl_up(v, o, 64);
     if (lane >= o) v += t;
   }
-  __syncthreads();
+  pfx_sync();
   if (lane == 63) sh[wave] = v;
-  __syncthreads();
+  pfx_sync();
   T off = 0, tot = 0;
 #pragma unroll
-  for (int k = 0; k < PFX_THREADS / 64; k++) {
+  for (int k = 0; k < NT / 64; k++) {
     const T x = sh[k];
     if (k < wave) off += x;
     tot += x;
@@ -1953,6 +1962,7 @@ __device__ __forceinline__ T pfx_block_scan(T v, T* sh, T& total) {
   total = tot;
   return v + off;
 }
+template <int NT>
 __device__ __forceinline__ float pfx_block_scan_max(float v, float* sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1960,40 +1970,41 @@ __device__ __forceinline__ float pfx_block_scan_max(float v, float* sh) {
     float t = __shfl_up(v, o, 64);
     if (lane >= o) v = fmaxf(v, t);
   }
-  __syncthreads();
+  pfx_sync();
   if (lane == 63) sh[wave] = v;
-  __syncthreads();
+  pfx_sync();
   float off = -INFINITY;
   for (int k = 0; k < wave; k++) off = fmaxf(off, sh[k]);
   return fmaxf(v, off);
 }
 
-// The running sum carried through [lo, hi) in index order by the whole workgroup (PFX_THREADS threads): r_io / carry_io
+// The running sum carried through [lo, hi) in index order by the whole workgroup (NT threads): r_io / carry_io
 // are the (workgroup-uniform) running sum and running maximum before element lo on entry and after element hi-1 on
 // exit.  With lo == 0 the first PFX_HEAD elements are added one by one.
+template <int NT>
 __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, long long lo, long long hi,
                                              float* __restrict__ runmax, float* __restrict__ prefix_opt,
-                                             float& r_io, float& carry_io) {
+                                             float& r_io, float& carry_io, int head_len = PFX_HEAD) {
   const long long n = hi;
-  __shared__ long long sh_ll[PFX_THREADS / 64];
-  __shared__ int sh_i[PFX_THREADS / 64];
-  __shared__ float sh_f[PFX_THREADS / 64];
+  __shared__ long long sh_ll[NT / 64];
+  __shared__ int sh_i[NT / 64];
+  __shared__ float sh_f[NT / 64];
   __shared__ int tie_pos[PFX_TIE_CAP];         // local element index of every tie in order, weight sign in bit 31
   __shared__ long long tie_sval[PFX_TIE_CAP];  // inclusive increment prefix at the tie
   __shared__ signed char tie_corr[PFX_TIE_CAP];
   __shared__ float head[PFX_HEAD];
-  __shared__ float last_val[PFX_THREADS], last_max[PFX_THREADS];
+  __shared__ float last_val[NT], last_max[NT];
   __shared__ int s_first_bad, s_first_cross, s_first_nz;
   __shared__ float s_r, s_carry;
   __shared__ long long s_base;
   const int tid = threadIdx.x;
-  __syncthreads();
+  pfx_sync();
   if (tid == 0) { s_r = r_io; s_carry = carry_io; s_base = lo; }
-  __syncthreads();
+  pfx_sync();
   if (lo == 0) {  // head: plain serial additions by one thread out of LDS
-    const int hn = (int)min((long long)PFX_HEAD, (long long)n);
-    for (int t = tid; t < hn; t += PFX_THREADS) head[t] = w[t];
-    __syncthreads();
+    const int hn = (int)min((long long)head_len, (long long)n);
+    for (int t = tid; t < hn; t += NT) head[t] = w[t];
+    pfx_sync();
     if (tid == 0) {
       float run = 0.f, mx = -INFINITY;
       for (int t = 0; t < hn; t++) {
@@ -2004,9 +2015,9 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       }
       s_r = run; s_carry = mx; s_base = hn;
     }
-    __syncthreads();
-    for (int t = tid; t < hn; t += PFX_THREADS) runmax[t] = head[t];
-    __syncthreads();
+    pfx_sync();
+    for (int t = tid; t < hn; t += NT) runmax[t] = head[t];
+    pfx_sync();
   }
 
   while (true) {
@@ -2014,7 +2025,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
     if (base >= n) break;
     const float r = s_r;
     const float carry = s_carry;
-    const int cnt = (int)min((long long)PFX_TILE, (long long)n - base);
+    const int cnt = (int)min((long long)(NT * PFX_K), (long long)n - base);
     const unsigned rb = __float_as_uint(r);
     const int re = (rb >> 23) & 0xFF;
     float wv[PFX_K];
@@ -2023,8 +2034,8 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       const int li = tid * PFX_K + k;
       wv[k] = (li < cnt) ? w[base + li] : 0.f;
     }
-    if (tid == 0) { s_first_bad = PFX_TILE; s_first_cross = PFX_TILE; s_first_nz = PFX_TILE; }
-    __syncthreads();  // also: everyone has read s_r / s_carry / s_base
+    if (tid == 0) { s_first_bad = (NT * PFX_K); s_first_cross = (NT * PFX_K); s_first_nz = (NT * PFX_K); }
+    pfx_sync();  // also: everyone has read s_r / s_carry / s_base
 
     if (r != r) {  // NaN running sum: every later prefix is NaN, the running maximum stays
 #pragma unroll
@@ -2035,9 +2046,9 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
           if (prefix_opt) prefix_opt[base + li] = r;
         }
       }
-      __syncthreads();
+      pfx_sync();
       if (tid == 0) s_base = base + cnt;
-      __syncthreads();
+      pfx_sync();
       continue;
     }
     const bool r_zero = (rb & 0x7FFFFFFFu) == 0;
@@ -2050,7 +2061,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
           const int li = tid * PFX_K + k;
           if (li < cnt && (__float_as_uint(wv[k]) & 0x7FFFFFFFu) != 0) atomicMin(&s_first_nz, li);
         }
-        __syncthreads();
+        pfx_sync();
         stop = min(s_first_nz, cnt);
       }
       const float m0 = fmaxf(carry, r);
@@ -2062,7 +2073,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
           if (prefix_opt) prefix_opt[base + li] = r;
         }
       }
-      __syncthreads();
+      pfx_sync();
       if (tid == 0) {
         float nr = r, nc = stop > 0 ? m0 : carry;
         long long nb = base + stop;
@@ -2075,7 +2086,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
         }
         s_r = nr; s_carry = nc; s_base = nb;
       }
-      __syncthreads();
+      pfx_sync();
       continue;
     }
 
@@ -2114,7 +2125,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       ntie += tie[k] ? 1 : 0;
     }
     long long tot_ll;
-    const long long sincl = pfx_block_scan<long long>(tsum, sh_ll, tot_ll);
+    const long long sincl = pfx_block_scan<NT, long long>(tsum, sh_ll, tot_ll);
     long long S[PFX_K];  // inclusive prefix of the increments at this thread's elements
     {
       long long acc = sincl - tsum;
@@ -2123,7 +2134,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
     }
     // ---- ties, in element order: the even neighbour wins, which depends on everything before the tie
     int tot_tie;
-    const int tincl = pfx_block_scan<int>(ntie, sh_i, tot_tie);
+    const int tincl = pfx_block_scan<NT, int>(ntie, sh_i, tot_tie);
     const int tfirst = tincl - ntie;
     {
       int pos = tfirst;
@@ -2139,7 +2150,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
           pos++;
         }
     }
-    __syncthreads();
+    pfx_sync();
     if (tid == 0 && tot_tie > 0) {
       long long c = 0;
       const int fb = s_first_bad;
@@ -2156,7 +2167,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
         c += corr;
       }
     }
-    __syncthreads();
+    pfx_sync();
     int csum = 0;
     int corr[PFX_K];
     {
@@ -2169,7 +2180,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       }
     }
     int tot_c;
-    const int cincl = pfx_block_scan<int>(csum, sh_i, tot_c);
+    const int cincl = pfx_block_scan<NT, int>(csum, sh_i, tot_c);
     // ---- mantissas, first element that leaves the binade
     long long state[PFX_K];
     {
@@ -2182,7 +2193,7 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
         if (li < cnt && (state[k] >= (1ll << 24) || state[k] < (1ll << 23))) atomicMin(&s_first_cross, li);
       }
     }
-    __syncthreads();
+    pfx_sync();
     const int stop = min(min(s_first_bad, s_first_cross), cnt);
     // ---- commit [0, stop): values and running maximum
     float val[PFX_K], lm[PFX_K];
@@ -2194,12 +2205,12 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       if (li < stop) m = fmaxf(m, val[k]);
       lm[k] = m;
     }
-    const float mincl = pfx_block_scan_max(m, sh_f);
+    const float mincl = pfx_block_scan_max<NT>(m, sh_f);
     float mexcl = __shfl_up(mincl, 1, 64);
     {  // exclusive maximum over the preceding threads
-      __syncthreads();
+      pfx_sync();
       last_max[tid] = mincl;
-      __syncthreads();
+      pfx_sync();
       mexcl = tid > 0 ? last_max[tid - 1] : -INFINITY;
     }
     const float mbase = fmaxf(carry, mexcl);
@@ -2215,10 +2226,10 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
         lastm = rm;
       }
     }
-    __syncthreads();
+    pfx_sync();
     last_val[tid] = lastv;   // value / running max at this thread's last committed element (if any)
     last_max[tid] = lastm;
-    __syncthreads();
+    pfx_sync();
     if (tid == 0) {
       float pv = r, pm = carry;  // value / running max at element stop-1
       if (stop > 0) {
@@ -2237,18 +2248,18 @@ __device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, lon
       }
       s_r = pv; s_carry = pm; s_base = nb;
     }
-    __syncthreads();
+    pfx_sync();
   }
   r_io = s_r;
   carry_io = s_carry;
-  __syncthreads();
+  pfx_sync();
 }
 
 __global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* __restrict__ w, int64_t n,
                                                                    float* __restrict__ runmax,
                                                                    float* __restrict__ prefix_opt) {
   float r = 0.f, carry = -INFINITY;
-  pfx_exact_range(w, 0, n, runmax, prefix_opt, r, carry);
+  pfx_exact_range<PFX_THREADS>(w, 0, n, runmax, prefix_opt, r, carry);
 }
 
 // ---- exact parallel prefix over many workgroups ---------------------------------------------------------------------
@@ -2314,9 +2325,10 @@ __device__ __forceinline__ PfxPair pfx_element_pair(unsigned f, bool tie) {
   p.a1 = f + (tie ? ((f & 1u) ^ 1u) : 0u);
   return p;
 }
-// inclusive scan of per-thread pairs over the workgroup (PFXM_THREADS threads); returns the EXCLUSIVE pair of this
-// thread and the workgroup total
-__device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh /*[PFXM_THREADS/64]*/, PfxPair& total) {
+// inclusive scan of per-thread pairs over a workgroup of NT threads; returns the EXCLUSIVE pair of this thread and the
+// workgroup total.  `sh` holds one slot per wave; safe to call repeatedly (leading barrier).
+template <int NT>
+__device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh, PfxPair& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -2325,11 +2337,12 @@ __device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh /*[PFXM_
     t.a1 = __shfl_up(v.a1, o, 64);
     if (lane >= o) v = pfx_compose(t, v);
   }
+  pfx_sync();
   if (lane == 63) sh[wave] = v;
-  __syncthreads();
+  pfx_sync();
   PfxPair pre = {0u, 0u}, tot = {0u, 0u};
 #pragma unroll
-  for (int k = 0; k < PFXM_THREADS / 64; k++) {
+  for (int k = 0; k < NT / 64; k++) {
     const PfxPair x = sh[k];
     if (k < wave) pre = pfx_compose(pre, x);
     tot = pfx_compose(tot, x);
@@ -2369,7 +2382,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_sum_kernel(const float
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
-  __syncthreads();
+  pfx_sync();
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < PFXM_THREADS / 64; k++) t += shd[k];
@@ -2392,7 +2405,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
   if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
+  pfx_sync();
   double before = 0.0;
   for (int k = 0; k < PFXM_THREADS / 64; k++) before += shd[k];
   const float r_pred = (float)before, r_end = (float)(before + ch[c].sum);
@@ -2417,7 +2430,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
   }
   if (anybad) s_bad = 1;   // benign race: every writer stores 1; ordered by the barrier inside the scan
   PfxPair total;
-  (void)pfx_pair_scan(mine, shp, total);
+  (void)pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
   if (threadIdx.x == 0) {
     const bool ok = s_bad == 0 && total.a0 < (1u << 24) && total.a1 < (1u << 24);
     ch[c].re = ok ? re : -1;
@@ -2426,39 +2439,144 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
   }
 }
 
-__global__ __launch_bounds__(PFX_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
+// A chunk the walk cannot take as one integer add (it holds a binade crossing or an irregular weight, or was
+// mispredicted), carried through in order by the walking workgroup: one scan per stretch between two real float
+// additions.  The walking workgroup has PFXM_THREADS threads holding 16 weights each, as in the fill kernel (one wave
+// per SIMD: a pass costs what ONE wave issues).  Anything that is not a positive normal running sum goes to
+// pfx_exact_range.
+#define PFXW_HEAD 64   // leading elements the walk adds one by one (tunable: TDR_PFX_HEAD)
+__device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long long lo, int cnt,
+                                               float* __restrict__ runmax, float* __restrict__ prefix_opt,
+                                               float& r, float& carry, int head_len) {
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  __shared__ int s_bad, s_cross;
+  __shared__ float s_last, s_wstop;
+  const int tid = threadIdx.x, t0 = tid * PFXM_K;
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  int pos = 0;   // workgroup-uniform: elements before pos are done
+  while (pos < cnt) {
+    const unsigned rb = __float_as_uint(r);
+    const unsigned re = rb >> 23;   // sign included
+    if (!(re >= 1u && re <= 254u)) {
+      // zero / subnormal / negative / inf / NaN running sum: the general path (with its serial head at the very start)
+      const long long a = lo + pos;
+      const long long b = a == 0 ? min((long long)head_len, (long long)cnt) : lo + cnt;
+      pfx_exact_range<PFXM_THREADS>(w, a, b, runmax, prefix_opt, r, carry, head_len);
+      pos = (int)(b - lo);
+      continue;
+    }
+    const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+    pfx_sync();
+    if (tid == 0) { s_bad = cnt; s_cross = cnt; s_last = r; s_wstop = 0.f; }
+    pfx_sync();
+    unsigned f[PFXM_K];
+    unsigned tiebits = 0u;
+    PfxPair mine = {0u, 0u};
+    {
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        const int li = t0 + k;
+        bool bad, tie;
+        pfx_classify(wv[k], (int)re - 127, f[k], tie, bad);
+        if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
+        if (bad) atomicMin(&s_bad, li);
+        tiebits |= tie ? (1u << k) : 0u;
+        mine = pfx_compose(mine, pfx_element_pair(f[k], tie));
+      }
+    }
+    PfxPair total;
+    const PfxPair ex = pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
+    unsigned st[PFXM_K];
+    {
+      unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);
+      int first = cnt;
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
+        st[k] = state;
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && state >= (1u << 24)) first = min(first, li);
+      }
+      if (first < cnt) atomicMin(&s_cross, first);
+    }
+    pfx_sync();
+    const int stop = min(s_bad, s_cross);   // first element that needs a real float addition (or cnt)
+    {
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        const int li = t0 + k;
+        if (li >= pos && li < stop) {
+          const float val = __uint_as_float((re << 23) | (st[k] & 0x7FFFFFu));
+          runmax[lo + li] = fmaxf(carry, val);
+          if (prefix_opt) prefix_opt[lo + li] = val;
+          if (li == stop - 1) s_last = val;
+        }
+        if (li == stop) s_wstop = wv[k];
+      }
+    }
+    pfx_sync();
+    r = s_last;                  // the sum after element stop-1 (unchanged when nothing was committed)
+    carry = fmaxf(carry, r);     // increments are non-negative: the last committed value is the largest
+    if (stop < cnt) {
+      const float nr = r + s_wstop;   // particle_filter.cpp:179, one real addition
+      if (nr == nr) carry = fmaxf(carry, nr);
+      if (tid == 0) {
+        runmax[lo + stop] = carry;
+        if (prefix_opt) prefix_opt[lo + stop] = nr;
+      }
+      r = nr;
+      pos = stop + 1;
+    } else {
+      pos = cnt;
+    }
+  }
+}
+
+#define PFXW_BLOCK 512   // chunk summaries / headers staged in LDS at a time
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
                                                                PfxChunk* __restrict__ ch, int nch,
                                                                float* __restrict__ runmax,
-                                                               float* __restrict__ prefix_opt) {
-  __shared__ int sm_re[PFX_THREADS];
-  __shared__ unsigned sm_d0[PFX_THREADS], sm_d1[PFX_THREADS];
+                                                               float* __restrict__ prefix_opt, int head_len) {
+  __shared__ int sm_re[PFXW_BLOCK], sm_acc[PFXW_BLOCK];
+  __shared__ unsigned sm_d0[PFXW_BLOCK], sm_d1[PFXW_BLOCK];
+  __shared__ float sm_r0[PFXW_BLOCK], sm_c0[PFXW_BLOCK];
   float r = 0.f, carry = -INFINITY;   // workgroup-uniform
-  for (int cb = 0; cb < nch; cb += PFX_THREADS) {
-    __syncthreads();
-    if (cb + (int)threadIdx.x < nch) {
-      const PfxChunk x = ch[cb + threadIdx.x];
-      sm_re[threadIdx.x] = x.re; sm_d0[threadIdx.x] = x.d0; sm_d1[threadIdx.x] = x.d1;
+  for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
+    pfx_sync();
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {
+      const PfxChunk x = ch[cb + t];
+      sm_re[t] = x.re; sm_d0[t] = x.d0; sm_d1[t] = x.d1;
     }
-    __syncthreads();
-    const int ce = min(nch, cb + PFX_THREADS);
+    pfx_sync();
+    const int ce = min(nch, cb + PFXW_BLOCK);
     for (int c = cb; c < ce; c++) {
       const unsigned rb = __float_as_uint(r);
       const int re = (int)(rb >> 23);                   // sign bit included: a negative sum never matches
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
       const unsigned D = (R & 1u) ? sm_d1[c - cb] : sm_d0[c - cb];
       const bool fast = sm_re[c - cb] == re && R + D < (1u << 24);   // sm_re is in [1, 254] or -1
+      // the waves run through this loop unsynchronised and all store the same words
       if (fast) {
-        if ((int)threadIdx.x == ((c - cb) & (PFX_THREADS - 1))) {
-          ch[c].r0 = r; ch[c].carry0 = carry; ch[c].accepted = 1;
-        }
+        sm_r0[c - cb] = r; sm_c0[c - cb] = carry; sm_acc[c - cb] = 1;
         r = __uint_as_float(((unsigned)re << 23) | ((R + D) & 0x7FFFFFu));
         carry = fmaxf(carry, r);
       } else {
-        if (threadIdx.x == 0) ch[c].accepted = 0;
+        sm_acc[c - cb] = 0;
         const long long lo = (long long)c * PFXM_CHUNK;
-        const long long hi = min((long long)n, lo + PFXM_CHUNK);
-        pfx_exact_range(w, lo, hi, runmax, prefix_opt, r, carry);
+        const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+        pfx_walk_chunk(w, lo, cnt, runmax, prefix_opt, r, carry, head_len);
       }
+#ifdef TDR_PFX_TIMING   // diagnostic build: time stamp (100 MHz) after every chunk in the header's dead `sum` slot
+      if (threadIdx.x == 0) *reinterpret_cast<long long*>(&ch[c].sum) = (long long)wall_clock64();
+#endif
+    }
+    pfx_sync();
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {   // for pfx_chunk_fill_kernel
+      PfxChunk* o = ch + cb + t;
+      o->r0 = sm_r0[t];
+      o->carry0 = sm_c0[t];
+      o->accepted = sm_acc[t];
     }
   }
 }
@@ -2488,7 +2606,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const floa
     mine = pfx_compose(mine, pfx_element_pair(f[k], tie[k]));
   }
   PfxPair total;
-  const PfxPair ex = pfx_pair_scan(mine, shp, total);
+  const PfxPair ex = pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
   unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);   // the exact mantissa before this thread's first element
   const int t0 = threadIdx.x * PFXM_K;
   float val[PFXM_K];
@@ -2534,7 +2652,13 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
   PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
   hipLaunchKernelGGL(pfx_chunk_sum_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
   hipLaunchKernelGGL(pfx_chunk_summary_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
-  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFX_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out);
+  static const int head_len = [] {
+    const char* e = getenv("TDR_PFX_HEAD");
+    const int v = e ? atoi(e) : PFXW_HEAD;
+    return v < 1 ? 1 : (v > PFX_HEAD ? PFX_HEAD : v);
+  }();
+  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXM_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
+                     head_len);
   hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,
                      runmax_out, prefix_out);
   return TDR_OK;
