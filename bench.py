@@ -227,7 +227,8 @@ def main():
             out["config"]["init_search_first_step_ms"] = init_step_ms
             out["config"]["init_search_particle_updates_per_s"] = n_global / (init_step_ms * 1e-3)
         if not a.no_cpu and a.cpu_sample != 0 and world == 1 and cfg.polar:
-            ns = a.cpu_sample if a.cpu_sample > 0 else max(256, int(800 * host_threads() * 1.64e6 / b_pu))
+            # ~12 s of CPU work: the oracle does ~880 config-2 particle-updates/s per host thread (measured on the GPU box)
+            ns = a.cpu_sample if a.cpu_sample > 0 else max(256, int(12 * 880 * host_threads() * 1.64e6 / b_pu))
             out["cpu_baseline"] = cpu_baseline(sc, cfg, min(ns, n_global), host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:
