@@ -2,8 +2,7 @@
 and against the committed golden fixtures.  Run on the MI355X box with `pytest -m gpu`.
 
 Tolerances (BASELINE.json north_star): per-particle weights within 1e-5 relative; resample indices bit-exact on
-identical weight inputs; raster counts exact integers (a bin-flip budget covers atan2f's last-ulp difference between
-the device libm and glibc).
+identical weight inputs; raster counts exact (the kernel's atan2f is glibc's algorithm restated, test_atan2f_bit_exact).
 """
 import os
 

@@ -61,7 +61,32 @@ def main():
             "morton1px": np.argsort(morton(row, col), kind="stable"),
             "morton.5px": np.argsort(morton(np.clip(np.floor(cy * 2), 0, 8191).astype(np.int64), np.clip(np.floor(cx * 2), 0, 8191).astype(np.int64)), kind="stable"),
         }
-        for loc in ((True,) if "sorted" in sys.argv else (False, True) if "quick" in sys.argv else (False, True, "rowmajor1px", "morton1px", "morton.5px")):
+        th = np.mod(states["theta"].astype(np.float64), 2 * np.pi)
+
+        def morton3(a, b, c):
+            key = np.zeros_like(a)
+            for bit in range(12):
+                key |= ((a >> bit) & 1) << (3 * bit)
+                key |= ((b >> bit) & 1) << (3 * bit + 1)
+                key |= ((c >> bit) & 1) << (3 * bit + 2)
+            return key
+        for q in (1.0, 2.0, 4.0):
+            for rref in (64.0, 128.0):
+                tb = np.floor(th / (q / rref)).astype(np.int64)
+                host_perms[f"m3 q={q:g} r={rref:g}"] = np.argsort(
+                    morton3(np.floor(cx / q).astype(np.int64).clip(0), np.floor(cy / q).astype(np.int64).clip(0), tb), kind="stable")
+        for deg in (1.0, 3.0):
+            tb = np.floor(th / np.deg2rad(deg)).astype(np.int64)
+            host_perms[f"theta{deg:g}deg+morton.5"] = np.lexsort((morton(np.floor(cy * 2).astype(np.int64).clip(0, 8191), np.floor(cx * 2).astype(np.int64).clip(0, 8191)), tb))
+        if "m3" in sys.argv:
+            locs = (True,) + tuple(x for x in host_perms if x.startswith(("m3", "theta")))
+        elif "sorted" in sys.argv:
+            locs = (True,)
+        elif "quick" in sys.argv:
+            locs = (False, True)
+        else:
+            locs = (False, True, "rowmajor1px", "morton1px", "morton.5px")
+        for loc in locs:
             if loc is True:
                 k.locality_order(st, n, m.rows, m.cols, perm)
             elif isinstance(loc, str):
