@@ -188,11 +188,17 @@ int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, co
                         float* dst, int64_t dst_cap, void* stream);
 
 /* ---- per-step consumers (src/particle_filter.cpp:191-236, 325-334, 343-357) --------------------------------- */
-/* out (device, 24 floats): mean[4] (meanLikelihood :191-203), cov[16] row-major about the mean (computeMeanCov,
- * about == NULL) or about the 4 device floats `about` (computeCov about the max-likelihood mlState :226-236),
- * geometric-mean scale (freezeScale :345-348), 3 spare. */
+/* out (device, TDR_MEAN_COV_FLOATS floats; the first 24 are the result, the rest is scratch for the multi-workgroup
+ * reductions): mean[4] (meanLikelihood :191-203), cov[16] row-major about the mean (computeMeanCov, about == NULL) or
+ * about the 4 device floats `about` (computeCov about the max-likelihood mlState :226-236), geometric-mean scale
+ * (freezeScale :345-348), 3 spare.  A pure function of (st, n, about). */
+#define TDR_MEAN_COV_FLOATS 4800
 int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, const float* about, float* out, void* stream);
 int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, void* stream);   /* freezeScale :350-352 */
+/* max_likelihood_particle_ (:145-147): out12 (device) = the 7 SoA fields of particle argmax (info[0] of
+ * tdr_k_update_weights), one spare, then its mlState {x, y, theta, scale} (state_particle.cpp:98-102).  Call before the
+ * resampled set replaces `st`. */
+int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t n, float* out12, void* stream);
 int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream);      /* updateMap :325-334 */
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */

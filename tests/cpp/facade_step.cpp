@@ -5,7 +5,9 @@
 //   filter->propagate(t, a); filter->update(top_down, top_down_geo, res); computeMeanCov / meanLikelihood / ...
 // Inputs and outputs are raw little-endian files in the directory given as argv[1] (written / read by
 // tests/test_gpu_facade.py, which compares them with the CPU oracle).
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -128,6 +130,38 @@ int main(int argc, char** argv) {
     stats[41] = (float)filter_->numParticles();
     stats[42] = filter_->isScaleFrozen() ? 1.f : 0.f;
     dump(dir + "/out_stats.bin", stats, 43);
+    // optional: latency of takeStep through the C++ classes (TDR_FACADE_BENCH = number of timed steps)
+    if (const char* e = std::getenv("TDR_FACADE_BENCH")) {
+      const int steps = std::atoi(e);
+      auto step = [&]() {
+        renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down);
+        filter_->propagate(motion_priort, omega);
+        if (use_device_scan) filter_->update(*renderer_, res);
+        else filter_->update(top_down, top_down_geo, res);
+        filter_->computeMeanCov(cov);   // publishPoseEst reads this every step (src/top_down_render.cpp:331-333)
+      };
+      if (const char* dr = std::getenv("TDR_FACADE_DEVICE_RNG")) filter_->configure(std::atoi(dr) == 0, 1);
+      for (int i = 0; i < 5; i++) step();
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < steps; i++) step();
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      std::printf("facade_bench steps=%d particles=%d ms_per_step=%.4f\n", steps, npart, ms / steps);
+      // the same calls one by one
+      double part[4] = {0, 0, 0, 0};
+      auto lap = [&](int k, auto&& fn) {
+        const auto a = std::chrono::steady_clock::now();
+        fn();
+        part[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+      };
+      for (int i = 0; i < steps; i++) {
+        lap(0, [&] { renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down); });
+        lap(1, [&] { filter_->propagate(motion_priort, omega); });
+        lap(2, [&] { if (use_device_scan) filter_->update(*renderer_, res); else filter_->update(top_down, top_down_geo, res); });
+        lap(3, [&] { filter_->computeMeanCov(cov); });
+      }
+      std::printf("facade_bench render=%.4f propagate=%.4f update=%.4f meancov=%.4f ms\n", part[0] / steps,
+                  part[1] / steps, part[2] / steps, part[3] / steps);
+    }
     delete renderer_;
     delete filter_;
     delete map_;

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tdr_k_gather_states": (_i, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tdr_init_particles_host": (_i, [_vp, _vp, _i, _i, _i, _f, C.POINTER(FilterParamsC), _i, _vp, C.POINTER(C.c_int64)]),
     "tdr_k_mean_cov": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_k_save_ml_state": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "tdr_k_set_scale": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_k_shift_init": (_i, [_vp, _i64, _i64, _f, _f, _vp]),
     "tdr_k_states_aos_to_soa": (_i, [_vp, _i64, _vp, _i64, _vp]),

@@ -93,7 +93,8 @@ struct tdr_filter {
   bool scale_frozen = false, maybe_uninit = true, parity_rng = true;
   int locality_every = 1;
   float uniform_scale = 0.f;
-  tdr_state ml_state{};
+  DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
+  bool have_ml = false;
   hipStream_t stream = nullptr;
 };
 
@@ -282,7 +283,7 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
   if (rc == TDR_OK) rc = f->idx.resize(cap);
   if (rc == TDR_OK) rc = f->perm.resize(cap);
   if (rc == TDR_OK) rc = f->info.resize(TDR_UW_INFO_FLOATS);
-  if (rc == TDR_OK) rc = f->stats.resize(24);
+  if (rc == TDR_OK) rc = f->stats.resize(TDR_MEAN_COV_FLOATS);
   if (rc == TDR_OK) rc = f->aos.resize(cap);
   if (rc == TDR_OK) rc = f->z4.resize(4 * cap);
   if (rc == TDR_OK && hipMemset(f->last_dist.p, 0, cap * sizeof(float)) != hipSuccess) rc = failh(TDR_ERR_HIP, "memset");
@@ -427,16 +428,11 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
   TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
   TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, 0, n_new, f->idx.p, f->stream));
   TTRY(tdr_k_gather_states(f->st.p, f->n_max, 0, f->idx.p, n_new, f->st_new.p, f->n_max, f->stream));
-  // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state
-  float info[8];
-  HTRY(hipMemcpyAsync(info, f->info.p, sizeof(info), hipMemcpyDeviceToHost, f->stream));
-  HTRY(hipStreamSynchronize(f->stream));
-  int32_t best;
-  std::memcpy(&best, &info[0], 4);
-  float mlf[TDR_ST_FIELDS];
-  for (int k = 0; k < TDR_ST_FIELDS; k++)
-    HTRY(hipMemcpy(&mlf[k], f->st.p + (size_t)k * f->n_max + best, sizeof(float), hipMemcpyDeviceToHost));
-  f->ml_state = tdr_state{mlf[0], mlf[1], mlf[2], mlf[3], mlf[4], mlf[5], (uint8_t)(mlf[6] != 0.f), {0, 0, 0}};
+  // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state (on the device:
+  // the update returns without waiting for the GPU)
+  TTRY(f->ml_dev.resize(12));
+  TTRY(tdr_k_save_ml_state(f->info.p, f->st.p, f->n_max, n, f->ml_dev.p, f->stream));
+  f->have_ml = true;
   std::swap(f->st.p, f->st_new.p);  // :187
   f->n = n_new;
   f->step++;
@@ -454,13 +450,6 @@ int tdr_filter_get_resample_indices(tdr_filter* f, int32_t* out, int64_t n) {
   return TDR_OK;
 }
 
-static void ml_of(const tdr_state& s, float out[4]) {  // StateParticle::mlState (state_particle.cpp:98-102)
-  out[0] = s.dx_m * s.scale + s.init_x_px;
-  out[1] = s.dy_m * s.scale + s.init_y_px;
-  out[2] = s.theta;
-  out[3] = s.scale;
-}
-
 // meanLikelihood + computeMeanCov (particle_filter.cpp:191-220); about_max != 0: maxLikelihood + computeCov (:222-236)
 int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[16]) {
   if (!f) return failh(TDR_ERR_ARG, "filter_mean_cov: null filter");
@@ -473,13 +462,12 @@ int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[
     HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
     if (state) std::memcpy(state, out, 4 * sizeof(float));
   } else {
-    float ref[4];
-    ml_of(f->ml_state, ref);
-    DevBuf<float> dref;
-    TTRY(dref.resize(4));
-    HTRY(hipMemcpy(dref.p, ref, sizeof(ref), hipMemcpyHostToDevice));
-    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, dref.p, f->stats.p, f->stream));
-    HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
+    float ref[4] = {0, 0, 0, 0};
+    if (!f->have_ml) return failh(TDR_ERR_ARG, "filter_mean_cov: no update yet, there is no max-likelihood particle");
+    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, f->ml_dev.p + 8, f->stats.p, f->stream));
+    HTRY(hipMemcpyAsync(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost, f->stream));
+    HTRY(hipMemcpyAsync(ref, f->ml_dev.p + 8, sizeof(ref), hipMemcpyDeviceToHost, f->stream));
+    HTRY(hipStreamSynchronize(f->stream));
     if (state) std::memcpy(state, ref, sizeof(ref));
   }
   if (cov) std::memcpy(cov, out + 4, 16 * sizeof(float));

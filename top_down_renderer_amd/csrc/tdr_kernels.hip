@@ -871,7 +871,7 @@ struct FinalizeArgs {
   float* best_theta;
 };
 
-__global__ void score_finalize_kernel(FinalizeArgs a) {
+__global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if (slot >= nact) return;
@@ -883,21 +883,48 @@ __global__ void score_finalize_kernel(FinalizeArgs a) {
     a.raw_w[p] = 0.f;
     return;
   }
+  // Per-chunk partial sums -> double totals, chunk order ascending for every slot.  The loads of FIN_B chunks x all
+  // slots are issued together (independent addresses, coalesced over the particles) before the dependent additions.
+  constexpr int FIN_B = 4, FIN_S = TDR_MAX_CLASSES + 2;   // slots: ncls class dots, normalisation, known count
+  double tot[FIN_S];
+#pragma unroll
+  for (int k = 0; k < FIN_S; k++) tot[k] = 0;
+  const int64_t cstride = (int64_t)(a.rf + 1) * a.npad;
+  auto slot_row = [&](int k) { return k < a.ncls ? k : (k == a.ncls ? a.rf - 1 : a.rf); };
+  int c0 = 0;
+  for (; c0 + FIN_B <= a.nchunks; c0 += FIN_B) {
+    float v[FIN_B][FIN_S];
+#pragma unroll
+    for (int b = 0; b < FIN_B; b++)
+#pragma unroll
+      for (int k = 0; k < FIN_S; k++)
+        if (k < a.ncls + 2) v[b][k] = a.part[(int64_t)(c0 + b) * cstride + (int64_t)slot_row(k) * a.npad + slot];
+#pragma unroll
+    for (int b = 0; b < FIN_B; b++)
+#pragma unroll
+      for (int k = 0; k < FIN_S; k++)
+        if (k < a.ncls + 2) tot[k] += (double)v[b][k];
+  }
+  for (; c0 < a.nchunks; c0++) {
+#pragma unroll
+    for (int k = 0; k < FIN_S; k++)
+      if (k < a.ncls + 2) tot[k] += (double)a.part[(int64_t)c0 * cstride + (int64_t)slot_row(k) * a.npad + slot];
+  }
+  double known = 0, norm = 0;
+#pragma unroll
+  for (int k = 0; k < FIN_S; k++) {
+    if (k == a.ncls) norm = tot[k];
+    if (k == a.ncls + 1) known = tot[k];
+  }
   // known fraction gate (state_particle.cpp:117-120); counts are exact integers in float
-  double known = 0;
-  for (int c = 0; c < a.nchunks; c++) known += (double)a.part[((int64_t)c * (a.rf + 1) + a.rf) * a.npad + slot];
   float cost;
   if ((float)known / (float)a.P < 0.5) {
     cost = __builtin_nanf("");
   } else {
     cost = 0.f;
-    for (int k = 0; k < a.ncls; k++) {
-      double dot = 0;
-      for (int c = 0; c < a.nchunks; c++) dot += (double)a.part[((int64_t)c * (a.rf + 1) + k) * a.npad + slot];
-      cost = (float)((double)cost + (double)(float)dot * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
-    }
-    double norm = 0;
-    for (int c = 0; c < a.nchunks; c++) norm += (double)a.part[((int64_t)c * (a.rf + 1) + a.rf - 1) * a.npad + slot];
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls) cost = (float)((double)cost + (double)(float)tot[k] * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
     cost = cost / (float)norm;  // :154
   }
   if (a.mode == 0) {
@@ -2637,10 +2664,10 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const floa
   }
 }
 
-// n below this: the single-wave serial kernel is faster than the workgroup passes
-#define TDR_PFX_EXACT_MIN_N 16384
-// n from this on (and a workspace): the multi-workgroup scan
-#define TDR_PFX_MULTI_MIN_N 32768
+// Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
+// 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 66 / 94 / 129):
+#define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
+#define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
 extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
   return n < 1 ? 0 : (int64_t)sizeof(PfxChunk) * cdiv(n, (int64_t)PFXM_CHUNK);
 }
@@ -2665,12 +2692,12 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
 }
 extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
-  if (n < TDR_PFX_EXACT_MIN_N)
-    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
-  else if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
+  if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
     const int rc = prefix_multi(w, n, runmax_out, nullptr, workspace, (hipStream_t)stream);
     if (rc) return rc;
-  } else
+  } else if (n < TDR_PFX_EXACT_MIN_N)
+    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  else
     hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
                        (float*)nullptr);
   LAUNCH_CHECK("prefix");
@@ -2808,9 +2835,127 @@ __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict_
   }
 }
 
+// Larger particle sets: the same two reductions over MC_WGS workgroups.  Per-workgroup partial sums (double) go to the
+// scratch part of `out`; they are combined in workgroup order, so the result is a pure function of the inputs.
+//   mc_sums_kernel (MC_WGS)  -> partial sums of {x, y, theta, scale, cos, sin, log scale}
+//   mc_cov_kernel  (MC_WGS)  -> every workgroup combines the partial sums (mean / reference), then its share of the
+//                               10 second moments about it
+//   mc_final_kernel (1)      -> combines both, writes the 24 result floats
+#define MC_WGS 128
+#define MC_THREADS 256
+#define MC_SINGLE_MAX_N 4096   // up to here one workgroup does everything in one launch
+struct McScratch {
+  double sums[MC_WGS][8];
+  double mom[MC_WGS][10];
+};
+static_assert(24 * 4 + sizeof(McScratch) <= TDR_MEAN_COV_FLOATS * 4, "TDR_MEAN_COV_FLOATS too small");
+__device__ __forceinline__ McScratch* mc_scratch(float* out) { return reinterpret_cast<McScratch*>(out + 24); }
+
+__global__ __launch_bounds__(MC_THREADS) void mc_sums_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
+                                                             float* __restrict__ out) {
+  __shared__ double shd[16];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int64_t p = (int64_t)blockIdx.x * MC_THREADS + threadIdx.x; p < n; p += (int64_t)MC_WGS * MC_THREADS) {
+    const float sc = st[TDR_ST_SCALE * cap + p];
+    const float x = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];  // mlState, state_particle.cpp:98-102
+    const float y = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+    const float th = st[TDR_ST_THETA * cap + p];
+    acc[0] += x; acc[1] += y; acc[2] += th; acc[3] += sc;
+    acc[4] += cos((double)th); acc[5] += sin((double)th);
+    acc[6] += log((double)sc);
+  }
+  McScratch* sc = mc_scratch(out);
+  for (int k = 0; k < 7; k++) {
+    const double t = block_sum_d(acc[k], shd);
+    if (threadIdx.x == 0) sc->sums[blockIdx.x][k] = t;
+  }
+}
+// mean / reference point from the partial sums, identically in every caller (workgroup order); `stage` = MC_WGS*8 doubles
+__device__ __forceinline__ void mc_means(const McScratch* sc, int64_t n, const float* about, double* stage,
+                                         double* sh /*[8]*/, float mean[4], float ref[4], float& geo) {
+  __syncthreads();
+  for (int t = threadIdx.x; t < MC_WGS * 8; t += MC_THREADS) stage[t] = (&sc->sums[0][0])[t];   // coalesced
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    double t = 0;
+    for (int g = 0; g < MC_WGS; g++) t += stage[g * 8 + threadIdx.x];
+    sh[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const float fn = (float)n;
+  mean[0] = (float)sh[0] / fn; mean[1] = (float)sh[1] / fn; mean[3] = (float)sh[3] / fn;
+  mean[2] = atan2f((float)sh[5] / fn, (float)sh[4] / fn);  // :202
+  geo = (float)exp(sh[6] / (double)n);                      // freezeScale geo-mean
+  for (int k = 0; k < 4; k++) ref[k] = about ? about[k] : mean[k];
+}
+__global__ __launch_bounds__(MC_THREADS) void mc_cov_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
+                                                            const float* __restrict__ about, float* __restrict__ out) {
+  __shared__ double shd[16];
+  __shared__ double shm[8];
+  __shared__ double stage[MC_WGS * 10];
+  McScratch* sc = mc_scratch(out);
+  float mean[4], ref[4], geo;
+  mc_means(sc, n, about, stage, shm, mean, ref, geo);
+  double c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t p = (int64_t)blockIdx.x * MC_THREADS + threadIdx.x; p < n; p += (int64_t)MC_WGS * MC_THREADS) {
+    const float s = st[TDR_ST_SCALE * cap + p];
+    float d[4];
+    d[0] = (st[TDR_ST_DX * cap + p] * s + st[TDR_ST_INIT_X * cap + p]) - ref[0];
+    d[1] = (st[TDR_ST_DY * cap + p] * s + st[TDR_ST_INIT_Y * cap + p]) - ref[1];
+    d[2] = st[TDR_ST_THETA * cap + p] - ref[2];
+    d[3] = s - ref[3];
+    while (d[2] > M_PI) d[2] = (float)((double)d[2] - 2 * M_PI);    // :215
+    while (d[2] < -M_PI) d[2] = (float)((double)d[2] + 2 * M_PI);   // :216
+    int k = 0;
+    for (int a = 0; a < 4; a++)
+      for (int b = a; b < 4; b++) c[k++] += (double)(d[a] * d[b]);
+  }
+  for (int k = 0; k < 10; k++) {
+    const double t = block_sum_d(c[k], shd);
+    if (threadIdx.x == 0) sc->mom[blockIdx.x][k] = t;
+  }
+}
+__global__ __launch_bounds__(MC_THREADS) void mc_final_kernel(int64_t n, const float* __restrict__ about,
+                                                              float* __restrict__ out) {
+  __shared__ double shm[8];
+  __shared__ double shc[10];
+  __shared__ double stage[MC_WGS * 10];
+  const McScratch* sc = mc_scratch(out);
+  float mean[4], ref[4], geo;
+  mc_means(sc, n, about, stage, shm, mean, ref, geo);
+  __syncthreads();
+  for (int t = threadIdx.x; t < MC_WGS * 10; t += MC_THREADS) stage[t] = (&sc->mom[0][0])[t];
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    double t = 0;
+    for (int g = 0; g < MC_WGS; g++) t += stage[g * 10 + threadIdx.x];
+    shc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 4; k++) out[k] = mean[k];
+    out[20] = geo;
+    out[21] = out[22] = out[23] = 0.f;
+    int k = 0;
+    for (int a = 0; a < 4; a++)
+      for (int b = a; b < 4; b++) {
+        const float v = (float)shc[k++] / (float)(n - 1);  // :219
+        out[4 + 4 * a + b] = v;
+        out[4 + 4 * b + a] = v;
+      }
+  }
+}
+
 extern "C" int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, const float* about, float* out, void* stream) {
   if (!st || !out || n < 1 || cap < n) return fail(TDR_ERR_ARG, "mean_cov: bad arguments");
-  hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, st, cap, n, about, out);
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= MC_SINGLE_MAX_N) {
+    hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, s, st, cap, n, about, out);
+  } else {
+    hipLaunchKernelGGL(mc_sums_kernel, dim3(MC_WGS), dim3(MC_THREADS), 0, s, st, cap, n, out);
+    hipLaunchKernelGGL(mc_cov_kernel, dim3(MC_WGS), dim3(MC_THREADS), 0, s, st, cap, n, about, out);
+    hipLaunchKernelGGL(mc_final_kernel, dim3(1), dim3(MC_THREADS), 0, s, n, about, out);
+  }
   LAUNCH_CHECK("mean_cov");
   return TDR_OK;
 }
@@ -2841,6 +2986,30 @@ extern "C" int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, flo
   hipLaunchKernelGGL(shift_init_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
                      dx, dy);
   LAUNCH_CHECK("shift_init");
+  return TDR_OK;
+}
+
+// max_likelihood_particle_ = particles_[argmax] (particle_filter.cpp:145-147) points at the PRE-resample particle:
+// keep its fields and its mlState (state_particle.cpp:98-102) on the device, so the update needs no host round trip.
+__global__ void save_ml_state_kernel(const float* __restrict__ info, const float* __restrict__ st, int64_t cap,
+                                     int64_t n, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t best = (int64_t)__float_as_int(info[0]);
+  if (best < 0 || best >= n) best = 0;
+  float f[TDR_ST_FIELDS];
+#pragma unroll
+  for (int k = 0; k < TDR_ST_FIELDS; k++) { f[k] = st[(int64_t)k * cap + best]; out[k] = f[k]; }
+  out[7] = 0.f;
+  out[8] = f[TDR_ST_DX] * f[TDR_ST_SCALE] + f[TDR_ST_INIT_X];
+  out[9] = f[TDR_ST_DY] * f[TDR_ST_SCALE] + f[TDR_ST_INIT_Y];
+  out[10] = f[TDR_ST_THETA];
+  out[11] = f[TDR_ST_SCALE];
+}
+extern "C" int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t n, float* out12,
+                                   void* stream) {
+  if (!info || !st || !out12 || n < 1 || cap < n) return fail(TDR_ERR_ARG, "save_ml_state: bad arguments");
+  hipLaunchKernelGGL(save_ml_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info, st, cap, n, out12);
+  LAUNCH_CHECK("save_ml_state");
   return TDR_OK;
 }
 

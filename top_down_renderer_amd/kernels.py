@@ -172,7 +172,7 @@ class HipKernels:
 
     def mean_cov(self, st, n, about=None):
         """about: optional device tensor of 4 floats (computeCov about that mlState); None = about the mean."""
-        out = self.empty((24,))
+        out = self.empty((4800,))   # TDR_MEAN_COV_FLOATS: 24 results + reduction scratch
         check(self.lib.tdr_k_mean_cov(_ptr(st), st.shape[1], n, _ptr(about), _ptr(out), self.stream()))
         return out
 

@@ -43,6 +43,9 @@ CONFIGS = {
     "c3": Config("c3", 100_000, 6, 256, 256, 4000, 1_000_000, seed=1236),
     "c4": Config("c4", 100_000, 6, 512, 512, 8000, 200_000, polar=False, seed=1237),
     "c5": Config("c5", 100_000, 6, 256, 256, 4000, 2_000_000, have_init=False, seed=1238),
+    # the reference node's own defaults: 20 000 particles (src/top_down_render.cpp:53), 100x25 polar image
+    # (samplePtsPolar(Vector2i(100, 25), 2*pi/100), :115); latency-bound on a GPU
+    "ref": Config("ref", 30_000, 6, 100, 25, 2000, 20_000, seed=1239, res=4.0),
     # micro shape for fixtures and pure-Python cross-checks
     "micro": Config("micro", 64, 3, 16, 8, 48, 32, seed=1230),
 }
