@@ -278,6 +278,27 @@ int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t*
 int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int img_h, int img_w,
                                  const int32_t* flatten_lut, int lut_size, int ncls, float resolution, int center_x,
                                  int center_y);                                          /* :320-341, cv::Mat form */
+/* ---- adaptive particle count from a Gaussian mixture (src/particle_filter.cpp:151-157, 245-318) ---- */
+/* out (device, [num][3] floats): mlState().head<3>() = {x, y, theta} of particle min(n-1, i*n/num) (:262-266). */
+int tdr_k_sample_ml_states(const float* st, int64_t cap, int64_t n, int num, float* out, void* stream);
+/* Deterministic EM fit of k full-covariance Gaussians to m samples of 4 doubles (host code, tdr_gmm.cpp; the
+ * reference uses cv::ml::EM, randomly initialised: parity unpinned).  weights [k], means [k][4], covs [k][4][4]. */
+int tdr_gmm_fit_host(const double* samples, int m, int k, int max_iter, double* weights, double* means, double* covs,
+                     double* mean_loglik);
+/* computeGMM's search for the cluster count around *num_gaussians_io (:259, 276-297) and the conversion of the clusters
+ * to means [k][3] = {x, y, atan2} / covs [k][9] (:303-312).  samples [m][4] = {x, y, 50 cos theta, 50 sin theta}. */
+int tdr_gmm_select_host(const double* samples, int m, int64_t num_particles, int* num_gaussians_io, int max_k,
+                        float* means_out, float* covs_out);
+/* num_particles_ of :151-157 from the clusters' covariances. */
+int64_t tdr_adaptive_count_host(const float* covs, int k, int64_t last_count, int64_t max_count);
+/* Handle layer: computeGMM (:252-318) on the filter's current particles (synchronous; the reference runs it in a
+ * detached thread once per second), getGMM (:238-243), and the count of :151-157 from the stored clusters
+ * (n_target for tdr_filter_update).  max_k bounds the arrays passed to get_gmm. */
+#define TDR_GMM_MAX_K 32
+int tdr_filter_compute_gmm(tdr_filter* f);
+int tdr_filter_get_gmm(tdr_filter* f, int max_k, int* k_out, float* means, float* covs);
+int64_t tdr_filter_adaptive_count(tdr_filter* f);
+
 /* internal: lets tdr_host.cpp report through tdr_last_error() */
 int tdr_set_error(int code, const char* msg);
 

@@ -3,8 +3,10 @@
 // (src/top_down_render.cpp:116, 333-359, 423-425, 591) compile against it unchanged; the work runs on the MI355X
 // through tdr_filter (include/tdr.h).  Documented differences:
 //   * an explicit seed (default 0) replaces std::random_device (src/particle_filter.cpp:4-5);
-//   * the adaptive particle count (:151-157) is an explicit input (setTargetCount) instead of an OpenCV EM thread:
-//     getGMM() returns one Gaussian (the particle mean / covariance), visualize() is not provided;
+//   * the mixture behind the adaptive particle count (:151-157, 245-318) is fitted on demand by computeGMM() with a
+//     deterministic EM (csrc/tdr_gmm.cpp) instead of cv::ml::EM in a detached thread; getGMM() returns it;
+//     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides; visualize() (OpenCV
+//     drawing) is not provided;
 //   * top_down_geo is accepted and ignored like in the reference's score (src/state_particle.cpp:145-152).
 #ifndef PARTICLE_FILTER_H_
 #define PARTICLE_FILTER_H_
@@ -39,12 +41,28 @@ class ParticleFilter {
     if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("update: fewer scan images than map classes");
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
-    check(tdr_filter_update(f_, buf.data(), nullptr, res, target_count_), "update");
+    check(tdr_filter_update(f_, buf.data(), nullptr, res, next_count()), "update");
   }
   // Extension: score against the renderer's last render without copying the images through the host.
   void update(const ScanRenderer& renderer, float res) {
-    check(tdr_filter_update(f_, nullptr, renderer.handle(), res, target_count_), "update");
+    check(tdr_filter_update(f_, nullptr, renderer.handle(), res, next_count()), "update");
   }
+  // getGMM (:238-243) / computeGMM (:252-318)
+  void computeGMM() { check(tdr_filter_compute_gmm(f_), "computeGMM"); }
+  void getGMM(std::vector<Eigen::Vector3f>& means, std::vector<Eigen::Matrix3f>& covs) {
+    float m[3 * TDR_GMM_MAX_K], c[9 * TDR_GMM_MAX_K];
+    int k = 0;
+    check(tdr_filter_get_gmm(f_, TDR_GMM_MAX_K, &k, m, c), "getGMM");
+    means.clear();
+    covs.clear();
+    for (int g = 0; g < k; g++) {
+      means.push_back(Eigen::Vector3f(m[3 * g], m[3 * g + 1], m[3 * g + 2]));
+      Eigen::Matrix3f cv;
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cv(i, j) = c[9 * g + 3 * i + j];
+      covs.push_back(cv);
+    }
+  }
+  void setAdaptiveCount(bool on) { adaptive_ = on; }   // :151-157 from the clusters of the last computeGMM
   void computeCov(Eigen::Matrix4f& cov) { stat(1, nullptr, &cov); }                        // :226-236
   void maxLikelihood(Eigen::Vector4f& state) { stat(1, &state, nullptr); }                 // :222-224
   void computeMeanCov(Eigen::Matrix4f& cov) { stat(0, nullptr, &cov); }                    // :205-220
@@ -108,11 +126,16 @@ class ParticleFilter {
     if (state) for (int i = 0; i < 4; i++) (*state)[i] = s[i];
     if (cov) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) (*cov)(i, j) = c[4 * i + j];
   }
+  int64_t next_count() {
+    if (target_count_ >= 0) return target_count_;
+    return adaptive_ ? tdr_filter_adaptive_count(f_) : -1;
+  }
   void check(int rc, const char* what) { if (rc != TDR_OK) fail(what); }
   [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + tdr_last_error()); }
 
   int max_num_particles_ = 0;
   int target_count_ = -1;
+  bool adaptive_ = false;
   TopDownMapPolar* map_;
   FilterParams params_;
   tdr_filter* f_ = nullptr;

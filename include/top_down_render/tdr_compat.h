@@ -54,6 +54,7 @@ class FixedVecShim {
  public:
   FixedVecShim() { for (int i = 0; i < N; i++) v_[i] = T(); }
   FixedVecShim(T a, T b) { static_assert(N == 2, "2 components"); v_[0] = a; v_[1] = b; }
+  FixedVecShim(T a, T b, T c) { static_assert(N == 3, "3 components"); v_[0] = a; v_[1] = b; v_[2] = c; }
   FixedVecShim(T a, T b, T c, T d) { static_assert(N == 4, "4 components"); v_[0] = a; v_[1] = b; v_[2] = c; v_[3] = d; }
   T& operator[](int i) { return v_[i]; }
   const T& operator[](int i) const { return v_[i]; }
@@ -67,17 +68,21 @@ class FixedVecShim {
 };
 typedef FixedVecShim<float, 2> Vector2f;
 typedef FixedVecShim<int, 2> Vector2i;
+typedef FixedVecShim<float, 3> Vector3f;
 typedef FixedVecShim<float, 4> Vector4f;
-class Matrix4f {  // column-major like Eigen's default
+template <int N>
+class SquareMatShim {  // column-major like Eigen's default
  public:
-  Matrix4f() { setZero(); }
-  float& operator()(int i, int j) { return v_[i + 4 * j]; }
-  const float& operator()(int i, int j) const { return v_[i + 4 * j]; }
+  SquareMatShim() { setZero(); }
+  float& operator()(int i, int j) { return v_[i + N * j]; }
+  const float& operator()(int i, int j) const { return v_[i + N * j]; }
   void setZero() { for (float& x : v_) x = 0; }
   float* data() { return v_; }
  private:
-  float v_[16];
+  float v_[N * N];
 };
+typedef SquareMatShim<3> Matrix3f;
+typedef SquareMatShim<4> Matrix4f;
 class VectorXi {
  public:
   VectorXi() {}

@@ -274,3 +274,88 @@ def read_eig(path, dtype):
         rows, cols = np.fromfile(f, np.int64, 2)
         data = np.fromfile(f, dtype, int(rows) * int(cols))
     return data.reshape(int(cols), int(rows)).T.copy()
+
+
+# ---- N3: the mixture behind the adaptive particle count (src/particle_filter.cpp:151-157, 245-318) ------------------
+# The reference fits cv::ml::EM (random k-means start; OpenCV is not available here: parity unpinned).  The product
+# fits a DETERMINISTIC mixture (top_down_renderer_amd/csrc/tdr_gmm.cpp); this is the same algorithm stated in NumPy:
+# seeding = sample nearest the overall mean + farthest-first traversal, 10 Lloyd iterations, EM with full covariances
+# + 1e-6 I, at most `max_iter` iterations, stop when the mean log-likelihood moves by < 1e-6.
+def gmm_fit(samples, k, max_iter=100):
+    X = np.asarray(samples, np.float64)
+    m, D = X.shape
+    reg = 1e-6
+    mean = X.sum(0) / m
+    idx = [int(np.argmin(((X - mean) ** 2).sum(1)))]
+    mind = np.full(m, np.inf)
+    while len(idx) < k:
+        mind = np.minimum(mind, ((X - X[idx[-1]]) ** 2).sum(1))
+        idx.append(int(np.argmax(mind)))
+    cen = X[idx].copy()
+    label = np.zeros(m, np.int64)
+    for _ in range(10):
+        d2 = ((X[:, None, :] - cen[None, :, :]) ** 2).sum(2)
+        label = np.argmin(d2, 1)
+        for c in range(k):
+            if (label == c).any():
+                cen[c] = X[label == c].sum(0) / (label == c).sum()
+    w = np.full(k, 1.0 / k)
+    mu = cen.copy()
+    cov = np.tile(np.eye(D), (k, 1, 1))
+    resp = np.zeros((m, k))
+    resp[np.arange(m), label] = 1.0
+
+    def m_step():
+        for c in range(k):
+            nk = resp[:, c].sum()
+            if not nk > 1e-10:
+                continue
+            mc = (resp[:, c, None] * X).sum(0) / nk
+            dx = X - mc
+            cc = (resp[:, c, None, None] * dx[:, :, None] * dx[:, None, :]).sum(0) / nk + reg * np.eye(D)
+            try:
+                np.linalg.cholesky(cc)
+            except np.linalg.LinAlgError:
+                continue
+            w[c], mu[c], cov[c] = nk / m, mc, cc
+
+    m_step()
+    prev = ll = -np.inf
+    for _ in range(max(1, max_iter)):
+        lp = np.empty((m, k))
+        for c in range(k):
+            L = np.linalg.cholesky(cov[c])
+            y = np.linalg.solve(L, (X - mu[c]).T)
+            lp[:, c] = np.log(w[c]) - 0.5 * (D * np.log(2 * np.pi) + 2 * np.log(np.diag(L)).sum() + (y * y).sum(0))
+        mx = lp.max(1)
+        lse = mx + np.log(np.exp(lp - mx[:, None]).sum(1))
+        resp = np.exp(lp - lse[:, None])
+        ll = lse.sum() / m
+        if abs(ll - prev) < 1e-6:
+            break
+        prev = ll
+        m_step()
+    return w, mu, cov, ll
+
+
+def gmm_select(samples, num_particles, num_gaussians, max_k=32):
+    """computeGMM's cluster-count search (:259, 276-297) and cluster conversion (:303-312)."""
+    X = np.asarray(samples, np.float64)
+    m = len(X)
+    k = max(1, min(num_particles // 20 + 1, num_gaussians))
+    k = min(k, max_k, m)
+    ll = gmm_fit(X, k)[3]
+    direction = 0
+    if k * 50 < num_particles and k + 1 <= min(max_k, m):
+        if ll + 0.3 < gmm_fit(X, k + 1)[3]:
+            direction = 1
+    if k > 1:
+        if ll - 0.3 < gmm_fit(X, k - 1)[3]:
+            direction = -1
+    k += direction
+    w, mu, cov, ll = gmm_fit(X, k)
+    means = np.stack([mu[:, 0], mu[:, 1], np.arctan2(mu[:, 3], mu[:, 2])], 1).astype(np.float32)
+    covs = np.zeros((k, 3, 3), np.float32)
+    covs[:, :2, :2] = cov[:, :2, :2]
+    covs[:, 2, 2] = 1
+    return k, means, covs

@@ -111,6 +111,20 @@ int main(int argc, char** argv) {
     filter_->maxLikelihood(ml);
     filter_->computeCov(cov_ml);
 
+    // getGMM / adaptive particle count (src/particle_filter.cpp:151-157, 238-318)
+    std::vector<Eigen::Vector3f> gmm_means;
+    std::vector<Eigen::Matrix3f> gmm_covs;
+    filter_->computeGMM();
+    filter_->getGMM(gmm_means, gmm_covs);
+    {
+      std::vector<float> g;
+      for (size_t c = 0; c < gmm_means.size(); c++) {
+        for (int i = 0; i < 3; i++) g.push_back(gmm_means[c][i]);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) g.push_back(gmm_covs[c](i, j));
+      }
+      dump(dir + "/out_gmm.bin", g.data(), g.size());
+    }
+
     // --- outputs -----------------------------------------------------------------------------------------------------
     std::vector<float> scan((size_t)ncls * nb * nr);
     for (int c = 0; c < ncls; c++) std::memcpy(scan.data() + (size_t)c * nb * nr, top_down[c].data(), (size_t)nb * nr * sizeof(float));

@@ -66,6 +66,13 @@ SIGNATURES = {
     "tdr_k_gather_states": (_i, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tdr_init_particles_host": (_i, [_vp, _vp, _i, _i, _i, _f, C.POINTER(FilterParamsC), _i, _vp, C.POINTER(C.c_int64)]),
     "tdr_k_mean_cov": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "tdr_k_sample_ml_states": (_i, [_vp, _i64, _i64, _i, _vp, _vp]),
+    "tdr_gmm_fit_host": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "tdr_gmm_select_host": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp]),
+    "tdr_adaptive_count_host": (_i64, [_vp, _i, _i64, _i64]),
+    "tdr_filter_compute_gmm": (_i, [_vp]),
+    "tdr_filter_get_gmm": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "tdr_filter_adaptive_count": (_i64, [_vp]),
     "tdr_k_save_ml_state": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "tdr_k_set_scale": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_k_shift_init": (_i, [_vp, _i64, _i64, _f, _f, _vp]),

@@ -6,7 +6,8 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = [os.path.join(PKG, "csrc", "tdr_kernels.hip"), os.path.join(PKG, "csrc", "tdr_host.cpp")]
+SRC = [os.path.join(PKG, "csrc", "tdr_kernels.hip"), os.path.join(PKG, "csrc", "tdr_host.cpp"),
+       os.path.join(PKG, "csrc", "tdr_gmm.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 

@@ -93,6 +93,9 @@ struct tdr_filter {
   bool scale_frozen = false, maybe_uninit = true, parity_rng = true;
   int locality_every = 1;
   float uniform_scale = 0.f;
+  DevBuf<float> gmm_samples;  // [num][3] device staging for computeGMM
+  int num_gaussians = 1;      // particle_filter.cpp:7
+  std::vector<float> gmm_means, gmm_covs;
   DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
   bool have_ml = false;
   hipStream_t stream = nullptr;
@@ -499,6 +502,47 @@ float tdr_filter_scale(tdr_filter* f) {
   return -1.f;
 }
 int64_t tdr_filter_num_particles(const tdr_filter* f) { return f ? f->n : 0; }
+
+// computeGMM (particle_filter.cpp:252-318): <= 1000 strided samples {x, y, 50 cos theta, 50 sin theta} -> mixture
+int tdr_filter_compute_gmm(tdr_filter* f) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_compute_gmm: null filter");
+  if (f->n < 1) return TDR_OK;
+  const int num = (int)std::min<int64_t>(1000, f->n);   // :262
+  TTRY(f->gmm_samples.resize((size_t)3 * num));
+  TTRY(tdr_k_sample_ml_states(f->st.p, f->n_max, f->n, num, f->gmm_samples.p, f->stream));
+  std::vector<float> h((size_t)3 * num);
+  HTRY(hipMemcpyAsync(h.data(), f->gmm_samples.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+  HTRY(hipStreamSynchronize(f->stream));
+  std::vector<double> x((size_t)4 * num);
+  for (int i = 0; i < num; i++) {
+    x[4 * i + 0] = h[3 * i + 0];
+    x[4 * i + 1] = h[3 * i + 1];
+    x[4 * i + 2] = 50 * std::cos(h[3 * i + 2]);   // :269-270 (float argument: the float overload)
+    x[4 * i + 3] = 50 * std::sin(h[3 * i + 2]);
+  }
+  int k = f->num_gaussians;
+  std::vector<float> means((size_t)3 * TDR_GMM_MAX_K), covs((size_t)9 * TDR_GMM_MAX_K);
+  TTRY(tdr_gmm_select_host(x.data(), num, f->n, &k, TDR_GMM_MAX_K, means.data(), covs.data()));
+  f->num_gaussians = k;
+  f->gmm_means.assign(means.begin(), means.begin() + 3 * k);
+  f->gmm_covs.assign(covs.begin(), covs.begin() + 9 * k);
+  return TDR_OK;
+}
+int tdr_filter_get_gmm(tdr_filter* f, int max_k, int* k_out, float* means, float* covs) {
+  if (!f || !k_out) return failh(TDR_ERR_ARG, "filter_get_gmm: bad arguments");
+  const int k = (int)(f->gmm_means.size() / 3);
+  *k_out = k;
+  if (k > max_k) return failh(TDR_ERR_ARG, "filter_get_gmm: %d clusters, room for %d", k, max_k);
+  if (means && k) std::memcpy(means, f->gmm_means.data(), f->gmm_means.size() * sizeof(float));
+  if (covs && k) std::memcpy(covs, f->gmm_covs.data(), f->gmm_covs.size() * sizeof(float));
+  return TDR_OK;
+}
+int64_t tdr_filter_adaptive_count(tdr_filter* f) {
+  if (!f) return -1;
+  const int k = (int)(f->gmm_means.size() / 3);
+  if (k == 0) return f->n;
+  return tdr_adaptive_count_host(f->gmm_covs.data(), k, f->n, f->n_max);
+}
 
 // ParticleFilter::updateMap(const cv::Mat& map, map_center) (particle_filter.cpp:320-341) for a class-index image
 int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int img_h, int img_w,

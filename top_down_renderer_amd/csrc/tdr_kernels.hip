@@ -3013,6 +3013,25 @@ extern "C" int tdr_k_save_ml_state(const float* info, const float* st, int64_t c
   return TDR_OK;
 }
 
+// computeGMM's sample set (src/particle_filter.cpp:262-272): mlState().head<3>() of every (n/num)-th particle.
+__global__ void sample_ml_states_kernel(const float* __restrict__ st, int64_t cap, int64_t n, int num,
+                                        float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  const int64_t p = min(n - 1, (int64_t)i * n / num);   // :265-266
+  const float sc = st[TDR_ST_SCALE * cap + p];
+  out[3 * i + 0] = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
+  out[3 * i + 1] = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+  out[3 * i + 2] = st[TDR_ST_THETA * cap + p];
+}
+extern "C" int tdr_k_sample_ml_states(const float* st, int64_t cap, int64_t n, int num, float* out, void* stream) {
+  if (!st || !out || n < 1 || cap < n || num < 1) return fail(TDR_ERR_ARG, "sample_ml_states: bad arguments");
+  hipLaunchKernelGGL(sample_ml_states_kernel, dim3((unsigned)cdiv(num, 256)), dim3(256), 0, (hipStream_t)stream, st,
+                     cap, n, num, out);
+  LAUNCH_CHECK("sample_ml_states");
+  return TDR_OK;
+}
+
 __global__ void selftest_atan2_kernel(const float* __restrict__ y, const float* __restrict__ x, int64_t n,
                                       float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

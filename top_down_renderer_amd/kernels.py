@@ -176,6 +176,23 @@ class HipKernels:
         check(self.lib.tdr_k_mean_cov(_ptr(st), st.shape[1], n, _ptr(about), _ptr(out), self.stream()))
         return out
 
+    def sample_ml_states(self, st, n, num):
+        """(num, 3) device tensor: mlState().head<3>() of particle min(n-1, i*n/num) (particle_filter.cpp:262-266)."""
+        out = self.empty((num, 3))
+        check(self.lib.tdr_k_sample_ml_states(_ptr(st), st.shape[1], n, num, _ptr(out), self.stream()))
+        return out
+
+    def gmm_select(self, samples, num_particles, num_gaussians, max_k=32):
+        """Host: the deterministic mixture fit + cluster-count search of tdr_gmm.cpp.  samples: (m, 4) float64.
+        Returns (k, means (k, 3) float32, covs (k, 3, 3) float32)."""
+        x = np.ascontiguousarray(samples, np.float64)
+        k = C.c_int(int(num_gaussians))
+        means = np.zeros((max_k, 3), np.float32)
+        covs = np.zeros((max_k, 9), np.float32)
+        check(self.lib.tdr_gmm_select_host(x.ctypes.data_as(C.c_void_p), len(x), int(num_particles), C.byref(k), max_k,
+                                           means.ctypes.data_as(C.c_void_p), covs.ctypes.data_as(C.c_void_p)))
+        return k.value, means[: k.value].copy(), covs[: k.value].reshape(-1, 3, 3).copy()
+
     def set_scale(self, st, n, scale_dev):
         check(self.lib.tdr_k_set_scale(_ptr(st), st.shape[1], n, _ptr(scale_dev), self.stream()))
 

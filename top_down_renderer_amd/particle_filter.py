@@ -117,6 +117,9 @@ class ParticleFilter:
         self._maybe_uninit = True
         self._uniform_scale = 0.0
         self._ml_state = None
+        self.num_gaussians_ = 1   # :7
+        self.gmm_means_ = np.zeros((0, 3), np.float32)
+        self.gmm_covs_ = np.zeros((0, 3, 3), np.float32)
         self._alloc()
         if map.haveMap():
             self.fp_c = params.to_c(map.numClasses())
@@ -314,6 +317,25 @@ class ParticleFilter:
     def meanLikelihood(self):
         st, n, _ = self._global_states()
         return self.k.mean_cov(st, n)[:4].cpu().numpy().copy()
+
+    # ---- particle_filter.cpp:238-318: the mixture behind the adaptive particle count --------------------------------
+    def computeGMM(self):
+        """computeGMM (:252-318) on the current particles, synchronously (the reference runs it in a detached thread
+        once per second).  cv::ml::EM is replaced by the deterministic fit of csrc/tdr_gmm.cpp (parity unpinned)."""
+        st, n, _ = self._global_states()
+        if n < 1:
+            return
+        num = min(1000, n)   # :262
+        h = self.k.sample_ml_states(st, n, num).cpu().numpy()
+        x = np.empty((num, 4), np.float64)
+        x[:, 0], x[:, 1] = h[:, 0], h[:, 1]
+        x[:, 2] = np.float32(50) * np.cos(h[:, 2])   # :269-270
+        x[:, 3] = np.float32(50) * np.sin(h[:, 2])
+        self.num_gaussians_, self.gmm_means_, self.gmm_covs_ = self.k.gmm_select(x, n, self.num_gaussians_)
+
+    def getGMM(self):
+        """(means [k][3] = x, y, theta; covs [k][3][3]) of the last computeGMM (:238-243)."""
+        return self.gmm_means_.copy(), self.gmm_covs_.copy()
 
     def computeMeanCov(self):
         if self.num_particles_ < 1:
