@@ -22,10 +22,10 @@ def env():
     return pkg, HipKernels()
 
 
-def _case(seed):
+def _case(seed, ncls=None):
     from top_down_renderer_amd import synth
     rng = np.random.default_rng(9000 + seed)
-    ncls = int(rng.integers(1, 9))
+    ncls = int(rng.integers(1, 9)) if ncls is None else ncls
     if ncls == 1:
         ncls = 2            # the generator keeps class 1 for roads
     nb = int(rng.choice([8, 12, 25, 36, 64, 100, 129]))
@@ -99,17 +99,27 @@ def test_random_shapes_against_oracle(env, oracle, seed):
         assert np.array_equal(got[name], ref[name]), name
 
 
-@pytest.mark.parametrize("seed", range(8))
-def test_random_init_search_against_oracle(env, oracle, seed):
+@pytest.mark.parametrize("seed,ncls,pile", [(s, None, 0) for s in range(8)] + [(20 + s, 4 + s % 3, 0) for s in range(9)] +
+                         [(40, 6, 3000), (41, 5, 2049)])
+def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
     """have_init = false: the 40-rotation search on random shapes; the chosen rotation is verified through the oracle's
-    cost at the GPU's theta (candidates can tie to within rounding)."""
+    cost at the GPU's theta (candidates can tie to within rounding).  4-6 classes take the matrix-core kernel
+    (score_init_mfma_kernel); `pile` points in one bin push a scan count past what f16 holds exactly, which must send the
+    search back to the vector kernel."""
     pkg, k = env
-    cfg, sc, maps, mask, st, params, rng = _case(100 + seed)
+    cfg, sc, maps, mask, st, params, rng = _case(100 + seed, ncls)
+    if pile:
+        lab = sc.lut[sc.pts[:, 3].astype(np.int64)]
+        r = np.hypot(sc.pts[:, 0], sc.pts[:, 1])
+        k0 = int(np.nonzero((lab >= 0) & (r > cfg.res) & (r < (cfg.nr - 1) * cfg.res))[0][0])   # a point that lands in the image
+        sc.pts = np.concatenate([sc.pts, np.repeat(sc.pts[k0:k0 + 1], pile, axis=0)])
     ncls, nb, nr = cfg.ncls, cfg.nb, cfg.nr
     params["fixed_scale"] = 1.0
     st["scale"] = 1.0
     st["have_init"] = 0
     scan_o = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, ncls, nb, nr)
+    if pile:
+        assert scan_o.max() >= pile or scan_o.sum(0).max() >= pile
     om = oracle.OracleMap(maps, mask, cfg.map_resolution)
     tab = oracle.polar_table(nb, nr, cfg.ang_res, cfg.map_resolution)
     fpo = oracle.make_params(ncls, **params)

@@ -971,6 +971,7 @@ struct InitArgs {
   const int* nrot;
   const int* shift;    // [nrot] device arrays (filled by init_rot_kernel)
   const float* theta;
+  const int* only_if;  // optional: the kernel runs only when this device word is non-zero (fallback after the MFMA pass)
   float* res_theta;  // [n] chosen rotation
   float* res_flag;   // [n] 0 = untouched, 1 = initialised, 2 = initialised but every rotation scored NaN
                      //     (weight 1/(FLT_MAX + reg), state_particle.cpp:193,212)
@@ -988,6 +989,7 @@ __global__ __launch_bounds__(64 * INIT_WAVES) void score_init_kernel(InitArgs a)
   __shared__ int x_rot[INIT_WAVES][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
+  if (a.only_if && *a.only_if == 0) return;               // (uniform) the MFMA pass already produced the results
   const int64_t slot = (int64_t)blockIdx.x * 64 + lane;   // all four waves work on the same 64 particles
   const bool valid = slot < a.n;
   const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
@@ -1133,10 +1135,155 @@ __global__ __launch_bounds__(64 * INIT_WAVES) void score_init_kernel(InitArgs a)
   }
 }
 
+// The same search on the matrix cores (records of 8 floats, i.e. 4-6 classes).  For one particle the 40 candidate
+// costs are  cost[m] = sum_{i,j,c} scan_c[(i + s_m) mod nb, j] * (w_c d_c[cell(i,j)]):  a contraction over
+// k = (sample, class) of a matrix A[m][k] that is the same for every particle (shifted scan records, from LDS) with
+// the particle's gathered window B[k][n].  v_mfma_f32_16x16x32_f16: 16 rotations x 16 particles x (4 samples x 8
+// record slots) per instruction.  Lane l holds, as its B fragment, the 8 slots of the record of particle l&15 at
+// sample 4t + (l>>4) — exactly the record it gathered — and as its A fragment the packed scan record at row
+// (4t + (l>>4) + s_m), m = l&15 (+16, +32 for the second and third tile of candidates), one ds_read_b128 each.
+//   * scan counts are integers: exact in f16 up to 2048 (a larger count raises *inexact and score_init_kernel redoes
+//     the search on the vector units);
+//   * distances (times 0.01 w_c, in f32) are split hi + lo into two f16 (relative error <= 2^-20), two MFMAs;
+//   * the normalisation  sum scanΣ * known  is a third MFMA with only slot 7 of B set; the known count is a plain add.
+// Products are exact and accumulate in f32 like the vector version.  Only the choice of the rotation comes out of
+// here; the weight itself is computed by the regular scoring pass at that rotation.
+typedef _Float16 tdr_h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 tdr_h2 __attribute__((ext_vector_type(2)));   // what v_cvt_pkrtz_f16_f32 returns
+typedef float tdr_f4 __attribute__((ext_vector_type(4)));
+#define INITM_TILES 3   // 48 candidate rows >= the 40 (41) rotations of the search
+static_assert(INITM_TILES * 16 >= INIT_MAXROT || INIT_MAXROT == 48, "rotation tiles");
+
+template <bool USCALE>
+__global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* __restrict__ inexact) {
+  constexpr int RF = 8;
+  extern __shared__ uint4 ring16[];   // [2*nb] packed scan records as 8 x f16 (row r and r+nb hold scan row r)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + wave * 16 + col;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  if (!__syncthreads_or(want)) return;   // nothing to initialise in this batch of 64 particles
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const int rowstride = (a.cols + 2) * (RF * 4);
+  const int kbase = (a.cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  int sh[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) {
+    const int m = 16 * T + col;
+    sh[T] = m < nrot ? a.shift[m] : -1;
+  }
+  float wc[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) wc[c] = c < a.ncls ? (float)(0.01 * (double)a.fp.class_weights[c]) : 0.f;
+  tdr_f4 accC[INITM_TILES], accN[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) { accC[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; accN[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; }
+  float known = 0.f;
+  const int steps = (a.nb + 3) / 4;
+
+  for (int j = 0; j < a.nr; j++) {
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* srow = scan4 + (int64_t)j * a.nb * 2;
+    __syncthreads();
+    bool big = false;
+    for (int t = threadIdx.x; t < a.nb; t += 256) {
+      const float4 v0 = srow[2 * t], v1 = srow[2 * t + 1];
+      big |= v0.x > 2048.f || v0.y > 2048.f || v0.z > 2048.f || v0.w > 2048.f || v1.x > 2048.f || v1.y > 2048.f ||
+             v1.w > 2048.f;
+      union { tdr_h2 h[4]; uint4 u; } pk;
+      pk.h[0] = __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y);
+      pk.h[1] = __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w);
+      pk.h[2] = __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y);
+      pk.h[3] = __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w);
+      ring16[t] = pk.u;
+      ring16[t + a.nb] = pk.u;
+    }
+    if (big) atomicOr(inexact, 1);
+    __syncthreads();
+    for (int t = 0; t < steps; t++) {
+      const int i = 4 * t + q;
+      const bool in = i < a.nb;
+      const int ic = in ? i : a.nb - 1;
+      // the lane's sample of its particle's window (top_down_map_polar.cpp:28-31)
+      const float2 tv = trow[ic];
+      float p0, p1;
+      if constexpr (USCALE) { p0 = tv.x; p1 = tv.y; }
+      else { p0 = (tv.x * scale) * a.res; p1 = (tv.y * scale) * a.res; }
+      p0 = __builtin_amdgcn_fmed3f(p0 + off0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1 + off1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      const unsigned bo = inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+      float4 m0 = *reinterpret_cast<const float4*>(recb + bo);
+      float4 m1 = *reinterpret_cast<const float4*>(recb + bo + 16);
+      if (!in) { m0 = make_float4(0.f, 0.f, 0.f, 0.f); m1 = m0; }
+      known += m1.w;
+      const float v[6] = {m0.x * wc[0], m0.y * wc[1], m0.z * wc[2], m0.w * wc[3], m1.x * wc[4], m1.y * wc[5]};
+      union { tdr_h2 h[4]; tdr_h8 v8; } bh, bl, bn;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[2 * c], v[2 * c + 1]);
+        bh.h[c] = hi;
+        bl.h[c] = __builtin_amdgcn_cvt_pkrtz(v[2 * c] - (float)hi[0], v[2 * c + 1] - (float)hi[1]);
+      }
+      bh.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+      bl.h[3] = bh.h[3];
+      bn.h[0] = bh.h[3]; bn.h[1] = bh.h[3]; bn.h[2] = bh.h[3];
+      bn.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, m1.w);
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) {
+        union { uint4 u; tdr_h8 v8; } av;
+        av.u = ring16[ic + (sh[T] < 0 ? 0 : sh[T])];
+        if (sh[T] < 0) av.u = make_uint4(0u, 0u, 0u, 0u);
+        accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bh.v8, accC[T], 0, 0, 0);
+        accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bl.v8, accC[T], 0, 0, 0);
+        accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bn.v8, accN[T], 0, 0, 0);
+      }
+    }
+  }
+  // this lane holds rows 4q..4q+3 of every tile for particle `col`; the four lanes of a particle share the samples
+  known += __shfl_xor(known, 16, 64);
+  known += __shfl_xor(known, 32, 64);
+  const bool unknown = (known / (float)a.P) < 0.5;   // state_particle.cpp:117-120
+  float best = 3.402823466e+38f;
+  int bm = -1;
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * T + 4 * q + r;
+      float cost = accC[T][r] / accN[T][r];             // :154
+      if (unknown) cost = __builtin_nanf("");
+      if (m < nrot && cost < best) { best = cost; bm = m; }   // :200-203 (NaN never wins)
+    }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {   // first minimum in rotation order over the particle's four lanes
+    const float oc = __shfl_xor(best, o, 64);
+    const int om = __shfl_xor(bm, o, 64);
+    const bool take = om >= 0 && (bm < 0 || oc < best || (oc == best && om < bm));
+    if (take) { best = oc; bm = om; }
+  }
+  if (q == 0 && want) {
+    a.res_theta[p] = bm >= 0 ? a.theta[bm] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bm < 0 ? 2.f : 1.f;
+  }
+}
+
 // candidate rotations of the search, generated exactly like the reference's loop (state_particle.cpp:197: float t,
 // double increment) together with their bin shifts (:124-128)
 __global__ void init_rot_kernel(int nb, int* __restrict__ shift, float* __restrict__ theta, int* __restrict__ nrot) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  nrot[1] = 0;   // the "scan counts too large for f16" flag of score_init_mfma_kernel
   int k = 0;
   for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {
     if (k >= INIT_MAXROT) break;
@@ -1163,6 +1310,13 @@ __global__ void init_fixup_kernel(const float* __restrict__ res_flag, int64_t n,
   if (p < n && res_flag[p] == 2.f) raw_w[p] = (float)(1. / (double)(3.402823466e+38f + regularization));
 }
 
+static bool init_use_mfma() {
+  static bool v = [] {
+    const char* e = getenv("TDR_INIT_MFMA");   // 0 = vector-unit search only (A/B and debugging)
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
 static int64_t score_wave_target() {
   static int64_t v = [] {
     // tuning knob.  Many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms):
@@ -1324,6 +1478,16 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     dim3 grid((unsigned)cdiv(n, 64)), block(64 * INIT_WAVES);
     const size_t lds = TDR_INIT_SCAN_LDS ? (size_t)2 * nb * rf * 4 : 0;
     const bool ks = tdr_has_kslot(map->ncls, rf), us = a.utab != nullptr;
+    ia.only_if = nullptr;
+    if (rf == 8 && ks && init_use_mfma()) {
+      // matrix-core pass first; the vector kernel below then runs only if a scan count did not fit f16
+      int* d_inexact = d_nrot + 1;
+      const size_t lds16 = (size_t)2 * nb * 16;
+      if (us) hipLaunchKernelGGL((score_init_mfma_kernel<true>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else hipLaunchKernelGGL((score_init_mfma_kernel<false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      LAUNCH_CHECK("score_init_mfma");
+      ia.only_if = d_inexact;
+    }
 #define TDR_LAUNCH_INIT(NV4)                                                                                \
   if (ks && us) hipLaunchKernelGGL((score_init_kernel<NV4, true, true>), grid, block, lds, s, ia);         \
   else if (ks) hipLaunchKernelGGL((score_init_kernel<NV4, true, false>), grid, block, lds, s, ia);         \
