@@ -1154,10 +1154,11 @@ typedef float tdr_f4 __attribute__((ext_vector_type(4)));
 #define INITM_TILES 3   // 48 candidate rows >= the 40 (41) rotations of the search
 static_assert(INITM_TILES * 16 >= INIT_MAXROT || INIT_MAXROT == 48, "rotation tiles");
 
-template <bool USCALE>
+// UNITW: all class weights are equal — a common factor does not move the minimum, so the distances go in unweighted.
+template <bool USCALE, bool UNITW>
 __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* __restrict__ inexact) {
   constexpr int RF = 8;
-  extern __shared__ uint4 ring16[];   // [2*nb] packed scan records as 8 x f16 (row r and r+nb hold scan row r)
+  extern __shared__ uint4 ring16[];   // [2*nb] packed scan records as 8 x f16 (row r and r+nb hold scan row r) + 1 zero row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, q = lane >> 4;
   const int64_t slot = (int64_t)blockIdx.x * 64 + wave * 16 + col;
@@ -1176,12 +1177,15 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
   const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
   const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
   const int nrot = *a.nrot;
+  // byte offset of the lane's candidate row within the ring for every tile; candidates past nrot read the zero row
+  const int zero_row = 2 * a.nb;
   int sh[INITM_TILES];
 #pragma unroll
   for (int T = 0; T < INITM_TILES; T++) {
     const int m = 16 * T + col;
     sh[T] = m < nrot ? a.shift[m] : -1;
   }
+  if (threadIdx.x == 0) ring16[zero_row] = make_uint4(0u, 0u, 0u, 0u);
   float wc[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) wc[c] = c < a.ncls ? (float)(0.01 * (double)a.fp.class_weights[c]) : 0.f;
@@ -1210,25 +1214,44 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
     }
     if (big) atomicOr(inexact, 1);
     __syncthreads();
+    // software pipeline: the record of step t+1 (and the table entry of step t+2) are requested before the matrix
+    // work of step t, so every wave keeps two gathers in flight
+    auto tab_at = [&](int t) -> float2 { return trow[min(4 * t + q, a.nb - 1)]; };
+    auto rec_addr = [&](float2 tv) -> const char* {
+      float p0, p1;
+      if constexpr (USCALE) { p0 = tv.x; p1 = tv.y; }
+      else { p0 = (tv.x * scale) * a.res; p1 = (tv.y * scale) * a.res; }   // top_down_map_polar.cpp:28
+      p0 = __builtin_amdgcn_fmed3f(p0 + off0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1 + off1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);   // :31
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      return recb + (inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u);
+    };
+    float2 tv_next = tab_at(1);
+    float4 n0, n1;
+    {
+      const char* r0 = rec_addr(tab_at(0));
+      n0 = *reinterpret_cast<const float4*>(r0);
+      n1 = *reinterpret_cast<const float4*>(r0 + 16);
+    }
     for (int t = 0; t < steps; t++) {
       const int i = 4 * t + q;
       const bool in = i < a.nb;
       const int ic = in ? i : a.nb - 1;
-      // the lane's sample of its particle's window (top_down_map_polar.cpp:28-31)
-      const float2 tv = trow[ic];
-      float p0, p1;
-      if constexpr (USCALE) { p0 = tv.x; p1 = tv.y; }
-      else { p0 = (tv.x * scale) * a.res; p1 = (tv.y * scale) * a.res; }
-      p0 = __builtin_amdgcn_fmed3f(p0 + off0, -1.f, rmaxf);
-      p1 = __builtin_amdgcn_fmed3f(p1 + off1, -1.f, cmaxf);
-      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
-      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
-      const unsigned bo = inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
-      float4 m0 = *reinterpret_cast<const float4*>(recb + bo);
-      float4 m1 = *reinterpret_cast<const float4*>(recb + bo + 16);
+      float4 m0 = n0, m1 = n1;
+      {
+        const char* r1 = rec_addr(tv_next);        // step t+1 (clamped to the ring: an in-range address)
+        tv_next = tab_at(t + 2);
+        n0 = *reinterpret_cast<const float4*>(r1);
+        n1 = *reinterpret_cast<const float4*>(r1 + 16);
+      }
       if (!in) { m0 = make_float4(0.f, 0.f, 0.f, 0.f); m1 = m0; }
       known += m1.w;
-      const float v[6] = {m0.x * wc[0], m0.y * wc[1], m0.z * wc[2], m0.w * wc[3], m1.x * wc[4], m1.y * wc[5]};
+      float v[6] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y};
+      if constexpr (!UNITW) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] *= wc[c];
+      }
       union { tdr_h2 h[4]; tdr_h8 v8; } bh, bl, bn;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -1240,15 +1263,16 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
       bl.h[3] = bh.h[3];
       bn.h[0] = bh.h[3]; bn.h[1] = bh.h[3]; bn.h[2] = bh.h[3];
       bn.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, m1.w);
+      union { uint4 u; tdr_h8 v8; } av[INITM_TILES];
 #pragma unroll
-      for (int T = 0; T < INITM_TILES; T++) {
-        union { uint4 u; tdr_h8 v8; } av;
-        av.u = ring16[ic + (sh[T] < 0 ? 0 : sh[T])];
-        if (sh[T] < 0) av.u = make_uint4(0u, 0u, 0u, 0u);
-        accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bh.v8, accC[T], 0, 0, 0);
-        accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bl.v8, accC[T], 0, 0, 0);
-        accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av.v8, bn.v8, accN[T], 0, 0, 0);
-      }
+      for (int T = 0; T < INITM_TILES; T++) av[T].u = ring16[sh[T] < 0 ? zero_row : ic + sh[T]];
+      // dependent MFMAs (same accumulator) are kept three instructions apart
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bh.v8, accC[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bn.v8, accN[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bl.v8, accC[T], 0, 0, 0);
     }
   }
   // this lane holds rows 4q..4q+3 of every tile for particle `col`; the four lanes of a particle share the samples
@@ -1482,9 +1506,14 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     if (rf == 8 && ks && init_use_mfma()) {
       // matrix-core pass first; the vector kernel below then runs only if a scan count did not fit f16
       int* d_inexact = d_nrot + 1;
-      const size_t lds16 = (size_t)2 * nb * 16;
-      if (us) hipLaunchKernelGGL((score_init_mfma_kernel<true>), grid, dim3(256), lds16, s, ia, d_inexact);
-      else hipLaunchKernelGGL((score_init_mfma_kernel<false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      const size_t lds16 = ((size_t)2 * nb + 1) * 16;
+      bool unitw = true;
+      for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
+      unitw &= fp->class_weights[0] > 0.f;
+      if (us && unitw) hipLaunchKernelGGL((score_init_mfma_kernel<true, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else if (us) hipLaunchKernelGGL((score_init_mfma_kernel<true, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else if (unitw) hipLaunchKernelGGL((score_init_mfma_kernel<false, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else hipLaunchKernelGGL((score_init_mfma_kernel<false, false>), grid, dim3(256), lds16, s, ia, d_inexact);
       LAUNCH_CHECK("score_init_mfma");
       ia.only_if = d_inexact;
     }
