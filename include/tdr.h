@@ -101,12 +101,16 @@ int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float*
  * pts: n points, `stride` floats apart (pcl::PointXYZI: stride 8, ioff 4; packed xyzi: stride 4, ioff 3);
  * lut256: flatten_lut_ (int32[256], -1 = ignore).  Outputs (either may be NULL):
  *   img_out  [ncls][nb*nr]   the reference's images (zero-filled, counts as float);
- *   pk_out   [nr][nb][rf]    the same counts interleaved per bin, slot rf-1 = sum over classes (scoring input). */
+ *   pk_out   [nr][nb][rf]    the same counts interleaved per bin, slot rf-1 = sum over classes (scoring input).
+ * workspace: device scratch of tdr_raster_workspace_bytes(n) bytes, or NULL.  With it every point's bin is computed
+ * once (one atan2f / sqrtf per point) and the LDS tiles stream 4-byte keys; without it every tile bins every point. */
+int64_t tdr_raster_workspace_bytes(int64_t n);
 int tdr_k_raster_polar(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
-                       const int32_t* lut256, int ncls, int nb, int nr, float* img_out, float* pk_out, void* stream);
+                       const int32_t* lut256, int ncls, int nb, int nr, float* img_out, float* pk_out, void* workspace,
+                       void* stream);
 /* ScanRenderer::renderSemanticTopDown (src/scan_renderer.cpp:55-78); img_out [ncls][rows*cols]. */
 int tdr_k_raster_cart(const float* pts, int stride, int ioff, int64_t n, float res, const int32_t* lut256, int ncls,
-                      int rows, int cols, float* img_out, float* pk_out, void* stream);
+                      int rows, int cols, float* img_out, float* pk_out, void* workspace, void* stream);
 /* Builds pk_out from caller-supplied images (ParticleFilter::update is handed images, particle_filter.cpp:94-95). */
 int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, void* stream);
 

@@ -53,7 +53,7 @@ def test_host_entry_points_without_gpu(lib, oracle):
 def test_argument_validation_happens_before_any_launch(lib):
     assert lib.tdr_k_pack_map(None, None, 3, 4, 4, None, None) == -1
     assert b"null" in lib.tdr_last_error()
-    assert lib.tdr_k_raster_polar(None, 4, 3, 10, C.c_float(1.0), C.c_float(0.1), None, 3, 16, 8, None, None, None) == -1
+    assert lib.tdr_k_raster_polar(None, 4, 3, 10, C.c_float(1.0), C.c_float(0.1), None, 3, 16, 8, None, None, None, None) == -1
     assert lib.tdr_k_resample(C.c_void_p(8), 4, 4, C.c_float(0.5), 3, 2, C.c_void_p(8), None) == -1
     assert lib.tdr_k_prefix(None, 0, None, None, None) == -1
     assert lib.tdr_prefix_workspace_bytes(0) == 0 and lib.tdr_prefix_workspace_bytes(4097) == 64

@@ -104,6 +104,39 @@ def test_raster_polar_vs_oracle(tdr, oracle, name):
     assert np.array_equal(got, ref)
 
 
+def test_raster_with_and_without_workspace(tdr, oracle):
+    """tdr_k_raster_polar / _cart: the two-phase raster (bins once, tiles stream keys) and the single-phase one (no
+    workspace) write the same images."""
+    pkg, k = tdr
+    import ctypes as C
+    from top_down_renderer_amd import synth
+    sc = synth.make_scene("c1", with_particles=False)
+    cfg = sc.cfg
+    pts = k.to_device(np.ascontiguousarray(sc.pts, np.float32))
+    lut = k.to_device(np.asarray(sc.lut, np.int32))
+    n = len(sc.pts)
+    rf = k.lib.tdr_rec_floats(cfg.ncls)
+    ref = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ws = k.empty((int(k.lib.tdr_raster_workspace_bytes(n)),), __import__("torch").uint8)
+    outs = []
+    for w in (None, ws):
+        img, pk = k.zeros((cfg.ncls, cfg.nb * cfg.nr)), k.zeros((cfg.nb * cfg.nr * rf,))
+        assert k.lib.tdr_k_raster_polar(C.c_void_p(pts.data_ptr()), 4, 3, n, C.c_float(cfg.res), C.c_float(cfg.ang_res),
+                                        C.c_void_p(lut.data_ptr()), cfg.ncls, cfg.nb, cfg.nr, C.c_void_p(img.data_ptr()),
+                                        C.c_void_p(pk.data_ptr()), C.c_void_p(w.data_ptr()) if w is not None else None,
+                                        k.stream()) == 0
+        outs.append((img.cpu().numpy(), pk.cpu().numpy()))
+        assert np.array_equal(outs[-1][0], ref)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    refc = oracle.raster_cart(sc.pts, cfg.res, sc.lut, cfg.ncls, 50, 64)
+    for w in (None, ws):
+        img = k.zeros((cfg.ncls, 50 * 64))
+        assert k.lib.tdr_k_raster_cart(C.c_void_p(pts.data_ptr()), 4, 3, n, C.c_float(cfg.res), C.c_void_p(lut.data_ptr()),
+                                       cfg.ncls, 50, 64, C.c_void_p(img.data_ptr()), None,
+                                       C.c_void_p(w.data_ptr()) if w is not None else None, k.stream()) == 0
+        assert np.array_equal(img.cpu().numpy(), refc)
+
+
 def test_atan2f_bit_exact(tdr):
     """The raster kernel's atan2f against the host libm the reference calls (glibc atan2f), bit for bit."""
     pkg, k = tdr

@@ -44,8 +44,9 @@ SIGNATURES = {
     "tdr_k_map_from_labels": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "tdr_k_unpack_map": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_polar_table_host": (_i, [_i, _i, _f, _f, _vp]),
-    "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tdr_raster_workspace_bytes": (_i64, [_i64]),
+    "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tdr_k_pack_scan": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,

@@ -76,6 +76,7 @@ struct tdr_map {
 struct tdr_renderer {
   DevBuf<int32_t> lut;
   DevBuf<float> pts, img, pk;
+  DevBuf<uint8_t> keys;  // per-point bin keys of the two-phase raster
   int ncls = 0, rows = 0, cols = 0;  // shape of the last render
   bool have_scan = false;
 };
@@ -252,10 +253,13 @@ int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride
   TTRY(r->img.resize(P * ncls));
   TTRY(r->pk.resize(P * tdr_rec_floats(ncls)));
   if (n > 0) HTRY(hipMemcpy(r->pts.p, pts, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
+  TTRY(r->keys.resize((size_t)tdr_raster_workspace_bytes(std::max<int64_t>(n, 1))));
   if (polar)
-    TTRY(tdr_k_raster_polar(r->pts.p, stride, ioff, n, res, ang_res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p, nullptr));
+    TTRY(tdr_k_raster_polar(r->pts.p, stride, ioff, n, res, ang_res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p,
+                            r->keys.p, nullptr));
   else
-    TTRY(tdr_k_raster_cart(r->pts.p, stride, ioff, n, res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p, nullptr));
+    TTRY(tdr_k_raster_cart(r->pts.p, stride, ioff, n, res, r->lut.p, ncls, rows, cols, r->img.p, r->pk.p, r->keys.p,
+                           nullptr));
   if (imgs_out) HTRY(hipMemcpy(imgs_out, r->img.p, P * ncls * sizeof(float), hipMemcpyDeviceToHost));
   else HTRY(hipDeviceSynchronize());
   r->ncls = ncls;

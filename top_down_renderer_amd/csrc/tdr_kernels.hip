@@ -320,7 +320,11 @@ struct RasterArgs {
   int ncls, rows, cols, rf, cpt, polar;
   float* img;
   float* pk;
+  uint32_t* keys;   // optional [n]: bin of every point, computed once by raster_keys_kernel (col << 20 | class << 16 | row)
 };
+#define RASTER_NO_BIN 0xFFFFFFFFu
+#define RASTER_KEY_MAX_COLS 4095
+#define RASTER_KEY_MAX_ROWS 65535
 
 // atan2f exactly as glibc computes it (the reference calls the host libm, src/scan_renderer_polar.cpp:97).
 // glibc's float atan2f / atanf are the fdlibm algorithms (argument reduction to four intervals + an 11-term odd/even
@@ -402,6 +406,31 @@ __device__ __forceinline__ bool raster_bin(const RasterArgs& a, float x, float y
   return row >= 0 && row < a.rows && col >= 0 && col < a.cols;
 }
 
+// Phase 1 (when the caller gave a workspace): the bin of every point once — atan2f / sqrtf per point instead of per
+// point and tile — as a 4-byte key the tiles then stream.
+__global__ __launch_bounds__(256) void raster_keys_kernel(RasterArgs a) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.n) return;
+  const float* p = a.pts + k * a.stride;
+  float x, y, cf;
+  if (a.stride == 4 && a.ioff == 3) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    x = v.x; y = v.y; cf = v.w;
+  } else {
+    x = p[0]; y = p[1]; cf = p[a.ioff];
+  }
+  uint32_t key = RASTER_NO_BIN;
+  int row, col;
+  if (raster_bin(a, x, y, row, col)) {
+    const int pc = (int)cf;
+    if (pc >= 0 && pc <= 255) {
+      const int c = a.lut[pc];
+      if (c >= 0 && c < a.ncls) key = ((uint32_t)col << 20) | ((uint32_t)c << 16) | (uint32_t)row;
+    }
+  }
+  a.keys[k] = key;
+}
+
 __global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
   extern __shared__ unsigned int cnt[];  // [cpt][ncls][rows]
   const int col0 = blockIdx.x * a.cpt;
@@ -411,6 +440,14 @@ __global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
   __shared__ int lut_s[256];
   if (threadIdx.x < 256) lut_s[threadIdx.x] = a.lut[threadIdx.x];
   __syncthreads();
+  if (a.keys) {
+    for (int64_t k = threadIdx.x; k < a.n; k += blockDim.x) {
+      const uint32_t key = a.keys[k];
+      const int col = (int)(key >> 20) - col0;
+      if (key == RASTER_NO_BIN || col < 0 || col >= ncol) continue;
+      atomicAdd(&cnt[(col * a.ncls + (int)((key >> 16) & 15u)) * a.rows + (int)(key & 0xFFFFu)], 1u);
+    }
+  } else
   for (int64_t k = threadIdx.x; k < a.n; k += blockDim.x) {
     const float* p = a.pts + k * a.stride;
     float x, y, cf;
@@ -457,9 +494,10 @@ __global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
   }
 }
 
+extern "C" int64_t tdr_raster_workspace_bytes(int64_t n) { return n < 1 ? 0 : 4 * n; }
 static int launch_raster(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
                          const int32_t* lut, int ncls, int rows, int cols, int polar, float* img, float* pk,
-                         void* stream) {
+                         void* workspace, void* stream) {
   if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "raster: bad image shape");
   if (n < 0 || (n > 0 && !pts) || !lut) return fail(TDR_ERR_ARG, "raster: null points / lut");
   if (stride < 3 || ioff < 0 || ioff >= stride) return fail(TDR_ERR_ARG, "raster: bad point stride / offset");
@@ -474,6 +512,11 @@ static int launch_raster(const float* pts, int stride, int ioff, int64_t n, floa
   // enough workgroups to spread over the chip when the image is small
   while (a.cpt > 1 && cdiv(cols, a.cpt) < 32) a.cpt = (a.cpt + 1) / 2;
   size_t lds = (size_t)a.cpt * per_col;
+  a.keys = nullptr;
+  if (workspace && n > 0 && cols <= RASTER_KEY_MAX_COLS && rows <= RASTER_KEY_MAX_ROWS) {
+    a.keys = reinterpret_cast<uint32_t*>(workspace);
+    hipLaunchKernelGGL(raster_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
   hipLaunchKernelGGL(raster_kernel, dim3((unsigned)cdiv(cols, a.cpt)), dim3(1024), lds, (hipStream_t)stream, a);
   LAUNCH_CHECK("raster");
   return TDR_OK;
@@ -481,12 +524,13 @@ static int launch_raster(const float* pts, int stride, int ioff, int64_t n, floa
 
 extern "C" int tdr_k_raster_polar(const float* pts, int stride, int ioff, int64_t n, float res, float ang_res,
                                   const int32_t* lut256, int ncls, int nb, int nr, float* img_out, float* pk_out,
-                                  void* stream) {
-  return launch_raster(pts, stride, ioff, n, res, ang_res, lut256, ncls, nb, nr, 1, img_out, pk_out, stream);
+                                  void* workspace, void* stream) {
+  return launch_raster(pts, stride, ioff, n, res, ang_res, lut256, ncls, nb, nr, 1, img_out, pk_out, workspace, stream);
 }
 extern "C" int tdr_k_raster_cart(const float* pts, int stride, int ioff, int64_t n, float res, const int32_t* lut256,
-                                 int ncls, int rows, int cols, float* img_out, float* pk_out, void* stream) {
-  return launch_raster(pts, stride, ioff, n, res, 1.f, lut256, ncls, rows, cols, 0, img_out, pk_out, stream);
+                                 int ncls, int rows, int cols, float* img_out, float* pk_out, void* workspace,
+                                 void* stream) {
+  return launch_raster(pts, stride, ioff, n, res, 1.f, lut256, ncls, rows, cols, 0, img_out, pk_out, workspace, stream);
 }
 
 __global__ void pack_scan_kernel(const float* __restrict__ img, int ncls, int rows, int cols, int rf,

@@ -41,6 +41,7 @@ class HipKernels:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ws = None
         self._pws = None
+        self._rws = None
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -102,18 +103,25 @@ class HipKernels:
         m.tab_host, m.tab, m.nb, m.nr, m.ang_res = tab, self.to_device(tab), nb, nr, float(ang_res)
 
     # ---- raster ---------------------------------------------------------------------------------------------
+    def _raster_workspace(self, n):
+        need = int(self.lib.tdr_raster_workspace_bytes(n))
+        if self._rws is None or self._rws.numel() < need:
+            self._rws = self.empty((max(need, 4),), torch.uint8)
+        return self._rws
+
     def raster_polar(self, pts, n, stride, ioff, res, ang_res, lut, ncls, nb, nr, want_img=True):
         img = self.empty((ncls, nb * nr)) if want_img else None
         pk = self.empty((nr * nb * self.lib.tdr_rec_floats(ncls),))
         check(self.lib.tdr_k_raster_polar(_ptr(pts), stride, ioff, n, C.c_float(res), C.c_float(ang_res), _ptr(lut),
-                                          ncls, nb, nr, _ptr(img), _ptr(pk), self.stream()))
+                                          ncls, nb, nr, _ptr(img), _ptr(pk), _ptr(self._raster_workspace(n)),
+                                          self.stream()))
         return img, pk
 
     def raster_cart(self, pts, n, stride, ioff, res, lut, ncls, rows, cols, want_img=True):
         img = self.empty((ncls, rows * cols)) if want_img else None
         pk = self.empty((rows * cols * self.lib.tdr_rec_floats(ncls),))
         check(self.lib.tdr_k_raster_cart(_ptr(pts), stride, ioff, n, C.c_float(res), _ptr(lut), ncls, rows, cols,
-                                         _ptr(img), _ptr(pk), self.stream()))
+                                         _ptr(img), _ptr(pk), _ptr(self._raster_workspace(n)), self.stream()))
         return img, pk
 
     def pack_scan(self, img, ncls, nb, nr):
