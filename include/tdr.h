@@ -173,7 +173,7 @@ int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, 
 /* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
 /* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum.
  * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  With a workspace and n >= 32768 the chain
- * is evaluated by many workgroups (per-chunk parity summaries, see tdr_kernels.hip); without one, by one workgroup.
+ * is evaluated by many workgroups (per-chunk parity summaries, see csrc/tdr_prefix.hip); without one, by one workgroup.
  * The bits written are the serial chain's either way. */
 int64_t tdr_prefix_workspace_bytes(int64_t n);
 int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream);

@@ -6,12 +6,13 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = [os.path.join(PKG, "csrc", "tdr_kernels.hip"), os.path.join(PKG, "csrc", "tdr_host.cpp"),
-       os.path.join(PKG, "csrc", "tdr_gmm.cpp")]
-HDR = [os.path.join(ROOT, "include", "tdr.h")]
+SRC = [os.path.join(PKG, "csrc", f) for f in
+       ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_filter.hip", "tdr_prefix.hip",
+        "tdr_host.cpp", "tdr_gmm.cpp")]
+HDR = [os.path.join(ROOT, "include", "tdr.h"), os.path.join(PKG, "csrc", "tdr_common.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 
-# -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see tdr_kernels.hip)
+# -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-I", os.path.join(ROOT, "include")]
 

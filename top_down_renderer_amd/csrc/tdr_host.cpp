@@ -1,5 +1,5 @@
 // tdr_host.cpp — the handle layer of the C ABI (include/tdr.h, "tdr_map_* / tdr_renderer_* / tdr_filter_*"):
-// C++ host code that owns device memory and sequences the hand-written HIP kernels (tdr_kernels.hip) exactly the way
+// C++ host code that owns device memory and sequences the hand-written HIP kernels (tdr_*.hip) exactly the way
 // the reference's classes sequence their Eigen loops.  One handle = one reference object:
 //     tdr_map       TopDownMapPolar   (include/top_down_render/top_down_map_polar.h:6-22)
 //     tdr_renderer  ScanRendererPolar (include/top_down_render/scan_renderer_polar.h:15-22)
@@ -18,7 +18,7 @@
 
 #include "tdr.h"
 
-extern "C" int tdr_set_error(int code, const char* msg);  // tdr_kernels.hip
+extern "C" int tdr_set_error(int code, const char* msg);  // tdr_core.hip
 
 namespace {
 

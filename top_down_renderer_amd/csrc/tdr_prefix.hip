@@ -1,0 +1,851 @@
+// tdr_prefix.hip — the serial float32 running sum of the resampling step, reproduced bit-exactly in parallel.
+#include "tdr_common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5: resample.  The running sum of particle_filter.cpp:179 is a serial float32 chain,
+//     prefix_j = fl(prefix_{j-1} + w_j),
+// and "bit-exact resample indices" needs exactly these values.  Two kernels produce them:
+//
+//  * prefix_serial_kernel — one wave, lane 0 performs the additions in index order (weights staged through LDS).
+//    Simple, ~10 ns per element; kept as the reference implementation and for small n.
+//  * prefix_exact_kernel — the same values computed in parallel.  While the running sum r stays inside one binade
+//    [2^e, 2^(e+1)) it is an integer multiple R*u of u = 2^(e-23) and fl(r + w) = (R + q)*u, where q is w/u rounded
+//    to nearest — a pure integer increment that depends on r only when w/u ends in exactly .5 (tie to even: the parity
+//    of R + floor(w/u)).  So per tile of 4096 weights the workgroup (i) classifies every weight into an integer
+//    increment / tie / "needs a real float add" (NaN, inf, larger than the binade), (ii) prefix-sums the increments,
+//    (iii) resolves the (rare) ties in order on one thread, (iv) prefix-sums the tie corrections, (v) finds the first
+//    element at which the sum leaves the binade or a real add is needed, commits everything before it, performs that
+//    one addition in float arithmetic and restarts behind it in the new binade.  A running sum of 1 crosses ~24
+//    binades, so a million weights take a few hundred workgroup passes instead of a million dependent additions.
+//    tests/test_gpu_parity.py compares both kernels with the CPU chain bit for bit on random and adversarial inputs.
+//
+// The running maximum makes "first j with prefix_j > sample" searchable even when weights are negative (NaN fill, :133).
+#define TDR_PFX_BLOCK 4096  // elements staged in LDS per pass (64 per lane)
+__global__ __launch_bounds__(64) void prefix_serial_kernel(const float* __restrict__ w, int64_t n,
+                                                           float* __restrict__ runmax) {
+  __shared__ float4 buf4[TDR_PFX_BLOCK / 4];
+  float* buf = reinterpret_cast<float*>(buf4);
+  const int lane = threadIdx.x;
+  float run = 0.f;        // the serial chain lives in lane 0
+  float carry_max = -INFINITY;
+  for (int64_t base = 0; base < n; base += TDR_PFX_BLOCK) {
+    const int cnt = (int)min((int64_t)TDR_PFX_BLOCK, n - base);
+    // coalesced stage-in (pad with zeros: x + 0 == x)
+    for (int t = lane; t < TDR_PFX_BLOCK; t += 64) buf[t] = (t < cnt) ? w[base + t] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const int q4 = (cnt + 3) / 4;
+#pragma unroll 4
+      for (int q = 0; q < q4; q++) {
+        float4 v = buf4[q];
+        run = run + v.x; v.x = run;   // particle_filter.cpp:179, one float add per weight, index order
+        run = run + v.y; v.y = run;
+        run = run + v.z; v.z = run;
+        run = run + v.w; v.w = run;
+        buf4[q] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // running maximum of the block's prefix values (max is associative: any order is exact)
+    float m = -INFINITY;
+    float loc[64];
+#pragma unroll
+    for (int t = 0; t < 64; t++) {
+      float x = buf[lane * 64 + t];
+      if (x != x) x = -INFINITY;  // a NaN prefix never exceeds a threshold (`running_sum > sample` is false)
+      m = fmaxf(m, x);
+      loc[t] = m;
+    }
+    float incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      float t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl = fmaxf(incl, t);
+    }
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -INFINITY;
+    excl = fmaxf(excl, carry_max);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 64; t++) buf[lane * 64 + t] = fmaxf(loc[t], excl);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < cnt; t += 64) runmax[base + t] = buf[t];
+    carry_max = fmaxf(__shfl(incl, 63, 64), carry_max);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- exact parallel prefix -------------------------------------------------------------------------------------------
+#define PFX_THREADS 1024
+#define PFX_K 8
+#define PFX_TILE (PFX_THREADS * PFX_K)
+#define PFX_TIE_CAP 2048   // ties resolved per pass; a (never observed) denser tile is simply cut at that tie
+#define PFX_HEAD 2048      // leading elements added one by one: the running sum crosses most of its binades here
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (~1 us each time); in the prefix kernels the threads exchange data through LDS alone — global memory is read-only
+// input (w, chunk headers of an earlier launch) or write-only output — so the store wait would be pure latency.
+__device__ __forceinline__ void pfx_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// inclusive block scan (sum) of one value per thread; `sh` holds one slot per wave
+template <int NT, class T>
+__device__ __forceinline__ T pfx_block_scan(T v, T* sh, T& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  pfx_sync();
+  if (lane == 63) sh[wave] = v;
+  pfx_sync();
+  T off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < NT / 64; k++) {
+    const T x = sh[k];
+    if (k < wave) off += x;
+    tot += x;
+  }
+  total = tot;
+  return v + off;
+}
+template <int NT>
+__device__ __forceinline__ float pfx_block_scan_max(float v, float* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v = fmaxf(v, t);
+  }
+  pfx_sync();
+  if (lane == 63) sh[wave] = v;
+  pfx_sync();
+  float off = -INFINITY;
+  for (int k = 0; k < wave; k++) off = fmaxf(off, sh[k]);
+  return fmaxf(v, off);
+}
+
+// The running sum carried through [lo, hi) in index order by the whole workgroup (NT threads): r_io / carry_io
+// are the (workgroup-uniform) running sum and running maximum before element lo on entry and after element hi-1 on
+// exit.  With lo == 0 the first PFX_HEAD elements are added one by one.
+template <int NT>
+__device__ __forceinline__ void pfx_exact_range(const float* __restrict__ w, long long lo, long long hi,
+                                             float* __restrict__ runmax, float* __restrict__ prefix_opt,
+                                             float& r_io, float& carry_io, int head_len = PFX_HEAD) {
+  const long long n = hi;
+  __shared__ long long sh_ll[NT / 64];
+  __shared__ int sh_i[NT / 64];
+  __shared__ float sh_f[NT / 64];
+  __shared__ int tie_pos[PFX_TIE_CAP];         // local element index of every tie in order, weight sign in bit 31
+  __shared__ long long tie_sval[PFX_TIE_CAP];  // inclusive increment prefix at the tie
+  __shared__ signed char tie_corr[PFX_TIE_CAP];
+  __shared__ float head[PFX_HEAD];
+  __shared__ float last_val[NT], last_max[NT];
+  __shared__ int s_first_bad, s_first_cross, s_first_nz;
+  __shared__ float s_r, s_carry;
+  __shared__ long long s_base;
+  const int tid = threadIdx.x;
+  pfx_sync();
+  if (tid == 0) { s_r = r_io; s_carry = carry_io; s_base = lo; }
+  pfx_sync();
+  if (lo == 0) {  // head: plain serial additions by one thread out of LDS
+    const int hn = (int)min((long long)head_len, (long long)n);
+    for (int t = tid; t < hn; t += NT) head[t] = w[t];
+    pfx_sync();
+    if (tid == 0) {
+      float run = 0.f, mx = -INFINITY;
+      for (int t = 0; t < hn; t++) {
+        run = run + head[t];  // particle_filter.cpp:179
+        if (prefix_opt) prefix_opt[t] = run;
+        if (run == run) mx = fmaxf(mx, run);
+        head[t] = mx;
+      }
+      s_r = run; s_carry = mx; s_base = hn;
+    }
+    pfx_sync();
+    for (int t = tid; t < hn; t += NT) runmax[t] = head[t];
+    pfx_sync();
+  }
+
+  while (true) {
+    const long long base = s_base;
+    if (base >= n) break;
+    const float r = s_r;
+    const float carry = s_carry;
+    const int cnt = (int)min((long long)(NT * PFX_K), (long long)n - base);
+    const unsigned rb = __float_as_uint(r);
+    const int re = (rb >> 23) & 0xFF;
+    float wv[PFX_K];
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      wv[k] = (li < cnt) ? w[base + li] : 0.f;
+    }
+    if (tid == 0) { s_first_bad = (NT * PFX_K); s_first_cross = (NT * PFX_K); s_first_nz = (NT * PFX_K); }
+    pfx_sync();  // also: everyone has read s_r / s_carry / s_base
+
+    if (r != r) {  // NaN running sum: every later prefix is NaN, the running maximum stays
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        const int li = tid * PFX_K + k;
+        if (li < cnt) {
+          runmax[base + li] = carry;
+          if (prefix_opt) prefix_opt[base + li] = r;
+        }
+      }
+      pfx_sync();
+      if (tid == 0) s_base = base + cnt;
+      pfx_sync();
+      continue;
+    }
+    const bool r_zero = (rb & 0x7FFFFFFFu) == 0;
+    const bool r_slow = (rb >> 31) != 0 || re == 0 || re == 255;  // negative, zero / subnormal, inf: plain float steps
+    if (r_slow) {
+      int stop = 0;  // leading elements that leave r unchanged (r == +-0 only: skip the run of zero weights)
+      if (r_zero) {
+#pragma unroll
+        for (int k = 0; k < PFX_K; k++) {
+          const int li = tid * PFX_K + k;
+          if (li < cnt && (__float_as_uint(wv[k]) & 0x7FFFFFFFu) != 0) atomicMin(&s_first_nz, li);
+        }
+        pfx_sync();
+        stop = min(s_first_nz, cnt);
+      }
+      const float m0 = fmaxf(carry, r);
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        const int li = tid * PFX_K + k;
+        if (li < stop) {
+          runmax[base + li] = m0;
+          if (prefix_opt) prefix_opt[base + li] = r;
+        }
+      }
+      pfx_sync();
+      if (tid == 0) {
+        float nr = r, nc = stop > 0 ? m0 : carry;
+        long long nb = base + stop;
+        if (stop < cnt) {  // one real float addition (particle_filter.cpp:179)
+          nr = r + w[base + stop];
+          if (nr == nr) nc = fmaxf(nc, nr);
+          runmax[base + stop] = nc;
+          if (prefix_opt) prefix_opt[base + stop] = nr;
+          nb = base + stop + 1;
+        }
+        s_r = nr; s_carry = nc; s_base = nb;
+      }
+      pfx_sync();
+      continue;
+    }
+
+    // ---- r is a positive normal float: r = R * 2^(e-23), R in [2^23, 2^24)
+    const int e = re - 127;
+    const long long R = (long long)((rb & 0x7FFFFFu) | 0x800000u);
+    long long inc[PFX_K];
+    bool tie[PFX_K], neg[PFX_K];
+    long long tsum = 0;
+    int ntie = 0;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      const unsigned b = __float_as_uint(wv[k]);
+      const int ew = (b >> 23) & 0xFF;
+      unsigned mw = b & 0x7FFFFFu;
+      const bool zero = (b & 0x7FFFFFFFu) == 0;
+      const int E = ew == 0 ? -126 : ew - 127;
+      if (ew != 0) mw |= 0x800000u;
+      const int sft = e - E;
+      const bool in = li < cnt;
+      const bool bad = in && ((ew == 255) || (sft < 0));  // NaN / inf / at least as large as the binade: real add
+      neg[k] = (b >> 31) != 0 && !zero;
+      const int sc = sft < 0 ? 0 : (sft > 26 ? 26 : sft);
+      const unsigned f = mw >> sc;
+      const unsigned rem = mw & ((1u << sc) - 1u);
+      const unsigned half = sc >= 1 ? (1u << (sc - 1)) : 0u;
+      const bool up = sc >= 1 && rem > half;
+      tie[k] = in && !bad && sc >= 1 && rem == half;
+      long long q = (long long)f + (up ? 1 : 0);  // |w|/u rounded to nearest (ties toward zero, patched below)
+      if (neg[k]) q = -q;
+      if (!in || bad) q = 0;
+      if (bad) atomicMin(&s_first_bad, li);
+      inc[k] = q;
+      tsum += q;
+      ntie += tie[k] ? 1 : 0;
+    }
+    long long tot_ll;
+    const long long sincl = pfx_block_scan<NT, long long>(tsum, sh_ll, tot_ll);
+    long long S[PFX_K];  // inclusive prefix of the increments at this thread's elements
+    {
+      long long acc = sincl - tsum;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) { acc += inc[k]; S[k] = acc; }
+    }
+    // ---- ties, in element order: the even neighbour wins, which depends on everything before the tie
+    int tot_tie;
+    const int tincl = pfx_block_scan<NT, int>(ntie, sh_i, tot_tie);
+    const int tfirst = tincl - ntie;
+    {
+      int pos = tfirst;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++)
+        if (tie[k]) {
+          if (pos < PFX_TIE_CAP) {
+            tie_pos[pos] = (tid * PFX_K + k) | (neg[k] ? (int)0x80000000 : 0);
+            tie_sval[pos] = S[k];
+          } else if (pos == PFX_TIE_CAP) {
+            atomicMin(&s_first_bad, tid * PFX_K + k);  // more ties than slots: cut the tile here
+          }
+          pos++;
+        }
+    }
+    pfx_sync();
+    if (tid == 0 && tot_tie > 0) {
+      long long c = 0;
+      const int fb = s_first_bad;
+      const int nt = min(tot_tie, PFX_TIE_CAP);
+      for (int t = 0; t < nt; t++) {
+        const int pk = tie_pos[t];
+        const int li = pk & 0x7FFFFFFF;
+        signed char corr = 0;
+        if (li < fb) {
+          const long long V = R + tie_sval[t] + c;  // mantissa if the tie is rounded toward zero
+          if (V & 1) corr = (pk < 0) ? -1 : 1;      // exact value is V +- 1/2: move to the even neighbour
+        }
+        tie_corr[t] = corr;
+        c += corr;
+      }
+    }
+    pfx_sync();
+    int csum = 0;
+    int corr[PFX_K];
+    {
+      int pos = tfirst;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        corr[k] = 0;
+        if (tie[k]) { corr[k] = pos < PFX_TIE_CAP ? tie_corr[pos] : 0; pos++; }
+        csum += corr[k];
+      }
+    }
+    int tot_c;
+    const int cincl = pfx_block_scan<NT, int>(csum, sh_i, tot_c);
+    // ---- mantissas, first element that leaves the binade
+    long long state[PFX_K];
+    {
+      int cacc = cincl - csum;
+#pragma unroll
+      for (int k = 0; k < PFX_K; k++) {
+        cacc += corr[k];
+        state[k] = R + S[k] + cacc;
+        const int li = tid * PFX_K + k;
+        if (li < cnt && (state[k] >= (1ll << 24) || state[k] < (1ll << 23))) atomicMin(&s_first_cross, li);
+      }
+    }
+    pfx_sync();
+    const int stop = min(min(s_first_bad, s_first_cross), cnt);
+    // ---- commit [0, stop): values and running maximum
+    float val[PFX_K], lm[PFX_K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      val[k] = __uint_as_float(((unsigned)re << 23) | ((unsigned)state[k] & 0x7FFFFFu));
+      if (li < stop) m = fmaxf(m, val[k]);
+      lm[k] = m;
+    }
+    const float mincl = pfx_block_scan_max<NT>(m, sh_f);
+    float mexcl = __shfl_up(mincl, 1, 64);
+    {  // exclusive maximum over the preceding threads
+      pfx_sync();
+      last_max[tid] = mincl;
+      pfx_sync();
+      mexcl = tid > 0 ? last_max[tid - 1] : -INFINITY;
+    }
+    const float mbase = fmaxf(carry, mexcl);
+    float lastv = r, lastm = carry;
+#pragma unroll
+    for (int k = 0; k < PFX_K; k++) {
+      const int li = tid * PFX_K + k;
+      if (li < stop) {
+        const float rm = fmaxf(mbase, lm[k]);
+        runmax[base + li] = rm;
+        if (prefix_opt) prefix_opt[base + li] = val[k];
+        lastv = val[k];
+        lastm = rm;
+      }
+    }
+    pfx_sync();
+    last_val[tid] = lastv;   // value / running max at this thread's last committed element (if any)
+    last_max[tid] = lastm;
+    pfx_sync();
+    if (tid == 0) {
+      float pv = r, pm = carry;  // value / running max at element stop-1
+      if (stop > 0) {
+        const int ot = (stop - 1) / PFX_K;
+        pv = last_val[ot];
+        pm = last_max[ot];
+      }
+      long long nb = base + stop;
+      if (stop < cnt) {  // one real float addition, then a new binade
+        const float nr = pv + w[base + stop];
+        if (nr == nr) pm = fmaxf(pm, nr);
+        runmax[base + stop] = pm;
+        if (prefix_opt) prefix_opt[base + stop] = nr;
+        pv = nr;
+        nb = base + stop + 1;
+      }
+      s_r = pv; s_carry = pm; s_base = nb;
+    }
+    pfx_sync();
+  }
+  r_io = s_r;
+  carry_io = s_carry;
+  pfx_sync();
+}
+
+__global__ __launch_bounds__(PFX_THREADS) void prefix_exact_kernel(const float* __restrict__ w, int64_t n,
+                                                                   float* __restrict__ runmax,
+                                                                   float* __restrict__ prefix_opt) {
+  float r = 0.f, carry = -INFINITY;
+  pfx_exact_range<PFX_THREADS>(w, 0, n, runmax, prefix_opt, r, carry);
+}
+
+// ---- exact parallel prefix over many workgroups ---------------------------------------------------------------------
+// Inside one binade (ulp u) the chain r <- fl(r + w) with w >= 0 is R <- R + a(R & 1): the increment of one element is
+// an integer that depends on the running mantissa only through its PARITY (round-half-even ties).  A run of elements is
+// therefore summarised by two integers (D0, D1) — its total increment entered with an even / odd mantissa — and
+// summaries compose associatively: (A then B)_p = A_p + B_{(p + A_p) & 1}.  That turns the chain into a scan:
+//   1. pfx_chunk_sum_kernel      — per chunk of PFXM_CHUNK weights: the sum in double
+//   2. pfx_chunk_summary_kernel  — per chunk: binade predicted from the double sum of everything before it; (D0, D1) in
+//                                  that binade, or "irregular" (NaN / inf / negative / weight above the binade)
+//   3. pfx_walk_kernel           — ONE workgroup walks the chunks in order with the exact running sum: a chunk whose
+//                                  prediction holds (same binade, R + D_p stays below 2^24) is a single integer add;
+//                                  any other chunk (the ~log2(n) binade crossings, irregular weights, the head) is
+//                                  processed on the spot by pfx_exact_range
+//   4. pfx_chunk_fill_kernel     — per accepted chunk: the same scan again, now with the exact starting mantissa,
+//                                  writes every element's running sum / running maximum
+// Every value written is the serial float32 chain's, whatever the prediction was: a wrong prediction only sends the
+// chunk down the slower path.
+#define PFXM_THREADS 256
+#define PFXM_K 16
+#define PFXM_CHUNK (PFXM_THREADS * PFXM_K)
+#define PFXM_SAT (1u << 30)
+struct PfxChunk {     // 32 bytes per chunk in the caller's workspace
+  double sum;         // 1: double sum of the chunk
+  int re;             // 2: predicted biased exponent of the running sum, or -1 = irregular
+  unsigned d0, d1;    // 2: total increment entered with an even / odd mantissa
+  float r0, carry0;   // 3: running sum / running maximum before the chunk's first element (accepted chunks)
+  int accepted;       // 3: 1 = pfx_chunk_fill_kernel writes this chunk's outputs
+};
+static_assert(sizeof(PfxChunk) == 32, "PfxChunk");
+
+struct PfxPair { unsigned a0, a1; };
+__device__ __forceinline__ unsigned pfx_sat(unsigned x) { return x > PFXM_SAT ? PFXM_SAT : x; }
+// first A, then B
+__device__ __forceinline__ PfxPair pfx_compose(PfxPair A, PfxPair B) {
+  PfxPair c;
+  c.a0 = pfx_sat(A.a0 + ((A.a0 & 1u) ? B.a1 : B.a0));
+  c.a1 = pfx_sat(A.a1 + ((A.a1 & 1u) ? B.a0 : B.a1));   // entered odd: the parity after A is (1 + A.a1) & 1
+  return c;
+}
+// One weight against the binade with exponent e (unbiased): f = floor(w/u) (+1 when the remainder exceeds one half),
+// tie = remainder exactly one half, bad = cannot be an integer increment (NaN, inf, negative, exponent above e).
+__device__ __forceinline__ void pfx_classify(float wv, int e, unsigned& f, bool& tie, bool& bad) {
+  const unsigned b = __float_as_uint(wv);
+  const int ew = (b >> 23) & 0xFF;
+  unsigned mw = b & 0x7FFFFFu;
+  const bool zero = (b & 0x7FFFFFFFu) == 0;
+  const int E = ew == 0 ? -126 : ew - 127;
+  if (ew != 0) mw |= 0x800000u;
+  const int sft = e - E;
+  bad = ew == 255 || sft < 0 || ((b >> 31) != 0 && !zero);
+  const int sc = sft < 0 ? 0 : (sft > 26 ? 26 : sft);
+  const unsigned q = mw >> sc;
+  const unsigned rem = mw & ((1u << sc) - 1u);
+  const unsigned half = sc >= 1 ? (1u << (sc - 1)) : 0u;
+  tie = sc >= 1 && rem == half;
+  f = q + ((sc >= 1 && rem > half) ? 1u : 0u);
+  if (bad) { f = 0; tie = false; }
+}
+__device__ __forceinline__ PfxPair pfx_element_pair(unsigned f, bool tie) {
+  PfxPair p;
+  p.a0 = f + (tie ? (f & 1u) : 0u);         // even mantissa + f + 1/2 -> the even neighbour
+  p.a1 = f + (tie ? ((f & 1u) ^ 1u) : 0u);
+  return p;
+}
+// inclusive scan of per-thread pairs over a workgroup of NT threads; returns the EXCLUSIVE pair of this thread and the
+// workgroup total.  `sh` holds one slot per wave; safe to call repeatedly (leading barrier).
+template <int NT>
+__device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh, PfxPair& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    PfxPair t;
+    t.a0 = __shfl_up(v.a0, o, 64);
+    t.a1 = __shfl_up(v.a1, o, 64);
+    if (lane >= o) v = pfx_compose(t, v);
+  }
+  pfx_sync();
+  if (lane == 63) sh[wave] = v;
+  pfx_sync();
+  PfxPair pre = {0u, 0u}, tot = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < NT / 64; k++) {
+    const PfxPair x = sh[k];
+    if (k < wave) pre = pfx_compose(pre, x);
+    tot = pfx_compose(tot, x);
+  }
+  total = tot;
+  PfxPair ex;
+  ex.a0 = __shfl_up(v.a0, 1, 64);
+  ex.a1 = __shfl_up(v.a1, 1, 64);
+  if (lane == 0) { ex.a0 = 0u; ex.a1 = 0u; }
+  return pfx_compose(pre, ex);
+}
+__device__ __forceinline__ void pfx_load_chunk(const float* __restrict__ w, long long lo, int cnt, float (&wv)[PFXM_K]) {
+  const int t0 = threadIdx.x * PFXM_K;
+  if (t0 + PFXM_K <= cnt && ((lo & 3) == 0)) {
+    const float4* p = reinterpret_cast<const float4*>(w + lo + t0);
+#pragma unroll
+    for (int k = 0; k < PFXM_K / 4; k++) {
+      const float4 v = p[k];
+      wv[4 * k] = v.x; wv[4 * k + 1] = v.y; wv[4 * k + 2] = v.z; wv[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PFXM_K; k++) wv[k] = (t0 + k < cnt) ? w[lo + t0 + k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_sum_kernel(const float* __restrict__ w, int64_t n,
+                                                                     PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXM_THREADS / 64];
+  const long long lo = (long long)blockIdx.x * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) acc += (double)wv[k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  pfx_sync();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < PFXM_THREADS / 64; k++) t += shd[k];
+    ch[blockIdx.x].sum = t;
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const float* __restrict__ w, int64_t n,
+                                                                         PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXM_THREADS / 64];
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  __shared__ int s_bad;
+  const int c = blockIdx.x;
+  const long long lo = (long long)c * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  // predicted running sum before the chunk: the double sums of the chunks before it, in chunk order per thread
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < c; j += PFXM_THREADS) acc += ch[j].sum;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  if (threadIdx.x == 0) s_bad = 0;
+  pfx_sync();
+  double before = 0.0;
+  for (int k = 0; k < PFXM_THREADS / 64; k++) before += shd[k];
+  const float r_pred = (float)before, r_end = (float)(before + ch[c].sum);
+  const unsigned pb = __float_as_uint(r_pred), eb = __float_as_uint(r_end);
+  const int re = (pb >> 23) & 0xFF;
+  // a chunk that is predicted to start and end in one binade of a positive normal sum; everything else is irregular
+  const bool plausible = (pb >> 31) == 0 && re != 0 && re != 255 && (int)((eb >> 23) & 0xFF) == re && (eb >> 31) == 0;
+  if (!plausible) {   // uniform across the workgroup
+    if (threadIdx.x == 0) { ch[c].re = -1; ch[c].d0 = 0u; ch[c].d1 = 0u; }
+    return;
+  }
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  PfxPair mine = {0u, 0u};
+  bool anybad = false;
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    unsigned f; bool tie, bad;
+    pfx_classify(wv[k], re - 127, f, tie, bad);
+    anybad |= bad;
+    mine = pfx_compose(mine, pfx_element_pair(f, tie));
+  }
+  if (anybad) s_bad = 1;   // benign race: every writer stores 1; ordered by the barrier inside the scan
+  PfxPair total;
+  (void)pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
+  if (threadIdx.x == 0) {
+    const bool ok = s_bad == 0 && total.a0 < (1u << 24) && total.a1 < (1u << 24);
+    ch[c].re = ok ? re : -1;
+    ch[c].d0 = total.a0;
+    ch[c].d1 = total.a1;
+  }
+}
+
+// A chunk the walk cannot take as one integer add (it holds a binade crossing or an irregular weight, or was
+// mispredicted), carried through in order by the walking workgroup: one scan per stretch between two real float
+// additions.  The walking workgroup has PFXM_THREADS threads holding 16 weights each, as in the fill kernel (one wave
+// per SIMD: a pass costs what ONE wave issues).  Anything that is not a positive normal running sum goes to
+// pfx_exact_range.
+#define PFXW_HEAD 64   // leading elements the walk adds one by one (tunable: TDR_PFX_HEAD)
+__device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long long lo, int cnt,
+                                               float* __restrict__ runmax, float* __restrict__ prefix_opt,
+                                               float& r, float& carry, int head_len) {
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  __shared__ int s_bad, s_cross;
+  __shared__ float s_last, s_wstop;
+  const int tid = threadIdx.x, t0 = tid * PFXM_K;
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  int pos = 0;   // workgroup-uniform: elements before pos are done
+  while (pos < cnt) {
+    const unsigned rb = __float_as_uint(r);
+    const unsigned re = rb >> 23;   // sign included
+    if (!(re >= 1u && re <= 254u)) {
+      // zero / subnormal / negative / inf / NaN running sum: the general path (with its serial head at the very start)
+      const long long a = lo + pos;
+      const long long b = a == 0 ? min((long long)head_len, (long long)cnt) : lo + cnt;
+      pfx_exact_range<PFXM_THREADS>(w, a, b, runmax, prefix_opt, r, carry, head_len);
+      pos = (int)(b - lo);
+      continue;
+    }
+    const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+    pfx_sync();
+    if (tid == 0) { s_bad = cnt; s_cross = cnt; s_last = r; s_wstop = 0.f; }
+    pfx_sync();
+    unsigned f[PFXM_K];
+    unsigned tiebits = 0u;
+    PfxPair mine = {0u, 0u};
+    {
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        const int li = t0 + k;
+        bool bad, tie;
+        pfx_classify(wv[k], (int)re - 127, f[k], tie, bad);
+        if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
+        if (bad) atomicMin(&s_bad, li);
+        tiebits |= tie ? (1u << k) : 0u;
+        mine = pfx_compose(mine, pfx_element_pair(f[k], tie));
+      }
+    }
+    PfxPair total;
+    const PfxPair ex = pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
+    unsigned st[PFXM_K];
+    {
+      unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);
+      int first = cnt;
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
+        st[k] = state;
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && state >= (1u << 24)) first = min(first, li);
+      }
+      if (first < cnt) atomicMin(&s_cross, first);
+    }
+    pfx_sync();
+    const int stop = min(s_bad, s_cross);   // first element that needs a real float addition (or cnt)
+    {
+#pragma unroll
+      for (int k = 0; k < PFXM_K; k++) {
+        const int li = t0 + k;
+        if (li >= pos && li < stop) {
+          const float val = __uint_as_float((re << 23) | (st[k] & 0x7FFFFFu));
+          runmax[lo + li] = fmaxf(carry, val);
+          if (prefix_opt) prefix_opt[lo + li] = val;
+          if (li == stop - 1) s_last = val;
+        }
+        if (li == stop) s_wstop = wv[k];
+      }
+    }
+    pfx_sync();
+    r = s_last;                  // the sum after element stop-1 (unchanged when nothing was committed)
+    carry = fmaxf(carry, r);     // increments are non-negative: the last committed value is the largest
+    if (stop < cnt) {
+      const float nr = r + s_wstop;   // particle_filter.cpp:179, one real addition
+      if (nr == nr) carry = fmaxf(carry, nr);
+      if (tid == 0) {
+        runmax[lo + stop] = carry;
+        if (prefix_opt) prefix_opt[lo + stop] = nr;
+      }
+      r = nr;
+      pos = stop + 1;
+    } else {
+      pos = cnt;
+    }
+  }
+}
+
+#define PFXW_BLOCK 512   // chunk summaries / headers staged in LDS at a time
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
+                                                               PfxChunk* __restrict__ ch, int nch,
+                                                               float* __restrict__ runmax,
+                                                               float* __restrict__ prefix_opt, int head_len) {
+  __shared__ int sm_re[PFXW_BLOCK], sm_acc[PFXW_BLOCK];
+  __shared__ unsigned sm_d0[PFXW_BLOCK], sm_d1[PFXW_BLOCK];
+  __shared__ float sm_r0[PFXW_BLOCK], sm_c0[PFXW_BLOCK];
+  float r = 0.f, carry = -INFINITY;   // workgroup-uniform
+  for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
+    pfx_sync();
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {
+      const PfxChunk x = ch[cb + t];
+      sm_re[t] = x.re; sm_d0[t] = x.d0; sm_d1[t] = x.d1;
+    }
+    pfx_sync();
+    const int ce = min(nch, cb + PFXW_BLOCK);
+    for (int c = cb; c < ce; c++) {
+      const unsigned rb = __float_as_uint(r);
+      const int re = (int)(rb >> 23);                   // sign bit included: a negative sum never matches
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      const unsigned D = (R & 1u) ? sm_d1[c - cb] : sm_d0[c - cb];
+      const bool fast = sm_re[c - cb] == re && R + D < (1u << 24);   // sm_re is in [1, 254] or -1
+      // the waves run through this loop unsynchronised and all store the same words
+      if (fast) {
+        sm_r0[c - cb] = r; sm_c0[c - cb] = carry; sm_acc[c - cb] = 1;
+        r = __uint_as_float(((unsigned)re << 23) | ((R + D) & 0x7FFFFFu));
+        carry = fmaxf(carry, r);
+      } else {
+        sm_acc[c - cb] = 0;
+        const long long lo = (long long)c * PFXM_CHUNK;
+        const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+        pfx_walk_chunk(w, lo, cnt, runmax, prefix_opt, r, carry, head_len);
+      }
+#ifdef TDR_PFX_TIMING   // diagnostic build: time stamp (100 MHz) after every chunk in the header's dead `sum` slot
+      if (threadIdx.x == 0) *reinterpret_cast<long long*>(&ch[c].sum) = (long long)wall_clock64();
+#endif
+    }
+    pfx_sync();
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {   // for pfx_chunk_fill_kernel
+      PfxChunk* o = ch + cb + t;
+      o->r0 = sm_r0[t];
+      o->carry0 = sm_c0[t];
+      o->accepted = sm_acc[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const float* __restrict__ w, int64_t n,
+                                                                      const PfxChunk* __restrict__ ch,
+                                                                      float* __restrict__ runmax,
+                                                                      float* __restrict__ prefix_opt) {
+  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  const int c = blockIdx.x;
+  const PfxChunk hdr = ch[c];
+  if (!hdr.accepted) return;   // written by the walk
+  const long long lo = (long long)c * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  const unsigned rb = __float_as_uint(hdr.r0);
+  const unsigned re = rb >> 23;
+  const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+  float wv[PFXM_K];
+  pfx_load_chunk(w, lo, cnt, wv);
+  unsigned f[PFXM_K];
+  bool tie[PFXM_K];
+  PfxPair mine = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    bool bad;
+    pfx_classify(wv[k], (int)re - 127, f[k], tie[k], bad);
+    mine = pfx_compose(mine, pfx_element_pair(f[k], tie[k]));
+  }
+  PfxPair total;
+  const PfxPair ex = pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
+  unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);   // the exact mantissa before this thread's first element
+  const int t0 = threadIdx.x * PFXM_K;
+  float val[PFXM_K];
+#pragma unroll
+  for (int k = 0; k < PFXM_K; k++) {
+    state += f[k] + (tie[k] ? ((state + f[k]) & 1u) : 0u);
+    val[k] = __uint_as_float((re << 23) | (state & 0x7FFFFFu));
+  }
+  const float carry = hdr.carry0;
+  if (t0 + PFXM_K <= cnt && ((lo & 3) == 0)) {
+    float4* o = reinterpret_cast<float4*>(runmax + lo + t0);
+#pragma unroll
+    for (int k = 0; k < PFXM_K / 4; k++)
+      o[k] = make_float4(fmaxf(carry, val[4 * k]), fmaxf(carry, val[4 * k + 1]), fmaxf(carry, val[4 * k + 2]),
+                         fmaxf(carry, val[4 * k + 3]));
+    if (prefix_opt) {
+      float4* q = reinterpret_cast<float4*>(prefix_opt + lo + t0);
+#pragma unroll
+      for (int k = 0; k < PFXM_K / 4; k++) q[k] = make_float4(val[4 * k], val[4 * k + 1], val[4 * k + 2], val[4 * k + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PFXM_K; k++)
+      if (t0 + k < cnt) {
+        runmax[lo + t0 + k] = fmaxf(carry, val[k]);
+        if (prefix_opt) prefix_opt[lo + t0 + k] = val[k];
+      }
+  }
+}
+
+// Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
+// 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 66 / 94 / 129):
+#define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
+#define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
+extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
+  return n < 1 ? 0 : (int64_t)sizeof(PfxChunk) * cdiv(n, (int64_t)PFXM_CHUNK);
+}
+static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* prefix_out, void* workspace,
+                        hipStream_t st) {
+  const int64_t nch64 = cdiv(n, (int64_t)PFXM_CHUNK);
+  if (nch64 > (1 << 24)) return fail(TDR_ERR_ARG, "prefix: n too large");
+  const int nch = (int)nch64;
+  PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
+  hipLaunchKernelGGL(pfx_chunk_sum_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
+  hipLaunchKernelGGL(pfx_chunk_summary_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
+  static const int head_len = [] {
+    const char* e = getenv("TDR_PFX_HEAD");
+    const int v = e ? atoi(e) : PFXW_HEAD;
+    return v < 1 ? 1 : (v > PFX_HEAD ? PFX_HEAD : v);
+  }();
+  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXM_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
+                     head_len);
+  hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,
+                     runmax_out, prefix_out);
+  return TDR_OK;
+}
+extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream) {
+  if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
+  if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
+    const int rc = prefix_multi(w, n, runmax_out, nullptr, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  } else if (n < TDR_PFX_EXACT_MIN_N)
+    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  else
+    hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
+                       (float*)nullptr);
+  LAUNCH_CHECK("prefix");
+  return TDR_OK;
+}
+// Test / diagnostic entry: mode 0 = serial kernel, 1 = exact parallel kernel in one workgroup, 2 = the multi-workgroup
+// scan (needs a workspace of tdr_prefix_workspace_bytes(n)); prefix_out (optional, modes 1 and 2) receives the raw
+// running sums.
+extern "C" int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out,
+                                 void* workspace, void* stream) {
+  if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix_mode: bad arguments");
+  if (mode == 2 && !workspace) return fail(TDR_ERR_ARG, "prefix_mode: mode 2 needs a workspace");
+  if (mode == 0)
+    hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
+  else if (mode == 2) {
+    const int rc = prefix_multi(w, n, runmax_out, prefix_out, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  } else
+    hipLaunchKernelGGL(prefix_exact_kernel, dim3(1), dim3(PFX_THREADS), 0, (hipStream_t)stream, w, n, runmax_out,
+                       prefix_out);
+  LAUNCH_CHECK("prefix_mode");
+  return TDR_OK;
+}

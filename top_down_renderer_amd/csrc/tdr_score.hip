@@ -1,0 +1,1110 @@
+// tdr_score.hip — per-particle window gather + class-wise score: polar, Cartesian, finalize, the 40-rotation init search.
+#include "tdr_common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2: scoring.  lane = particle, 64 particles per wave, 4 waves per workgroup; grid.y = chunk of range rings.
+// All lanes of a wave visit the same window sample (i,j) at the same time, so their map reads fall on neighbouring
+// cells when the particles are neighbours (tdr_k_locality_order) and coalesce in L1/L2 instead of being 64
+// unrelated gathers; the rotation enters only as a per-lane row offset into the ring of scan records held in LDS.
+struct ScoreArgs {
+  const float* rec;     // map cell records
+  int rows, cols;       // map
+  float resolution;
+  const float* tab;     // [P][2]
+  const float* utab;    // [P][2] (tab*scale)*res when all particles share one scale, else NULL
+  const float* scan_pk; // [nr][nb][rf]
+  int nb, nr;
+  float res;
+  const float* st;      // [7][cap]
+  int64_t cap, n;
+  const int32_t* order; // slot -> particle (NULL = identity)
+  const int32_t* count; // optional device count limiting the active slots (init search)
+  int use_theta_override;
+  float theta_override;
+  int rpc, nchunks;     // rings per chunk
+  int64_t npad;         // slots padded to a multiple of 64
+  float* part;          // [nchunks][rf+1][npad]
+};
+
+__device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
+  // state_particle.cpp:124-128
+  int s = (int)round((double)(rot * (float)nb / 2) / M_PI);
+  s %= nb;
+  if (s < 0) s += nb;
+  return s;
+}
+
+// roundf (half away from zero) of a coordinate already clamped to [-1, limit], as an int, in two VALU ops:
+//     roundf(x) == floor(fl(x + (0.5 - 2^-25)))   for every float x in [-1, 2^23]
+// (the float addition's own rounding lands exact .5 ties on the next integer and everything below them under it;
+// checked exhaustively on the CPU over [-1, 8] and on the GPU by tests/test_gpu_parity.py).  The generic expansion
+// of roundf costs seven.
+__device__ __forceinline__ int round_half_away_clamped(float x) {
+  const float y = x + 0.49999997f;
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  return r;
+}
+
+template <int NV4, int U, bool KSLOT, bool USCALE>
+__global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
+  constexpr int RF = 4 * NV4;
+  extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]: row r and r+nb hold scan row r (no wrap arithmetic)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if TDR_XCD_SWIZZLE
+  // Workgroups are dealt round-robin over the 8 XCDs; remap so that each XCD (its own L2) gets a contiguous run of
+  // particle batches (Morton neighbours) instead of every 8th one.  Speed only: any mapping gives the same results.
+  const unsigned nbx = gridDim.x, per = (nbx + 7) / 8;
+  unsigned bx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (nbx % 8 != 0) bx = blockIdx.x;  // keep it a bijection
+#else
+  const unsigned bx = blockIdx.x;
+#endif
+  const int64_t slot = ((int64_t)bx * 4 + wave) * 64 + lane;
+  const int64_t nact = a.count ? (int64_t)*a.count : a.n;
+  if ((int64_t)bx * 256 >= nact) return;  // whole workgroup idle (uniform)
+  const bool valid = slot < nact;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];  // :162
+  const float off0 = cy / a.resolution;  // top_down_map_polar.cpp:29
+  const float off1 = cx / a.resolution;  // :30
+  const float theta = a.use_theta_override ? a.theta_override : a.st[TDR_ST_THETA * a.cap + p];
+  const int shift = rot_shift_dev(theta, a.nb);  // scan row paired with window row i is (i + shift) mod nb
+
+  const int j0 = blockIdx.y * a.rpc, j1 = min(a.nr, j0 + a.rpc);
+  const int rowstride = (a.cols + 2) * (RF * 4);            // bytes per guarded map row
+  const int kbase = (a.cols + 3) * (RF * 4);                // byte offset of cell (0,0)
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nb2 = 2 * a.nb;
+
+  float acc2[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
+  float known2 = 0.f;
+
+  // USCALE: every particle has the same scale, so (tab*scale)*res was evaluated once per step into a.utab and is
+  // wave-uniform here; otherwise it is evaluated per lane.  Identical float operations either way.
+  auto cell_offset = [&](float2 t) -> unsigned {
+    float p0, p1;
+    if constexpr (USCALE) {
+      p0 = t.x;
+      p1 = t.y;
+    } else {
+      p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
+      p1 = (t.y * scale) * a.res;
+    }
+    p0 = p0 + off0;
+    p1 = p1 + off1;
+    // clamp into the guard ring, then round like `pts.round().cast<int>()` (:31)
+    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+#if TDR_OOB_ALIAS
+    // every out-of-bounds sample reads the SAME guard record (always cache-resident) instead of a distinct one
+    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+    return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+#else
+    return (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase));  // v_mad_i32_i24 + v_lshl_add
+#endif
+  };
+
+  for (int j = j0; j < j1; j++) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nb * NV4; t += 256) {
+      const float4 v = scan4[(int64_t)j * a.nb * NV4 + t];
+      const int row = t / NV4, pl = t - row * NV4;
+      ring[pl * nb2 + row] = v;
+      ring[pl * nb2 + row + a.nb] = v;
+    }
+    __syncthreads();
+    float acc[RF];
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[k] = 0.f;
+    float known = 0.f;
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* rl = ring + shift;
+    int i = 0;
+    // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together,
+    // then the FMAs — the wave keeps 2*U*NV4 16-byte loads outstanding instead of waiting per sample.
+    for (; i + U <= a.nb; i += U) {
+      unsigned boff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(trow[i + u]);
+      float4 m[U][NV4], s[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) s[u][v] = rl[v * nb2 + i + u];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[u][v].x, acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[u][v].y, acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[u][v].z, acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[u][v].w, acc[4 * v + 3]);
+        }
+        if (!KSLOT) known += m[u][NV4 - 1].w;
+      }
+    }
+    for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
+      const unsigned bo = cell_offset(trow[i]);
+#pragma unroll
+      for (int v = 0; v < NV4; v++) {
+        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+        const float4 s = rl[v * nb2 + i];
+        acc[4 * v + 0] = __builtin_fmaf(s.x, m.x, acc[4 * v + 0]);
+        acc[4 * v + 1] = __builtin_fmaf(s.y, m.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = __builtin_fmaf(s.z, m.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = __builtin_fmaf(s.w, m.w, acc[4 * v + 3]);
+        if (!KSLOT && v == NV4 - 1) known += m.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
+    known2 += known;
+  }
+  if (slot < a.npad) {
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
+    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
+  }
+}
+
+// K2c: Cartesian scoring (BASELINE config 4).  The reference's StateParticle never reaches the Cartesian
+// TopDownMap::getLocalMap, so the Cartesian score is DEFINED as: window sampled by getLocalMap
+// (src/top_down_map.cpp:429-459 via samplePts :367-389) at rot = theta, res = res*scale, scored by getCostForRot
+// with shift 0 (src/state_particle.cpp:132-143) (definition recorded in include/tdr.h:tdr_k_score_cart and DESIGN.md).
+// Same mapping as the polar kernel (lane = particle); the rotation now lives in the sampling, so the scan record of
+// sample (i,j) is the same for every lane and comes through the scalar cache instead of LDS.
+struct CartArgs {
+  const float* rec;
+  int map_rows, map_cols;
+  float resolution;
+  const float* scan_pk;  // [cols][rows][rf]
+  int rows, cols;        // window (image) shape
+  float res;
+  const float* st;
+  int64_t cap, n;
+  const int32_t* order;
+  int cpc, nchunks;      // window columns per chunk
+  int64_t npad;
+  float* part;
+};
+
+__device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
+  // Eigen LinSpaced<float>, |high| == |low| here, so never the flipped branch of linspaced_op_impl
+  return (i == size1) ? high : (low + (float)i * step);
+}
+
+template <int NV4, int U, bool KSLOT>
+__global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
+  constexpr int RF = 4 * NV4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  if ((int64_t)blockIdx.x * 256 >= a.n) return;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const float theta = a.st[TDR_ST_THETA * a.cap + p];
+  const float off0 = cy / a.resolution;  // samplePts(center/resolution, ...): x_vals += center[1] (top_down_map.cpp:387)
+  const float off1 = cx / a.resolution;  // y_vals += center[0] (:388)
+  const float resq = (a.res * scale) / a.resolution;  // res/params_.resolution (:434)
+  // glibc's cosf/sinf are correctly rounded in practice; the device float versions are not -> evaluate in double
+  const float c = (float)cos((double)theta), s = (float)sin((double)theta);
+  const float ns = -s;
+  const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
+  const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
+  const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
+  const float step_c = a.cols == 1 ? 0.f : (hi_c - lo_c) / (float)(a.cols - 1);
+  const int r1 = a.rows == 1 ? 1 : a.rows - 1, c1 = a.cols == 1 ? 1 : a.cols - 1;
+
+  const int j0 = blockIdx.y * a.cpc, j1 = min(a.cols, j0 + a.cpc);
+  const int rowstride = (a.map_cols + 2) * (RF * 4);
+  const int kbase = (a.map_cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+
+  float acc2[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
+  float known2 = 0.f;
+
+  for (int j = j0; j < j1; j++) {
+    const float xj = linspaced_dev(j, c1, lo_c, hi_c, step_c);
+    const float A = ns * xj, B = c * xj;  // rotm * pts (:383-385): q0 = c*y + (-s)*x, q1 = s*y + c*x
+    auto cell_offset = [&](int i) -> unsigned {
+      const float yi = linspaced_dev(i, r1, lo_r, hi_r, step_r);
+      float p0 = c * yi + A;
+      float p1 = s * yi + B;
+      p0 = p0 + off0;
+      p1 = p1 + off1;
+      p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);  // :437
+      const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
+      return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+    };
+    float acc[RF];
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[k] = 0.f;
+    float known = 0.f;
+    const float4* srow = scan4 + (int64_t)j * a.rows * NV4;  // wave-uniform: scalar loads
+    int i = 0;
+    for (; i + U <= a.rows; i += U) {
+      unsigned boff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(i + u);
+      float4 m[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          const float4 sv = srow[(i + u) * NV4 + v];
+          acc[4 * v + 0] = __builtin_fmaf(sv.x, m[u][v].x, acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(sv.y, m[u][v].y, acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(sv.z, m[u][v].z, acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(sv.w, m[u][v].w, acc[4 * v + 3]);
+        }
+        if (!KSLOT) known += m[u][NV4 - 1].w;
+      }
+    }
+    for (; i < a.rows; i++) {
+      const unsigned bo = cell_offset(i);
+#pragma unroll
+      for (int v = 0; v < NV4; v++) {
+        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+        const float4 sv = srow[i * NV4 + v];
+        acc[4 * v + 0] = __builtin_fmaf(sv.x, m.x, acc[4 * v + 0]);
+        acc[4 * v + 1] = __builtin_fmaf(sv.y, m.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = __builtin_fmaf(sv.z, m.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = __builtin_fmaf(sv.w, m.w, acc[4 * v + 3]);
+        if (!KSLOT && v == NV4 - 1) known += m.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
+    known2 += known;
+  }
+  if (slot < a.npad) {
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
+    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
+  }
+}
+
+// Gates of state_particle.cpp:163-176.  scale_lo / scale_hi = pow(10, scale_log_min/max) evaluated on the host
+// (glibc pow, like the reference).
+struct GateArgs {
+  int force_on_map, scale_unknown;
+  float width, height;  // map size * resolution (state_particle.cpp:11,46-47)
+  double scale_lo, scale_hi;
+};
+static GateArgs make_gate(const tdr_filter_params* fp, const tdr_map_desc* map) {
+  GateArgs g;
+  g.force_on_map = fp->force_on_map;
+  g.scale_unknown = fp->fixed_scale < 0;
+  g.width = (float)map->cols * map->resolution;
+  g.height = (float)map->rows * map->resolution;
+  g.scale_lo = std::pow(10, fp->scale_log_min);
+  g.scale_hi = std::pow(10, fp->scale_log_max);
+  return g;
+}
+__device__ __forceinline__ bool particle_gated(const GateArgs& g, float cx, float cy, float scale) {
+  if (g.force_on_map) {
+    if (cx < 0 || cy < 0 || cx > g.width || cy > g.height) return true;  // :163-168
+  }
+  if (g.scale_unknown) {
+    if ((double)scale < g.scale_lo || (double)scale > g.scale_hi) return true;  // :169-176
+  }
+  return false;
+}
+
+struct FinalizeArgs {
+  const float* part;
+  int rf, nchunks;
+  int64_t npad, n, cap;
+  const int32_t* order;
+  const int32_t* count;
+  float* st;
+  tdr_filter_params fp;
+  GateArgs gate;
+  int64_t P;
+  int ncls;
+  int mode;             // 0: write raw weight; 1: init-search accumulate (best cost / theta)
+  int first;            // mode 1: first rotation (initialise best)
+  float theta_override;
+  float* raw_w;
+  float* best_cost;
+  float* best_theta;
+};
+
+__global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nact = a.count ? (int64_t)*a.count : a.n;
+  if (slot >= nact) return;
+  const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  if (a.mode == 0 && particle_gated(a.gate, cx, cy, scale)) {
+    a.raw_w[p] = 0.f;
+    return;
+  }
+  // Per-chunk partial sums -> double totals, chunk order ascending for every slot.  The loads of FIN_B chunks x all
+  // slots are issued together (independent addresses, coalesced over the particles) before the dependent additions.
+  constexpr int FIN_B = 4, FIN_S = TDR_MAX_CLASSES + 2;   // slots: ncls class dots, normalisation, known count
+  double tot[FIN_S];
+#pragma unroll
+  for (int k = 0; k < FIN_S; k++) tot[k] = 0;
+  const int64_t cstride = (int64_t)(a.rf + 1) * a.npad;
+  auto slot_row = [&](int k) { return k < a.ncls ? k : (k == a.ncls ? a.rf - 1 : a.rf); };
+  int c0 = 0;
+  for (; c0 + FIN_B <= a.nchunks; c0 += FIN_B) {
+    float v[FIN_B][FIN_S];
+#pragma unroll
+    for (int b = 0; b < FIN_B; b++)
+#pragma unroll
+      for (int k = 0; k < FIN_S; k++)
+        if (k < a.ncls + 2) v[b][k] = a.part[(int64_t)(c0 + b) * cstride + (int64_t)slot_row(k) * a.npad + slot];
+#pragma unroll
+    for (int b = 0; b < FIN_B; b++)
+#pragma unroll
+      for (int k = 0; k < FIN_S; k++)
+        if (k < a.ncls + 2) tot[k] += (double)v[b][k];
+  }
+  for (; c0 < a.nchunks; c0++) {
+#pragma unroll
+    for (int k = 0; k < FIN_S; k++)
+      if (k < a.ncls + 2) tot[k] += (double)a.part[(int64_t)c0 * cstride + (int64_t)slot_row(k) * a.npad + slot];
+  }
+  double known = 0, norm = 0;
+#pragma unroll
+  for (int k = 0; k < FIN_S; k++) {
+    if (k == a.ncls) norm = tot[k];
+    if (k == a.ncls + 1) known = tot[k];
+  }
+  // known fraction gate (state_particle.cpp:117-120); counts are exact integers in float
+  float cost;
+  if ((float)known / (float)a.P < 0.5) {
+    cost = __builtin_nanf("");
+  } else {
+    cost = 0.f;
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls) cost = (float)((double)cost + (double)(float)tot[k] * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
+    cost = cost / (float)norm;  // :154
+  }
+  if (a.mode == 0) {
+    a.raw_w[p] = (float)(1. / (double)(cost + a.fp.regularization));  // :212
+  } else {
+    float best = a.first ? 3.402823466e+38f : a.best_cost[slot];
+    float bt = a.first ? 0.f : a.best_theta[slot];
+    if (cost < best) { best = cost; bt = a.theta_override; }  // :200-203 (NaN never wins)
+    a.best_cost[slot] = best;
+    a.best_theta[slot] = bt;
+  }
+}
+
+// The 40-rotation initialisation search of state_particle.cpp:195-206 in ONE pass over the window: the candidate
+// rotations are the same for every particle, so for rotation t the scan row paired with window row i — (i + s_t) mod nb
+// — is the same for all lanes, and a map record gathered once is multiplied against all candidates' scan records
+// (the reference also gathers once and scores 40 times).  One workgroup = one batch of 64 particles; its 4 waves
+// split the candidates (INIT_TW each), gather the same records (the repeats hit L1), read the candidates' scan records
+// through the scalar cache (they are wave-uniform) and keep INIT_TW x rf accumulators per lane.  Sums run in float over the whole window, which is only used to pick the best rotation:
+// the weight itself is then produced by the regular scoring pass at that rotation.
+#ifndef INIT_TW
+#define INIT_TW 6          // candidate rotations per wave
+#endif
+#ifndef INIT_WAVES
+#define INIT_WAVES 8       // waves per workgroup, all on the same 64 particles (A/B on MI355X, 250k particles:
+#endif                     // 4x11 401 ms, 6x8 630 ms, 8x6 285 ms, 12x4 422 ms, 16x3 447 ms; scalar-cache scan reads 773 ms)
+#define INIT_MAXROT (INIT_WAVES * INIT_TW)
+struct InitArgs {
+  const float* rec;
+  int rows, cols;
+  float resolution;
+  const float* tab;
+  const float* utab;
+  const float* scan_pk;
+  int nb, nr;
+  float res;
+  const float* st;     // read-only here: results go to res_theta / res_flag (keeps every other load scalarisable)
+  int64_t cap, n;
+  const int32_t* order;
+  tdr_filter_params fp;
+  GateArgs gate;
+  int64_t P;
+  int ncls;
+  const int* nrot;
+  const int* shift;    // [nrot] device arrays (filled by init_rot_kernel)
+  const float* theta;
+  const int* only_if;  // optional: the kernel runs only when this device word is non-zero (fallback after the MFMA pass)
+  float* res_theta;  // [n] chosen rotation
+  float* res_flag;   // [n] 0 = untouched, 1 = initialised, 2 = initialised but every rotation scored NaN
+                     //     (weight 1/(FLT_MAX + reg), state_particle.cpp:193,212)
+};
+
+template <int NV4, bool KSLOT, bool USCALE>
+__global__ __launch_bounds__(64 * INIT_WAVES) void score_init_kernel(InitArgs a) {
+  constexpr int RF = 4 * NV4;
+  constexpr int U = 1;
+#if TDR_INIT_SCAN_LDS
+  extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]
+  const int nb2 = 2 * a.nb;
+#endif
+  __shared__ float x_cost[INIT_WAVES][64];
+  __shared__ int x_rot[INIT_WAVES][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
+  if (a.only_if && *a.only_if == 0) return;               // (uniform) the MFMA pass already produced the results
+  const int64_t slot = (int64_t)blockIdx.x * 64 + lane;   // all four waves work on the same 64 particles
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  // every wave of the workgroup looks at the same 64 particles, so this per-wave vote is the same in all of them
+  // (and, unlike __syncthreads_or, involves no LDS atomic that would stop the compiler from using scalar loads)
+  if (__ballot(want) == 0) return;  // nothing to initialise in this batch
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const int rowstride = (a.cols + 2) * (RF * 4);
+  const int kbase = (a.cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  int sh[INIT_TW];
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++) {
+    const int t = wave * INIT_TW + r;
+    sh[r] = t < nrot ? a.shift[t] : 0;
+  }
+  float acc[INIT_TW][RF];
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++)
+#pragma unroll
+    for (int k = 0; k < RF; k++) acc[r][k] = 0.f;
+  float known = 0.f;
+
+  auto cell_offset = [&](float2 t) -> unsigned {
+    float p0, p1;
+    if constexpr (USCALE) { p0 = t.x; p1 = t.y; }
+    else { p0 = (t.x * scale) * a.res; p1 = (t.y * scale) * a.res; }
+    p0 = p0 + off0;
+    p1 = p1 + off1;
+    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+    return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+  };
+
+  for (int j = 0; j < a.nr; j++) {
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* srow = scan4 + (int64_t)j * a.nb * NV4;  // ring j of the packed scan
+#if TDR_INIT_SCAN_LDS
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nb * NV4; t += 64 * INIT_WAVES) {
+      const float4 v = srow[t];
+      const int row = t / NV4, pl = t - row * NV4;
+      ring[pl * nb2 + row] = v;
+      ring[pl * nb2 + row + a.nb] = v;
+    }
+    __syncthreads();
+#endif
+    int i = 0;
+    for (; i + U <= a.nb; i += U) {
+      unsigned boff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(trow[i + u]);
+      float4 m[U][NV4];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (!KSLOT) known += m[u][NV4 - 1].w;
+#pragma unroll
+        for (int r = 0; r < INIT_TW; r++) {
+#pragma unroll
+          for (int v = 0; v < NV4; v++) {
+#if TDR_INIT_SCAN_LDS
+            const float4 sv = ring[v * nb2 + sh[r] + i + u];  // same address in every lane: LDS broadcast
+#else
+            int row = sh[r] + i + u;                    // wave-uniform: the record comes through the scalar cache
+            row -= row >= a.nb ? a.nb : 0;
+            const float4 sv = srow[row * NV4 + v];
+#endif
+            acc[r][4 * v + 0] = __builtin_fmaf(sv.x, m[u][v].x, acc[r][4 * v + 0]);
+            acc[r][4 * v + 1] = __builtin_fmaf(sv.y, m[u][v].y, acc[r][4 * v + 1]);
+            acc[r][4 * v + 2] = __builtin_fmaf(sv.z, m[u][v].z, acc[r][4 * v + 2]);
+            acc[r][4 * v + 3] = __builtin_fmaf(sv.w, m[u][v].w, acc[r][4 * v + 3]);
+          }
+        }
+      }
+    }
+    for (; i < a.nb; i++) {
+      const unsigned bo = cell_offset(trow[i]);
+      float4 m[NV4];
+#pragma unroll
+      for (int v = 0; v < NV4; v++) m[v] = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
+      if (!KSLOT) known += m[NV4 - 1].w;
+#pragma unroll
+      for (int r = 0; r < INIT_TW; r++)
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+#if TDR_INIT_SCAN_LDS
+          const float4 sv = ring[v * nb2 + sh[r] + i];
+#else
+          int row = sh[r] + i;
+          row -= row >= a.nb ? a.nb : 0;
+          const float4 sv = srow[row * NV4 + v];
+#endif
+          acc[r][4 * v + 0] = __builtin_fmaf(sv.x, m[v].x, acc[r][4 * v + 0]);
+          acc[r][4 * v + 1] = __builtin_fmaf(sv.y, m[v].y, acc[r][4 * v + 1]);
+          acc[r][4 * v + 2] = __builtin_fmaf(sv.z, m[v].z, acc[r][4 * v + 2]);
+          acc[r][4 * v + 3] = __builtin_fmaf(sv.w, m[v].w, acc[r][4 * v + 3]);
+        }
+    }
+  }
+  // cost of each candidate (state_particle.cpp:117-120,136-139,154), best of this wave's candidates in order
+  const float kn = KSLOT ? acc[0][RF - 2] : known;
+  const bool unknown = (kn / (float)a.P) < 0.5;
+  float cw[RF];
+#pragma unroll
+  for (int k = 0; k < RF; k++) cw[k] = k < 16 ? a.fp.class_weights[k < 16 ? k : 0] : 0.f;
+  float best = 3.402823466e+38f;
+  int best_t = -1;
+#pragma unroll
+  for (int r = 0; r < INIT_TW; r++) {
+    const int t = wave * INIT_TW + r;
+    float cost = 0.f;
+#pragma unroll
+    for (int k = 0; k < RF - 1; k++)   // constant indices only: a dynamic index would push the arguments to scratch
+      if (k < a.ncls) cost = (float)((double)cost + (double)acc[r][k] * 0.01 * (double)cw[k]);
+    cost = cost / acc[r][RF - 1];
+    if (unknown) cost = __builtin_nanf("");
+    if (t < nrot && cost < best) { best = cost; best_t = t; }  // :200-203 (NaN never wins)
+  }
+  x_cost[wave][lane] = best;
+  x_rot[wave][lane] = best_t;
+  __syncthreads();
+  if (wave == 0 && want) {
+    float b = 3.402823466e+38f;
+    int bt = -1;
+    for (int wv = 0; wv < INIT_WAVES; wv++)   // waves hold the candidates in loop order: strict '<' keeps the first minimum
+      if (x_cost[wv][lane] < b) { b = x_cost[wv][lane]; bt = x_rot[wv][lane]; }
+    a.res_theta[p] = bt >= 0 ? a.theta[bt] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bt < 0 ? 2.f : 1.f;
+  }
+}
+
+// The same search on the matrix cores (records of 8 floats, i.e. 4-6 classes).  For one particle the 40 candidate
+// costs are  cost[m] = sum_{i,j,c} scan_c[(i + s_m) mod nb, j] * (w_c d_c[cell(i,j)]):  a contraction over
+// k = (sample, class) of a matrix A[m][k] that is the same for every particle (shifted scan records, from LDS) with
+// the particle's gathered window B[k][n].  v_mfma_f32_16x16x32_f16: 16 rotations x 16 particles x (4 samples x 8
+// record slots) per instruction.  Lane l holds, as its B fragment, the 8 slots of the record of particle l&15 at
+// sample 4t + (l>>4) — exactly the record it gathered — and as its A fragment the packed scan record at row
+// (4t + (l>>4) + s_m), m = l&15 (+16, +32 for the second and third tile of candidates), one ds_read_b128 each.
+//   * scan counts are integers: exact in f16 up to 2048 (a larger count raises *inexact and score_init_kernel redoes
+//     the search on the vector units);
+//   * distances (times 0.01 w_c, in f32) are split hi + lo into two f16 (relative error <= 2^-20), two MFMAs;
+//   * the normalisation  sum scanΣ * known  is a third MFMA with only slot 7 of B set; the known count is a plain add.
+// Products are exact and accumulate in f32 like the vector version.  Only the choice of the rotation comes out of
+// here; the weight itself is computed by the regular scoring pass at that rotation.
+typedef _Float16 tdr_h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 tdr_h2 __attribute__((ext_vector_type(2)));   // what v_cvt_pkrtz_f16_f32 returns
+typedef float tdr_f4 __attribute__((ext_vector_type(4)));
+#define INITM_TILES 3   // 48 candidate rows >= the 40 (41) rotations of the search
+static_assert(INITM_TILES * 16 >= INIT_MAXROT || INIT_MAXROT == 48, "rotation tiles");
+
+// UNITW: all class weights are equal — a common factor does not move the minimum, so the distances go in unweighted.
+template <bool USCALE, bool UNITW>
+__global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* __restrict__ inexact) {
+  constexpr int RF = 8;
+  extern __shared__ uint4 ring16[];   // [2*nb] packed scan records as 8 x f16 (row r and r+nb hold scan row r) + 1 zero row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + wave * 16 + col;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  if (!__syncthreads_or(want)) return;   // nothing to initialise in this batch of 64 particles
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const int rowstride = (a.cols + 2) * (RF * 4);
+  const int kbase = (a.cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  // byte offset of the lane's candidate row within the ring for every tile; candidates past nrot read the zero row
+  const int zero_row = 2 * a.nb;
+  int sh[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) {
+    const int m = 16 * T + col;
+    sh[T] = m < nrot ? a.shift[m] : -1;
+  }
+  if (threadIdx.x == 0) ring16[zero_row] = make_uint4(0u, 0u, 0u, 0u);
+  float wc[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) wc[c] = c < a.ncls ? (float)(0.01 * (double)a.fp.class_weights[c]) : 0.f;
+  tdr_f4 accC[INITM_TILES], accN[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) { accC[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; accN[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; }
+  float known = 0.f;
+  const int steps = (a.nb + 3) / 4;
+
+  for (int j = 0; j < a.nr; j++) {
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* srow = scan4 + (int64_t)j * a.nb * 2;
+    __syncthreads();
+    bool big = false;
+    for (int t = threadIdx.x; t < a.nb; t += 256) {
+      const float4 v0 = srow[2 * t], v1 = srow[2 * t + 1];
+      big |= v0.x > 2048.f || v0.y > 2048.f || v0.z > 2048.f || v0.w > 2048.f || v1.x > 2048.f || v1.y > 2048.f ||
+             v1.w > 2048.f;
+      union { tdr_h2 h[4]; uint4 u; } pk;
+      pk.h[0] = __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y);
+      pk.h[1] = __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w);
+      pk.h[2] = __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y);
+      pk.h[3] = __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w);
+      ring16[t] = pk.u;
+      ring16[t + a.nb] = pk.u;
+    }
+    if (big) atomicOr(inexact, 1);
+    __syncthreads();
+    // software pipeline: the record of step t+1 (and the table entry of step t+2) are requested before the matrix
+    // work of step t, so every wave keeps two gathers in flight
+    auto tab_at = [&](int t) -> float2 { return trow[min(4 * t + q, a.nb - 1)]; };
+    auto rec_addr = [&](float2 tv) -> const char* {
+      float p0, p1;
+      if constexpr (USCALE) { p0 = tv.x; p1 = tv.y; }
+      else { p0 = (tv.x * scale) * a.res; p1 = (tv.y * scale) * a.res; }   // top_down_map_polar.cpp:28
+      p0 = __builtin_amdgcn_fmed3f(p0 + off0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1 + off1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);   // :31
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      return recb + (inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u);
+    };
+    float2 tv_next = tab_at(1);
+    float4 n0, n1;
+    {
+      const char* r0 = rec_addr(tab_at(0));
+      n0 = *reinterpret_cast<const float4*>(r0);
+      n1 = *reinterpret_cast<const float4*>(r0 + 16);
+    }
+    for (int t = 0; t < steps; t++) {
+      const int i = 4 * t + q;
+      const bool in = i < a.nb;
+      const int ic = in ? i : a.nb - 1;
+      float4 m0 = n0, m1 = n1;
+      {
+        const char* r1 = rec_addr(tv_next);        // step t+1 (clamped to the ring: an in-range address)
+        tv_next = tab_at(t + 2);
+        n0 = *reinterpret_cast<const float4*>(r1);
+        n1 = *reinterpret_cast<const float4*>(r1 + 16);
+      }
+      if (!in) { m0 = make_float4(0.f, 0.f, 0.f, 0.f); m1 = m0; }
+      known += m1.w;
+      float v[6] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y};
+      if constexpr (!UNITW) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] *= wc[c];
+      }
+      union { tdr_h2 h[4]; tdr_h8 v8; } bh, bl, bn;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[2 * c], v[2 * c + 1]);
+        bh.h[c] = hi;
+        bl.h[c] = __builtin_amdgcn_cvt_pkrtz(v[2 * c] - (float)hi[0], v[2 * c + 1] - (float)hi[1]);
+      }
+      bh.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+      bl.h[3] = bh.h[3];
+      bn.h[0] = bh.h[3]; bn.h[1] = bh.h[3]; bn.h[2] = bh.h[3];
+      bn.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, m1.w);
+      union { uint4 u; tdr_h8 v8; } av[INITM_TILES];
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) av[T].u = ring16[sh[T] < 0 ? zero_row : ic + sh[T]];
+      // dependent MFMAs (same accumulator) are kept three instructions apart
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bh.v8, accC[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bn.v8, accN[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T].v8, bl.v8, accC[T], 0, 0, 0);
+    }
+  }
+  // this lane holds rows 4q..4q+3 of every tile for particle `col`; the four lanes of a particle share the samples
+  known += __shfl_xor(known, 16, 64);
+  known += __shfl_xor(known, 32, 64);
+  const bool unknown = (known / (float)a.P) < 0.5;   // state_particle.cpp:117-120
+  float best = 3.402823466e+38f;
+  int bm = -1;
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * T + 4 * q + r;
+      float cost = accC[T][r] / accN[T][r];             // :154
+      if (unknown) cost = __builtin_nanf("");
+      if (m < nrot && cost < best) { best = cost; bm = m; }   // :200-203 (NaN never wins)
+    }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {   // first minimum in rotation order over the particle's four lanes
+    const float oc = __shfl_xor(best, o, 64);
+    const int om = __shfl_xor(bm, o, 64);
+    const bool take = om >= 0 && (bm < 0 || oc < best || (oc == best && om < bm));
+    if (take) { best = oc; bm = om; }
+  }
+  if (q == 0 && want) {
+    a.res_theta[p] = bm >= 0 ? a.theta[bm] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bm < 0 ? 2.f : 1.f;
+  }
+}
+
+// candidate rotations of the search, generated exactly like the reference's loop (state_particle.cpp:197: float t,
+// double increment) together with their bin shifts (:124-128)
+__global__ void init_rot_kernel(int nb, int* __restrict__ shift, float* __restrict__ theta, int* __restrict__ nrot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  nrot[1] = 0;   // the "scan counts too large for f16" flag of score_init_mfma_kernel
+  int k = 0;
+  for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {
+    if (k >= INIT_MAXROT) break;
+    theta[k] = t;
+    shift[k] = rot_shift_dev(t, nb);
+    k++;
+  }
+  *nrot = k;
+}
+
+// state_.theta = best_theta; state_.have_init = true (state_particle.cpp:205-206)
+__global__ void init_apply_kernel(const float* __restrict__ res_theta, const float* __restrict__ res_flag, int64_t n,
+                                  float* __restrict__ st, int64_t cap) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && res_flag[p] != 0.f) {
+    st[TDR_ST_THETA * cap + p] = res_theta[p];
+    st[TDR_ST_HAVE_INIT * cap + p] = 1.f;
+  }
+}
+// particles whose init search found no valid rotation keep best_cost = FLT_MAX (:193) -> weight 1/(FLT_MAX + reg)
+__global__ void init_fixup_kernel(const float* __restrict__ res_flag, int64_t n, float regularization,
+                                  float* __restrict__ raw_w) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && res_flag[p] == 2.f) raw_w[p] = (float)(1. / (double)(3.402823466e+38f + regularization));
+}
+
+static bool init_use_mfma() {
+  static bool v = [] {
+    const char* e = getenv("TDR_INIT_MFMA");   // 0 = vector-unit search only (A/B and debugging)
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+static int64_t score_wave_target() {
+  static int64_t v = [] {
+    // tuning knob.  Many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms):
+    // workgroups of one ring chunk run together, so the concurrently touched part of the map is a thin annulus that
+    // L2 can hold, and the slow (scattered) batches no longer leave a long tail.
+    const char* e = getenv("TDR_SCORE_WAVES");
+    long t = e ? atol(e) : 0;
+    return (int64_t)(t > 0 ? t : 131072);
+  }();
+  return v;
+}
+static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks) {
+  int64_t nbatches = cdiv(std::max<int64_t>(n, 1), 64);
+  int64_t want = std::max<int64_t>(1, cdiv(score_wave_target(), nbatches));  // enough waves to fill the chip
+  nchunks = (int)std::min<int64_t>(nr, want);
+  rpc = (int)cdiv(nr, nchunks);
+  nchunks = (int)cdiv(nr, rpc);
+}
+
+__global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float scale, float res,
+                            float* __restrict__ utab) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n2) utab[k] = (tab[k] * scale) * res;  // `ang_sample_pts_*scale*res` (top_down_map_polar.cpp:28)
+}
+
+extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n) {
+  int rpc, nchunks;
+  choose_chunks(n, nr, rpc, nchunks);
+  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  int rf = tdr_rec_floats(ncls);
+  // partials + best_cost + best_theta + list + count(64) + uniform-scale table
+  return (size_t)((int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64 + 2 * (int64_t)nb * nr);
+}
+static float* ws_utab(float* workspace, int rf, int nchunks, int64_t npad) {
+  return workspace + (int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64;
+}
+static int fill_utab(ScoreArgs& a, float* workspace, int rf, float uniform_scale, hipStream_t s) {
+  a.utab = nullptr;
+  if (!(uniform_scale > 0.f)) return TDR_OK;
+  float* ut = ws_utab(workspace, rf, a.nchunks, a.npad);
+  const int64_t n2 = 2 * (int64_t)a.nb * a.nr;
+  hipLaunchKernelGGL(utab_kernel, dim3((unsigned)cdiv(n2, 256)), dim3(256), 0, s, a.tab, n2, uniform_scale, a.res, ut);
+  LAUNCH_CHECK("utab");
+  a.utab = ut;
+  return TDR_OK;
+}
+
+// Optional in-library timing of the dominant kernel (bench.py's roofline figure): HIP events recorded on the launch
+// stream right around score_polar_kernel, read back after the timed region.
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+struct ScoreProfScope {
+  hipStream_t s;
+  hipEvent_t stop = nullptr;
+  explicit ScoreProfScope(hipStream_t s_) : s(s_) {
+    if (!g_prof_on) return;
+    if (g_prof_used == g_prof_events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      g_prof_events.emplace_back(a, b);
+    }
+    auto& ev = g_prof_events[g_prof_used++];
+    (void)hipEventRecord(ev.first, s);
+    stop = ev.second;
+  }
+  ~ScoreProfScope() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
+extern "C" int tdr_profile_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof_used = 0;
+  return TDR_OK;
+}
+extern "C" int tdr_profile_score_ms(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return fail(TDR_ERR_ARG, "profile_score_ms: null pointer");
+  double tot = 0;
+  for (size_t i = 0; i < g_prof_used; i++) {
+    HIP_TRY(hipEventSynchronize(g_prof_events[i].second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)g_prof_used;
+  g_prof_used = 0;
+  return TDR_OK;
+}
+
+static int launch_score(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
+  size_t lds = (size_t)2 * a.nb * rf * 4;
+  const bool ks = tdr_has_kslot(ncls, rf);
+  ScoreProfScope prof(s);
+  const bool us = a.utab != nullptr;
+#define TDR_LAUNCH_SCORE(NV4)                                                                                   \
+  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true>), grid, block, lds, s, a);   \
+  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false>), grid, block, lds, s, a);   \
+  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true>), grid, block, lds, s, a);   \
+  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false>), grid, block, lds, s, a);
+  switch (rf / 4) {
+    case 1: TDR_LAUNCH_SCORE(1) break;
+    case 2: TDR_LAUNCH_SCORE(2) break;
+    case 3: TDR_LAUNCH_SCORE(3) break;
+    case 4: TDR_LAUNCH_SCORE(4) break;
+    default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
+  }
+#undef TDR_LAUNCH_SCORE
+  LAUNCH_CHECK("score_polar");
+  return TDR_OK;
+}
+
+extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
+                                 float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
+                                 const int32_t* perm, float uniform_scale, int init_search, float* raw_w,
+                                 float* workspace, void* stream) {
+  if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score: n=%lld exceeds capacity %lld", (long long)n, (long long)cap);
+  if (n == 0) return TDR_OK;
+  if (nb < 1 || nr < 1) return fail(TDR_ERR_ARG, "score: bad image shape");
+  if (map->ncls < 1 || map->ncls > TDR_MAX_CLASSES || fp->num_classes != map->ncls)
+    return fail(TDR_ERR_ARG, "score: class count mismatch (map %d, params %d)", map->ncls, fp->num_classes);
+  const int rf = tdr_rec_floats(map->ncls);
+  if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score: map record size %d != %d", map->rec_floats, rf);
+  if ((size_t)2 * nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score: nb too large for the LDS scan ring");
+  if (!(map->resolution > 0.f)) return fail(TDR_ERR_ARG, "score: map resolution must be > 0");
+  hipStream_t s = (hipStream_t)stream;
+
+  ScoreArgs a;
+  a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
+  a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
+  a.use_theta_override = 0; a.theta_override = 0.f;
+  choose_chunks(n, nr, a.rpc, a.nchunks);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  int rc = fill_utab(a, workspace, rf, uniform_scale, s);
+  if (rc) return rc;
+  float* res_flag = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;  // npad floats
+  float* res_theta = res_flag + a.npad;                                // npad floats
+  if (init_search) {
+    // state_particle.cpp:195-206 first: it fixes theta / have_init of the un-initialised particles, the regular pass
+    // below then scores every particle at its (possibly just chosen) rotation
+    InitArgs ia;
+    ia.rec = a.rec; ia.rows = a.rows; ia.cols = a.cols; ia.resolution = a.resolution;
+    ia.tab = a.tab; ia.utab = a.utab; ia.scan_pk = a.scan_pk; ia.nb = nb; ia.nr = nr; ia.res = res;
+    ia.st = st; ia.cap = cap; ia.n = n; ia.order = perm; ia.fp = *fp; ia.gate = make_gate(fp, map);
+    ia.P = (int64_t)nb * nr; ia.ncls = map->ncls; ia.res_flag = res_flag; ia.res_theta = res_theta;
+    // rotation table lives behind the result arrays: [shift INIT_MAXROT][theta INIT_MAXROT][nrot]
+    int* d_shift = reinterpret_cast<int*>(res_theta + a.npad);
+    float* d_theta = reinterpret_cast<float*>(d_shift + INIT_MAXROT);
+    int* d_nrot = reinterpret_cast<int*>(d_theta + INIT_MAXROT);
+    hipLaunchKernelGGL(init_rot_kernel, dim3(1), dim3(64), 0, s, nb, d_shift, d_theta, d_nrot);
+    LAUNCH_CHECK("init_rot");
+    ia.shift = d_shift; ia.theta = d_theta; ia.nrot = d_nrot;
+    HIP_TRY(hipMemsetAsync(res_flag, 0, sizeof(float) * (size_t)n, s));
+    dim3 grid((unsigned)cdiv(n, 64)), block(64 * INIT_WAVES);
+    const size_t lds = TDR_INIT_SCAN_LDS ? (size_t)2 * nb * rf * 4 : 0;
+    const bool ks = tdr_has_kslot(map->ncls, rf), us = a.utab != nullptr;
+    ia.only_if = nullptr;
+    if (rf == 8 && ks && init_use_mfma()) {
+      // matrix-core pass first; the vector kernel below then runs only if a scan count did not fit f16
+      int* d_inexact = d_nrot + 1;
+      const size_t lds16 = ((size_t)2 * nb + 1) * 16;
+      bool unitw = true;
+      for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
+      unitw &= fp->class_weights[0] > 0.f;
+      if (us && unitw) hipLaunchKernelGGL((score_init_mfma_kernel<true, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else if (us) hipLaunchKernelGGL((score_init_mfma_kernel<true, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else if (unitw) hipLaunchKernelGGL((score_init_mfma_kernel<false, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+      else hipLaunchKernelGGL((score_init_mfma_kernel<false, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      LAUNCH_CHECK("score_init_mfma");
+      ia.only_if = d_inexact;
+    }
+#define TDR_LAUNCH_INIT(NV4)                                                                                \
+  if (ks && us) hipLaunchKernelGGL((score_init_kernel<NV4, true, true>), grid, block, lds, s, ia);         \
+  else if (ks) hipLaunchKernelGGL((score_init_kernel<NV4, true, false>), grid, block, lds, s, ia);         \
+  else if (us) hipLaunchKernelGGL((score_init_kernel<NV4, false, true>), grid, block, lds, s, ia);         \
+  else hipLaunchKernelGGL((score_init_kernel<NV4, false, false>), grid, block, lds, s, ia);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_INIT(1) break;
+      case 2: TDR_LAUNCH_INIT(2) break;
+      default: return fail(TDR_ERR_ARG, "score: init search supports up to 7 classes (record of %d floats)", rf);
+    }
+#undef TDR_LAUNCH_INIT
+    LAUNCH_CHECK("score_init");
+    hipLaunchKernelGGL(init_apply_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_theta,
+                       (const float*)res_flag, n, st, cap);
+    LAUNCH_CHECK("init_apply");
+  }
+  rc = launch_score(a, rf, map->ncls, s);
+  if (rc) return rc;
+
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
+  f.gate = make_gate(fp, map);
+  f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
+  f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  LAUNCH_CHECK("score_finalize");
+  if (init_search) {
+    hipLaunchKernelGGL(init_fixup_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_flag, n,
+                       fp->regularization, raw_w);
+    LAUNCH_CHECK("init_fixup");
+  }
+  return TDR_OK;
+}
+
+extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n) {
+  (void)rows;
+  int cpc, nchunks;
+  choose_chunks(n, cols, cpc, nchunks);
+  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  return (size_t)((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64);
+}
+
+extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
+                                const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
+                                float* raw_w, float* workspace, void* stream) {
+  if (!map || !map->rec || !scan_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score_cart: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_cart: n exceeds capacity");
+  if (n == 0) return TDR_OK;
+  if (rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "score_cart: bad window shape");
+  if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_cart: class count mismatch");
+  const int rf = tdr_rec_floats(map->ncls);
+  if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score_cart: map record size mismatch");
+  hipStream_t s = (hipStream_t)stream;
+  CartArgs a;
+  a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.resolution = map->resolution;
+  a.scan_pk = scan_pk; a.rows = rows; a.cols = cols; a.res = res;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm;
+  choose_chunks(n, cols, a.cpc, a.nchunks);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
+  const bool ks = tdr_has_kslot(map->ncls, rf);
+  {
+    ScoreProfScope prof(s);
+#define TDR_LAUNCH_CART(NV4)                                                                        \
+  if (ks) hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, true>), grid, block, 0, s, a);    \
+  else hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, false>), grid, block, 0, s, a);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_CART(1) break;
+      case 2: TDR_LAUNCH_CART(2) break;
+      case 3: TDR_LAUNCH_CART(3) break;
+      case 4: TDR_LAUNCH_CART(4) break;
+      default: return fail(TDR_ERR_ARG, "score_cart: unsupported record size %d", rf);
+    }
+#undef TDR_LAUNCH_CART
+  }
+  LAUNCH_CHECK("score_cart");
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
+  f.gate = make_gate(fp, map);
+  f.gate.force_on_map = 0;   // the Cartesian definition has no gates (include/tdr.h)
+  f.gate.scale_unknown = 0;
+  f.P = (int64_t)rows * cols; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
+  f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  LAUNCH_CHECK("score_finalize(cart)");
+  return TDR_OK;
+}
+
+// Self-test hook: the scoring loop's coordinate rounding applied to caller-supplied floats (clamped to [-1, limit]
+// like the loop does), so the GPU tests can compare it with roundf over whole float ranges.
+__global__ void selftest_round_kernel(const float* __restrict__ x, int64_t n, float limit, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = round_half_away_clamped(__builtin_amdgcn_fmed3f(x[i], -1.f, limit));
+}
+extern "C" int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream) {
+  if (!x || !out || n < 1) return fail(TDR_ERR_ARG, "selftest_round: bad arguments");
+  hipLaunchKernelGGL(selftest_round_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, limit,
+                     out);
+  LAUNCH_CHECK("selftest_round");
+  return TDR_OK;
+}
