@@ -223,6 +223,12 @@ int tdr_k_states_soa_to_aos(const float* st, int64_t cap, int64_t n, tdr_state* 
 size_t tdr_locality_tmp_ints(int64_t n, int map_rows, int map_cols);
 int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols, int32_t* perm_out,
                          int32_t* keys_tmp, void* stream);
+/* The same for windows that rotate with the particle (Cartesian scoring, top_down_map.cpp:367-389): Morton order of
+ * (x, y, theta), theta quantised so that one step moves a sample `theta_radius` cells from the centre by half a cell.
+ * keys_tmp: tdr_locality_pose_tmp_ints(n) int32 of device scratch, 8-byte aligned. */
+size_t tdr_locality_pose_tmp_ints(int64_t n);
+int tdr_k_locality_order_pose(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols, float theta_radius,
+                              int32_t* perm_out, int32_t* keys_tmp, void* stream);
 
 /* =================================================================================================================
  * Handle layer: C++ host code (csrc/tdr_host.cpp) that owns the device memory and sequences the kernels above the way

@@ -111,6 +111,8 @@ SIGNATURES = {
     "tdr_filter_update_map": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i]),
     "tdr_set_error": (_i, [_i, C.c_char_p]),
     "tdr_locality_tmp_ints": (C.c_size_t, [_i64, _i, _i]),
+    "tdr_locality_pose_tmp_ints": (C.c_size_t, [_i64]),
+    "tdr_k_locality_order_pose": (_i, [_vp, _i64, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "tdr_k_locality_order": (_i, [_vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),
 }
 

@@ -843,6 +843,69 @@ __global__ void loc_key_kernel(const float* __restrict__ st, int64_t cap, int64_
   vals[p] = (int32_t)p;
 }
 
+// Cartesian windows rotate with the particle (top_down_map.cpp:367-389), so two particles read the same cells only if
+// they agree in heading as well as in position: the key interleaves (x, y, theta), theta quantised so that one step
+// moves a sample at `theta_radius` cells from the centre by half a cell.  (Polar windows do not rotate — theta only
+// shifts the scan rows — and are ordered by position alone.)
+__device__ __forceinline__ uint64_t spread_bits21_3(uint64_t v) {   // bit i -> bit 3i
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x1F00000000FFFFull;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__global__ void loc_key_pose_kernel(const float* __restrict__ st, int64_t cap, int64_t n, float xmax, float ymax,
+                                    float theta_step, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float sc = st[TDR_ST_SCALE * cap + p];
+  float cx = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
+  float cy = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+  float th = st[TDR_ST_THETA * cap + p];
+  if (!(cx == cx)) cx = 0.f;
+  if (!(cy == cy)) cy = 0.f;
+  if (!(fabsf(th) < 1e6f)) th = 0.f;
+  th = th - 6.2831855f * floorf(th / 6.2831855f);   // [0, 2 pi): any consistent reduction will do for an ordering
+  const uint64_t hx = (uint64_t)fminf(fmaxf(cx * 2.f, 0.f), xmax);
+  const uint64_t hy = (uint64_t)fminf(fmaxf(cy * 2.f, 0.f), ymax);
+  const uint64_t ht = (uint64_t)fminf(fmaxf(th / theta_step, 0.f), 2097151.f);
+  keys[p] = spread_bits21_3(hx) | (spread_bits21_3(hy) << 1) | (spread_bits21_3(ht) << 2);
+  vals[p] = (int32_t)p;
+}
+static size_t radix_tmp_bytes64(int64_t n) {
+  size_t bytes = 0;
+  uint64_t* k = nullptr;
+  int32_t* v = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, 63u, (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) bytes = (size_t)(n + 4096) * 32;
+  return bytes;
+}
+extern "C" size_t tdr_locality_pose_tmp_ints(int64_t n) {
+  if (n < 1) n = 1;
+  return (size_t)(5 * n + 64) + (radix_tmp_bytes64(n) + 3) / 4 + 64;
+}
+extern "C" int tdr_k_locality_order_pose(const float* st, int64_t cap, int64_t n, int map_rows, int map_cols,
+                                         float theta_radius, int32_t* perm_out, int32_t* keys_tmp, void* stream) {
+  if (!st || !perm_out || !keys_tmp || n < 0 || cap < n || map_rows < 1 || map_cols < 1 || !(theta_radius > 0.f))
+    return fail(TDR_ERR_ARG, "locality_order_pose: bad arguments");
+  if (map_rows > 1000000 || map_cols > 1000000) return fail(TDR_ERR_ARG, "locality_order_pose: map too large");
+  if (n == 0) return TDR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // [keys_in 2n][keys_out 2n][vals_in n][pad][sort scratch], 8-byte aligned (the caller's buffer is)
+  uint64_t* keys_in = reinterpret_cast<uint64_t*>(keys_tmp);
+  uint64_t* keys_out = keys_in + n;
+  int32_t* vals_in = keys_tmp + 4 * n;
+  void* tmp = keys_tmp + 5 * n + 64 - ((5 * n) % 64);
+  size_t tmp_bytes = radix_tmp_bytes64(n);
+  hipLaunchKernelGGL(loc_key_pose_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, st, cap, n,
+                     (float)(2 * map_cols - 1), (float)(2 * map_rows - 1), 0.5f / theta_radius, keys_in, vals_in);
+  LAUNCH_CHECK("loc_key_pose");
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm_out, (size_t)n, 0u, 63u, s, false));
+  return TDR_OK;
+}
+
 static size_t radix_tmp_bytes(int64_t n) {
   size_t bytes = 0;
   uint32_t* k = nullptr;

@@ -213,6 +213,13 @@ class HipKernels:
         check(self.lib.tdr_k_locality_order(_ptr(st), st.shape[1], n, rows, cols, _ptr(perm), _ptr(tmp),
                                             self.stream()))
 
+    def locality_order_pose(self, st, n, rows, cols, perm, theta_radius):
+        """Order for windows that rotate with the particle (Cartesian scoring): Morton code of (x, y, theta)."""
+        need = int(self.lib.tdr_locality_pose_tmp_ints(n))
+        tmp = self.empty((need + 2,), torch.int32)
+        check(self.lib.tdr_k_locality_order_pose(_ptr(st), st.shape[1], n, rows, cols, C.c_float(theta_radius),
+                                                 _ptr(perm), _ptr(tmp), self.stream()))
+
     def states_to_device(self, states_aos, st, n):
         """states_aos: numpy structured array with the reference's 28-byte State layout."""
         raw = self.to_device(np.ascontiguousarray(states_aos).view(np.uint8).reshape(-1))

@@ -231,7 +231,11 @@ class ParticleFilter:
         if self.locality_every and (self.perm is None or self.step_ % self.locality_every == 0):
             if self.perm is None:
                 self.perm = k.zeros((self.cap_local,), torch.int32)
-            k.locality_order(self.st, nl, m.rows, m.cols, self.perm)
+            if getattr(m, "polar", True):
+                k.locality_order(self.st, nl, m.rows, m.cols, self.perm)
+            else:   # Cartesian windows rotate with the particle: heading belongs in the key
+                wr, wc = m.window_shape()
+                k.locality_order_pose(self.st, nl, m.rows, m.cols, self.perm, theta_radius=(wr + wc) / 16.0)
         if getattr(m, "polar", True):
             k.score(m.dev, scan_pk, float(res), self.fp_c, self.st, nl, self.raw_w,
                     perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
