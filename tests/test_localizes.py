@@ -70,3 +70,35 @@ def test_gpu_likelihood_peaks_at_the_true_pose(name, search):
         assert abs(err) <= np.deg2rad(9.0) + 0.5 * float(cfg.ang_res), f"init search chose a heading {np.rad2deg(err):.1f} deg off"
     else:
         _check_peak(f.raw_weights(), grid)
+
+
+@pytest.mark.gpu
+def test_gpu_filter_converges_on_the_true_pose():
+    """Closed loop through the class surface: propagate -> update (score, statistics, running sum, resample, gather)
+    repeated on a static scene.  The particle cloud (sigma 30 px / 10 deg + 10 % uniform over the 1000 px map) must
+    collapse around the pose the scan was rendered from.  The likelihood is flat along the road the pose sits on and
+    the weights are regularised (1 / (cost + 0.15)), so where exactly the cloud condenses is up to resampling noise:
+    the bounds are those of the basin, not of the peak (test_gpu_likelihood_peaks_at_the_true_pose pins the peak)."""
+    import top_down_renderer_amd as pkg
+    from top_down_renderer_amd.kernels import HipKernels
+    k = HipKernels()
+    sc = synth.make_scene("c1", n_particles=4000)
+    cfg = sc.cfg
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    r.renderSemanticTopDown(sc.pts, cfg.res, cfg.ang_res)
+    f = pkg.ParticleFilter(len(sc.states), m, pkg.FilterParams(fixed_scale=1.0), seed=5, kernels=k, init_particles=False)
+    f.set_states(sc.states)
+    cov0 = f.computeMeanCov()
+    for _ in range(10):
+        f.propagate((0.0, 0.0), 0.0)
+        f.update(r.last_scan(), None, cfg.res)
+    mean, cov = f.meanLikelihood(), f.computeMeanCov()
+    cx, cy, th = sc.pose
+    assert np.hypot(mean[0] - cx, mean[1] - cy) < 25, (mean, sc.pose)
+    assert abs(np.angle(np.exp(1j * (float(mean[2]) - th)))) < np.deg2rad(4)
+    assert cov[0, 0] + cov[1, 1] < 0.02 * (cov0[0, 0] + cov0[1, 1])
+    ml = f.maxLikelihood()
+    assert np.hypot(ml[0] - cx, ml[1] - cy) < 25
