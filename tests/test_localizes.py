@@ -92,13 +92,17 @@ def test_gpu_filter_converges_on_the_true_pose():
     f = pkg.ParticleFilter(len(sc.states), m, pkg.FilterParams(fixed_scale=1.0), seed=5, kernels=k, init_particles=False)
     f.set_states(sc.states)
     cov0 = f.computeMeanCov()
-    for _ in range(10):
-        f.propagate((0.0, 0.0), 0.0)
+    # a standing robot is not updated at all (weights are blended with 1/N by min(5 * distance travelled, 1),
+    # particle_filter.cpp:137-141): move 0.2 m per step, which saturates the blend and drifts 8 px in total.  Weights are
+    # 1 / (cost + 0.15), at most ~2:1 between good and bad particles here, so the cloud condenses over tens of steps
+    for _ in range(40):
+        f.propagate((0.2, 0.0), 0.0)
         f.update(r.last_scan(), None, cfg.res)
+        assert f.weights().max() > 1.05 / len(sc.states)
     mean, cov = f.meanLikelihood(), f.computeMeanCov()
     cx, cy, th = sc.pose
-    assert np.hypot(mean[0] - cx, mean[1] - cy) < 25, (mean, sc.pose)
+    assert np.hypot(mean[0] - cx, mean[1] - cy) < 30, (mean, sc.pose)
     assert abs(np.angle(np.exp(1j * (float(mean[2]) - th)))) < np.deg2rad(4)
-    assert cov[0, 0] + cov[1, 1] < 0.02 * (cov0[0, 0] + cov0[1, 1])
+    assert cov[0, 0] + cov[1, 1] < 0.1 * (cov0[0, 0] + cov0[1, 1])
     ml = f.maxLikelihood()
-    assert np.hypot(ml[0] - cx, ml[1] - cy) < 25
+    assert np.hypot(ml[0] - cx, ml[1] - cy) < 40
