@@ -455,23 +455,21 @@ __device__ __forceinline__ PfxPair pfx_compose(PfxPair A, PfxPair B) {
   c.a1 = pfx_sat(A.a1 + ((A.a1 & 1u) ? B.a0 : B.a1));   // entered odd: the parity after A is (1 + A.a1) & 1
   return c;
 }
-// One weight against the binade with exponent e (unbiased): f = floor(w/u) (+1 when the remainder exceeds one half),
-// tie = remainder exactly one half, bad = cannot be an integer increment (NaN, inf, negative, exponent above e).
-__device__ __forceinline__ void pfx_classify(float wv, int e, unsigned& f, bool& tie, bool& bad) {
-  const unsigned b = __float_as_uint(wv);
-  const int ew = (b >> 23) & 0xFF;
-  unsigned mw = b & 0x7FFFFFu;
-  const bool zero = (b & 0x7FFFFFFFu) == 0;
-  const int E = ew == 0 ? -126 : ew - 127;
-  if (ew != 0) mw |= 0x800000u;
-  const int sft = e - E;
-  bad = ew == 255 || sft < 0 || ((b >> 31) != 0 && !zero);
-  const int sc = sft < 0 ? 0 : (sft > 26 ? 26 : sft);
-  const unsigned q = mw >> sc;
-  const unsigned rem = mw & ((1u << sc) - 1u);
-  const unsigned half = sc >= 1 ? (1u << (sc - 1)) : 0u;
-  tie = sc >= 1 && rem == half;
-  f = q + ((sc >= 1 && rem > half) ? 1u : 0u);
+// One weight against the binade of a running sum with biased exponent `re` (PFXM_RE_MIN <= re <= PFXM_RE_MAX), ulp
+// u = 2^(re-150): f = round-half-down(w/u), tie = the remainder is exactly one half, bad = cannot be an integer increment
+// (NaN, inf, negative, or at least twice the binade's lower end).  w * 2^(150-re) is exact (a power-of-two scaling
+// inside the normal range; a product that underflows is far below one half anyway), and so are floor and the
+// remainder, so this is the integer classification of pfx_exact_range in a handful of float operations.
+#define PFXM_RE_MIN 24
+#define PFXM_RE_MAX 254
+__device__ __forceinline__ void pfx_classify(float wv, unsigned re, unsigned& f, bool& tie, bool& bad) {
+  const float scale = __uint_as_float((277u - re) << 23);   // 2^(150 - re) = 1/u
+  const float t = wv * scale;
+  bad = !(wv >= 0.f) || !(t < 16777216.f);
+  const float fl = floorf(t);
+  const float fr = t - fl;
+  tie = fr == 0.5f;
+  f = (unsigned)fl + (fr > 0.5f ? 1u : 0u);
   if (bad) { f = 0; tie = false; }
 }
 __device__ __forceinline__ PfxPair pfx_element_pair(unsigned f, bool tie) {
@@ -567,7 +565,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
   const unsigned pb = __float_as_uint(r_pred), eb = __float_as_uint(r_end);
   const int re = (pb >> 23) & 0xFF;
   // a chunk that is predicted to start and end in one binade of a positive normal sum; everything else is irregular
-  const bool plausible = (pb >> 31) == 0 && re != 0 && re != 255 && (int)((eb >> 23) & 0xFF) == re && (eb >> 31) == 0;
+  const bool plausible = (pb >> 31) == 0 && re >= PFXM_RE_MIN && re <= PFXM_RE_MAX && (int)((eb >> 23) & 0xFF) == re && (eb >> 31) == 0;
   if (!plausible) {   // uniform across the workgroup
     if (threadIdx.x == 0) { ch[c].re = -1; ch[c].d0 = 0u; ch[c].d1 = 0u; }
     return;
@@ -579,7 +577,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
 #pragma unroll
   for (int k = 0; k < PFXM_K; k++) {
     unsigned f; bool tie, bad;
-    pfx_classify(wv[k], re - 127, f, tie, bad);
+    pfx_classify(wv[k], (unsigned)re, f, tie, bad);
     anybad |= bad;
     mine = pfx_compose(mine, pfx_element_pair(f, tie));
   }
@@ -613,8 +611,8 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
   while (pos < cnt) {
     const unsigned rb = __float_as_uint(r);
     const unsigned re = rb >> 23;   // sign included
-    if (!(re >= 1u && re <= 254u)) {
-      // zero / subnormal / negative / inf / NaN running sum: the general path (with its serial head at the very start)
+    if (!(re >= PFXM_RE_MIN && re <= PFXM_RE_MAX)) {
+      // zero / tiny / huge / negative / inf / NaN running sum: the general path (with its serial head at the very start)
       const long long a = lo + pos;
       const long long b = a == 0 ? min((long long)head_len, (long long)cnt) : lo + cnt;
       pfx_exact_range<PFXM_THREADS>(w, a, b, runmax, prefix_opt, r, carry, head_len);
@@ -633,7 +631,7 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
       for (int k = 0; k < PFXM_K; k++) {
         const int li = t0 + k;
         bool bad, tie;
-        pfx_classify(wv[k], (int)re - 127, f[k], tie, bad);
+        pfx_classify(wv[k], re, f[k], tie, bad);
         if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
         if (bad) atomicMin(&s_bad, li);
         tiebits |= tie ? (1u << k) : 0u;
@@ -710,7 +708,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __r
       const int re = (int)(rb >> 23);                   // sign bit included: a negative sum never matches
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
       const unsigned D = (R & 1u) ? sm_d1[c - cb] : sm_d0[c - cb];
-      const bool fast = sm_re[c - cb] == re && R + D < (1u << 24);   // sm_re is in [1, 254] or -1
+      const bool fast = sm_re[c - cb] == re && R + D < (1u << 24);   // sm_re is in [PFXM_RE_MIN, PFXM_RE_MAX] or -1
       // the waves run through this loop unsynchronised and all store the same words
       if (fast) {
         sm_r0[c - cb] = r; sm_c0[c - cb] = carry; sm_acc[c - cb] = 1;
@@ -757,7 +755,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const floa
 #pragma unroll
   for (int k = 0; k < PFXM_K; k++) {
     bool bad;
-    pfx_classify(wv[k], (int)re - 127, f[k], tie[k], bad);
+    pfx_classify(wv[k], re, f[k], tie[k], bad);
     mine = pfx_compose(mine, pfx_element_pair(f[k], tie[k]));
   }
   PfxPair total;
