@@ -81,7 +81,7 @@ def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan, labels
     w_o, best_o, _ = oracle.update_weights(raw_o, last)
     idx_o = oracle.resample_prefix(w_o, n, rng.uniform())
     new_o = oracle.gather_states(st_o, idx_o)
-    assert np.abs(scan - scan_o).sum() / 2 <= 2 and scan.sum() == scan_o.sum()
+    assert np.array_equal(scan, scan_o)   # raster: exact
     assert np.allclose(w, w_o, rtol=2e-5, atol=0)
     assert (idx != idx_o).sum() <= 2 + n // 200
     same = idx == idx_o
@@ -96,3 +96,14 @@ def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan, labels
     assert np.allclose(stats[20:24], ml_o, rtol=1e-5, atol=1e-4)
     assert np.allclose(stats[24:40].reshape(4, 4), oracle.cov_about(new_o, ml_o), rtol=2e-3, atol=1e-2)
     assert stats[40] == 1.0 and stats[41] == n and stats[42] == 1.0
+    # getGMM after computeGMM on the resampled set (src/particle_filter.cpp:238-318; deterministic fit, parity unpinned)
+    from oracle import np_oracle as no
+    gmm = np.fromfile(os.path.join(d, "out_gmm.bin"), np.float32).reshape(-1, 12)
+    idx_s = np.minimum(n - 1, np.arange(min(1000, n)) * n // min(1000, n))
+    sx = (st["dx_m"] * st["scale"] + st["init_x_px"]).astype(np.float32)[idx_s]
+    sy = (st["dy_m"] * st["scale"] + st["init_y_px"]).astype(np.float32)[idx_s]
+    sth = st["theta"][idx_s]
+    x = np.column_stack([sx, sy, np.float32(50) * np.cos(sth), np.float32(50) * np.sin(sth)]).astype(np.float64)
+    kk, means_o, covs_o = no.gmm_select(x, n, 1)
+    assert len(gmm) == kk
+    assert np.allclose(gmm[:, :3], means_o, atol=2e-3) and np.allclose(gmm[:, 3:].reshape(-1, 3, 3), covs_o, rtol=2e-3, atol=2e-3)
