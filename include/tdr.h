@@ -263,9 +263,13 @@ void tdr_renderer_destroy(tdr_renderer* r);
 int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride, int ioff, int64_t n, float res,
                         float ang_res, int ncls, int rows, int cols, float* imgs_out);
 
+/* seed: the reference seeds its std::mt19937 from std::random_device (src/particle_filter.cpp:4-5), i.e. not
+ * reproducibly.  seed == 0 stands for that case: propagate's noise is then drawn on the device (counter-based, 4 us).
+ * seed != 0: every draw comes from std::mt19937(seed) in the reference's order, propagate's 4N normals included (host
+ * code, ~35 ns per draw) — the mode the parity tests use.  tdr_filter_configure changes the mode afterwards. */
 int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_filter** out);
 void tdr_filter_destroy(tdr_filter* f);
-/* parity_rng: propagate consumes host std::mt19937 normals in the reference's order (default 1); 0 = device RNG.
+/* parity_rng: propagate consumes host std::mt19937 normals in the reference's order; 0 = device RNG.
  * locality_every: > 0 processes particles in Morton order of their map position (default 1; results unchanged). */
 int tdr_filter_configure(tdr_filter* f, int parity_rng, int locality_every);
 int tdr_filter_initialize_particles(tdr_filter* f);                                      /* particle_filter.cpp:19-84 */

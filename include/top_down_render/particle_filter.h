@@ -2,7 +2,9 @@
 // Same constructor and method signatures as the reference, so the call sites of TopDownRender
 // (src/top_down_render.cpp:116, 333-359, 423-425, 591) compile against it unchanged; the work runs on the MI355X
 // through tdr_filter (include/tdr.h).  Documented differences:
-//   * an explicit seed (default 0) replaces std::random_device (src/particle_filter.cpp:4-5);
+//   * an explicit seed replaces std::random_device (src/particle_filter.cpp:4-5): the default 0 means "unseeded" —
+//     propagate then draws its noise on the device; a non-zero seed reproduces the reference's std::mt19937 draw order
+//     (host code, 80 000 serial draws per step at 20 000 particles); configure() switches explicitly;
 //   * the mixture behind the adaptive particle count (:151-157, 245-318) is fitted on demand by computeGMM() with a
 //     deterministic EM (csrc/tdr_gmm.cpp) instead of cv::ml::EM in a detached thread; getGMM() returns it;
 //     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides; visualize() (OpenCV

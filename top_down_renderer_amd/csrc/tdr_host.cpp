@@ -278,6 +278,9 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
   f->n_max = n_max;
   f->seed = seed;
   f->rng = tdr_rng_create(seed);  // explicit seed instead of std::random_device (particle_filter.cpp:4-5)
+  // seed 0 = "unseeded", like the reference's std::random_device: nothing to reproduce, so propagate draws its noise on
+  // the device; a non-zero seed asks for the reference-ordered std::mt19937 stream (tdr_filter_configure overrides)
+  f->parity_rng = seed != 0;
   int rc = TDR_OK;
   const size_t cap = (size_t)n_max;
   if (rc == TDR_OK) rc = f->st.resize(TDR_ST_FIELDS * cap);
