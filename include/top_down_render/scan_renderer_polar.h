@@ -1,21 +1,38 @@
-// ScanRendererPolar — reference surface: include/top_down_render/scan_renderer_polar.h:15-22.
-#ifndef SCAN_RENDERER_POLAR_H_
-#define SCAN_RENDERER_POLAR_H_
+// ScanRendererPolar over libtdr_hip — the class surface TopDownRender uses (reference:
+// include/top_down_render/scan_renderer_polar.h:15-22, call sites src/top_down_render.cpp:117,539).
+//
+// Header-only: all work happens in ScanRenderer::render (scan_renderer.h), which copies the cloud to the GPU, runs the
+// two raster kernels of csrc/tdr_raster.hip and copies the class images back into the caller's Eigen arrays.  The
+// packed copy of the render stays on the device, so ParticleFilter::update(const ScanRenderer&, res) can score it
+// without another round trip.
+//
+// Image convention (src/scan_renderer_polar.cpp:93-108): imgs[c] has one ROW per theta bin and one COLUMN per range
+// bin, column-major like every Eigen::ArrayXXf; a point (x, y) lands in row round(atan2(x, y) / ang_res) + rows / 2 and
+// column round(hypot(x, y) / res); points at the origin and points whose class the flatten LUT maps to -1 are skipped;
+// fewer images than one per class -> the call returns without touching anything, like the reference (:85).
+#ifndef TDR_FACADE_SCAN_RENDERER_POLAR_H_
+#define TDR_FACADE_SCAN_RENDERER_POLAR_H_
 
 #include "top_down_render/scan_renderer.h"
 
 class ScanRendererPolar : public ScanRenderer {
  public:
   explicit ScanRendererPolar(const Eigen::VectorXi& flatten_lut) : ScanRenderer(flatten_lut) {}
-  // src/scan_renderer_polar.cpp:83-109; imgs[c] is (theta bins x range bins)
+
+  // Semantic render, polar: see the convention above.
   void renderSemanticTopDown(const pcl::PointCloud<pcl::PointXYZI>::ConstPtr& cloud, float res, float ang_res,
                              std::vector<Eigen::ArrayXXf>& imgs) {
-    render(1, cloud, res, ang_res, imgs);
+    constexpr int kPolar = 1;
+    render(kPolar, cloud, res, ang_res, imgs);
   }
-  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr&, float, float,
+
+  // The geometric render is commented out at its only call site (src/top_down_render.cpp:540) and its score term is
+  // commented out too (src/state_particle.cpp:145-152).  What survives of it is the zero-fill with which the reference
+  // function begins (src/scan_renderer_polar.cpp:11-13), so publishGeometricTopDown keeps receiving blank images.
+  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr& /*cloud*/, float /*res*/, float /*ang_res*/,
                               std::vector<Eigen::ArrayXXf>& imgs) {
-    for (auto& im : imgs) im.setZero();  // src/scan_renderer_polar.cpp:11-13; see ScanRenderer::renderGeometricTopDown
+    for (Eigen::ArrayXXf& im : imgs) im.setZero();
   }
 };
 
-#endif  // SCAN_RENDERER_POLAR_H_
+#endif  // TDR_FACADE_SCAN_RENDERER_POLAR_H_
