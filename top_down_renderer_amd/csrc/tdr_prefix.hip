@@ -507,18 +507,19 @@ __device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh, PfxPair
   if (lane == 0) { ex.a0 = 0u; ex.a1 = 0u; }
   return pfx_compose(pre, ex);
 }
-__device__ __forceinline__ void pfx_load_chunk(const float* __restrict__ w, long long lo, int cnt, float (&wv)[PFXM_K]) {
-  const int t0 = threadIdx.x * PFXM_K;
-  if (t0 + PFXM_K <= cnt && ((lo & 3) == 0)) {
+template <int K>
+__device__ __forceinline__ void pfx_load_chunk(const float* __restrict__ w, long long lo, int cnt, float (&wv)[K]) {
+  const int t0 = threadIdx.x * K;
+  if (t0 + K <= cnt && ((lo & 3) == 0)) {
     const float4* p = reinterpret_cast<const float4*>(w + lo + t0);
 #pragma unroll
-    for (int k = 0; k < PFXM_K / 4; k++) {
+    for (int k = 0; k < K / 4; k++) {
       const float4 v = p[k];
       wv[4 * k] = v.x; wv[4 * k + 1] = v.y; wv[4 * k + 2] = v.z; wv[4 * k + 3] = v.w;
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < PFXM_K; k++) wv[k] = (t0 + k < cnt) ? w[lo + t0 + k] : 0.f;
+    for (int k = 0; k < K; k++) wv[k] = (t0 + k < cnt) ? w[lo + t0 + k] : 0.f;
   }
 }
 
@@ -594,18 +595,22 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
 
 // A chunk the walk cannot take as one integer add (it holds a binade crossing or an irregular weight, or was
 // mispredicted), carried through in order by the walking workgroup: one scan per stretch between two real float
-// additions.  The walking workgroup has PFXM_THREADS threads holding 16 weights each, as in the fill kernel (one wave
-// per SIMD: a pass costs what ONE wave issues).  Anything that is not a positive normal running sum goes to
+// additions.  The walking workgroup has PFXW_THREADS threads holding PFXW_K weights each (two waves per SIMD: the
+// dependent instruction chains of one wave hide behind the other's).  Anything that is not a positive normal running sum goes to
 // pfx_exact_range.
+#ifndef PFXW_THREADS
+#define PFXW_THREADS 512   // the walking workgroup: PFXW_THREADS x PFXW_K = one chunk
+#endif
+#define PFXW_K (PFXM_CHUNK / PFXW_THREADS)
 #define PFXW_HEAD 64   // leading elements the walk adds one by one (tunable: TDR_PFX_HEAD)
 __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long long lo, int cnt,
                                                float* __restrict__ runmax, float* __restrict__ prefix_opt,
                                                float& r, float& carry, int head_len) {
-  __shared__ PfxPair shp[PFXM_THREADS / 64];
+  __shared__ PfxPair shp[PFXW_THREADS / 64];
   __shared__ int s_bad, s_cross;
   __shared__ float s_last, s_wstop;
-  const int tid = threadIdx.x, t0 = tid * PFXM_K;
-  float wv[PFXM_K];
+  const int tid = threadIdx.x, t0 = tid * PFXW_K;
+  float wv[PFXW_K];
   pfx_load_chunk(w, lo, cnt, wv);
   int pos = 0;   // workgroup-uniform: elements before pos are done
   while (pos < cnt) {
@@ -615,7 +620,7 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
       // zero / tiny / huge / negative / inf / NaN running sum: the general path (with its serial head at the very start)
       const long long a = lo + pos;
       const long long b = a == 0 ? min((long long)head_len, (long long)cnt) : lo + cnt;
-      pfx_exact_range<PFXM_THREADS>(w, a, b, runmax, prefix_opt, r, carry, head_len);
+      pfx_exact_range<PFXW_THREADS>(w, a, b, runmax, prefix_opt, r, carry, head_len);
       pos = (int)(b - lo);
       continue;
     }
@@ -623,12 +628,12 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
     pfx_sync();
     if (tid == 0) { s_bad = cnt; s_cross = cnt; s_last = r; s_wstop = 0.f; }
     pfx_sync();
-    unsigned f[PFXM_K];
+    unsigned f[PFXW_K];
     unsigned tiebits = 0u;
     PfxPair mine = {0u, 0u};
     {
 #pragma unroll
-      for (int k = 0; k < PFXM_K; k++) {
+      for (int k = 0; k < PFXW_K; k++) {
         const int li = t0 + k;
         bool bad, tie;
         pfx_classify(wv[k], re, f[k], tie, bad);
@@ -639,13 +644,13 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
       }
     }
     PfxPair total;
-    const PfxPair ex = pfx_pair_scan<PFXM_THREADS>(mine, shp, total);
-    unsigned st[PFXM_K];
+    const PfxPair ex = pfx_pair_scan<PFXW_THREADS>(mine, shp, total);
+    unsigned st[PFXW_K];
     {
       unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);
       int first = cnt;
 #pragma unroll
-      for (int k = 0; k < PFXM_K; k++) {
+      for (int k = 0; k < PFXW_K; k++) {
         state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
         st[k] = state;
         const int li = t0 + k;
@@ -657,7 +662,7 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
     const int stop = min(s_bad, s_cross);   // first element that needs a real float addition (or cnt)
     {
 #pragma unroll
-      for (int k = 0; k < PFXM_K; k++) {
+      for (int k = 0; k < PFXW_K; k++) {
         const int li = t0 + k;
         if (li >= pos && li < stop) {
           const float val = __uint_as_float((re << 23) | (st[k] & 0x7FFFFFu));
@@ -687,7 +692,7 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
 }
 
 #define PFXW_BLOCK 512   // chunk summaries / headers staged in LDS at a time
-__global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
+__global__ __launch_bounds__(PFXW_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
                                                                PfxChunk* __restrict__ ch, int nch,
                                                                float* __restrict__ runmax,
                                                                float* __restrict__ prefix_opt, int head_len) {
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __r
   float r = 0.f, carry = -INFINITY;   // workgroup-uniform
   for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
     pfx_sync();
-    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXW_THREADS) {
       const PfxChunk x = ch[cb + t];
       sm_re[t] = x.re; sm_d0[t] = x.d0; sm_d1[t] = x.d1;
     }
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_walk_kernel(const float* __r
 #endif
     }
     pfx_sync();
-    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXM_THREADS) {   // for pfx_chunk_fill_kernel
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXW_THREADS) {   // for pfx_chunk_fill_kernel
       PfxChunk* o = ch + cb + t;
       o->r0 = sm_r0[t];
       o->carry0 = sm_c0[t];
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const floa
 }
 
 // Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
-// 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 66 / 94 / 129):
+// 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 53 / 74 / 101):
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
 #define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
 extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
@@ -810,7 +815,7 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
     const int v = e ? atoi(e) : PFXW_HEAD;
     return v < 1 ? 1 : (v > PFX_HEAD ? PFX_HEAD : v);
   }();
-  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXM_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
+  hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
                      head_len);
   hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,
                      runmax_out, prefix_out);
