@@ -253,6 +253,7 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
                        int lut_size, int ncls, float resolution, int center_x, int center_y);
 int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res);                 /* top_down_map_polar.cpp:7-19 */
 int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map);
+int tdr_map_center(const tdr_map* m, int* center_x, int* center_y);                      /* mapCenter(), top_down_map.h:72 */
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
 
 int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out);              /* scan_renderer.cpp:3-5 */

@@ -76,7 +76,11 @@ class TopDownMap {
     tdr_map_info(m_, nullptr, &rows, &cols, nullptr, nullptr);
     return Eigen::Vector2i(cols, rows);
   }
-  Eigen::Vector2i mapCenter() const { return map_center_; }
+  Eigen::Vector2i mapCenter() const {   // asks the handle: ParticleFilter::updateMap moves the centre too
+    int cx = map_center_[0], cy = map_center_[1];
+    tdr_map_center(m_, &cx, &cy);
+    return Eigen::Vector2i(cx, cy);
+  }
   int numClasses() const { return params_.num_classes; }
   float resolution() const { return params_.resolution; }
   bool haveMap() const {

@@ -1,0 +1,146 @@
+// facade_session.cpp — the parts of the class surface facade_step.cpp does not touch, in the order a localisation
+// session uses them (reference: src/top_down_render.cpp:81,115-117 initialize; :331-359 publishPoseEst; :574-593
+// aerialMapCallback; src/particle_filter.cpp:19-84 initializeParticles):
+//   map from a label image -> ParticleFilter constructor draws the initial particles around the configured pose with
+//   an unknown scale -> getClassesAtPoint -> two steps -> freezeScale -> computeGMM + adaptive particle count ->
+//   updateMap with a moved centre.
+// Inputs / outputs: raw files in argv[1], like facade_step.cpp (tests/test_facade.py compares with the CPU oracle).
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "top_down_render/particle_filter.h"
+#include "top_down_render/scan_renderer_polar.h"
+
+template <class T>
+static std::vector<T> slurp(const std::string& path) {
+  std::ifstream in(path, std::ios::binary | std::ios::ate);
+  if (!in) throw std::runtime_error("cannot open " + path);
+  std::vector<T> v((size_t)in.tellg() / sizeof(T));
+  in.seekg(0);
+  in.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+  return v;
+}
+template <class T>
+static void dump(const std::string& path, const T* p, size_t n) {
+  std::ofstream out(path, std::ios::binary | std::ios::trunc);
+  out.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 2; }
+  const std::string dir = argv[1];
+  try {
+    int ncls, rows, cols, nb, nr, npts, npart;
+    float res, ang_res, init_x, init_y, init_cov, init_deg, init_deg_cov;
+    unsigned seed;
+    {
+      std::ifstream meta(dir + "/meta.txt");
+      meta >> ncls >> rows >> cols >> nb >> nr >> npts >> npart >> res >> ang_res >> seed >> init_x >> init_y >> init_cov >>
+          init_deg >> init_deg_cov;
+      if (!meta) throw std::runtime_error("bad meta.txt");
+    }
+    auto labels = slurp<uint8_t>(dir + "/labels.bin");
+    auto pts = slurp<float>(dir + "/pts.bin");
+
+    TopDownMap::Params map_params;
+    map_params.num_classes = ncls;
+    map_params.resolution = 1;
+    for (int c = 0; c < ncls; c++) map_params.flatten_lut.push_back(c);
+    TopDownMapPolar* map_ = new TopDownMapPolar(map_params);
+    if (map_->haveMap()) throw std::runtime_error("haveMap() before any map arrived");
+    map_->updateMap(labels.data(), rows, cols, Eigen::Vector2i(0, 0));
+    map_->samplePtsPolar(Eigen::Vector2i(nb, nr), ang_res);
+
+    FilterParams fp;
+    fp.pos_cov = 0.3f;
+    fp.theta_cov = (float)(M_PI / 100);
+    fp.regularization = 0.15f;
+    fp.fixed_scale = -1.f;                      // unknown scale: log-uniform draw per particle (:40-58), scale gate on
+    fp.init_pos_px_x = init_x; fp.init_pos_px_y = init_y; fp.init_pos_px_cov = init_cov;
+    fp.init_pos_deg_theta = init_deg; fp.init_pos_deg_cov = init_deg_cov;
+    for (int c = 0; c < ncls; c++) fp.class_weights.push_back(1.f);
+    ParticleFilter* filter_ = new ParticleFilter(npart, map_, fp, seed);   // initializeParticles() (:14-16)
+    auto st0 = filter_->states();
+    dump(dir + "/out_init_states.bin", st0.data(), st0.size());
+
+    // getClassesAtPoint (src/top_down_map.cpp:159-175) at the first particles' cells
+    std::vector<int> cls_out;
+    for (int i = 0; i < 16 && i < (int)st0.size(); i++) {
+      std::vector<int> classes;
+      map_->getClassesAtPoint(Eigen::Vector2i((int)st0[i].init_x_px, (int)st0[i].init_y_px), classes);
+      for (int c = 0; c < ncls; c++) cls_out.push_back(c < (int)classes.size() ? classes[c] : -1);
+    }
+    dump(dir + "/out_classes.bin", cls_out.data(), cls_out.size());
+
+    Eigen::VectorXi flatten_lut = Eigen::VectorXi::Constant(256, -1);
+    for (int c = 0; c < ncls; c++) flatten_lut[c] = c;
+    ScanRendererPolar* renderer_ = new ScanRendererPolar(flatten_lut);
+    pcl::PointCloud<PointType>::Ptr cloud_ptr(new pcl::PointCloud<PointType>());
+    for (int i = 0; i < npts; i++) {
+      PointType p{};
+      p.x = pts[8 * i]; p.y = pts[8 * i + 1]; p.z = pts[8 * i + 2]; p.intensity = pts[8 * i + 4];
+      cloud_ptr->push_back(p);
+    }
+    std::vector<Eigen::ArrayXXf> top_down, top_down_geo;
+    for (int i = 0; i < map_->numClasses(); i++) top_down.push_back(Eigen::ArrayXXf(nb, nr));
+    for (int i = 0; i < 2; i++) top_down_geo.push_back(Eigen::ArrayXXf(nb, nr));
+
+    Eigen::Vector2f motion(1.f, 0.25f);
+    for (int step = 0; step < 2; step++) {
+      renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down);
+      filter_->propagate(motion, 0.01f);
+      filter_->update(top_down, top_down_geo, res);
+      if (step == 0) {
+        auto st1 = filter_->states();
+        dump(dir + "/out_states_step1.bin", st1.data(), st1.size());
+        auto w1 = filter_->weights(npart);
+        dump(dir + "/out_weights_step1.bin", w1.data(), w1.size());
+        auto i1 = filter_->resampleIndices();
+        dump(dir + "/out_idx_step1.bin", i1.data(), i1.size());
+      }
+    }
+    auto st2 = filter_->states();
+    dump(dir + "/out_states_step2.bin", st2.data(), st2.size());
+    float misc[8] = {filter_->scale(), filter_->isScaleFrozen() ? 1.f : 0.f, 0, 0, 0, 0, 0, 0};
+
+    filter_->freezeScale();                       // :343-357
+    auto st3 = filter_->states();
+    dump(dir + "/out_states_frozen.bin", st3.data(), st3.size());
+    misc[2] = filter_->scale();
+    misc[3] = filter_->isScaleFrozen() ? 1.f : 0.f;
+
+    // one more step with the scale frozen (propagate stops drawing the fourth normal, state_particle.cpp:70-73)
+    renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down);
+    filter_->propagate(motion, 0.01f);
+    filter_->update(top_down, top_down_geo, res);
+    auto st4 = filter_->states();
+    dump(dir + "/out_states_step3.bin", st4.data(), st4.size());
+
+    // adaptive particle count from the mixture (:151-157, 252-318)
+    filter_->computeGMM();
+    filter_->setAdaptiveCount(true);
+    renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down);
+    filter_->propagate(motion, 0.01f);
+    filter_->update(top_down, top_down_geo, res);
+    misc[4] = (float)filter_->numParticles();
+    filter_->setAdaptiveCount(false);
+
+    // a new aerial map with a moved centre shifts every particle's init position (:325-334)
+    auto before = filter_->states();
+    filter_->updateMap(labels.data(), rows, cols, map_params.flatten_lut, Eigen::Vector2i(7, -3));
+    auto after = filter_->states();
+    misc[5] = after[0].init_x_px - before[0].init_x_px;
+    misc[6] = after[0].init_y_px - before[0].init_y_px;
+    misc[7] = (float)map_->mapCenter()[0] * 1000.f + (float)map_->mapCenter()[1];
+    dump(dir + "/out_misc.bin", misc, 8);
+    delete renderer_;
+    delete filter_;
+    delete map_;
+    std::puts("facade_session ok");
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "facade_session failed: %s\n", e.what());
+    return 1;
+  }
+}

@@ -28,6 +28,17 @@ def facade_exe():
     return exe
 
 
+@pytest.fixture(scope="module")
+def session_exe():
+    from top_down_renderer_amd import build
+    build.build()
+    exe = os.path.join(tempfile.mkdtemp(prefix="tdr_facade_"), "facade_session")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "facade_session.cpp"), "-o", exe, "-L", PKG, "-ltdr_hip",
+                    f"-Wl,-rpath,{PKG}"], check=True)
+    return exe
+
+
 def test_facade_compiles_and_fails_loudly_without_gpu(facade_exe):
     import torch
     if torch.cuda.is_available():
@@ -107,3 +118,82 @@ def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan, labels
     kk, means_o, covs_o = no.gmm_select(x, n, 1)
     assert len(gmm) == kk
     assert np.allclose(gmm[:, :3], means_o, atol=2e-3) and np.allclose(gmm[:, 3:].reshape(-1, 3, 3), covs_o, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_facade_session_matches_oracle(session_exe, oracle):
+    """tests/cpp/facade_session.cpp: constructor-time initializeParticles with an unknown scale, getClassesAtPoint, two
+    steps, freezeScale, one more step, computeGMM + adaptive particle count, updateMap with a moved centre — through the
+    C++ classes, each stage against the oracle (later stages on the states the GPU path itself produced)."""
+    from oracle import np_oracle as no
+    from top_down_renderer_amd import synth
+    sc = synth.make_scene("c1", with_particles=False)
+    cfg = sc.cfg
+    n, seed = 1500, 23
+    d = tempfile.mkdtemp(prefix="tdr_session_")
+    img = np.where(sc.lab >= 0, sc.lab, 200).astype(np.uint8)[::-1].copy()      # cv::Mat layout, 200 = unlabelled
+    img.tofile(os.path.join(d, "labels.bin"))
+    kw = dict(fixed_scale=-1.0, init_pos_px_x=float(sc.pose[0]), init_pos_px_y=float(sc.pose[1]), init_pos_px_cov=12.0,
+              init_pos_deg_theta=float(np.rad2deg(sc.pose[2])), init_pos_deg_cov=4.0)
+    open(os.path.join(d, "meta.txt"), "w").write(
+        f"{cfg.ncls} {cfg.map_size} {cfg.map_size} {cfg.nb} {cfg.nr} {len(sc.pts)} {n} {cfg.res} {float(cfg.ang_res)!r} "
+        f"{seed} {kw['init_pos_px_x']!r} {kw['init_pos_px_y']!r} {kw['init_pos_px_cov']} {kw['init_pos_deg_theta']!r} "
+        f"{kw['init_pos_deg_cov']}\n")
+    pcl = np.zeros((len(sc.pts), 8), np.float32)
+    pcl[:, :3], pcl[:, 3], pcl[:, 4] = sc.pts[:, :3], 1.0, sc.pts[:, 3]
+    pcl.tofile(os.path.join(d, "pts.bin"))
+    r = subprocess.run([session_exe, d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rd = lambda name, dt: np.fromfile(os.path.join(d, name), dt)  # noqa: E731
+    # the map the label image turns into (bit-exact ingest, tests/test_ingest.py) and the oracle's filter on it
+    lut = -np.ones(256, np.int32)
+    lut[: cfg.ncls] = np.arange(cfg.ncls)
+    maps, mask = no.load_compressed_raster_map(img, lut, cfg.ncls, 1.0)
+    om = oracle.OracleMap(maps, mask, 1.0)
+    fpo = oracle.make_params(cfg.ncls, **kw)
+    rng = oracle.Rng(seed)
+    st_o = oracle.initialize_particles(om, fpo, n, rng)
+    st0 = rd("out_init_states.bin", oracle.STATE_DTYPE)
+    assert st0.tobytes() == st_o.tobytes()                      # same std::mt19937 stream, same rejections
+    assert len(np.unique(st0["scale"])) >= 5                    # unknown scale: a ladder of scales (:40-58)
+    cls = rd("out_classes.bin", np.int32).reshape(-1, cfg.ncls)
+    for i in range(len(cls)):
+        bits = oracle.classes_at_point(om, int(st0["init_x_px"][i]), int(st0["init_y_px"][i]))
+        assert [c for c in cls[i] if c >= 0] == [c for c in range(cfg.ncls) if bits >> c & 1]
+    # step 1, oracle in lock step (same generator continues)
+    last = oracle.propagate(st_o, 1.0, 0.25, 0.01, False, fpo, rng)
+    scan_o = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, 1.0)
+    raw_o = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan_o, cfg.res, fpo, st_o)
+    w_o, _, _ = oracle.update_weights(raw_o, last)
+    idx_o = oracle.resample_prefix(w_o, n, rng.uniform())
+    new_o = oracle.gather_states(st_o, idx_o)
+    w1, idx1, st1 = rd("out_weights_step1.bin", np.float32), rd("out_idx_step1.bin", np.int32), rd("out_states_step1.bin", oracle.STATE_DTYPE)
+    assert np.isnan(raw_o).any()                                # the scale gate fired for some particles
+    assert np.allclose(w1, w_o, rtol=3e-5, atol=0)
+    assert (idx1 != idx_o).sum() <= 2 + n // 200
+    same = idx1 == idx_o
+    for name in ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale"):
+        assert np.allclose(st1[name][same], new_o[name][same], rtol=3e-6, atol=3e-6), name
+    # freezeScale (src/particle_filter.cpp:343-357) on the states the GPU path had after step 2
+    st2, st3 = rd("out_states_step2.bin", oracle.STATE_DTYPE), rd("out_states_frozen.bin", oracle.STATE_DTYPE)
+    misc = rd("out_misc.bin", np.float32)
+    assert misc[0] == -1.0 and misc[1] == 0.0                   # scale() before freezing: unknown (:359-367)
+    ref2 = st2.copy()
+    gm = oracle.freeze_scale(ref2)
+    assert np.allclose(st3["scale"], gm, rtol=2e-6) and len(np.unique(st3["scale"])) == 1
+    for name in ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta"):
+        assert np.array_equal(st3[name], st2[name])
+    assert np.isclose(misc[2], gm, rtol=2e-6) and misc[3] == 1.0
+    # after freezing, propagate leaves the scale alone (state_particle.cpp:70-73)
+    st4 = rd("out_states_step3.bin", oracle.STATE_DTYPE)
+    assert np.all(st4["scale"] == st3["scale"][0])
+    # adaptive particle count (:151-157) from computeGMM on the step-3 states
+    idx_s = np.minimum(n - 1, np.arange(min(1000, n)) * n // min(1000, n))
+    sx = (st4["dx_m"] * st4["scale"] + st4["init_x_px"]).astype(np.float32)[idx_s]
+    sy = (st4["dy_m"] * st4["scale"] + st4["init_y_px"]).astype(np.float32)[idx_s]
+    x = np.column_stack([sx, sy, np.float32(50) * np.cos(st4["theta"][idx_s]), np.float32(50) * np.sin(st4["theta"][idx_s])]).astype(np.float64)
+    _, _, covs = no.gmm_select(x, n, 1)
+    assert int(misc[4]) == oracle.adaptive_count(covs[:, :2, :2], n, n)
+    # updateMap with a moved centre (:325-334)
+    assert misc[5] == 7.0 and misc[6] == -3.0 and misc[7] == 6997.0

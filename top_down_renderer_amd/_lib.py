@@ -89,6 +89,7 @@ SIGNATURES = {
     "tdr_filter_update_map_labels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _i]),
     "tdr_map_sample_pts_polar": (_i, [_vp, _i, _i, _f]),
     "tdr_map_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
+    "tdr_map_center": (_i, [_vp, _vp, _vp]),
     "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),
     "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
     "tdr_renderer_destroy": (None, [_vp]),

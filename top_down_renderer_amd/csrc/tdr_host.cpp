@@ -210,6 +210,15 @@ int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resol
   return TDR_OK;
 }
 
+// TopDownMap::mapCenter() (top_down_map.h:72): the centre given with the last map, whoever set it (the map's own
+// updateMap or ParticleFilter::updateMap)
+int tdr_map_center(const tdr_map* m, int* center_x, int* center_y) {
+  if (!m || !center_x || !center_y) return failh(TDR_ERR_ARG, "map_center: bad arguments");
+  *center_x = m->center_x;
+  *center_y = m->center_y;
+  return TDR_OK;
+}
+
 // TopDownMap::getClassesAtPoint(Vector2i) (top_down_map.cpp:159-170): bit c set = class c present (< 1 px away)
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits) {
   if (!m || !class_bits || !m->have_map) return failh(TDR_ERR_ARG, "classes_at_point: no map");
