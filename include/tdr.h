@@ -159,6 +159,9 @@ int tdr_propagate_normals_host(void* rng, int64_t n, int scale_freeze, float* z4
 /* ParticleFilter::initializeParticles particle loop (src/particle_filter.cpp:57-71) with the StateParticle
  * constructor (src/state_particle.cpp:3-49): host-side, serial mt19937 draws with on-road rejection.
  * class_maps: HOST copy of class_maps_ (column-major [ncls][rows*cols]); out must hold max_num+16 states. */
+/* One particle drawn like StateParticle's constructor (src/state_particle.cpp:3-49). */
+int tdr_init_particle_host(void* rng, const float* class_maps, int ncls, int rows, int cols, float resolution,
+                           const tdr_filter_params* fp, tdr_state* out);
 int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int rows, int cols, float resolution,
                             const tdr_filter_params* fp, int max_num, tdr_state* out, int64_t* n_out);
 
@@ -190,6 +193,16 @@ int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, i
  * buffer of a sharded filter and idx holds global particle indices (rank*src_shard + local). */
 int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, const int32_t* idx, int64_t n_new,
                         float* dst, int64_t dst_cap, void* stream);
+
+/* ---- getLocalMap materialised (src/top_down_map_polar.cpp:21-53, src/top_down_map.cpp:429-459) ----------------- */
+/* The window of ONE pose as the reference's arrays: dists_out (device) [ncls][rows*cols] column-major images,
+ * mask_out (device) [rows*cols], 1 = unknown or outside the map.  Polar: rows = nb, cols = nr, `tab` from
+ * tdr_polar_table_host, centre (cx, cy) in metres like StateParticle's (cx / resolution is the cell).  Cartesian:
+ * samplePts(center / resolution, rot, cols, rows, res / resolution) (top_down_map.cpp:433-434). */
+int tdr_k_local_map_polar(const tdr_map_desc* map, const float* tab, int nb, int nr, float cx, float cy, float scale,
+                          float res, float* dists_out, uint8_t* mask_out, void* stream);
+int tdr_k_local_map_cart(const tdr_map_desc* map, int rows, int cols, float cx, float cy, float rot, float res,
+                         float* dists_out, uint8_t* mask_out, void* stream);
 
 /* ---- per-step consumers (src/particle_filter.cpp:191-236, 325-334, 343-357) --------------------------------- */
 /* out (device, TDR_MEAN_COV_FLOATS floats; the first 24 are the result, the rest is scratch for the multi-workgroup
@@ -254,6 +267,11 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
 int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res);                 /* top_down_map_polar.cpp:7-19 */
 int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map);
 int tdr_map_center(const tdr_map* m, int* center_x, int* center_y);                      /* mapCenter(), top_down_map.h:72 */
+/* getLocalMap (polar != 0: top_down_map_polar.cpp:21-53 with scale_or_rot = scale and the table of
+ * tdr_map_sample_pts_polar, rows/cols ignored; else top_down_map.cpp:429-459 with scale_or_rot = rot).
+ * dists_out HOST [ncls][rows*cols], mask_out HOST [rows*cols]. */
+int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
+                      float* dists_out, uint8_t* mask_out);
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
 
 int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out);              /* scan_renderer.cpp:3-5 */
@@ -281,6 +299,17 @@ int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega);       
  * trip); n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
 int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target);
 int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n);
+/* The per-particle surface of StateParticle (include/top_down_render/state_particle.h:42-53) on a filter:
+ * computeWeight for every particle without statistics / resampling (state_particle.cpp:157-219) and its result
+ * (weight(), :55), lastDist(), propagate with the caller's scale_freeze flag (:57-78), the constructor's draw of one
+ * particle (:3-49), and the generator shared with the caller (state_particle.h:61-64: `mt19937` is a std::mt19937* of
+ * this library's libstdc++, not owned; the filter then consumes it in the reference's draw order). */
+int tdr_filter_compute_weights(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res);
+int tdr_filter_get_raw_weights(tdr_filter* f, float* out, int64_t n);
+int tdr_filter_get_last_dist(tdr_filter* f, float* out, int64_t n);
+int tdr_filter_propagate_freeze(tdr_filter* f, float tx, float ty, float omega, int scale_freeze);
+int tdr_filter_init_one(tdr_filter* f);
+int tdr_filter_share_rng(tdr_filter* f, void* mt19937);
 int tdr_filter_get_resample_indices(tdr_filter* f, int32_t* out, int64_t n);
 /* about_max == 0: meanLikelihood + computeMeanCov (:191-220); != 0: maxLikelihood + computeCov (:222-236). */
 int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[16]);

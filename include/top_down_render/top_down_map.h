@@ -68,6 +68,18 @@ class TopDownMap {
     for (int c = 0; c < params_.num_classes; c++)
       if (bits & (1u << c)) classes.push_back(c);
   }
+  // getLocalMap (src/top_down_map.cpp:429-459): the Cartesian window of one pose; sizes are read off dists[0] like the
+  // reference does; dists.size() < 1 -> nothing happens (:431).  mask: 1 = unknown or outside the map.
+  void getLocalMap(Eigen::Vector2f center, float rot, float res, std::vector<Eigen::ArrayXXf>& dists,
+                   Eigen::ArrayXXc& mask) {
+    if (dists.size() < 1) return;
+    local_map(0, center, rot, res, (int)dists[0].rows(), (int)dists[0].cols(), dists, mask);
+  }
+  // getLocalGeoMap (:461-490): the geometric layers have no consumer (src/state_particle.cpp:145-152 is commented out)
+  // and are not carried here: the outputs are zeroed.
+  void getLocalGeoMap(Eigen::Vector2f, float, float, std::vector<Eigen::ArrayXXf>& dists) {
+    for (Eigen::ArrayXXf& d : dists) d.setZero();
+  }
   void getClassesAtPoint(const Eigen::Vector2f& center, std::vector<int>& classes) {      // :172-175
     getClassesAtPoint(Eigen::Vector2i((int)(center[0] / params_.resolution), (int)(center[1] / params_.resolution)), classes);
   }
@@ -91,6 +103,18 @@ class TopDownMap {
   tdr_map* handle() const { return m_; }
 
  protected:
+  void local_map(int polar, const Eigen::Vector2f& center, float scale_or_rot, float res, int rows, int cols,
+                 std::vector<Eigen::ArrayXXf>& dists, Eigen::ArrayXXc& mask) {
+    const int ncls = params_.num_classes;
+    if ((int)dists.size() < ncls) throw std::invalid_argument("getLocalMap: fewer output arrays than map classes");
+    const size_t P = (size_t)rows * cols;
+    std::vector<float> d(P * ncls);
+    std::vector<uint8_t> k(P);
+    if (tdr_map_local_map(m_, polar, center[0], center[1], scale_or_rot, res, rows, cols, d.data(), k.data()) != TDR_OK)
+      throw std::runtime_error(std::string("getLocalMap: ") + tdr_last_error());
+    for (int c = 0; c < ncls; c++) std::memcpy(dists[c].data(), d.data() + P * c, P * sizeof(float));
+    std::memcpy(mask.data(), k.data(), P);
+  }
   Params params_;
   Eigen::Vector2i map_center_;
   tdr_map* m_ = nullptr;

@@ -1,5 +1,8 @@
-// TopDownMapPolar — reference surface: include/top_down_render/top_down_map_polar.h:6-22.  The per-pose window gather
-// (getLocalMap, src/top_down_map_polar.cpp:21-53) is fused into the scoring kernel and never materialised.
+// TopDownMapPolar — reference surface: include/top_down_render/top_down_map_polar.h:6-22.
+//
+// Inside ParticleFilter::update the per-pose window gather (getLocalMap, src/top_down_map_polar.cpp:21-53) is fused
+// into the scoring kernel and never materialised; the methods below materialise it for one pose on request
+// (tdr_map_local_map), like the reference's public method.
 #ifndef TOP_DOWN_MAP_POLAR_H_
 #define TOP_DOWN_MAP_POLAR_H_
 
@@ -13,7 +16,30 @@ class TopDownMapPolar : public TopDownMap {
   void samplePtsPolar(Eigen::Vector2i shape, float ang_res) {                              // :7-19
     if (tdr_map_sample_pts_polar(m_, shape[0], shape[1], ang_res) != TDR_OK)
       throw std::runtime_error(std::string("samplePtsPolar: ") + tdr_last_error());
+    shape_ = shape;
   }
+  // :21-53.  dists[c] / mask are (theta bins x range bins) as set by samplePtsPolar; mask: 1 = unknown or outside.
+  void getLocalMap(Eigen::Vector2f center, float scale, float res, std::vector<Eigen::ArrayXXf>& dists,
+                   Eigen::ArrayXXc& mask) {
+    if (dists.size() < 1) return;   // :25
+    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1] || mask.rows() * mask.cols() != dists[0].rows() * dists[0].cols())
+      throw std::invalid_argument("getLocalMap: output arrays do not have the shape given to samplePtsPolar");
+    local_map(1, center, scale, res, shape_[0], shape_[1], dists, mask);
+  }
+  void getLocalMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists, Eigen::ArrayXXc& mask) {
+    getLocalMap(center, 1.f, res, dists, mask);                                           // :78-81
+  }
+  // The geometric layers are never filled in the reference either (geo_maps_ stays empty unless getGeoRasterMap is
+  // called, which nothing does; the consumer is commented out, src/state_particle.cpp:145-152): the outputs are zeroed.
+  void getLocalGeoMap(Eigen::Vector2f, float, float, std::vector<Eigen::ArrayXXf>& dists) {
+    for (Eigen::ArrayXXf& d : dists) d.setZero();
+  }
+  void getLocalGeoMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists) {
+    getLocalGeoMap(center, 1.f, res, dists);
+  }
+
+ private:
+  Eigen::Vector2i shape_{100, 50};
 };
 
 #endif  // TOP_DOWN_MAP_POLAR_H_

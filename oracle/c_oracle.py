@@ -264,6 +264,13 @@ def classes_at_point(m, px, py):
     return int(lib().orc_classes_at_point(C.byref(m.c), C.c_int(px), C.c_int(py)))
 
 
+def init_particle(m, fp, rng):
+    """StateParticle's constructor draw (src/state_particle.cpp:3-49): one state from the shared generator."""
+    out = np.zeros(1, STATE_DTYPE)
+    lib().orc_init_particle(C.byref(m.c), C.byref(fp), rng.h, _p(out))
+    return out
+
+
 def initialize_particles(m, fp, max_num, rng):
     out = np.zeros(max_num + 16, STATE_DTYPE)
     n = lib().orc_initialize_particles(C.byref(m.c), C.byref(fp), C.c_int(max_num), rng.h, _p(out))

@@ -6,7 +6,9 @@
 //   updateMap with a moved centre.
 // Inputs / outputs: raw files in argv[1], like facade_step.cpp (tests/test_facade.py compares with the CPU oracle).
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <random>
 #include <string>
 
 #include "top_down_render/particle_filter.h"
@@ -72,6 +74,66 @@ int main(int argc, char** argv) {
       for (int c = 0; c < ncls; c++) cls_out.push_back(c < (int)classes.size() ? classes[c] : -1);
     }
     dump(dir + "/out_classes.bin", cls_out.data(), cls_out.size());
+
+    // getLocalMap (src/top_down_map_polar.cpp:21-53): the window of the first particle, materialised
+    {
+      std::vector<Eigen::ArrayXXf> dists;
+      for (int c = 0; c < ncls; c++) dists.push_back(Eigen::ArrayXXf(nb, nr));
+      Eigen::ArrayXXc wmask(nb, nr);
+      const State& s0 = st0[0];
+      map_->getLocalMap(Eigen::Vector2f(s0.dx_m * s0.scale + s0.init_x_px, s0.dy_m * s0.scale + s0.init_y_px), s0.scale,
+                        res, dists, wmask);
+      std::vector<float> w((size_t)(ncls + 1) * nb * nr);
+      for (int c = 0; c < ncls; c++) std::memcpy(w.data() + (size_t)c * nb * nr, dists[c].data(), (size_t)nb * nr * sizeof(float));
+      for (int k = 0; k < nb * nr; k++) w[(size_t)ncls * nb * nr + k] = (float)wmask(k);
+      dump(dir + "/out_window.bin", w.data(), w.size());
+    }
+
+    // StateParticle (include/top_down_render/state_particle.h:40-66): two particles sharing ONE generator, as in the
+    // reference's filter; constructor draw, computeWeight, propagate with and without scale freeze
+    std::vector<float> sp_out;
+    {
+      std::mt19937 gen(seed + 1);
+      StateParticle a(&gen, map_, &fp), b(&gen, map_, &fp);
+      std::vector<Eigen::ArrayXXf> scan_imgs, geo;
+      for (int c = 0; c < ncls; c++) scan_imgs.push_back(Eigen::ArrayXXf(nb, nr));
+      {
+        pcl::PointCloud<PointType>::Ptr cl(new pcl::PointCloud<PointType>());
+        for (int i = 0; i < npts; i++) {
+          PointType p{};
+          p.x = pts[8 * i]; p.y = pts[8 * i + 1]; p.z = pts[8 * i + 2]; p.intensity = pts[8 * i + 4];
+          cl->push_back(p);
+        }
+        Eigen::VectorXi lut = Eigen::VectorXi::Constant(256, -1);
+        for (int c = 0; c < ncls; c++) lut[c] = c;
+        ScanRendererPolar rr(lut);
+        rr.renderSemanticTopDown(cl, res, ang_res, scan_imgs);
+      }
+      StateParticle* ps[2] = {&a, &b};
+      for (StateParticle* p : ps) {
+        State s = p->state();
+        const float* f = reinterpret_cast<const float*>(&s);
+        for (int i = 0; i < 6; i++) sp_out.push_back(f[i]);
+        sp_out.push_back(s.have_init ? 1.f : 0.f);
+      }
+      Eigen::Vector2f tr(1.f, 0.25f);
+      a.propagate(tr, 0.01f, false);
+      b.propagate(tr, 0.01f, true);
+      for (StateParticle* p : ps) {
+        p->computeWeight(scan_imgs, geo, res);
+        State s = p->state();
+        const float* f = reinterpret_cast<const float*>(&s);
+        for (int i = 0; i < 6; i++) sp_out.push_back(f[i]);
+        sp_out.push_back(s.have_init ? 1.f : 0.f);
+        sp_out.push_back(p->weight());
+        sp_out.push_back(p->lastDist());
+        const Eigen::Vector4f ml = p->mlState();
+        for (int i = 0; i < 4; i++) sp_out.push_back(ml[i]);
+      }
+      a.setScale(2.5f);
+      sp_out.push_back(a.state().scale);
+    }
+    dump(dir + "/out_state_particles.bin", sp_out.data(), sp_out.size());
 
     Eigen::VectorXi flatten_lut = Eigen::VectorXi::Constant(256, -1);
     for (int c = 0; c < ncls; c++) flatten_lut[c] = c;

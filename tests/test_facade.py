@@ -160,6 +160,36 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     for i in range(len(cls)):
         bits = oracle.classes_at_point(om, int(st0["init_x_px"][i]), int(st0["init_y_px"][i]))
         assert [c for c in cls[i] if c >= 0] == [c for c in range(cfg.ncls) if bits >> c & 1]
+    # getLocalMap of the first particle (src/top_down_map_polar.cpp:21-53): the oracle's window, value for value
+    tab0 = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, 1.0)
+    s0 = st0[0]
+    d_o, k_o = oracle.local_map_polar(om, tab0, np.float32(s0["dx_m"] * s0["scale"] + s0["init_x_px"]),
+                                      np.float32(s0["dy_m"] * s0["scale"] + s0["init_y_px"]), s0["scale"], cfg.res)
+    win = rd("out_window.bin", np.float32).reshape(cfg.ncls + 1, -1)
+    assert np.array_equal(win[: cfg.ncls], d_o) and np.array_equal(win[cfg.ncls], k_o.astype(np.float32))
+    # StateParticle: two particles on one shared generator (constructor draw, propagate with / without scale freeze,
+    # computeWeight, weight, lastDist, mlState, setScale)
+    sp = rd("out_state_particles.bin", np.float32)
+    g2 = oracle.Rng(seed + 1)
+    pa, pb = oracle.init_particle(om, fpo, g2), oracle.init_particle(om, fpo, g2)
+    fields = ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale")
+    for j, pp in enumerate((pa, pb)):
+        assert np.array_equal(sp[7 * j: 7 * j + 6], np.asarray([pp[f][0] for f in fields], np.float32))
+        assert sp[7 * j + 6] == float(pp["have_init"][0])
+    la = oracle.propagate(pa, 1.0, 0.25, 0.01, False, fpo, g2)
+    lb = oracle.propagate(pb, 1.0, 0.25, 0.01, True, fpo, g2)
+    scan_sp = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    for j, (pp, ll) in enumerate(((pa, la), (pb, lb))):
+        o = 14 + 13 * j
+        assert np.allclose(sp[o: o + 6], [pp[f][0] for f in fields], rtol=2e-6, atol=2e-6)   # sin/cos of propagate
+        w_ref = oracle.compute_weights(om, tab0, cfg.nb, cfg.nr, scan_sp, cfg.res, fpo, pp.copy())[0]
+        assert (np.isnan(w_ref) and np.isnan(sp[o + 7])) or np.isclose(sp[o + 7], w_ref, rtol=3e-5)
+        assert np.isclose(sp[o + 8], ll[0], rtol=1e-6)
+        s1 = pp[0]
+        assert np.allclose(sp[o + 9: o + 13], [s1["dx_m"] * s1["scale"] + s1["init_x_px"], s1["dy_m"] * s1["scale"] + s1["init_y_px"],
+                                              s1["theta"], s1["scale"]], rtol=2e-6, atol=2e-5)
+    assert sp[14 + 26] == 2.5
+    assert sp[14 + 13 + 5] == sp[7 + 5]          # scale_freeze = true: b's scale did not move (:70-73)
     # step 1, oracle in lock step (same generator continues)
     last = oracle.propagate(st_o, 1.0, 0.25, 0.01, False, fpo, rng)
     scan_o = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)

@@ -337,6 +337,41 @@ def test_score_cartesian_vs_oracle(tdr, oracle):
         _assert_weights(f.raw_weights(), ref, rtol=2e-5)   # cos/sin of theta: last-ulp differences move a few samples
 
 
+def test_local_map_polar_and_cartesian_bit_exact(tdr, oracle):
+    """getLocalMap materialised (top_down_map_polar.cpp:21-53, top_down_map.cpp:429-459): the window addressing of the
+    scoring kernels as a function of its own — every gathered value and mask bit against the oracle, for poses inside,
+    at the border of and outside the map, several scales / rotations / resolutions."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("lm", 2000, 5, 36, 20, 300, 8, seed=91, res=1.3, map_resolution=0.5)
+    sc = synth.make_scene(cfg, with_particles=False)
+    rows, cols = 270, 300                      # non-square map
+    maps, mask = np.ascontiguousarray(sc.class_maps[:, :rows, :cols]), np.ascontiguousarray(sc.class_mask[:rows, :cols])
+    om = oracle.OracleMap(maps, mask, cfg.map_resolution)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, cfg.map_resolution)
+    mp = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), maps, mask, kernels=k)
+    mp.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    mc = pkg.TopDownMap(pkg.Params(resolution=cfg.map_resolution), maps, mask, kernels=k)
+    rng = np.random.default_rng(17)
+    poses = [(75.0, 60.0), (0.2, 0.2), (149.9, 134.9), (-40.0, 30.0), (400.0, 400.0), (75.25, -3.0)]
+    poses += [tuple(rng.uniform(-20, 170, 2)) for _ in range(10)]
+    for cx, cy in poses:
+        scale, res, rot = float(rng.uniform(0.4, 3.0)), float(rng.choice([0.5, 1.0, 1.3])), float(rng.uniform(-4, 4))
+        d_o, k_o = oracle.local_map_polar(om, tab, cx, cy, scale, res)
+        d, m = mp.getLocalMap((cx, cy), scale, res)
+        assert np.array_equal(np.stack([x.T.ravel() for x in d]), d_o) and np.array_equal(m.T.ravel(), k_o)
+        wr, wc = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        d_o, k_o = oracle.local_map_cart(om, cx, cy, rot, res, wr, wc)
+        d, m = mc.getLocalMap((cx, cy), rot, res, (wr, wc))
+        got = np.stack([x.T.ravel() for x in d])
+        bad = int((got != d_o).any(0).sum())
+        assert bad <= max(1, wr * wc // 200), f"{bad} of {wr * wc} Cartesian samples differ"   # cos/sin of rot, last ulp
+        assert int((m.T.ravel() != k_o).sum()) <= max(1, wr * wc // 200)
+    d1, m1 = mp.getLocalMap((75.0, 60.0), 1.3)                     # 3-argument overload: scale = 1 (:78-81)
+    d2, m2 = mp.getLocalMap((75.0, 60.0), 1.0, 1.3)
+    assert all(np.array_equal(a, b) for a, b in zip(d1, d2)) and np.array_equal(m1, m2)
+
+
 # ---- A10 propagate ------------------------------------------------------------------------------------------------------
 def test_propagate_golden(tdr, g):
     pkg, k = tdr

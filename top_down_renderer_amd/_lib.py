@@ -90,6 +90,9 @@ SIGNATURES = {
     "tdr_map_sample_pts_polar": (_i, [_vp, _i, _i, _f]),
     "tdr_map_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
     "tdr_map_center": (_i, [_vp, _vp, _vp]),
+    "tdr_map_local_map": (_i, [_vp, _i, _f, _f, _f, _f, _i, _i, _vp, _vp]),
+    "tdr_k_local_map_polar": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "tdr_k_local_map_cart": (_i, [_vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),
     "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
     "tdr_renderer_destroy": (None, [_vp]),
@@ -102,6 +105,13 @@ SIGNATURES = {
     "tdr_filter_get_states": (_i, [_vp, _vp, _i64]),
     "tdr_filter_propagate": (_i, [_vp, _f, _f, _f]),
     "tdr_filter_update": (_i, [_vp, _vp, _vp, _f, _i64]),
+    "tdr_filter_compute_weights": (_i, [_vp, _vp, _vp, _f]),
+    "tdr_filter_get_raw_weights": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_get_last_dist": (_i, [_vp, _vp, _i64]),
+    "tdr_filter_propagate_freeze": (_i, [_vp, _f, _f, _f, _i]),
+    "tdr_filter_init_one": (_i, [_vp]),
+    "tdr_filter_share_rng": (_i, [_vp, _vp]),
+    "tdr_init_particle_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "tdr_filter_get_weights": (_i, [_vp, _vp, _i64]),
     "tdr_filter_get_resample_indices": (_i, [_vp, _vp, _i64]),
     "tdr_filter_mean_cov": (_i, [_vp, _i, _vp, _vp]),

@@ -145,6 +145,17 @@ static tdr_state draw_particle(std::mt19937& gen, const float* maps, int ncls, i
   }
   return st;
 }
+// StateParticle's constructor with init == true (src/state_particle.cpp:3-49): one particle from the shared generator.
+extern "C" int tdr_init_particle_host(void* rng, const float* class_maps, int ncls, int rows, int cols, float resolution,
+                                      const tdr_filter_params* fp, tdr_state* out) {
+  if (!rng || !class_maps || !fp || !out) return fail(TDR_ERR_ARG, "init_particle: bad arguments");
+  if (ncls < 2) return fail(TDR_ERR_ARG, "init_particle: class 1 (road) is required for the on-road test");
+  bool any_road = false;
+  for (size_t k = 0; k < (size_t)rows * cols && !any_road; k++) any_road = class_maps[(size_t)rows * cols + k] < 1;
+  if (!any_road) return fail(TDR_ERR_ARG, "init_particle: the map has no road cell, rejection sampling cannot end");
+  *out = draw_particle(*(std::mt19937*)rng, class_maps, ncls, rows, cols, resolution, fp);
+  return TDR_OK;
+}
 extern "C" int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int rows, int cols,
                                        float resolution, const tdr_filter_params* fp, int max_num, tdr_state* out,
                                        int64_t* n_out) {

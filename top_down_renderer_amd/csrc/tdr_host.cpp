@@ -94,6 +94,7 @@ struct tdr_filter {
   bool scale_frozen = false, maybe_uninit = true, parity_rng = true;
   int locality_every = 1;
   float uniform_scale = 0.f;
+  bool rng_owned = true;      // false after tdr_filter_share_rng: the generator belongs to the caller
   DevBuf<float> gmm_samples;  // [num][3] device staging for computeGMM
   int num_gaussians = 1;      // particle_filter.cpp:7
   std::vector<float> gmm_means, gmm_covs;
@@ -219,6 +220,28 @@ int tdr_map_center(const tdr_map* m, int* center_x, int* center_y) {
   return TDR_OK;
 }
 
+// getLocalMap through the handle: one window, host arrays out
+int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
+                      float* dists_out, uint8_t* mask_out) {
+  if (!m || !m->have_map || !dists_out || !mask_out) return failh(TDR_ERR_ARG, "map_local_map: no map / null output");
+  if (polar) {
+    if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "map_local_map: samplePtsPolar was never called");
+    rows = m->nb;
+    cols = m->nr;
+  }
+  if (rows < 1 || cols < 1) return failh(TDR_ERR_ARG, "map_local_map: bad window shape");
+  const size_t P = (size_t)rows * cols;
+  DevBuf<float> d;
+  DevBuf<uint8_t> k;
+  TTRY(d.resize(P * m->desc.ncls));
+  TTRY(k.resize(P));
+  if (polar) TTRY(tdr_k_local_map_polar(&m->desc, m->tab.p, rows, cols, cx, cy, scale_or_rot, res, d.p, k.p, nullptr));
+  else TTRY(tdr_k_local_map_cart(&m->desc, rows, cols, cx, cy, scale_or_rot, res, d.p, k.p, nullptr));
+  HTRY(hipMemcpy(dists_out, d.p, P * m->desc.ncls * sizeof(float), hipMemcpyDeviceToHost));
+  HTRY(hipMemcpy(mask_out, k.p, P, hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
 // TopDownMap::getClassesAtPoint(Vector2i) (top_down_map.cpp:159-170): bit c set = class c present (< 1 px away)
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits) {
   if (!m || !class_bits || !m->have_map) return failh(TDR_ERR_ARG, "classes_at_point: no map");
@@ -315,7 +338,7 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
 }
 void tdr_filter_destroy(tdr_filter* f) {
   if (!f) return;
-  if (f->rng) tdr_rng_destroy(f->rng);
+  if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
   delete f;
 }
 
@@ -388,27 +411,80 @@ int tdr_filter_initialize_particles(tdr_filter* f) {
 }
 
 // ParticleFilter::propagate (particle_filter.cpp:86-92)
-int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega) {
-  if (!f) return failh(TDR_ERR_ARG, "filter_propagate: null filter");
+static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool scale_freeze) {
   if (f->n == 0) return TDR_OK;
   const float* z = nullptr;
   if (f->parity_rng) {
     std::vector<float> zh((size_t)4 * f->n);
-    TTRY(tdr_propagate_normals_host(f->rng, f->n, f->scale_frozen ? 1 : 0, zh.data()));
+    TTRY(tdr_propagate_normals_host(f->rng, f->n, scale_freeze ? 1 : 0, zh.data()));
     HTRY(hipMemcpyAsync(f->z4.p, zh.data(), zh.size() * sizeof(float), hipMemcpyHostToDevice, f->stream));
     HTRY(hipStreamSynchronize(f->stream));
     z = f->z4.p;
   }
-  return tdr_k_propagate(f->st.p, f->n_max, f->n, f->last_dist.p, tx, ty, omega, f->scale_frozen ? 1 : 0,
-                         f->fp.pos_cov, f->fp.theta_cov, z, f->seed, f->step, 0, f->stream);
+  return tdr_k_propagate(f->st.p, f->n_max, f->n, f->last_dist.p, tx, ty, omega, scale_freeze ? 1 : 0, f->fp.pos_cov,
+                         f->fp.theta_cov, z, f->seed, f->step, 0, f->stream);
+}
+int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_propagate: null filter");
+  return filter_propagate(f, tx, ty, omega, f->scale_frozen);
+}
+// StateParticle::propagate(trans, omega, scale_freeze) (state_particle.cpp:57-78): the freeze flag is the caller's
+int tdr_filter_propagate_freeze(tdr_filter* f, float tx, float ty, float omega, int scale_freeze) {
+  if (!f) return failh(TDR_ERR_ARG, "filter_propagate_freeze: null filter");
+  return filter_propagate(f, tx, ty, omega, scale_freeze != 0);
+}
+// The filter draws from the caller's std::mt19937 from now on (the reference's particles share ONE generator with
+// their filter, state_particle.h:61-64).  `mt19937` must point to a std::mt19937 of the libstdc++ this library was
+// built with; it is not owned.
+int tdr_filter_share_rng(tdr_filter* f, void* mt19937) {
+  if (!f || !mt19937) return failh(TDR_ERR_ARG, "filter_share_rng: bad arguments");
+  if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
+  f->rng = mt19937;
+  f->rng_owned = false;
+  f->parity_rng = true;
+  return TDR_OK;
+}
+// StateParticle's constructor with init == true (state_particle.cpp:3-49) for particle 0 of the filter
+int tdr_filter_init_one(tdr_filter* f) {
+  if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_init_one: no map");
+  tdr_map* m = f->map;
+  tdr_state st;
+  TTRY(tdr_init_particle_host(f->rng, m->maps_host.data(), m->desc.ncls, m->desc.rows, m->desc.cols, m->desc.resolution,
+                              &f->fp, &st));
+  return tdr_filter_set_states(f, &st, 1);
 }
 
 // ParticleFilter::update (particle_filter.cpp:94-189).  scan_imgs: HOST [ncls][nb*nr] column-major images, or NULL to
 // score against `renderer`'s last render without a host round trip.  n_target < 0 keeps the particle count
 // (the adaptive count of :151-157 is an explicit input; the reference feeds it from an OpenCV EM thread).
+static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res);
+static int filter_resample(tdr_filter* f, int64_t n_target);
 int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target) {
   if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_update: no map");
   if (f->n == 0) return TDR_OK;  // :96-99
+  TTRY(filter_score(f, scan_imgs, renderer, res));
+  const int64_t n = f->n;
+  TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
+  return filter_resample(f, n_target);
+}
+// StateParticle::computeWeight for every particle (state_particle.cpp:157-219): raw weights only, no statistics, no
+// resampling; read them with tdr_filter_get_raw_weights
+int tdr_filter_compute_weights(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res) {
+  if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_compute_weights: no map");
+  if (f->n == 0) return TDR_OK;
+  return filter_score(f, scan_imgs, renderer, res);
+}
+int tdr_filter_get_raw_weights(tdr_filter* f, float* out, int64_t n) {
+  if (!f || !out || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_get_raw_weights: bad arguments");
+  HTRY(hipMemcpy(out, f->raw_w.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+int tdr_filter_get_last_dist(tdr_filter* f, float* out, int64_t n) {
+  if (!f || !out || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_get_last_dist: bad arguments");
+  HTRY(hipMemcpy(out, f->last_dist.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res) {
   tdr_map* m = f->map;
   if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "filter_update: samplePtsPolar was never called");
   f->fp.num_classes = m->desc.ncls;
@@ -440,7 +516,11 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
                          f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised
   if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
-  TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
+  return TDR_OK;
+}
+// statistics are done: running sum, resample, gather, bookkeeping (particle_filter.cpp:151-188)
+static int filter_resample(tdr_filter* f, int64_t n_target) {
+  const int64_t n = f->n;
   int64_t n_new = n;
   if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));
   const float shift = tdr_rng_uniform_host(f->rng);  // :172-173

@@ -311,6 +311,77 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   }
 }
 
+// getLocalMap as a function of its own (src/top_down_map_polar.cpp:21-53, src/top_down_map.cpp:429-459): the window
+// of ONE pose written out as the reference's arrays — dists [ncls][rows*cols] column-major images, mask [rows*cols]
+// (1 = unknown / out of bounds).  The scoring kernels never materialise it; this is the class-surface method and the
+// direct parity check of the window addressing (tests/test_gpu_parity.py::test_local_map_*).  One thread per sample,
+// the same float operations as the scoring loops.
+struct LocalMapArgs {
+  const float* rec;
+  int map_rows, map_cols, ncls, rf;
+  float resolution;
+  const float* tab;     // polar: [P][2]
+  int rows, cols;       // window shape (polar: nb x nr)
+  float cx, cy, scale_or_rot, res;
+  float* dists;
+  uint8_t* mask;
+};
+template <bool POLAR>
+__global__ void local_map_kernel(LocalMapArgs a) {
+  const int64_t P = (int64_t)a.rows * a.cols;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const float off0 = a.cy / a.resolution, off1 = a.cx / a.resolution;
+  float p0, p1;
+  if constexpr (POLAR) {
+    p0 = (a.tab[2 * k] * a.scale_or_rot) * a.res + off0;      // top_down_map_polar.cpp:28-30
+    p1 = (a.tab[2 * k + 1] * a.scale_or_rot) * a.res + off1;
+  } else {
+    const int i = (int)(k % a.rows), j = (int)(k / a.rows);
+    const float resq = a.res / a.resolution;                    // top_down_map.cpp:434
+    const float c = (float)cos((double)a.scale_or_rot), s = (float)sin((double)a.scale_or_rot);
+    const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
+    const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
+    const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
+    const float step_c = a.cols == 1 ? 0.f : (hi_c - lo_c) / (float)(a.cols - 1);
+    const float yi = linspaced_dev(i, a.rows == 1 ? 1 : a.rows - 1, lo_r, hi_r, step_r);
+    const float xj = linspaced_dev(j, a.cols == 1 ? 1 : a.cols - 1, lo_c, hi_c, step_c);
+    p0 = (c * yi + (-s) * xj) + off0;                           // samplePts :383-388
+    p1 = (s * yi + c * xj) + off1;
+  }
+  p0 = __builtin_amdgcn_fmed3f(p0, -1.f, (float)a.map_rows);
+  p1 = __builtin_amdgcn_fmed3f(p1, -1.f, (float)a.map_cols);
+  const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+  const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
+  const float* r = a.rec + ((int64_t)(ri + 1) * (a.map_cols + 2) + (ci + 1)) * a.rf;   // guard ring: always valid
+  for (int c = 0; c < a.ncls; c++) a.dists[(int64_t)c * P + k] = inb ? r[c] : 0.f;
+  a.mask[k] = inb ? (uint8_t)(r[a.rf - 1] == 0.f ? 1 : 0) : (uint8_t)1;
+}
+static int launch_local_map(bool polar, const tdr_map_desc* map, const float* tab, int rows, int cols, float cx, float cy,
+                            float scale_or_rot, float res, float* dists_out, uint8_t* mask_out, void* stream) {
+  if (!map || !map->rec || !dists_out || !mask_out || (polar && !tab))
+    return fail(TDR_ERR_ARG, "local_map: null pointer");
+  if (rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "local_map: bad window shape");
+  if (!(map->resolution > 0.f)) return fail(TDR_ERR_ARG, "local_map: map resolution must be > 0");
+  LocalMapArgs a;
+  a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.ncls = map->ncls; a.rf = map->rec_floats;
+  a.resolution = map->resolution; a.tab = tab; a.rows = rows; a.cols = cols; a.cx = cx; a.cy = cy;
+  a.scale_or_rot = scale_or_rot; a.res = res; a.dists = dists_out; a.mask = mask_out;
+  const dim3 grid((unsigned)cdiv((int64_t)rows * cols, 256)), block(256);
+  if (polar) hipLaunchKernelGGL((local_map_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((local_map_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
+  LAUNCH_CHECK("local_map");
+  return TDR_OK;
+}
+extern "C" int tdr_k_local_map_polar(const tdr_map_desc* map, const float* tab, int nb, int nr, float cx, float cy,
+                                     float scale, float res, float* dists_out, uint8_t* mask_out, void* stream) {
+  return launch_local_map(true, map, tab, nb, nr, cx, cy, scale, res, dists_out, mask_out, stream);
+}
+extern "C" int tdr_k_local_map_cart(const tdr_map_desc* map, int rows, int cols, float cx, float cy, float rot,
+                                    float res, float* dists_out, uint8_t* mask_out, void* stream) {
+  return launch_local_map(false, map, nullptr, rows, cols, cx, cy, rot, res, dists_out, mask_out, stream);
+}
+
 // Gates of state_particle.cpp:163-176.  scale_lo / scale_hi = pow(10, scale_log_min/max) evaluated on the host
 // (glibc pow, like the reference).
 struct GateArgs {

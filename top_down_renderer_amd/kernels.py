@@ -124,6 +124,22 @@ class HipKernels:
                                          _ptr(img), _ptr(pk), _ptr(self._raster_workspace(n)), self.stream()))
         return img, pk
 
+    # ---- getLocalMap materialised ----------------------------------------------------------------------------
+    def local_map(self, m, polar, cx, cy, scale_or_rot, res, rows=None, cols=None):
+        """(dists (ncls, rows*cols) float32, mask (rows*cols,) uint8) device tensors: the window of one pose
+        (top_down_map_polar.cpp:21-53 / top_down_map.cpp:429-459)."""
+        if polar:
+            rows, cols = m.nb, m.nr
+        d = self.empty((m.ncls, rows * cols))
+        k = self.empty((rows * cols,), torch.uint8)
+        if polar:
+            check(self.lib.tdr_k_local_map_polar(C.byref(m.desc), _ptr(m.tab), rows, cols, C.c_float(cx), C.c_float(cy),
+                                                 C.c_float(scale_or_rot), C.c_float(res), _ptr(d), _ptr(k), self.stream()))
+        else:
+            check(self.lib.tdr_k_local_map_cart(C.byref(m.desc), rows, cols, C.c_float(cx), C.c_float(cy),
+                                                C.c_float(scale_or_rot), C.c_float(res), _ptr(d), _ptr(k), self.stream()))
+        return d, k
+
     def pack_scan(self, img, ncls, nb, nr):
         pk = self.empty((nr * nb * self.lib.tdr_rec_floats(ncls),))
         check(self.lib.tdr_k_pack_scan(_ptr(img), ncls, nb, nr, _ptr(pk), self.stream()))

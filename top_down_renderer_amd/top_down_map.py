@@ -97,6 +97,15 @@ class TopDownMap:
                 out.append(cls)
         return out
 
+    # top_down_map.cpp:429-459
+    def getLocalMap(self, center, rot, res, shape):
+        """Cartesian window of one pose: (dists [ncls] list of (rows, cols) arrays, mask (rows, cols) uint8, 1 = unknown
+        / outside).  `shape` = (rows, cols) stands for the sizes the reference reads off the caller's arrays."""
+        rows, cols = int(shape[0]), int(shape[1])
+        d, k = self.k.local_map(self.dev, False, float(center[0]), float(center[1]), float(rot), float(res), rows, cols)
+        d = d.cpu().numpy().reshape(self.dev.ncls, cols, rows)
+        return [d[c].T.copy() for c in range(self.dev.ncls)], k.cpu().numpy().reshape(cols, rows).T.copy()
+
     # --- window (image) shape of the scan the filter scores against -------------------------------------------------
     polar = False
 
@@ -154,6 +163,14 @@ class TopDownMapPolar(TopDownMap):
     def samplePtsPolar(self, shape, ang_res):
         """top_down_map_polar.cpp:7-19; shape = (theta bins, range bins)."""
         self.k.set_polar_table(self.dev, int(shape[0]), int(shape[1]), float(ang_res))
+
+    # top_down_map_polar.cpp:21-53 (and the 3-argument overload with scale = 1, :78-81)
+    def getLocalMap(self, center, scale_or_res, res=None):   # noqa: D401  (getLocalMap(center, scale, res) / (center, res))
+        scale, res = (1.0, scale_or_res) if res is None else (scale_or_res, res)
+        d, k = self.k.local_map(self.dev, True, float(center[0]), float(center[1]), float(scale), float(res))
+        nb, nr = self.nb, self.nr
+        d = d.cpu().numpy().reshape(self.dev.ncls, nr, nb)
+        return [d[c].T.copy() for c in range(self.dev.ncls)], k.cpu().numpy().reshape(nr, nb).T.copy()
 
     polar = True
 
