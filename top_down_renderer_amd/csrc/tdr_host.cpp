@@ -45,6 +45,9 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;             // owns device memory
+  DevBuf& operator=(const DevBuf&) = delete;
   int resize(size_t count) {
     if (count <= n) return TDR_OK;
     if (p) (void)hipFree(p);
