@@ -169,7 +169,7 @@ int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int ro
 /* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, TDR_UW_INFO_FLOATS floats: the first 8
  * are {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}, the rest is scratch for
  * the multi-workgroup reductions).  The result is a pure function of (raw_w, last_dist, n). */
-#define TDR_UW_INFO_FLOATS 8192
+#define TDR_UW_INFO_FLOATS 65536
 int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out, float* info_out,
                          void* stream);
 

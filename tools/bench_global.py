@@ -27,7 +27,7 @@ def main():
         raw[rng.random(n) < 0.05] = np.nan
         ld = np.abs(rng.normal(0, 1, n)).astype(np.float32)
         raw_d, ld_d = k.to_device(raw), k.to_device(ld)
-        w, runmax, info = k.zeros((n,)), k.zeros((n,)), k.zeros((8192,))
+        w, runmax, info = k.zeros((n,)), k.zeros((n,)), k.zeros((65536,))
         nl = n // world
         idx = k.zeros((nl,), torch.int32)
         src = k.to_device(rng.random((world * 7 * nl,)).astype(np.float32))

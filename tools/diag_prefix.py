@@ -9,7 +9,7 @@ for n in [100_000, 800_000]:
     raw = np.exp(rng.normal(0, 1.5, n)).astype(np.float32)
     raw[rng.random(n) < 0.05] = np.nan
     ld = np.abs(rng.normal(0, 1, n)).astype(np.float32)
-    w, runmax, info = k.zeros((n,)), k.zeros((n,)), k.zeros((8192,))
+    w, runmax, info = k.zeros((n,)), k.zeros((n,)), k.zeros((65536,))
     k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
     for rep in range(3):
         k.prefix(w, n, runmax)

@@ -60,6 +60,11 @@ int tdr_fail(int code, const char* fmt, ...);
   } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// tdr_prefix.hip: final value of a serial float32 chain over the raw weights (kind 0: sum of the non-NaN weights;
+// kind 1: float-accumulated squared deviations of the weights below *mean_dev), see there
+int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n, float* total_out, void* workspace,
+                    hipStream_t st);
 // a record with a spare slot (ncls + 2 <= rf) carries `known` twice: slot rf-2 pairs with a constant 1 of the scan record
 __host__ __device__ inline bool tdr_has_kslot(int ncls, int rf) { return ncls + 2 <= rf; }
 #endif  // TDR_COMMON_H_

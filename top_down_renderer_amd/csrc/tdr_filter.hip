@@ -288,9 +288,11 @@ __global__ __launch_bounds__(1024) void update_weights_kernel(const float* __res
   }
 }
 
-// Multi-workgroup form of the same statistics for large n: five grid-wide passes, each workgroup reducing its own
-// contiguous chunk in a fixed order and every workgroup re-reducing the G per-workgroup partials in index order, so
-// the result is again a pure function of (raw_w, last_dist, n) — identical on every rank — without grid barriers.
+// Multi-workgroup form for large n: grid-wide passes, each workgroup reducing its own contiguous chunk in a fixed order
+// and every workgroup re-reducing the G per-workgroup partials in index order, so the result is again a pure function
+// of (raw_w, last_dist, n) — identical on every rank — without grid barriers.  Here the reference's two SERIAL float
+// chains (`sum`, `bottom_stddev`, :108-126) are reproduced exactly (tdr_chain_total): at these sizes their own rounding,
+// ~sqrt(n) 2^-24, is larger than the 1e-5 weight tolerance, and it ends up in the value written into NaN particles.
 // Scratch lives behind the 8 info floats (TDR_UW_INFO_FLOATS in total).
 #define UW_G 256
 struct UwScratch {
@@ -335,37 +337,35 @@ __global__ __launch_bounds__(256) void uw_pass1(const float* __restrict__ raw, i
   const long long tc = block_sum_ll(c, shl);
   if (threadIdx.x == 0) { s1->a[blockIdx.x] = ts; s1->b[blockIdx.x] = (double)tc; }
 }
-// pass 2: squared deviations of the weights below the mean (:118-125)
+// The serial float chains of :108-126 (`sum`, `bottom_stddev`) evaluated exactly by tdr_chain_total land here.
+struct UwExact {
+  float sum, mean, bsum, pad;
+};
+// pass 2: the mean (:117) from the exact `sum` chain; count of the weights below it (:118-125)
 __global__ __launch_bounds__(256) void uw_pass2(const float* __restrict__ raw, int64_t n, const UwScratch* s1,
-                                                UwScratch* s2) {
-  __shared__ double shd[4];
+                                                UwScratch* s2, UwExact* ex) {
   __shared__ long long shl[4];
-  const float sum = (float)uw_total(s1->a);
-  const float mean = sum / (float)(long long)uw_total(s1->b);
+  const float mean = ex->sum / (float)(long long)uw_total(s1->b);
   int64_t lo, hi;
   uw_chunk(n, lo, hi);
-  double bs = 0;
   long long cu = 0;
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
     const float v = raw[i];
-    if (!isnan(v) && v < mean) {
-      const double d = (double)(v - mean);
-      bs += d * d;
-      cu++;
-    }
+    if (!isnan(v) && v < mean) cu++;
   }
-  const double tb = block_sum_d(bs, shd);
   const long long tc = block_sum_ll(cu, shl);
-  if (threadIdx.x == 0) { s2->a[blockIdx.x] = tb; s2->b[blockIdx.x] = (double)tc; }
+  if (threadIdx.x == 0) {
+    s2->b[blockIdx.x] = (double)tc;
+    if (blockIdx.x == 0) ex->mean = mean;   // every workgroup computed the same value
+  }
 }
 // pass 3: NaN fill / all-ones fallback (:129-134) and the first normalisation sum
-__global__ __launch_bounds__(256) void uw_pass3(const float* __restrict__ raw, int64_t n, const UwScratch* s1,
+__global__ __launch_bounds__(256) void uw_pass3(const float* __restrict__ raw, int64_t n, const UwExact* ex,
                                                 const UwScratch* s2, UwScratch* s3, float* __restrict__ w) {
   __shared__ double shd[4];
-  const float sum = (float)uw_total(s1->a);
-  const float mean = sum / (float)(long long)uw_total(s1->b);
+  const float sum = ex->sum, mean = ex->mean;
   const long long num_under = (long long)uw_total(s2->b);
-  const float bottom = sqrtf((float)uw_total(s2->a) / (float)num_under);
+  const float bottom = sqrtf(ex->bsum / (float)num_under);   // :126
   const bool fallback = (sum == 0.f || num_under < 1);
   const float fill = mean - bottom;
   int64_t lo, hi;
@@ -428,14 +428,13 @@ __global__ __launch_bounds__(256) void uw_pass5(int64_t n, const UwScratch* s4, 
   }
 }
 __global__ __launch_bounds__(256) void uw_pass6(int64_t n, const UwScratch* s1, const UwScratch* s2,
-                                                const UwScratch* s5, float* info) {
+                                                const UwScratch* s5, const UwExact* ex, float* info) {
   __shared__ float sb[UW_G];
   __shared__ long long si[UW_G];
   for (int g = threadIdx.x; g < UW_G; g += blockDim.x) { sb[g] = (float)s5->a[g]; si[g] = (long long)s5->b[g]; }
-  const float sum = (float)uw_total(s1->a);
+  const float sum = ex->sum, mean = ex->mean;
   const long long nv = (long long)uw_total(s1->b), nu = (long long)uw_total(s2->b);
-  const float mean = sum / (float)nv;
-  const float bottom = sqrtf((float)uw_total(s2->a) / (float)nu);
+  const float bottom = sqrtf(ex->bsum / (float)nu);
   if (threadIdx.x != 0) return;
   float best = -INFINITY;
   long long besti = 0x7fffffffffffffffll;
@@ -458,17 +457,28 @@ extern "C" int tdr_k_update_weights(const float* raw_w, const float* last_dist, 
     LAUNCH_CHECK("update_weights");
     return TDR_OK;
   }
-  static_assert(8 * sizeof(float) + 5 * sizeof(UwScratch) + 64 <= TDR_UW_INFO_FLOATS * sizeof(float), "info scratch");
+  // scratch behind the 8 info floats: 5 x UwScratch, UwExact, then the chunk headers of the two exact chains
+  constexpr size_t kFixed = 8 * sizeof(float) + 64 + 5 * sizeof(UwScratch) + sizeof(UwExact) + 64;
+  static_assert(kFixed + 32 * 1024 <= TDR_UW_INFO_FLOATS * sizeof(float), "info scratch");
   UwScratch* sc = reinterpret_cast<UwScratch*>(
       (reinterpret_cast<uintptr_t>(info_out + 8) + 63) & ~(uintptr_t)63);
+  UwExact* ex = reinterpret_cast<UwExact*>(sc + 5);
+  void* chain_ws = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ex + 1) + 63) & ~(uintptr_t)63);
+  const size_t chain_room = TDR_UW_INFO_FLOATS * sizeof(float) - kFixed;
+  if ((size_t)tdr_prefix_workspace_bytes(n) > chain_room)
+    return fail(TDR_ERR_ARG, "update_weights: n = %lld needs more than TDR_UW_INFO_FLOATS of scratch", (long long)n);
   hipLaunchKernelGGL(uw_pass1, dim3(UW_G), dim3(256), 0, s, raw_w, n, sc + 0);
-  hipLaunchKernelGGL(uw_pass2, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwScratch*)(sc + 0), sc + 1);
-  hipLaunchKernelGGL(uw_pass3, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwScratch*)(sc + 0),
-                     (const UwScratch*)(sc + 1), sc + 2, w_out);
+  int rc = tdr_chain_total(raw_w, nullptr, 0, n, &ex->sum, chain_ws, s);                     // `sum` (:108-116)
+  if (rc) return rc;
+  hipLaunchKernelGGL(uw_pass2, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwScratch*)(sc + 0), sc + 1, ex);
+  rc = tdr_chain_total(raw_w, &ex->mean, 1, n, &ex->bsum, chain_ws, s);                      // `bottom_stddev` (:118-125)
+  if (rc) return rc;
+  hipLaunchKernelGGL(uw_pass3, dim3(UW_G), dim3(256), 0, s, raw_w, n, (const UwExact*)ex, (const UwScratch*)(sc + 1),
+                     sc + 2, w_out);
   hipLaunchKernelGGL(uw_pass4, dim3(UW_G), dim3(256), 0, s, last_dist, n, (const UwScratch*)(sc + 2), sc + 3, w_out);
   hipLaunchKernelGGL(uw_pass5, dim3(UW_G), dim3(256), 0, s, n, (const UwScratch*)(sc + 3), sc + 4, w_out);
   hipLaunchKernelGGL(uw_pass6, dim3(1), dim3(256), 0, s, n, (const UwScratch*)(sc + 0), (const UwScratch*)(sc + 1),
-                     (const UwScratch*)(sc + 4), info_out);
+                     (const UwScratch*)(sc + 4), (const UwExact*)ex, info_out);
   LAUNCH_CHECK("update_weights(multi)");
   return TDR_OK;
 }

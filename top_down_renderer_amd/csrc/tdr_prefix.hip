@@ -795,6 +795,255 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_fill_kernel(const floa
   }
 }
 
+// ---- totals of serial float32 chains with double addends ---------------------------------------------------------------
+// ParticleFilter::update's statistics are serial chains too (src/particle_filter.cpp:108-126):
+//     sum           : float += float            over the valid (non-NaN) raw weights
+//     bottom_stddev : float += pow(w - mean, 2)  = (float)((double)acc + x), x an exact double, over the weights below the mean
+// Only their FINAL values are used.  Both are evaluated by the scan of this file with the addend as a double made on the
+// fly from (raw, mean): for a float chain r <- (float)((double)r + x) the step is x first rounded to the double grid of
+// the sum's binade — 2^-29 ulp(r), and because R is an integer that rounding does not depend on R — and then to the
+// float grid with the parity rule of pfx_classify.  (A float addend lies on the double grid or is far below half an
+// ulp, so the `sum` chain is the plain float chain.)  Chunks as above: double sum -> predicted binade + parity summary
+// -> one walking workgroup; no fill pass.
+struct ChainSrc {
+  const float* raw;    // raw weights
+  const float* mean;   // device scalar (kind 1)
+  int kind;            // 0: valid raw weights; 1: squared deviations of the weights below the mean
+};
+__device__ __forceinline__ double chain_addend(const ChainSrc& s, long long i, float mean) {
+  const float v = s.raw[i];
+  if (s.kind == 0) return (v != v) ? 0.0 : (double)v;                       // :111-115
+  if (v != v || !(v < mean)) return 0.0;                                    // :120
+  const double d = (double)(v - mean);                                      // float subtraction, then pow(double, 2)
+  return d * d;
+}
+__device__ __forceinline__ void chain_classify(double x, unsigned re, unsigned& f, bool& tie, bool& bad) {
+  const double scale = __longlong_as_double((long long)(1023 + 150 - (int)re) << 52);   // 2^(150 - re) = 1/u
+  const double t = x * scale;
+  bad = !(x >= 0.0) || !(t < 4194304.0);                 // negative / NaN / inf, or not small against the sum: real add
+  const double tg = (t + 8388608.0) - 8388608.0;         // t on the double grid of [2^23, 2^24): multiples of 2^-29
+  const double fl = floor(tg);
+  const double fr = tg - fl;
+  tie = fr == 0.5;
+  f = (unsigned)fl + (fr > 0.5 ? 1u : 0u);
+  if (bad) { f = 0; tie = false; }
+}
+#define CHAIN_K (PFXM_CHUNK / PFXW_THREADS)
+#ifndef CHAIN_HEAD
+#define CHAIN_HEAD 1024   // leading addends added one by one (<= PFXM_CHUNK)
+#endif
+__device__ __forceinline__ void chain_load(const ChainSrc& s, long long lo, int cnt, float mean, double (&xv)[CHAIN_K]) {
+  const int t0 = threadIdx.x * CHAIN_K;
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) xv[k] = (t0 + k < cnt) ? chain_addend(s, lo + t0 + k, mean) : 0.0;
+}
+__global__ __launch_bounds__(PFXW_THREADS) void chain_sum_kernel(ChainSrc s, int64_t n, PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXW_THREADS / 64];
+  const long long lo = (long long)blockIdx.x * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  const float mean = s.kind ? *s.mean : 0.f;
+  double xv[CHAIN_K];
+  chain_load(s, lo, cnt, mean, xv);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) acc += xv[k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < PFXW_THREADS / 64; k++) t += shd[k];
+    ch[blockIdx.x].sum = t;
+  }
+}
+__global__ __launch_bounds__(PFXW_THREADS) void chain_summary_kernel(ChainSrc s, int64_t n, PfxChunk* __restrict__ ch) {
+  __shared__ double shd[PFXW_THREADS / 64];
+  __shared__ PfxPair shp[PFXW_THREADS / 64];
+  __shared__ int s_bad;
+  const int c = blockIdx.x;
+  const long long lo = (long long)c * PFXM_CHUNK;
+  const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < c; j += PFXW_THREADS) acc += ch[j].sum;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  double before = 0.0;
+  for (int k = 0; k < PFXW_THREADS / 64; k++) before += shd[k];
+  const float r_pred = (float)before, r_end = (float)(before + ch[c].sum);
+  const unsigned pb = __float_as_uint(r_pred), eb = __float_as_uint(r_end);
+  const int re = (pb >> 23) & 0xFF;
+  const bool plausible = (pb >> 31) == 0 && re >= PFXM_RE_MIN && re <= PFXM_RE_MAX && (int)((eb >> 23) & 0xFF) == re && (eb >> 31) == 0;
+  if (!plausible) {
+    if (threadIdx.x == 0) { ch[c].re = -1; ch[c].d0 = 0u; ch[c].d1 = 0u; }
+    return;
+  }
+  const float mean = s.kind ? *s.mean : 0.f;
+  double xv[CHAIN_K];
+  chain_load(s, lo, cnt, mean, xv);
+  PfxPair mine = {0u, 0u};
+  bool anybad = false;
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) {
+    unsigned f; bool tie, bad;
+    chain_classify(xv[k], (unsigned)re, f, tie, bad);
+    anybad |= bad;
+    mine = pfx_compose(mine, pfx_element_pair(f, tie));
+  }
+  if (anybad) s_bad = 1;
+  PfxPair total;
+  (void)pfx_pair_scan<PFXW_THREADS>(mine, shp, total);
+  if (threadIdx.x == 0) {
+    const bool ok = s_bad == 0 && total.a0 < (1u << 24) && total.a1 < (1u << 24);
+    ch[c].re = ok ? re : -1;
+    ch[c].d0 = total.a0;
+    ch[c].d1 = total.a1;
+  }
+}
+// one chunk on the spot: like pfx_walk_chunk, without outputs and with the real additions done in double
+__device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo, int cnt, float mean, float& r,
+                                                 int pos_start) {
+  __shared__ PfxPair shp[PFXW_THREADS / 64];
+  __shared__ int s_bad, s_cross, s_nz;
+  __shared__ unsigned s_state;
+  __shared__ double s_xstop;
+  const int tid = threadIdx.x, t0 = tid * CHAIN_K;
+  double xv[CHAIN_K];
+  chain_load(s, lo, cnt, mean, xv);
+  int pos = pos_start;
+  while (pos < cnt) {
+    const unsigned rb = __float_as_uint(r);
+    const unsigned re = rb >> 23;   // sign included
+    pfx_sync();
+    if (tid == 0) { s_bad = cnt; s_cross = cnt; s_nz = cnt; s_xstop = 0.0; s_state = 0u; }
+    pfx_sync();
+    if (!(re >= PFXM_RE_MIN && re <= PFXM_RE_MAX)) {
+      // zero / tiny / huge / inf / NaN running sum: zero addends change nothing, the next other one is really added
+      int first = cnt;
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && xv[k] != 0.0) first = min(first, li);
+      }
+      if (first < cnt) atomicMin(&s_nz, first);
+      pfx_sync();
+      const int stop = s_nz;
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++)
+        if (t0 + k == stop) s_xstop = xv[k];
+      pfx_sync();
+      if (stop < cnt) r = (float)((double)r + s_xstop);
+      pos = stop < cnt ? stop + 1 : cnt;
+      continue;
+    }
+    const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+    unsigned f[CHAIN_K];
+    unsigned tiebits = 0u;
+    PfxPair mine = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      const int li = t0 + k;
+      bool bad, tie;
+      chain_classify(xv[k], re, f[k], tie, bad);
+      if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
+      if (bad) atomicMin(&s_bad, li);
+      tiebits |= tie ? (1u << k) : 0u;
+      mine = pfx_compose(mine, pfx_element_pair(f[k], tie));
+    }
+    PfxPair total;
+    const PfxPair ex = pfx_pair_scan<PFXW_THREADS>(mine, shp, total);
+    unsigned st[CHAIN_K];
+    {
+      unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);
+      int first = cnt;
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
+        st[k] = state;
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && state >= (1u << 24)) first = min(first, li);
+      }
+      if (first < cnt) atomicMin(&s_cross, first);
+    }
+    pfx_sync();
+    const int stop = min(s_bad, s_cross);
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      const int li = t0 + k;
+      if (li >= pos && li == stop - 1) s_state = st[k];
+      if (li == stop) s_xstop = xv[k];
+    }
+    pfx_sync();
+    if (stop > pos) r = __uint_as_float((re << 23) | (s_state & 0x7FFFFFu));
+    if (stop < cnt) {
+      r = (float)((double)r + s_xstop);   // one real addition, in the reference's types
+      pos = stop + 1;
+    } else {
+      pos = cnt;
+    }
+  }
+}
+__global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, int64_t n, const PfxChunk* __restrict__ ch,
+                                                                 int nch, float* __restrict__ total_out) {
+  __shared__ int sm_re[PFXW_BLOCK];
+  __shared__ unsigned sm_d0[PFXW_BLOCK], sm_d1[PFXW_BLOCK];
+  const float mean = s.kind ? *s.mean : 0.f;
+  // head: the sum of unnormalised weights crosses a binade every time it doubles — about ten times within the first
+  // thousand addends — so those are added one by one by a single thread out of LDS
+  __shared__ double head[CHAIN_HEAD];
+  __shared__ float s_head_r;
+  const int hn = (int)min((long long)CHAIN_HEAD, (long long)n);
+  for (int t = threadIdx.x; t < hn; t += PFXW_THREADS) head[t] = chain_addend(s, t, mean);
+  pfx_sync();
+  if (threadIdx.x == 0) {
+    float run = 0.f;
+    for (int t = 0; t < hn; t++) run = (float)((double)run + head[t]);
+    s_head_r = run;
+  }
+  pfx_sync();
+  float r = s_head_r;   // workgroup-uniform
+  for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
+    pfx_sync();
+    for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXW_THREADS) {
+      const PfxChunk x = ch[cb + t];
+      sm_re[t] = x.re; sm_d0[t] = x.d0; sm_d1[t] = x.d1;
+    }
+    pfx_sync();
+    const int ce = min(nch, cb + PFXW_BLOCK);
+    for (int c = cb; c < ce; c++) {
+      const unsigned rb = __float_as_uint(r);
+      const int re = (int)(rb >> 23);
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      const unsigned D = (R & 1u) ? sm_d1[c - cb] : sm_d0[c - cb];
+      if (c > 0 && sm_re[c - cb] == re && R + D < (1u << 24)) {
+        r = __uint_as_float(((unsigned)re << 23) | ((R + D) & 0x7FFFFFu));
+      } else {
+        const long long lo = (long long)c * PFXM_CHUNK;
+        chain_walk_chunk(s, lo, (int)min((long long)PFXM_CHUNK, (long long)n - lo), mean, r, c == 0 ? hn : 0);
+      }
+    }
+  }
+  if (threadIdx.x == 0) *total_out = r;
+}
+// raw: [n] raw weights; kind 0: total = serial float sum of the non-NaN weights; kind 1: total = serial
+// float-accumulated sum of pow(w - *mean_dev, 2) over the non-NaN weights below *mean_dev.  workspace: chunk headers,
+// tdr_prefix_workspace_bytes(n).  total_out: one device float.
+int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n, float* total_out, void* workspace,
+                    hipStream_t st) {
+  const int64_t nch64 = cdiv(n, (int64_t)PFXM_CHUNK);
+  if (nch64 > (1 << 24)) return fail(TDR_ERR_ARG, "chain_total: n too large");
+  const int nch = (int)nch64;
+  PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
+  ChainSrc s{raw, mean_dev, kind};
+  hipLaunchKernelGGL(chain_sum_kernel, dim3(nch), dim3(PFXW_THREADS), 0, st, s, n, ch);
+  hipLaunchKernelGGL(chain_summary_kernel, dim3(nch), dim3(PFXW_THREADS), 0, st, s, n, ch);
+  hipLaunchKernelGGL(chain_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, s, n, (const PfxChunk*)ch, nch, total_out);
+  return TDR_OK;
+}
+
 // Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
 // 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 53 / 74 / 101):
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below

@@ -135,7 +135,7 @@ class ParticleFilter:
         self.raw_w = k.zeros((cap,))
         self.idx = k.zeros((cap,), torch.int32)
         self.perm = None
-        self.info = k.zeros((8192,))   # TDR_UW_INFO_FLOATS
+        self.info = k.zeros((65536,))   # TDR_UW_INFO_FLOATS
         self.weights_ = k.zeros((N,))
         self.runmax = k.zeros((N,))
         if self.comm.world > 1:
