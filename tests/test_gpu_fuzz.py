@@ -186,3 +186,33 @@ def test_random_cartesian_against_oracle(env, oracle, seed):
     f.set_states(st)
     f.update(r.last_scan(), None, cfg.res)
     _assert_weights(f.raw_weights(), ref, 3e-5)   # cos/sin of theta: last-ulp differences move a few samples
+
+
+@pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 5)))
+def test_random_statistics_serial_chains_bit_exact(env, oracle, seed):
+    """Above 32 k particles the weight statistics reproduce the reference's serial float chains (`sum`, `mean`,
+    `bottom_stddev`, particle_filter.cpp:108-126) bit for bit: random raw-weight vectors of random length."""
+    pkg, k = env
+    rng = np.random.default_rng(31000 + seed)
+    f32 = np.float32
+    n = int(rng.integers(32769, 400_000))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        raw = np.exp(rng.normal(0, rng.uniform(0.1, 5), n))
+    elif kind == 1:
+        raw = rng.integers(1, 1 << int(rng.integers(2, 14)), n) * 2.0 ** -int(rng.integers(0, 20))
+    elif kind == 2:
+        raw = 1.0 / (rng.random(n) * rng.uniform(0.1, 50) + 0.15)          # 1 / (cost + regularisation)
+    elif kind == 3:
+        raw = rng.choice(rng.random(int(rng.integers(1, 40))) * 7, n)      # few distinct values: ties in bulk
+    else:
+        raw = rng.random(n) * 10.0 ** rng.uniform(-35, 30)
+    raw = raw.astype(f32)
+    raw[rng.random(n) < rng.choice([0.0, 0.01, 0.3, 0.9])] = np.nan
+    ld = rng.random(n).astype(f32)
+    w, info = k.zeros((n,)), k.zeros((65536,))
+    k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
+    with np.errstate(all="ignore"):
+        ref, best, stats = oracle.update_weights(raw, ld)
+    assert np.array_equal(info[1:4].cpu().numpy(), np.asarray(stats[:3], f32), equal_nan=True)
+    assert np.allclose(w.cpu().numpy(), ref, rtol=3e-6, atol=0, equal_nan=True)
