@@ -712,7 +712,8 @@ typedef float tdr_f4 __attribute__((ext_vector_type(4)));
 static_assert(INITM_TILES * 16 >= INIT_MAXROT || INIT_MAXROT == 48, "rotation tiles");
 
 // UNITW: all class weights are equal — a common factor does not move the minimum, so the distances go in unweighted.
-template <bool USCALE, bool UNITW>
+// SEVEN: 7 classes — slot 6 of the record is a seventh distance (no spare slot), slot 7 still `known` / the scan's sum.
+template <bool USCALE, bool UNITW, bool SEVEN>
 __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* __restrict__ inexact) {
   constexpr int RF = 8;
   extern __shared__ uint4 ring16[];   // [2*nb] packed scan records as 8 x f16 (row r and r+nb hold scan row r) + 1 zero row
@@ -743,9 +744,9 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
     sh[T] = m < nrot ? a.shift[m] : -1;
   }
   if (threadIdx.x == 0) ring16[zero_row] = make_uint4(0u, 0u, 0u, 0u);
-  float wc[6];
+  float wc[7];
 #pragma unroll
-  for (int c = 0; c < 6; c++) wc[c] = c < a.ncls ? (float)(0.01 * (double)a.fp.class_weights[c]) : 0.f;
+  for (int c = 0; c < 7; c++) wc[c] = c < a.ncls ? (float)(0.01 * (double)a.fp.class_weights[c]) : 0.f;
   tdr_f4 accC[INITM_TILES], accN[INITM_TILES];
 #pragma unroll
   for (int T = 0; T < INITM_TILES; T++) { accC[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; accN[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; }
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
     for (int t = threadIdx.x; t < a.nb; t += 256) {
       const float4 v0 = srow[2 * t], v1 = srow[2 * t + 1];
       big |= v0.x > 2048.f || v0.y > 2048.f || v0.z > 2048.f || v0.w > 2048.f || v1.x > 2048.f || v1.y > 2048.f ||
-             v1.w > 2048.f;
+             v1.z > 2048.f || v1.w > 2048.f;
       union { tdr_h2 h[4]; uint4 u; } pk;
       pk.h[0] = __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y);
       pk.h[1] = __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w);
@@ -804,10 +805,10 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
       }
       if (!in) { m0 = make_float4(0.f, 0.f, 0.f, 0.f); m1 = m0; }
       known += m1.w;
-      float v[6] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y};
+      float v[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, SEVEN ? m1.z : 0.f, 0.f};
       if constexpr (!UNITW) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) v[c] *= wc[c];
+        for (int c = 0; c < 7; c++) v[c] *= wc[c];
       }
       union { tdr_h2 h[4]; tdr_h8 v8; } bh, bl, bn;
 #pragma unroll
@@ -816,9 +817,16 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
         bh.h[c] = hi;
         bl.h[c] = __builtin_amdgcn_cvt_pkrtz(v[2 * c] - (float)hi[0], v[2 * c + 1] - (float)hi[1]);
       }
-      bh.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
-      bl.h[3] = bh.h[3];
-      bn.h[0] = bh.h[3]; bn.h[1] = bh.h[3]; bn.h[2] = bh.h[3];
+      const tdr_h2 zero2 = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+      if constexpr (SEVEN) {
+        const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[6], 0.f);
+        bh.h[3] = hi;
+        bl.h[3] = __builtin_amdgcn_cvt_pkrtz(v[6] - (float)hi[0], 0.f);
+      } else {
+        bh.h[3] = zero2;
+        bl.h[3] = zero2;
+      }
+      bn.h[0] = zero2; bn.h[1] = zero2; bn.h[2] = zero2;
       bn.h[3] = __builtin_amdgcn_cvt_pkrtz(0.f, m1.w);
       union { uint4 u; tdr_h8 v8; } av[INITM_TILES];
 #pragma unroll
@@ -1060,17 +1068,27 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     const size_t lds = TDR_INIT_SCAN_LDS ? (size_t)2 * nb * rf * 4 : 0;
     const bool ks = tdr_has_kslot(map->ncls, rf), us = a.utab != nullptr;
     ia.only_if = nullptr;
-    if (rf == 8 && ks && init_use_mfma()) {
+    if (rf == 8 && (ks || map->ncls == 7) && init_use_mfma()) {
       // matrix-core pass first; the vector kernel below then runs only if a scan count did not fit f16
       int* d_inexact = d_nrot + 1;
       const size_t lds16 = ((size_t)2 * nb + 1) * 16;
       bool unitw = true;
       for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
       unitw &= fp->class_weights[0] > 0.f;
-      if (us && unitw) hipLaunchKernelGGL((score_init_mfma_kernel<true, true>), grid, dim3(256), lds16, s, ia, d_inexact);
-      else if (us) hipLaunchKernelGGL((score_init_mfma_kernel<true, false>), grid, dim3(256), lds16, s, ia, d_inexact);
-      else if (unitw) hipLaunchKernelGGL((score_init_mfma_kernel<false, true>), grid, dim3(256), lds16, s, ia, d_inexact);
-      else hipLaunchKernelGGL((score_init_mfma_kernel<false, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      const int variant = (us ? 4 : 0) | (unitw ? 2 : 0) | (ks ? 0 : 1);
+      switch (variant) {
+#define TDR_LAUNCH_MFMA(US, UW, SV) \
+  hipLaunchKernelGGL((score_init_mfma_kernel<US, UW, SV>), grid, dim3(256), lds16, s, ia, d_inexact); break;
+        case 0: TDR_LAUNCH_MFMA(false, false, false)
+        case 1: TDR_LAUNCH_MFMA(false, false, true)
+        case 2: TDR_LAUNCH_MFMA(false, true, false)
+        case 3: TDR_LAUNCH_MFMA(false, true, true)
+        case 4: TDR_LAUNCH_MFMA(true, false, false)
+        case 5: TDR_LAUNCH_MFMA(true, false, true)
+        case 6: TDR_LAUNCH_MFMA(true, true, false)
+        default: TDR_LAUNCH_MFMA(true, true, true)
+#undef TDR_LAUNCH_MFMA
+      }
       LAUNCH_CHECK("score_init_mfma");
       ia.only_if = d_inexact;
     }
