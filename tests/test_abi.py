@@ -56,6 +56,16 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.tdr_k_raster_polar(None, 4, 3, 10, C.c_float(1.0), C.c_float(0.1), None, 3, 16, 8, None, None, None, None) == -1
     assert lib.tdr_k_resample(C.c_void_p(8), 4, 4, C.c_float(0.5), 3, 2, C.c_void_p(8), None) == -1
     assert lib.tdr_k_prefix(None, 0, None, None, None) == -1
+    # maps beyond the 4 GiB the scoring loops address with 32-bit offsets are refused, not wrapped around
+    from top_down_renderer_amd import _lib
+    desc = _lib.MapDescC()
+    desc.rec, desc.ncls, desc.rows, desc.cols, desc.rec_floats, desc.resolution = 8, 6, 20000, 20000, 8, 1.0
+    fp = _lib.FilterParamsC()
+    fp.num_classes = 6
+    dummy = C.c_void_p(8)
+    assert lib.tdr_k_score_polar(C.byref(desc), dummy, dummy, 64, 16, C.c_float(1.0), C.byref(fp), dummy, 10, 10, None,
+                                 C.c_float(0.0), 0, dummy, dummy, None) == -1
+    assert b"4 GiB" in lib.tdr_last_error()
     assert lib.tdr_prefix_workspace_bytes(0) == 0 and lib.tdr_prefix_workspace_bytes(4097) == 64
 
 

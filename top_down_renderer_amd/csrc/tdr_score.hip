@@ -996,6 +996,17 @@ extern "C" int tdr_profile_score_ms(double* total_ms, int64_t* launches) {
   return TDR_OK;
 }
 
+// The scoring loops address map records with 32-bit byte offsets (v_mad_i32_i24 + 32-bit adds): the guarded record
+// grid must stay below 4 GiB (11 583^2 cells of 32 bytes) and a guarded row below 2^24 bytes.
+static int check_map_addressing(const tdr_map_desc* map, int rf, const char* who) {
+  const uint64_t row_bytes = (uint64_t)(map->cols + 2) * rf * 4;
+  const uint64_t total = row_bytes * (uint64_t)(map->rows + 2);
+  if (row_bytes >= (1u << 24) || total > 0xFFFFFFFFull)
+    return fail(TDR_ERR_ARG, "%s: map of %d x %d cells (%d-float records) exceeds the 4 GiB the kernels address", who,
+                map->rows, map->cols, rf);
+  return TDR_OK;
+}
+
 static int launch_score(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
   size_t lds = (size_t)2 * a.nb * rf * 4;
@@ -1034,6 +1045,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score: map record size %d != %d", map->rec_floats, rf);
   if ((size_t)2 * nb * rf * 4 > 64 * 1024) return fail(TDR_ERR_ARG, "score: nb too large for the LDS scan ring");
   if (!(map->resolution > 0.f)) return fail(TDR_ERR_ARG, "score: map resolution must be > 0");
+  if (int rc0 = check_map_addressing(map, rf, "score")) return rc0;
   hipStream_t s = (hipStream_t)stream;
 
   ScoreArgs a;
@@ -1146,6 +1158,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   if (fp->num_classes != map->ncls) return fail(TDR_ERR_ARG, "score_cart: class count mismatch");
   const int rf = tdr_rec_floats(map->ncls);
   if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score_cart: map record size mismatch");
+  if (int rc0 = check_map_addressing(map, rf, "score_cart")) return rc0;
   hipStream_t s = (hipStream_t)stream;
   CartArgs a;
   a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.resolution = map->resolution;
