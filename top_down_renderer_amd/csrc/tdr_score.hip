@@ -906,6 +906,8 @@ static bool init_use_mfma() {
   }();
   return v;
 }
+// the Cartesian kernel likes twice as many, shorter waves (A/B on MI355X, config 4: x1 183 ms, x2 179 ms, x4 177 ms)
+#define TDR_CART_WAVE_MUL 2
 static int64_t score_wave_target() {
   static int64_t v = [] {
     // tuning knob.  Many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms):
@@ -917,9 +919,9 @@ static int64_t score_wave_target() {
   }();
   return v;
 }
-static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks) {
+static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks, int target_mul = 1) {
   int64_t nbatches = cdiv(std::max<int64_t>(n, 1), 64);
-  int64_t want = std::max<int64_t>(1, cdiv(score_wave_target(), nbatches));  // enough waves to fill the chip
+  int64_t want = std::max<int64_t>(1, cdiv(score_wave_target() * target_mul, nbatches));  // enough waves to fill the chip
   nchunks = (int)std::min<int64_t>(nr, want);
   rpc = (int)cdiv(nr, nchunks);
   nchunks = (int)cdiv(nr, rpc);
@@ -1142,7 +1144,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
 extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n) {
   (void)rows;
   int cpc, nchunks;
-  choose_chunks(n, cols, cpc, nchunks);
+  choose_chunks(n, cols, cpc, nchunks, TDR_CART_WAVE_MUL);
   int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   return (size_t)((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64);
 }
@@ -1164,7 +1166,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.resolution = map->resolution;
   a.scan_pk = scan_pk; a.rows = rows; a.cols = cols; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm;
-  choose_chunks(n, cols, a.cpc, a.nchunks);
+  choose_chunks(n, cols, a.cpc, a.nchunks, TDR_CART_WAVE_MUL);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
