@@ -46,9 +46,20 @@ __device__ __forceinline__ int round_half_away_clamped(float x) {
   return r;
 }
 
+#ifdef TDR_SCORE_TIMELINE   // diagnostic build: start / end time stamp (100 MHz) of every workgroup
+#define TDR_TL_MAX (1 << 17)
+__device__ unsigned long long g_timeline[2 * TDR_TL_MAX];
+extern "C" int tdr_debug_read_timeline(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int NV4, int U, bool KSLOT, bool USCALE>
 __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
+#ifdef TDR_SCORE_TIMELINE
+  const unsigned tl_id = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0 && tl_id < TDR_TL_MAX) g_timeline[2 * tl_id] = wall_clock64();
+#endif
   extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]: row r and r+nb hold scan row r (no wrap arithmetic)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if TDR_XCD_SWIZZLE
@@ -179,6 +190,10 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
     for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
     o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
   }
+#ifdef TDR_SCORE_TIMELINE
+  __syncthreads();
+  if (threadIdx.x == 0 && tl_id < TDR_TL_MAX) g_timeline[2 * tl_id + 1] = wall_clock64();
+#endif
 }
 
 // K2c: Cartesian scoring (BASELINE config 4).  The reference's StateParticle never reaches the Cartesian
