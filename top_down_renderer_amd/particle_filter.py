@@ -78,12 +78,13 @@ class _Comm:
             self.dist = dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
-    def all_gather(self, out, inp):
-        """out: [world * len(inp)] contiguous, rank-major."""
+    def all_gather(self, out, inp, async_op=False):
+        """out: [world * len(inp)] contiguous, rank-major.  async_op: returns a handle whose wait() orders the current
+        stream behind the collective (RCCL runs it on its own stream, so kernels launched meanwhile overlap it)."""
         if self.world == 1:
             out.copy_(inp)
-        else:
-            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            return None
+        return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
     def broadcast(self, t, src=0):
         if self.world > 1:
@@ -262,6 +263,12 @@ class ParticleFilter:
             raw_glob, ld_glob = self.raw_glob, self.ld_glob
         else:
             raw_glob, ld_glob = self.raw_w, self.last_dist
+        # the pre-resample states are final now: their all-gather (28 B x N) runs behind the statistics and the running sum
+        st_work, sa = None, None
+        if comm.world > 1:
+            sa = self.st_all[: comm.world * 7 * nl]
+            self._st_send = self.st[:, :nl].contiguous().view(-1)
+            st_work = comm.all_gather(sa, self._st_send, async_op=True)
         k.update_weights(raw_glob, ld_glob, n, self.weights_, self.info)
         self._n_weights = n
 
@@ -284,8 +291,8 @@ class ParticleFilter:
         i0 = comm.rank * nl_new
         k.resample(self.runmax, n, n_new, float(shift), i0, i0 + nl_new, self.idx)
         if comm.world > 1:
-            sa = self.st_all[: comm.world * 7 * nl]
-            comm.all_gather(sa, self.st[:, :nl].contiguous().view(-1))
+            if st_work is not None:
+                st_work.wait()
             k.gather_states(sa, self.idx, nl_new, self.st_new, src_shard=nl)
             self._save_ml_state(sa, nl)
         else:
