@@ -168,7 +168,11 @@ int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int ro
 /* ---- ParticleFilter::update, weight statistics (src/particle_filter.cpp:107-147) ---------------------------- */
 /* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, TDR_UW_INFO_FLOATS floats: the first 8
  * are {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}, the rest is scratch for
- * the multi-workgroup reductions).  The result is a pure function of (raw_w, last_dist, n). */
+ * the multi-workgroup reductions and the chunk headers of the exact chains).  The result is a pure function of
+ * (raw_w, last_dist, n).  Above 32768 particles `sum`, `mean` and `bottom_stddev` are the reference's serial float32
+ * accumulations bit for bit (csrc/tdr_prefix.hip: tdr_chain_total); below, they are summed in double (the difference,
+ * ~sqrt(n) 2^-24 relative, stays under the 1e-5 weight tolerance there).  n is limited to what the scratch holds
+ * (~7 million). */
 #define TDR_UW_INFO_FLOATS 65536
 int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out, float* info_out,
                          void* stream);
