@@ -89,6 +89,34 @@ int main(int argc, char** argv) {
       dump(dir + "/out_window.bin", w.data(), w.size());
     }
 
+    // the Cartesian pair: ScanRenderer::renderSemanticTopDown (src/scan_renderer.cpp:55-78) and
+    // TopDownMap::getLocalMap(center, rot, res, ...) (src/top_down_map.cpp:429-459) on a 40 x 56 window
+    {
+      const int wr = 40, wc = 56;
+      Eigen::VectorXi lut = Eigen::VectorXi::Constant(256, -1);
+      for (int c = 0; c < ncls; c++) lut[c] = c;
+      ScanRenderer cart(lut);
+      pcl::PointCloud<PointType>::Ptr cl(new pcl::PointCloud<PointType>());
+      for (int i = 0; i < npts; i++) {
+        PointType p{};
+        p.x = pts[8 * i]; p.y = pts[8 * i + 1]; p.z = pts[8 * i + 2]; p.intensity = pts[8 * i + 4];
+        cl->push_back(p);
+      }
+      std::vector<Eigen::ArrayXXf> imgs, dists;
+      for (int c = 0; c < ncls; c++) { imgs.push_back(Eigen::ArrayXXf(wr, wc)); dists.push_back(Eigen::ArrayXXf(wr, wc)); }
+      cart.renderSemanticTopDown(cl, res, imgs);
+      Eigen::ArrayXXc wmask(wr, wc);
+      TopDownMap* base = map_;   // the Cartesian overload lives in the base class
+      base->getLocalMap(Eigen::Vector2f(st0[0].init_x_px, st0[0].init_y_px), 0.6f, 1.5f, dists, wmask);
+      std::vector<float> out((size_t)(2 * ncls + 1) * wr * wc);
+      for (int c = 0; c < ncls; c++) {
+        std::memcpy(out.data() + (size_t)c * wr * wc, imgs[c].data(), (size_t)wr * wc * sizeof(float));
+        std::memcpy(out.data() + (size_t)(ncls + c) * wr * wc, dists[c].data(), (size_t)wr * wc * sizeof(float));
+      }
+      for (int k = 0; k < wr * wc; k++) out[(size_t)2 * ncls * wr * wc + k] = (float)wmask(k);
+      dump(dir + "/out_cartesian.bin", out.data(), out.size());
+    }
+
     // StateParticle (include/top_down_render/state_particle.h:40-66): two particles sharing ONE generator, as in the
     // reference's filter; constructor draw, computeWeight, propagate with and without scale freeze
     std::vector<float> sp_out;

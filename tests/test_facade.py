@@ -167,6 +167,13 @@ def test_facade_session_matches_oracle(session_exe, oracle):
                                       np.float32(s0["dy_m"] * s0["scale"] + s0["init_y_px"]), s0["scale"], cfg.res)
     win = rd("out_window.bin", np.float32).reshape(cfg.ncls + 1, -1)
     assert np.array_equal(win[: cfg.ncls], d_o) and np.array_equal(win[cfg.ncls], k_o.astype(np.float32))
+    # Cartesian render + Cartesian getLocalMap through the C++ base classes
+    wr, wc = 40, 56
+    cart = rd("out_cartesian.bin", np.float32).reshape(2 * cfg.ncls + 1, wr * wc)
+    assert np.array_equal(cart[: cfg.ncls], oracle.raster_cart(sc.pts, cfg.res, sc.lut, cfg.ncls, wr, wc))
+    dc_o, kc_o = oracle.local_map_cart(om, float(st0["init_x_px"][0]), float(st0["init_y_px"][0]), 0.6, 1.5, wr, wc)
+    nbad = int((cart[cfg.ncls: 2 * cfg.ncls] != dc_o).any(0).sum()) + int((cart[2 * cfg.ncls] != kc_o).sum())
+    assert nbad <= wr * wc // 200 + 1        # cos / sin of the rotation: last-ulp differences may move a sample
     # StateParticle: two particles on one shared generator (constructor draw, propagate with / without scale freeze,
     # computeWeight, weight, lastDist, mlState, setScale)
     sp = rd("out_state_particles.bin", np.float32)
