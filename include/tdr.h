@@ -169,10 +169,9 @@ int tdr_init_particles_host(void* rng, const float* class_maps, int ncls, int ro
 /* raw_w, last_dist: [n] -> w_out [n] final normalised weights; info_out (device, TDR_UW_INFO_FLOATS floats: the first 8
  * are {argmax (as int bits), sum, mean, bottom_stddev, fallback, num_valid, num_under, 0}, the rest is scratch for
  * the multi-workgroup reductions and the chunk headers of the exact chains).  The result is a pure function of
- * (raw_w, last_dist, n).  Above 32768 particles `sum`, `mean` and `bottom_stddev` are the reference's serial float32
- * accumulations bit for bit (csrc/tdr_prefix.hip: tdr_chain_total); below, they are summed in double (the difference,
- * ~sqrt(n) 2^-24 relative, stays under the 1e-5 weight tolerance there).  n is limited to what the scratch holds
- * (~7 million). */
+ * (raw_w, last_dist, n).  `sum`, `mean` and `bottom_stddev` are the reference's serial float32 accumulations bit for
+ * bit at every n (csrc/tdr_prefix.hip: uw_small_kernel up to 32768 particles, tdr_chain_total above).  n is limited
+ * to what the scratch holds (~7 million). */
 #define TDR_UW_INFO_FLOATS 65536
 int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, float* w_out, float* info_out,
                          void* stream);
@@ -229,6 +228,16 @@ int tdr_profile_enable(int on);
 int tdr_profile_score_ms(double* total_ms, int64_t* launches);
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
+/* sinf / cosf on the device are the HOST libm's, bit for bit (csrc/tdr_sincosf.h: glibc >= 2.28's double-precision
+ * algorithm restated).  glibc ships two builds of it, plain and FMA-contracted, and picks one per CPU at load time;
+ * tdr_libm_variant() probes the host's sinf / cosf where the two differ: 1 = fused, 0 = plain, -1 = neither (an
+ * unknown libm: the kernels then use the fused form and indices derived from sin / cos are unpinned).
+ * tdr_libm_force_variant(0 | 1) overrides the probe (tests), -1 returns to it.  tdr_sincosf_host evaluates the
+ * restatement on the host (variant 0 | 1), tdr_k_selftest_sincos on the device with the variant in force. */
+int tdr_libm_variant(void);
+int tdr_libm_force_variant(int variant);
+int tdr_sincosf_host(const float* x, int64_t n, int variant, float* sin_out, float* cos_out);
+int tdr_k_selftest_sincos(const float* x, int64_t n, float* sin_out, float* cos_out, void* stream);
 /* Self-test hook: out[i] = the raster kernel's atan2f(y[i], x[i]) (bit-identical to glibc's atan2f). */
 int tdr_k_selftest_atan2(const float* y, const float* x, int64_t n, float* out, void* stream);
 
@@ -269,6 +278,7 @@ int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, 
 int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut,
                        int lut_size, int ncls, float resolution, int center_x, int center_y);
 int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res);                 /* top_down_map_polar.cpp:7-19 */
+int tdr_map_polar_shape(const tdr_map* m, int* nb, int* nr);   /* the shape of the last samplePtsPolar (0, 0 before) */
 int tdr_map_info(const tdr_map* m, int* ncls, int* rows, int* cols, float* resolution, int* have_map);
 int tdr_map_center(const tdr_map* m, int* center_x, int* center_y);                      /* mapCenter(), top_down_map.h:72 */
 /* getLocalMap (polar != 0: top_down_map_polar.cpp:21-53 with scale_or_rot = scale and the table of
@@ -300,7 +310,8 @@ int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n);
 int tdr_filter_get_states(tdr_filter* f, tdr_state* out, int64_t n);
 int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega);                /* particle_filter.cpp:86-92 */
 /* particle_filter.cpp:94-189.  scan_imgs: HOST [ncls][nb*nr] images or NULL (= renderer's last render, no host round
- * trip); n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
+ * trip), (nb, nr) = tdr_map_polar_shape — the caller checks its images against it, ncls*nb*nr floats are read;
+ * n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
 int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target);
 int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n);
 /* The per-particle surface of StateParticle (include/top_down_render/state_particle.h:42-53) on a filter:

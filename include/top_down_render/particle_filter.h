@@ -7,12 +7,15 @@
 //     (host code, 80 000 serial draws per step at 20 000 particles); configure() switches explicitly;
 //   * the mixture behind the adaptive particle count (:151-157, 245-318) is fitted on demand by computeGMM() with a
 //     deterministic EM (csrc/tdr_gmm.cpp) instead of cv::ml::EM in a detached thread; getGMM() returns it;
-//     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides; visualize() (OpenCV
-//     drawing) is not provided;
+//     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides;
+//   * visualize(cv::Mat&) (:373-423) is drawing code: with OpenCV present it draws the particles / mixture / best
+//     particle from a host copy of the states; without OpenCV it is a no-op (there is nothing to draw with);
 //   * top_down_geo is accepted and ignored like in the reference's score (src/state_particle.cpp:145-152).
 #ifndef PARTICLE_FILTER_H_
 #define PARTICLE_FILTER_H_
 
+#include <algorithm>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,7 +30,11 @@ class ParticleFilter {
     max_num_particles_ = N;
     tdr_filter_params c = to_tdr_params(params_, map_->numClasses());
     if (tdr_filter_create(map_->handle(), N, &c, seed, &f_) != TDR_OK) fail("ParticleFilter");
-    if (map_->haveMap()) check(tdr_filter_initialize_particles(f_), "initializeParticles");  // particle_filter.cpp:14-16
+    if (map_->haveMap() && tdr_filter_initialize_particles(f_) != TDR_OK) {   // particle_filter.cpp:14-16
+      const std::string msg = std::string("initializeParticles: ") + tdr_last_error();
+      tdr_filter_destroy(f_);   // the destructor does not run for a constructor that throws
+      throw std::runtime_error(msg);
+    }
   }
   ~ParticleFilter() { tdr_filter_destroy(f_); }
   ParticleFilter(const ParticleFilter&) = delete;
@@ -38,9 +45,17 @@ class ParticleFilter {
   }
   void update(std::vector<Eigen::ArrayXXf>& top_down_scan, std::vector<Eigen::ArrayXXf>& /*top_down_geo*/, float res) {  // :94-189
     if (top_down_scan.empty() || numParticles() == 0) return;
-    const size_t P = (size_t)top_down_scan[0].size();
     const int ncls = map_->numClasses();
     if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("update: fewer scan images than map classes");
+    // tdr_filter_update reads ncls * nb * nr floats, (nb, nr) = the shape given to samplePtsPolar: every image must
+    // have exactly that shape (the reference indexes the images with the table's size too, state_particle.cpp:178-188)
+    const Eigen::Vector2i shape = map_->polarShape();
+    const size_t P = (size_t)shape[0] * shape[1];
+    for (int c = 0; c < ncls; c++)
+      if (top_down_scan[c].rows() != shape[0] || top_down_scan[c].cols() != shape[1])
+        throw std::invalid_argument("update: scan image " + std::to_string(c) + " is " + std::to_string(top_down_scan[c].rows()) +
+                                    "x" + std::to_string(top_down_scan[c].cols()) + ", samplePtsPolar was given " +
+                                    std::to_string(shape[0]) + "x" + std::to_string(shape[1]));
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
     check(tdr_filter_update(f_, buf.data(), nullptr, res, next_count()), "update");
@@ -85,19 +100,69 @@ class ParticleFilter {
                                 map_center[1]), "updateMap");
   }
 
-  // updateMap (:320-341) for a class-index image in cv::Mat CV_8UC1 layout; the map's Params carry the flatten LUT
+  // updateMap (:320-341) for a class-index image in cv::Mat CV_8UC1 layout with an explicit flatten LUT
   void updateMap(const uint8_t* label_img, int img_h, int img_w, const std::vector<int>& flatten_lut,
                  const Eigen::Vector2i& map_center) {
     std::vector<int32_t> lut(flatten_lut.begin(), flatten_lut.end());
     check(tdr_filter_update_map_labels(f_, label_img, img_h, img_w, lut.data(), (int)lut.size(), map_->numClasses(),
                                        map_->resolution(), map_center[0], map_center[1]), "updateMap");
   }
-#ifdef CV_VERSION
-  void updateMap(const cv::Mat& map, const std::vector<int>& flatten_lut, const Eigen::Vector2i& map_center) {
-    cv::Mat m = map.isContinuous() ? map : map.clone();
-    updateMap(m.ptr<uint8_t>(), m.rows, m.cols, flatten_lut, map_center);
+  // The reference's signature (particle_filter.h:41, call site src/top_down_render.cpp:591): a class-index image, the
+  // flatten LUT comes from the map's Params like in TopDownMap::updateMap (src/top_down_map.cpp:146-148).
+  void updateMap(const cv::Mat& map, const Eigen::Vector2i& map_center) {
+    if (map.empty()) throw std::invalid_argument("updateMap: empty image");
+    const std::vector<int>& lut = map_->params().flatten_lut;
+    if (lut.empty()) throw std::invalid_argument("updateMap: the map's Params::flatten_lut is not set");
+    if (map.isContinuous()) return updateMap(map.ptr<uint8_t>(), map.rows, map.cols, lut, map_center);
+    std::vector<uint8_t> packed((size_t)map.rows * map.cols);
+    for (int r = 0; r < map.rows; r++) std::memcpy(packed.data() + (size_t)r * map.cols, map.ptr<uint8_t>(r), (size_t)map.cols);
+    updateMap(packed.data(), map.rows, map.cols, lut, map_center);
   }
+  // visualize (:373-423, call site src/top_down_render.cpp:431): particles as red arrows (green dots when outside the
+  // image), the mixture of the last computeGMM as blue ellipses, the max-likelihood particle as a blue arrow.
+  void visualize(cv::Mat& img) {
+#ifdef TDR_HAVE_OPENCV
+    const int H = img.size().height, W = img.size().width;
+    for (const State& p : states()) {
+      const float x = p.dx_m * p.scale + p.init_x_px, y = p.dy_m * p.scale + p.init_y_px;   // mlState (:98-102)
+      cv::Point pt((int)x, (int)((float)H - y));
+      if (pt.x < 0 || pt.x > W || pt.y < 0 || pt.y > H) {
+        pt.x = std::min(std::max(pt.x, 5), W - 5);
+        pt.y = std::min(std::max(pt.y, 5), H - 5);
+        cv::circle(img, pt, 2, cv::Scalar(0, 255, 0), -1);
+      } else {
+        const cv::Point dir((int)(std::cos(p.theta) * 5), (int)(-std::sin(p.theta) * 5));
+        cv::arrowedLine(img, pt - dir, pt + dir, cv::Scalar(0, 0, 255), 2, cv::LINE_AA, 0, 0.3);
+      }
+    }
+    std::vector<Eigen::Vector3f> means;
+    std::vector<Eigen::Matrix3f> covs;
+    getGMM(means, covs);
+    for (size_t i = 0; i < means.size(); i++) {
+      // eigen-decomposition of the symmetric 2x2 position block in closed form (ascending eigenvalues)
+      const float a = covs[i](0, 0), b = covs[i](0, 1), d = covs[i](1, 1);
+      const float tr = a + d, disc = std::sqrt(std::max(0.f, (a - d) * (a - d) / 4 + b * b));
+      const float l0 = tr / 2 - disc, l1 = tr / 2 + disc;
+      if (l0 < 0 || l1 < 0) break;
+      float vx = b, vy = l0 - a;                       // eigenvector of l0
+      if (std::fabs(vx) + std::fabs(vy) < 1e-12f) { vx = 1; vy = 0; }
+      const float angle = std::atan2(-vy, vx);
+      const cv::Point center((int)means[i][0], (int)((float)H - means[i][1]));
+      cv::ellipse(img, center, cv::Size((int)std::sqrt(l0), (int)std::sqrt(l1)) * 2, angle * 180 / M_PI, 0, 360,
+                  cv::Scalar(255, 0, 0), 2);
+      const cv::Point dir((int)(std::cos(means[i][2]) * 5), (int)(-std::sin(means[i][2]) * 5));
+      cv::arrowedLine(img, center - dir, center + dir, cv::Scalar(255, 0, 0), 2, cv::LINE_AA, 0, 0.3);
+    }
+    float s[4], c[16];
+    if (tdr_filter_mean_cov(f_, 1, s, c) == TDR_OK) {   // fails before the first update: no best particle yet
+      const cv::Point pt((int)s[0], (int)((float)H - s[1]));
+      const cv::Point dir((int)(std::cos(s[2]) * 5), (int)(-std::sin(s[2]) * 5));
+      cv::arrowedLine(img, pt - dir, pt + dir, cv::Scalar(255, 0, 0), 2, cv::LINE_AA, 0, 0.3);
+    }
+#else
+    (void)img;   // no OpenCV in this build: nothing to draw with
 #endif
+  }
 
   // --- beyond the reference's surface -------------------------------------------------------------------------------
   void setTargetCount(int n) { target_count_ = n; }  // explicit adaptive particle count; < 0 keeps N

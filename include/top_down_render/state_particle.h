@@ -71,10 +71,15 @@ class StateParticle {
     if (!gen || !map || !params) throw std::invalid_argument("StateParticle: null argument");
     tdr_filter_params c = to_tdr_params(*params_, map_->numClasses());
     if (tdr_filter_create(map_->handle(), 1, &c, /*seed (unused: the generator is shared)*/ 1, &f_) != TDR_OK) fail("StateParticle");
-    check(tdr_filter_share_rng(f_, gen), "share_rng");
-    check(tdr_filter_configure(f_, /*parity_rng=*/1, /*locality_every=*/0), "configure");
-    if (init && map_->haveMap()) check(tdr_filter_init_one(f_), "init");
-    else setState(State());
+    try {
+      check(tdr_filter_share_rng(f_, gen), "share_rng");
+      check(tdr_filter_configure(f_, /*parity_rng=*/1, /*locality_every=*/0), "configure");
+      if (init && map_->haveMap()) check(tdr_filter_init_one(f_), "init");
+      else setState(State());
+    } catch (...) {
+      tdr_filter_destroy(f_);   // the destructor does not run for a constructor that throws
+      throw;
+    }
   }
   ~StateParticle() { tdr_filter_destroy(f_); }
   StateParticle(const StateParticle&) = delete;
@@ -83,31 +88,35 @@ class StateParticle {
   void propagate(Eigen::Vector2f& trans, float omega, bool scale_freeze = false) {   // :57-78
     check(tdr_filter_propagate_freeze(f_, trans[0], trans[1], omega, scale_freeze ? 1 : 0), "propagate");
   }
-  State state() {
+  State state() const {
     State s;
     check(tdr_filter_get_states(f_, reinterpret_cast<tdr_state*>(&s), 1), "state");
     return s;
   }
-  Eigen::Vector4f mlState() {                                                         // :98-102
+  Eigen::Vector4f mlState() const {                                                   // :98-102
     const State s = state();
     return Eigen::Vector4f(s.dx_m * s.scale + s.init_x_px, s.dy_m * s.scale + s.init_y_px, s.theta, s.scale);
   }
-  void setState(State s) { check(tdr_filter_set_states(f_, reinterpret_cast<const tdr_state*>(&s), 1), "setState"); }
+  void setState(const State& s) { check(tdr_filter_set_states(f_, reinterpret_cast<const tdr_state*>(&s), 1), "setState"); }
   // :157-219.  top_down_geo is accepted and ignored like in the reference's score (:145-152).
   void computeWeight(std::vector<Eigen::ArrayXXf>& top_down_scan, std::vector<Eigen::ArrayXXf>& /*top_down_geo*/, float res) {
     const int ncls = map_->numClasses();
     if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("computeWeight: fewer scan images than map classes");
-    const size_t P = (size_t)top_down_scan[0].size();
+    const Eigen::Vector2i shape = map_->polarShape();
+    const size_t P = (size_t)shape[0] * shape[1];
+    for (int c = 0; c < ncls; c++)
+      if (top_down_scan[c].rows() != shape[0] || top_down_scan[c].cols() != shape[1])
+        throw std::invalid_argument("computeWeight: scan image shape differs from the shape given to samplePtsPolar");
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
     check(tdr_filter_compute_weights(f_, buf.data(), nullptr, res), "computeWeight");
   }
-  float weight() {                                                                    // :55
+  float weight() const {                                                              // :55
     float w = 0;
     check(tdr_filter_get_raw_weights(f_, &w, 1), "weight");
     return w;
   }
-  float lastDist() {
+  float lastDist() const {
     float d = 0;
     check(tdr_filter_get_last_dist(f_, &d, 1), "lastDist");
     return d;
@@ -120,8 +129,8 @@ class StateParticle {
   void updateSize() {}   // :108-110 caches the map size in metres; here the gate reads the map at score time
 
  private:
-  void check(int rc, const char* what) { if (rc != TDR_OK) fail(what); }
-  [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("StateParticle::") + what + ": " + tdr_last_error()); }
+  void check(int rc, const char* what) const { if (rc != TDR_OK) fail(what); }
+  [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string("StateParticle::") + what + ": " + tdr_last_error()); }
   TopDownMapPolar* map_;
   FilterParams* params_;
   tdr_filter* f_ = nullptr;

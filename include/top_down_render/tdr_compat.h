@@ -17,6 +17,12 @@
 #if __has_include(<pcl/point_cloud.h>) && __has_include(<pcl/point_types.h>)
 #define TDR_HAVE_PCL 1
 #endif
+#if __has_include(<opencv2/core.hpp>) && __has_include(<opencv2/imgproc.hpp>)
+#define TDR_HAVE_OPENCV 1
+#endif
+#if __has_include(<semantics_manager/semantic_color_lut.h>)
+#define TDR_HAVE_SEMANTICS_MANAGER 1
+#endif
 #endif
 
 #ifdef TDR_HAVE_EIGEN
@@ -119,6 +125,37 @@ class PointCloud {
 };
 }  // namespace pcl
 #endif
+// cv::Mat appears in two signatures of the reference's surface (updateMap, visualize).  Without OpenCV a minimal
+// stand-in carries what those methods need: an 8-bit single-channel image (rows x cols, row 0 = top, `step` bytes per row).
+#ifdef TDR_HAVE_OPENCV
+#include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>
+#else
+namespace cv {
+class Mat {
+ public:
+  Mat() {}
+  Mat(int r, int c, uint8_t* d, size_t row_bytes = 0) : rows(r), cols(c), data(d), step(row_bytes ? row_bytes : (size_t)c) {}
+  int rows = 0, cols = 0;
+  uint8_t* data = nullptr;
+  size_t step = 0;
+  bool isContinuous() const { return step == (size_t)cols; }
+  bool empty() const { return !data || rows < 1 || cols < 1; }
+  template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + (size_t)r * step); }
+  template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + (size_t)r * step); }
+};
+}  // namespace cv
+#endif
+
+// TopDownMap::Params::color_lut (top_down_map.h:56) is a semantics_manager type used only by the static-map loader
+// (SVG / colour PNG -> class image), which is outside the per-scan path.  The member exists so that
+// `params.color_lut = class_params.color_lut` (src/top_down_render.cpp:173) compiles unchanged.
+#ifdef TDR_HAVE_SEMANTICS_MANAGER
+#include <semantics_manager/semantic_color_lut.h>
+#else
+class SemanticColorLut {};
+#endif
+
 static_assert(sizeof(pcl::PointXYZI) == 32, "pcl::PointXYZI is 32 bytes (x,y,z,pad,intensity,pad,pad,pad)");
 
 #endif  // TOP_DOWN_RENDER_TDR_COMPAT_H_

@@ -15,8 +15,9 @@
 
 class TopDownMap {
  public:
-  struct Params {  // top_down_map.h:54-62 (color_lut belongs to the load-time ingest)
+  struct Params {  // top_down_map.h:54-62, member for member
     std::string map_path = "";
+    SemanticColorLut color_lut;   // static-map loader only (outside the per-scan path); carried, never read
     std::vector<int> flatten_lut;
     int num_classes = 0;
     std::vector<int> exclusive_classes;
@@ -55,12 +56,14 @@ class TopDownMap {
       throw std::runtime_error(std::string("TopDownMap::updateMap: ") + tdr_last_error());
     map_center_ = map_center;
   }
-#ifdef CV_VERSION
-  void updateMap(const cv::Mat& map, const Eigen::Vector2i& map_center) {  // the reference's signature
-    cv::Mat m = map.isContinuous() ? map : map.clone();
-    updateMap(m.ptr<uint8_t>(), m.rows, m.cols, map_center);
+  void updateMap(const cv::Mat& map, const Eigen::Vector2i& map_center) {  // the reference's signature (:146-157)
+    if (map.empty()) throw std::invalid_argument("updateMap: empty image");
+    if (map.isContinuous()) return updateMap(map.ptr<uint8_t>(), map.rows, map.cols, map_center);
+    std::vector<uint8_t> packed((size_t)map.rows * map.cols);   // a view with row padding: pack the rows
+    for (int r = 0; r < map.rows; r++) std::memcpy(packed.data() + (size_t)r * map.cols, map.ptr<uint8_t>(r), (size_t)map.cols);
+    updateMap(packed.data(), map.rows, map.cols, map_center);
   }
-#endif
+  const Params& params() const { return params_; }
   void getClassesAtPoint(const Eigen::Vector2i& center_ind, std::vector<int>& classes) {  // top_down_map.cpp:159-170
     classes.clear();
     uint32_t bits = 0;

@@ -38,6 +38,8 @@ class TopDownMapPolar : public TopDownMap {
     getLocalGeoMap(center, 1.f, res, dists);
   }
 
+  Eigen::Vector2i polarShape() const { return shape_; }   // (theta bins, range bins) of the last samplePtsPolar
+
  private:
   Eigen::Vector2i shape_{100, 50};
 };

@@ -68,8 +68,13 @@ def _run_filter(group, out_path):
         log[f"idx{step}"] = f.resample_indices()
         log[f"st{step}"] = f.get_states().view(np.uint8).reshape(-1, 28)
         log[f"n{step}"] = np.int64(f.numParticles())
-        log[f"ml{step}"] = f.maxLikelihood()
+        # the reference node's order (top_down_render.cpp:333,354): computeMeanCov and meanLikelihood FIRST — both
+        # all-gather the resampled states — then computeCov and maxLikelihood, which must still see the PRE-resample
+        # max-likelihood particle (also across the change of N at step 1)
         log[f"cov{step}"] = f.computeMeanCov()
+        log[f"mean{step}"] = f.meanLikelihood()
+        log[f"covml{step}"] = f.computeCov()
+        log[f"ml{step}"] = f.maxLikelihood()
     log["calls"] = np.asarray([c[1] for c in k.calls if c[0] == "score"], np.int64)
     np.savez(out_path, **log)
 
@@ -108,6 +113,26 @@ def test_two_ranks_equal_one_rank_bit_for_bit(runs):
             assert np.array_equal(both, single[f"{key}{step}"], equal_nan=True), (key, step)
         assert np.array_equal(r0[f"ml{step}"], single[f"ml{step}"]) and np.array_equal(r1[f"ml{step}"], single[f"ml{step}"])
         assert np.allclose(r0[f"cov{step}"], single[f"cov{step}"], rtol=1e-5, atol=1e-5)
+        for key in ("mean", "covml"):
+            assert np.allclose(r0[f"{key}{step}"], single[f"{key}{step}"], rtol=1e-5, atol=1e-5), (key, step)
+            assert np.array_equal(r0[f"{key}{step}"], r1[f"{key}{step}"]), (key, step)
+
+
+def test_max_likelihood_is_the_pre_resample_argmax(runs, oracle):
+    """maxLikelihood after the pose statistics (the reference node's call order) is mlState of the particle that won the
+    update — recomputed here from the logged pre-resample quantities of the single-rank run."""
+    single, r0, r1 = runs
+    sc, cfg, st = _scene()
+    fp = oracle.make_params(cfg.ncls, regularization=0.3)
+    rng = oracle.Rng(99)
+    oracle.propagate(st, 1.0, 0.2, 0.02, True, fp, rng)     # step 0's pre-resample set (propagate is deterministic)
+    best = int(np.argmax(single["w0"]))
+    s = st[best]
+    # theta of an un-initialised winner is chosen by the search; position and scale are not touched by it
+    exp = np.asarray([s["dx_m"] * s["scale"] + s["init_x_px"], s["dy_m"] * s["scale"] + s["init_y_px"]], np.float32)
+    for run in (single, r0, r1):
+        assert np.allclose(run["ml0"][:2], exp, rtol=1e-6, atol=1e-4)
+        assert run["ml0"][3] == s["scale"]
 
 
 def test_each_rank_scores_only_its_shard(runs):

@@ -39,6 +39,21 @@ def session_exe():
     return exe
 
 
+def test_reference_call_sites_compile_unchanged():
+    """tests/cpp/call_sites.cpp writes out every call TopDownRender makes into the hot-path classes (src/top_down_render.cpp
+    :81,115-117,173-177,333-359,423-431,508,529-540,591) with the node's argument types — among them the three the
+    round-1 surface lacked: `params.color_lut = ...` (:173), `filter_->visualize(img)` (:431) and the two-argument
+    `filter_->updateMap(img, centre)` (:591).  -Wall -Werror, linked against libtdr_hip.so."""
+    from top_down_renderer_amd import build
+    build.build()
+    exe = os.path.join(tempfile.mkdtemp(prefix="tdr_facade_"), "call_sites")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "call_sites.cpp"), "-o", exe, "-L", PKG, "-ltdr_hip",
+                    f"-Wl,-rpath,{PKG}"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "call sites compile" in r.stdout
+
+
 def test_facade_compiles_and_fails_loudly_without_gpu(facade_exe):
     import torch
     if torch.cuda.is_available():
@@ -93,19 +108,20 @@ def test_facade_take_step_matches_oracle(facade_exe, oracle, device_scan, labels
     idx_o = oracle.resample_prefix(w_o, n, rng.uniform())
     new_o = oracle.gather_states(st_o, idx_o)
     assert np.array_equal(scan, scan_o)   # raster: exact
-    assert np.allclose(w, w_o, rtol=2e-5, atol=0)
+    assert np.allclose(w, w_o, rtol=1e-5, atol=0)
     assert (idx != idx_o).sum() <= 2 + n // 200
     same = idx == idx_o
     for name in ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale"):
-        assert np.allclose(st[name][same], new_o[name][same], rtol=2e-6, atol=2e-6), name
-    mean_o, cov_o = oracle.mean_cov(new_o)
-    assert np.allclose(stats[:4], mean_o, rtol=1e-4, atol=1e-3)
-    assert np.allclose(stats[4:20].reshape(4, 4), cov_o, rtol=2e-3, atol=1e-2)
+        assert np.array_equal(st[name][same], new_o[name][same]), name     # propagate is bit for bit
+    # pose statistics of the particle set the GPU path ended with (summation order is all that differs)
+    mean_o, cov_o = oracle.mean_cov(st)
+    assert np.allclose(stats[:4], mean_o, rtol=2e-5, atol=2e-5)
+    assert np.allclose(stats[4:20].reshape(4, 4), cov_o, rtol=1e-4, atol=1e-4)
     s = st_o[best_o]
     ml_o = np.asarray([s["dx_m"] * s["scale"] + s["init_x_px"], s["dy_m"] * s["scale"] + s["init_y_px"], s["theta"],
                        s["scale"]], np.float32)
     assert np.allclose(stats[20:24], ml_o, rtol=1e-5, atol=1e-4)
-    assert np.allclose(stats[24:40].reshape(4, 4), oracle.cov_about(new_o, ml_o), rtol=2e-3, atol=1e-2)
+    assert np.allclose(stats[24:40].reshape(4, 4), oracle.cov_about(st, ml_o), rtol=1e-4, atol=1e-4)
     assert stats[40] == 1.0 and stats[41] == n and stats[42] == 1.0
     # getGMM after computeGMM on the resampled set (src/particle_filter.cpp:238-318; deterministic fit, parity unpinned)
     from oracle import np_oracle as no
@@ -188,10 +204,10 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     scan_sp = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
     for j, (pp, ll) in enumerate(((pa, la), (pb, lb))):
         o = 14 + 13 * j
-        assert np.allclose(sp[o: o + 6], [pp[f][0] for f in fields], rtol=2e-6, atol=2e-6)   # sin/cos of propagate
+        assert np.array_equal(sp[o: o + 6], np.asarray([pp[f][0] for f in fields], np.float32))   # bit for bit
         w_ref = oracle.compute_weights(om, tab0, cfg.nb, cfg.nr, scan_sp, cfg.res, fpo, pp.copy())[0]
-        assert (np.isnan(w_ref) and np.isnan(sp[o + 7])) or np.isclose(sp[o + 7], w_ref, rtol=3e-5)
-        assert np.isclose(sp[o + 8], ll[0], rtol=1e-6)
+        assert (np.isnan(w_ref) and np.isnan(sp[o + 7])) or np.isclose(sp[o + 7], w_ref, rtol=1e-5)
+        assert sp[o + 8] == ll[0]
         s1 = pp[0]
         assert np.allclose(sp[o + 9: o + 13], [s1["dx_m"] * s1["scale"] + s1["init_x_px"], s1["dy_m"] * s1["scale"] + s1["init_y_px"],
                                               s1["theta"], s1["scale"]], rtol=2e-6, atol=2e-5)
@@ -207,11 +223,11 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     new_o = oracle.gather_states(st_o, idx_o)
     w1, idx1, st1 = rd("out_weights_step1.bin", np.float32), rd("out_idx_step1.bin", np.int32), rd("out_states_step1.bin", oracle.STATE_DTYPE)
     assert np.isnan(raw_o).any()                                # the scale gate fired for some particles
-    assert np.allclose(w1, w_o, rtol=3e-5, atol=0)
+    assert np.allclose(w1, w_o, rtol=1e-5, atol=0)
     assert (idx1 != idx_o).sum() <= 2 + n // 200
     same = idx1 == idx_o
     for name in ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale"):
-        assert np.allclose(st1[name][same], new_o[name][same], rtol=3e-6, atol=3e-6), name
+        assert np.array_equal(st1[name][same], new_o[name][same]), name
     # freezeScale (src/particle_filter.cpp:343-357) on the states the GPU path had after step 2
     st2, st3 = rd("out_states_step2.bin", oracle.STATE_DTYPE), rd("out_states_frozen.bin", oracle.STATE_DTYPE)
     misc = rd("out_misc.bin", np.float32)

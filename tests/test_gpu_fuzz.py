@@ -106,7 +106,8 @@ def test_random_shapes_against_oracle(env, oracle, seed):
 
 @pytest.mark.parametrize("seed,ncls,pile", [(s, None, 0) for s in range(8)] +
                          [(20 + s, 4 + s % 4, 0) for s in range(max(12, N_SEEDS // 4))] +
-                         [(40, 6, 3000), (41, 5, 2049)])
+                         [(40, 6, 3000), (41, 5, 2049)] +
+                         [(50, 8, 0), (51, 11, 0), (52, 12, 0), (53, 15, 0)])   # 12- and 16-float records: vector kernel
 def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
     """have_init = false: the 40-rotation search on random shapes; the chosen rotation is verified through the oracle's
     cost at the GPU's theta (candidates can tie to within rounding).  4-7 classes take the matrix-core kernel
@@ -140,17 +141,21 @@ def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
     raw_g = f.raw_w[: len(st)].cpu().numpy()
     got = k.states_to_host(f.st, len(st), st.dtype)
     assert np.array_equal(got["have_init"], st_o["have_init"])
-    _assert_weights(raw_g, raw_o, 2e-5)
     same = got["theta"] == st_o["theta"]
     assert same.mean() > 0.9
-    # where another candidate was chosen its cost is within rounding of the oracle's minimum
+    _assert_weights(raw_g[same], raw_o[same], 1e-5)
+    # Where another candidate was chosen: the weight is the oracle's AT THAT rotation (1e-5), and that rotation ties
+    # with the oracle's minimum to within the rounding of the candidates' float sums (the reference's own Eigen sums
+    # have unspecified order) — a margin on the search's choice, not on any weight.
     diff = np.nonzero(~same)[0]
     if len(diff):
         st2 = st_o.copy()
         st2["theta"][diff] = got["theta"][diff]
         st2["have_init"] = 1
         raw2 = oracle.compute_weights(om, tab, nb, nr, scan_o, cfg.res, fpo, st2)
-        _assert_weights(raw2[diff], raw_o[diff], 2e-5)
+        _assert_weights(raw_g[diff], raw2[diff], 1e-5)
+        tie = np.abs(raw2[diff] - raw_o[diff]) / np.maximum(np.abs(raw_o[diff]), 1e-30)
+        assert np.nanmax(tie, initial=0.0) <= 2e-5, f"chosen rotation is not a near-tie: {np.nanmax(tie):.2e}"
 
 
 @pytest.mark.parametrize("seed", range(max(8, N_SEEDS // 6)))
@@ -185,17 +190,18 @@ def test_random_cartesian_against_oracle(env, oracle, seed):
                            locality_every=int(rng.integers(0, 2)))
     f.set_states(st)
     f.update(r.last_scan(), None, cfg.res)
-    _assert_weights(f.raw_weights(), ref, 3e-5)   # cos/sin of theta: last-ulp differences move a few samples
+    _assert_weights(f.raw_weights(), ref, 1e-5)   # cos/sin of theta are the host libm's bit for bit
 
 
 @pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 5)))
 def test_random_statistics_serial_chains_bit_exact(env, oracle, seed):
-    """Above 32 k particles the weight statistics reproduce the reference's serial float chains (`sum`, `mean`,
-    `bottom_stddev`, particle_filter.cpp:108-126) bit for bit: random raw-weight vectors of random length."""
+    """The weight statistics reproduce the reference's serial float chains (`sum`, `mean`, `bottom_stddev`,
+    particle_filter.cpp:108-126) bit for bit: random raw-weight vectors of random length, on both sides of the
+    32 768-particle switch between the one-workgroup and the multi-workgroup kernels."""
     pkg, k = env
     rng = np.random.default_rng(31000 + seed)
     f32 = np.float32
-    n = int(rng.integers(32769, 400_000))
+    n = int(rng.integers(1, 32769)) if seed % 2 else int(rng.integers(32769, 400_000))
     kind = int(rng.integers(0, 5))
     if kind == 0:
         raw = np.exp(rng.normal(0, rng.uniform(0.1, 5), n))

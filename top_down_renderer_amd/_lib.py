@@ -37,6 +37,10 @@ SIGNATURES = {
     "tdr_rec_floats": (_i, [_i]),
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_selftest_atan2": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "tdr_libm_variant": (_i, []),
+    "tdr_libm_force_variant": (_i, [_i]),
+    "tdr_sincosf_host": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "tdr_k_selftest_sincos": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "tdr_k_selftest_round": (_i, [_vp, _i64, _f, _vp, _vp]),
     "tdr_k_pack_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "tdr_map_ingest_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
@@ -88,6 +92,7 @@ SIGNATURES = {
     "tdr_map_set_labels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _i]),
     "tdr_filter_update_map_labels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _i]),
     "tdr_map_sample_pts_polar": (_i, [_vp, _i, _i, _f]),
+    "tdr_map_polar_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tdr_map_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
     "tdr_map_center": (_i, [_vp, _vp, _vp]),
     "tdr_map_local_map": (_i, [_vp, _i, _f, _f, _f, _f, _i, _i, _vp, _vp]),

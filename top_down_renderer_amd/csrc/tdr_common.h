@@ -59,12 +59,18 @@ int tdr_fail(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return fail(TDR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// tdr_core.hip: 1 if the device should evaluate sinf / cosf like glibc's FMA-contracted build, 0 like its plain build
+// (whichever the host's libm runs; tdr_sincosf.h)
+int tdr_libm_fma();
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // tdr_prefix.hip: final value of a serial float32 chain over the raw weights (kind 0: sum of the non-NaN weights;
 // kind 1: float-accumulated squared deviations of the weights below *mean_dev), see there
 int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n, float* total_out, void* workspace,
                     hipStream_t st);
+// tdr_prefix.hip: particle_filter.cpp:107-147 for n <= 32768 in one launch, both serial chains exact
+int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st);
 // a record with a spare slot (ncls + 2 <= rf) carries `known` twice: slot rf-2 pairs with a constant 1 of the scan record
 __host__ __device__ inline bool tdr_has_kslot(int ncls, int rf) { return ncls + 2 <= rf; }
 #endif  // TDR_COMMON_H_

@@ -1,5 +1,6 @@
 // tdr_core.hip — error plumbing and the small host-side entry points of include/tdr.h.
 #include "tdr_common.h"
+#include "tdr_sincosf.h"
 
 static thread_local char g_err[512] = "";
 int tdr_fail(int code, const char* fmt, ...) {
@@ -19,3 +20,68 @@ extern "C" int tdr_device_count(void) {
   return n;
 }
 extern "C" int tdr_rec_floats(int ncls) { return 4 * ((ncls + 1 + 3) / 4); }
+
+// ---- which build of sinf / cosf does the host's libm run?  (tdr_sincosf.h) ----------------------------------------
+// Arguments on which glibc's plain and FMA-contracted builds of s_sinf.c / s_cosf.c round differently (all 34 of them,
+// found by sweeping the 2^32 floats): the host's answers there tell the two apart.
+static const uint32_t kSinProbe[] = {0x4255b0a9u, 0x42a35c07u, 0x42a35d44u, 0x42a97360u, 0x42cf5854u, 0x42e87a55u};
+static const uint32_t kCosProbe[] = {0x418a3adbu, 0x418a3adcu, 0x418a3addu, 0x418a3adeu, 0x41bc76d9u, 0x4202eb4bu,
+                                     0x42687a55u, 0x4280ce28u, 0x42870e40u, 0x42c55faau, 0x42d8d23eu};
+static int probe_libm() {
+  bool fused = true, plain = true;
+  auto same = [](float a, float b) { return std::memcmp(&a, &b, 4) == 0; };
+  for (int sgn = 0; sgn < 2; sgn++) {
+    for (uint32_t u : kSinProbe) {
+      u |= (uint32_t)sgn << 31;
+      float y;
+      std::memcpy(&y, &u, 4);
+      volatile float yy = y;   // keep the call a run-time call into libm
+      const float h = std::sin((float)yy);
+      fused &= same(h, tdr_libm::sinf_<true>(y));
+      plain &= same(h, tdr_libm::sinf_<false>(y));
+    }
+    for (uint32_t u : kCosProbe) {
+      u |= (uint32_t)sgn << 31;
+      float y;
+      std::memcpy(&y, &u, 4);
+      volatile float yy = y;
+      const float h = std::cos((float)yy);
+      fused &= same(h, tdr_libm::cosf_<true>(y));
+      plain &= same(h, tdr_libm::cosf_<false>(y));
+    }
+  }
+  return fused ? 1 : (plain ? 0 : -1);
+}
+static int g_libm_forced = -2;
+extern "C" int tdr_libm_variant(void) {
+  static const int probed = probe_libm();
+  return g_libm_forced > -2 ? g_libm_forced : probed;
+}
+extern "C" int tdr_libm_force_variant(int variant) {
+  if (variant < -2 || variant > 1) return fail(TDR_ERR_ARG, "libm_force_variant: -2 (probe), 0 (plain) or 1 (fused)");
+  g_libm_forced = variant == -1 ? -2 : variant;
+  return TDR_OK;
+}
+int tdr_libm_fma() { return tdr_libm_variant() != 0; }   // an unrecognised libm is treated like the fused build
+extern "C" int tdr_sincosf_host(const float* x, int64_t n, int variant, float* sin_out, float* cos_out) {
+  if (!x || n < 0 || (variant != 0 && variant != 1)) return fail(TDR_ERR_ARG, "sincosf_host: bad arguments");
+  for (int64_t i = 0; i < n; i++) {
+    if (sin_out) sin_out[i] = tdr_libm::sinf_v(x[i], variant);
+    if (cos_out) cos_out[i] = tdr_libm::cosf_v(x[i], variant);
+  }
+  return TDR_OK;
+}
+__global__ void selftest_sincos_kernel(const float* __restrict__ x, int64_t n, int fma, float* __restrict__ so,
+                                       float* __restrict__ co) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (so) so[i] = tdr_libm::sinf_v(x[i], fma);
+  if (co) co[i] = tdr_libm::cosf_v(x[i], fma);
+}
+extern "C" int tdr_k_selftest_sincos(const float* x, int64_t n, float* sin_out, float* cos_out, void* stream) {
+  if (!x || n < 1) return fail(TDR_ERR_ARG, "selftest_sincos: bad arguments");
+  hipLaunchKernelGGL(selftest_sincos_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     tdr_libm_fma(), sin_out, cos_out);
+  LAUNCH_CHECK("selftest_sincos");
+  return TDR_OK;
+}

@@ -4,6 +4,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "tdr_common.h"
+#include "tdr_sincosf.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // K3: propagate (state_particle.cpp:57-78).  z*sigma+mu spelled without contraction like libstdc++'s
@@ -22,7 +23,8 @@ __device__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 __global__ void propagate_kernel(float* __restrict__ st, int64_t cap, int64_t n, float* __restrict__ last_dist,
                                  float tx, float ty, float omega, int scale_freeze, float pos_cov, float theta_cov,
-                                 const float* __restrict__ z4, uint64_t seed, uint64_t step, int64_t index_base) {
+                                 const float* __restrict__ z4, uint64_t seed, uint64_t step, int64_t index_base,
+                                 int libm_fma) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   float z[4];
@@ -41,9 +43,9 @@ __global__ void propagate_kernel(float* __restrict__ st, int64_t cap, int64_t n,
   }
   float theta = st[TDR_ST_THETA * cap + p];
   float dx = st[TDR_ST_DX * cap + p], dy = st[TDR_ST_DY * cap + p];
-  // Rotation2D<float>(theta) * trans; sin/cos evaluated in double and rounded (glibc's sinf/cosf are correctly
-  // rounded in practice, the device float versions are not)
-  const float c = (float)cos((double)theta), s = (float)sin((double)theta);
+  // Rotation2D<float>(theta) * trans (:58): std::cos / std::sin of a float = the host libm's cosf / sinf, restated
+  // bit for bit (tdr_sincosf.h)
+  const float c = tdr_libm::cosf_v(theta, libm_fma), s = tdr_libm::sinf_v(theta, libm_fma);
   const float gx = c * tx + (-s) * ty;
   const float gy = s * tx + c * ty;
   const float lx = dx, ly = dy;
@@ -74,7 +76,8 @@ extern "C" int tdr_k_propagate(float* st, int64_t cap, int64_t n, float* last_di
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "propagate: n exceeds capacity");
   if (n == 0) return TDR_OK;
   hipLaunchKernelGGL(propagate_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, st, cap, n,
-                     last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4, seed, step, index_base);
+                     last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4, seed, step, index_base,
+                     tdr_libm_fma());
   LAUNCH_CHECK("propagate");
   return TDR_OK;
 }
@@ -185,9 +188,10 @@ extern "C" int tdr_init_particles_host(void* rng, const float* class_maps, int n
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K4: weight statistics (particle_filter.cpp:107-147).  One 1024-thread workgroup; sums in double with a fixed
-// strided/tree order, so the result depends only on (raw_w, last_dist, n) — identical on every rank that holds the
-// all-gathered weights.
+// K4: weight statistics (particle_filter.cpp:107-147).  Sums that the reference leaves to Eigen (unspecified order) are
+// taken in double with a fixed order, the reference's two serial float chains (`sum`, `bottom_stddev`) exactly, so the
+// result depends only on (raw_w, last_dist, n) — identical on every rank that holds the all-gathered weights.  Up to
+// 32768 particles everything is one launch of one workgroup (uw_small_kernel, tdr_prefix.hip); above, the passes below.
 __device__ double block_sum_d(double v, double* sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -211,84 +215,7 @@ __device__ long long block_sum_ll(long long v, long long* sh) {
   return t;
 }
 
-__global__ __launch_bounds__(1024) void update_weights_kernel(const float* __restrict__ raw,
-                                                             const float* __restrict__ last_dist, int64_t n,
-                                                             float* __restrict__ w, float* __restrict__ info) {
-  __shared__ double shd[16];
-  __shared__ long long shl[16];
-  __shared__ float sh_best[16];
-  __shared__ long long sh_besti[16];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  // :108-116
-  double s = 0;
-  long long cnt = 0;
-  for (int64_t i = tid; i < n; i += nt) {
-    float v = raw[i];
-    if (!isnan(v)) { s += (double)v; cnt++; }
-  }
-  const float sum = (float)block_sum_d(s, shd);
-  const long long num_valid = block_sum_ll(cnt, shl);
-  const float mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
-  // :118-126
-  double bs = 0;
-  long long cu = 0;
-  for (int64_t i = tid; i < n; i += nt) {
-    float v = raw[i];
-    if (!isnan(v) && v < mean) {
-      double d = (double)(v - mean);
-      bs += d * d;
-      cu++;
-    }
-  }
-  const float bsum = (float)block_sum_d(bs, shd);
-  const long long num_under = block_sum_ll(cu, shl);
-  const float bottom = sqrtf(bsum / (float)num_under);
-  const bool fallback = (sum == 0.f || num_under < 1);  // :129
-  const float fill = mean - bottom;                      // :133
-  double s1 = 0;
-  for (int64_t i = tid; i < n; i += nt) {
-    float v = raw[i];
-    v = fallback ? 1.f : (isnan(v) ? fill : v);
-    w[i] = v;
-    s1 += (double)v;
-  }
-  const float fs1 = (float)block_sum_d(s1, shd);
-  const float invn_den = (float)n;
-  double s2 = 0;
-  for (int64_t i = tid; i < n; i += nt) {  // :135, :138-141
-    float v = w[i] / fs1;
-    float d = fminf(last_dist[i] * 5.f, 1.f);
-    v = d * v + (1.f - d) / invn_den;
-    w[i] = v;
-    s2 += (double)v;
-  }
-  const float fs2 = (float)block_sum_d(s2, shd);
-  float best = -INFINITY;
-  long long besti = 0x7fffffffffffffffll;
-  for (int64_t i = tid; i < n; i += nt) {  // :142, :145-147 (first maximum)
-    float v = w[i] / fs2;
-    w[i] = v;
-    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    float ob = __shfl_down(best, o, 64);
-    long long oi = __shfl_down(besti, o, 64);
-    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-  }
-  __syncthreads();
-  if ((tid & 63) == 0) { sh_best[tid >> 6] = best; sh_besti[tid >> 6] = besti; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int k = 1; k < (nt >> 6); k++)
-      if (sh_best[k] > best || (sh_best[k] == best && sh_besti[k] < besti)) { best = sh_best[k]; besti = sh_besti[k]; }
-    if (besti == 0x7fffffffffffffffll) besti = 0;
-    info[0] = __int_as_float((int)besti);
-    info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = fallback ? 1.f : 0.f;
-    info[5] = (float)num_valid; info[6] = (float)num_under; info[7] = 0.f;
-  }
-}
-
-// Multi-workgroup form for large n: grid-wide passes, each workgroup reducing its own contiguous chunk in a fixed order
+// Multi-workgroup form for large n (> 32768): grid-wide passes, each workgroup reducing its own contiguous chunk in a fixed order
 // and every workgroup re-reducing the G per-workgroup partials in index order, so the result is again a pure function
 // of (raw_w, last_dist, n) — identical on every rank — without grid barriers.  Here the reference's two SERIAL float
 // chains (`sum`, `bottom_stddev`, :108-126) are reproduced exactly (tdr_chain_total): at these sizes their own rounding,
@@ -453,7 +380,8 @@ extern "C" int tdr_k_update_weights(const float* raw_w, const float* last_dist, 
   if (n < 1) return fail(TDR_ERR_ARG, "update_weights: n must be >= 1");
   hipStream_t s = (hipStream_t)stream;
   if (n <= TDR_UW_SINGLE_MAX_N) {
-    hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(1024), 0, s, raw_w, last_dist, n, w_out, info_out);
+    const int rc = tdr_uw_small(raw_w, last_dist, n, w_out, info_out, s);
+    if (rc) return rc;
     LAUNCH_CHECK("update_weights");
     return TDR_OK;
   }
@@ -538,7 +466,8 @@ extern "C" int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t sr
 // ------------------------------------------------------------------------------------------------------------------
 // K6: pose statistics (particle_filter.cpp:191-236) + geometric-mean scale (:343-357).  Double accumulation.
 __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
-                                                       const float* __restrict__ about, float* __restrict__ out) {
+                                                       const float* __restrict__ about, float* __restrict__ out,
+                                                       int libm_fma) {
   __shared__ double shd[16];
   __shared__ float ref[4];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -549,7 +478,7 @@ __global__ __launch_bounds__(1024) void mean_cov_kernel(const float* __restrict_
     const float y = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
     const float th = st[TDR_ST_THETA * cap + p];
     acc[0] += x; acc[1] += y; acc[2] += th; acc[3] += sc;
-    acc[4] += cos((double)th); acc[5] += sin((double)th);
+    acc[4] += (double)tdr_libm::cosf_v(th, libm_fma); acc[5] += (double)tdr_libm::sinf_v(th, libm_fma);   // :198-199
     acc[6] += log((double)sc);
   }
   double tot[7];
@@ -613,7 +542,7 @@ static_assert(24 * 4 + sizeof(McScratch) <= TDR_MEAN_COV_FLOATS * 4, "TDR_MEAN_C
 __device__ __forceinline__ McScratch* mc_scratch(float* out) { return reinterpret_cast<McScratch*>(out + 24); }
 
 __global__ __launch_bounds__(MC_THREADS) void mc_sums_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int libm_fma) {
   __shared__ double shd[16];
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int64_t p = (int64_t)blockIdx.x * MC_THREADS + threadIdx.x; p < n; p += (int64_t)MC_WGS * MC_THREADS) {
@@ -622,7 +551,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_sums_kernel(const float* __rest
     const float y = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
     const float th = st[TDR_ST_THETA * cap + p];
     acc[0] += x; acc[1] += y; acc[2] += th; acc[3] += sc;
-    acc[4] += cos((double)th); acc[5] += sin((double)th);
+    acc[4] += (double)tdr_libm::cosf_v(th, libm_fma); acc[5] += (double)tdr_libm::sinf_v(th, libm_fma);   // :198-199
     acc[6] += log((double)sc);
   }
   McScratch* sc = mc_scratch(out);
@@ -711,9 +640,9 @@ extern "C" int tdr_k_mean_cov(const float* st, int64_t cap, int64_t n, const flo
   if (!st || !out || n < 1 || cap < n) return fail(TDR_ERR_ARG, "mean_cov: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (n <= MC_SINGLE_MAX_N) {
-    hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, s, st, cap, n, about, out);
+    hipLaunchKernelGGL(mean_cov_kernel, dim3(1), dim3(1024), 0, s, st, cap, n, about, out, tdr_libm_fma());
   } else {
-    hipLaunchKernelGGL(mc_sums_kernel, dim3(MC_WGS), dim3(MC_THREADS), 0, s, st, cap, n, out);
+    hipLaunchKernelGGL(mc_sums_kernel, dim3(MC_WGS), dim3(MC_THREADS), 0, s, st, cap, n, out, tdr_libm_fma());
     hipLaunchKernelGGL(mc_cov_kernel, dim3(MC_WGS), dim3(MC_THREADS), 0, s, st, cap, n, about, out);
     hipLaunchKernelGGL(mc_final_kernel, dim3(1), dim3(MC_THREADS), 0, s, n, about, out);
   }

@@ -94,6 +94,7 @@ struct tdr_filter {
   DevBuf<tdr_state> aos;
   void* rng = nullptr;
   uint64_t seed = 0, step = 0;
+  uint64_t prop_calls = 0;    // device RNG: every propagate call draws fresh noise (counter = calls so far)
   bool scale_frozen = false, maybe_uninit = true, parity_rng = true;
   int locality_every = 1;
   float uniform_scale = 0.f;
@@ -201,6 +202,14 @@ int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res) {
   TTRY(tdr_polar_table_host(nb, nr, ang_res, m->desc.resolution, tab.data()));
   TTRY(m->tab.resize(tab.size()));
   HTRY(hipMemcpy(m->tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  return TDR_OK;
+}
+
+// the (theta bins, range bins) given to samplePtsPolar last: the shape ParticleFilter::update's images must have
+int tdr_map_polar_shape(const tdr_map* m, int* nb, int* nr) {
+  if (!m || !nb || !nr) return failh(TDR_ERR_ARG, "map_polar_shape: bad arguments");
+  *nb = m->nb;
+  *nr = m->nr;
   return TDR_OK;
 }
 
@@ -425,7 +434,7 @@ static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool
     z = f->z4.p;
   }
   return tdr_k_propagate(f->st.p, f->n_max, f->n, f->last_dist.p, tx, ty, omega, scale_freeze ? 1 : 0, f->fp.pos_cov,
-                         f->fp.theta_cov, z, f->seed, f->step, 0, f->stream);
+                         f->fp.theta_cov, z, f->seed, f->prop_calls++, 0, f->stream);
 }
 int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega) {
   if (!f) return failh(TDR_ERR_ARG, "filter_propagate: null filter");

@@ -1044,6 +1044,118 @@ int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n
   return TDR_OK;
 }
 
+// ---- ParticleFilter::update's statistics for small particle sets, in ONE launch ------------------------------------
+// src/particle_filter.cpp:107-147 for n <= TDR_UW_SMALL_MAX_N — the reference's own operating point (20 000 particles,
+// src/top_down_render.cpp:53): one workgroup evaluates both serial float chains exactly (head one by one, then chunk by
+// chunk with chain_walk_chunk; no prediction pass, there are at most 8 chunks) and runs the fill / normalise / argmax
+// passes behind them.  Same results as the multi-workgroup path of tdr_filter.hip, bit for bit in `sum`, `mean`,
+// `bottom_stddev` (tests/test_gpu_parity.py::test_update_weights_serial_chains_bit_exact).
+__device__ __forceinline__ float chain_total_block(const ChainSrc& s, int64_t n, float mean) {
+  __shared__ double head[CHAIN_HEAD];
+  __shared__ float s_head_r;
+  const int hn = (int)min((long long)CHAIN_HEAD, (long long)n);
+  pfx_sync();
+  for (int t = threadIdx.x; t < hn; t += PFXW_THREADS) head[t] = chain_addend(s, t, mean);
+  pfx_sync();
+  if (threadIdx.x == 0) {
+    float run = 0.f;
+    for (int t = 0; t < hn; t++) run = (float)((double)run + head[t]);
+    s_head_r = run;
+  }
+  pfx_sync();
+  float r = s_head_r;   // workgroup-uniform
+  const int nch = (int)((n + PFXM_CHUNK - 1) / PFXM_CHUNK);
+  for (int c = 0; c < nch; c++) {
+    const long long lo = (long long)c * PFXM_CHUNK;
+    const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+    if (c == 0 && hn >= cnt) continue;
+    chain_walk_chunk(s, lo, cnt, mean, r, c == 0 ? hn : 0);
+  }
+  return r;
+}
+__device__ __forceinline__ double uws_sum_d(double v, double* sh) {   // block sum, fixed order: a pure function of the inputs
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < PFXW_THREADS / 64; w++) t += sh[w];
+  return t;
+}
+__global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __restrict__ raw,
+                                                                const float* __restrict__ last_dist, int64_t n,
+                                                                float* __restrict__ w, float* __restrict__ info) {
+  __shared__ double shd[PFXW_THREADS / 64];
+  __shared__ float sh_best[PFXW_THREADS / 64];
+  __shared__ long long sh_besti[PFXW_THREADS / 64];
+  const int tid = threadIdx.x;
+  constexpr int nt = PFXW_THREADS;
+  // :108-116  sum (serial float chain, exact) and the count of valid weights
+  double cnt = 0;
+  for (int64_t i = tid; i < n; i += nt) cnt += (raw[i] == raw[i]) ? 1.0 : 0.0;
+  const long long num_valid = (long long)uws_sum_d(cnt, shd);
+  ChainSrc s0{raw, nullptr, 0};
+  const float sum = chain_total_block(s0, n, 0.f);
+  const float mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
+  // :118-126  bottom_stddev (serial float chain with double addends, exact) and the count below the mean
+  double cu = 0;
+  for (int64_t i = tid; i < n; i += nt) {
+    const float v = raw[i];
+    cu += (v == v && v < mean) ? 1.0 : 0.0;
+  }
+  const long long num_under = (long long)uws_sum_d(cu, shd);
+  ChainSrc s1{raw, nullptr, 1};
+  const float bsum = chain_total_block(s1, n, mean);
+  const float bottom = sqrtf(bsum / (float)num_under);
+  const bool fallback = (sum == 0.f || num_under < 1);  // :129
+  const float fill = mean - bottom;                      // :133
+  double s1a = 0;
+  for (int64_t i = tid; i < n; i += nt) {
+    float v = raw[i];
+    v = fallback ? 1.f : (v != v ? fill : v);
+    w[i] = v;
+    s1a += (double)v;
+  }
+  const float fs1 = (float)uws_sum_d(s1a, shd);
+  const float fn = (float)n;
+  double s2 = 0;
+  for (int64_t i = tid; i < n; i += nt) {  // :135, :138-141
+    float v = w[i] / fs1;
+    const float d = fminf(last_dist[i] * 5.f, 1.f);
+    v = d * v + (1.f - d) / fn;
+    w[i] = v;
+    s2 += (double)v;
+  }
+  const float fs2 = (float)uws_sum_d(s2, shd);
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffll;
+  for (int64_t i = tid; i < n; i += nt) {  // :142, :145-147 (first maximum)
+    const float v = w[i] / fs2;
+    w[i] = v;
+    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_down(best, o, 64);
+    const long long oi = __shfl_down(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { sh_best[tid >> 6] = best; sh_besti[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < nt / 64; k++)
+      if (sh_best[k] > best || (sh_best[k] == best && sh_besti[k] < besti)) { best = sh_best[k]; besti = sh_besti[k]; }
+    if (besti == 0x7fffffffffffffffll) besti = 0;
+    info[0] = __int_as_float((int)besti);
+    info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = fallback ? 1.f : 0.f;
+    info[5] = (float)num_valid; info[6] = (float)num_under; info[7] = 0.f;
+  }
+}
+int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st) {
+  hipLaunchKernelGGL(uw_small_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, raw, last_dist, n, w, info);
+  return TDR_OK;
+}
+
 // Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
 // 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 53 / 74 / 101):
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below

@@ -89,6 +89,10 @@ __device__ __forceinline__ float tdr_atan2f(float y, float x) {
 
 __device__ __forceinline__ bool raster_bin(const RasterArgs& a, float x, float y, int& row, int& col) {
   if (x == 0.f && y == 0.f) return false;
+  // A non-finite coordinate never lands in the image: the reference's float -> int conversions of NaN / inf give INT_MIN
+  // on x86-64, which fails `>= 0` (scan_renderer_polar.cpp:102, scan_renderer.cpp:71); the GPU's conversion of NaN gives
+  // 0, so the point is dropped here (organised PCL clouds with is_dense == false carry NaN points).
+  if (!(fabsf(x) < INFINITY) || !(fabsf(y) < INFINITY)) return false;
   if (a.polar) {
     float theta = tdr_atan2f(x, y);  // glibc-exact, see above
     float r = sqrtf(x * x + y * y);
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void raster_keys_kernel(RasterArgs a) {
   uint32_t key = RASTER_NO_BIN;
   int row, col;
   if (raster_bin(a, x, y, row, col)) {
-    const int pc = (int)cf;
+    const int pc = (cf == cf) ? (int)cf : -1;   // NaN label: x86 converts to INT_MIN, outside the LUT
     if (pc >= 0 && pc <= 255) {
       const int c = a.lut[pc];
       if (c >= 0 && c < a.ncls) key = ((uint32_t)col << 20) | ((uint32_t)c << 16) | (uint32_t)row;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(1024) void raster_kernel(RasterArgs a) {
     if (!raster_bin(a, x, y, row, col)) continue;
     col -= col0;
     if (col < 0 || col >= ncol) continue;
-    int pc = (int)cf;
+    int pc = (cf == cf) ? (int)cf : -1;   // NaN label: x86 converts to INT_MIN, outside the LUT
     if (pc < 0 || pc > 255) continue;
     int c = lut_s[pc];
     if (c < 0 || c >= a.ncls) continue;

@@ -1,5 +1,6 @@
 // tdr_score.hip — per-particle window gather + class-wise score: polar, Cartesian, finalize, the 40-rotation init search.
 #include "tdr_common.h"
+#include "tdr_sincosf.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2: scoring.  lane = particle, 64 particles per wave, 4 waves per workgroup; grid.y = chunk of range rings.
@@ -215,6 +216,7 @@ struct CartArgs {
   int cpc, nchunks;      // window columns per chunk
   int64_t npad;
   float* part;
+  int libm_fma;          // which build of sinf / cosf the host's libm runs (tdr_sincosf.h)
 };
 
 __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   const float off0 = cy / a.resolution;  // samplePts(center/resolution, ...): x_vals += center[1] (top_down_map.cpp:387)
   const float off1 = cx / a.resolution;  // y_vals += center[0] (:388)
   const float resq = (a.res * scale) / a.resolution;  // res/params_.resolution (:434)
-  // glibc's cosf/sinf are correctly rounded in practice; the device float versions are not -> evaluate in double
-  const float c = (float)cos((double)theta), s = (float)sin((double)theta);
+  // cos(rot), sin(rot) of top_down_map.cpp:381-385 = the host libm's cosf / sinf, bit for bit (tdr_sincosf.h)
+  const float c = tdr_libm::cosf_v(theta, a.libm_fma), s = tdr_libm::sinf_v(theta, a.libm_fma);
   const float ns = -s;
   const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
   const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
@@ -340,6 +342,7 @@ struct LocalMapArgs {
   float cx, cy, scale_or_rot, res;
   float* dists;
   uint8_t* mask;
+  int libm_fma;
 };
 template <bool POLAR>
 __global__ void local_map_kernel(LocalMapArgs a) {
@@ -354,7 +357,7 @@ __global__ void local_map_kernel(LocalMapArgs a) {
   } else {
     const int i = (int)(k % a.rows), j = (int)(k / a.rows);
     const float resq = a.res / a.resolution;                    // top_down_map.cpp:434
-    const float c = (float)cos((double)a.scale_or_rot), s = (float)sin((double)a.scale_or_rot);
+    const float c = tdr_libm::cosf_v(a.scale_or_rot, a.libm_fma), s = tdr_libm::sinf_v(a.scale_or_rot, a.libm_fma);   // :381-385
     const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
     const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
     const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
@@ -382,6 +385,7 @@ static int launch_local_map(bool polar, const tdr_map_desc* map, const float* ta
   a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.ncls = map->ncls; a.rf = map->rec_floats;
   a.resolution = map->resolution; a.tab = tab; a.rows = rows; a.cols = cols; a.cx = cx; a.cy = cy;
   a.scale_or_rot = scale_or_rot; a.res = res; a.dists = dists_out; a.mask = mask_out;
+  a.libm_fma = tdr_libm_fma();
   const dim3 grid((unsigned)cdiv((int64_t)rows * cols, 256)), block(256);
   if (polar) hipLaunchKernelGGL((local_map_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((local_map_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
@@ -1129,7 +1133,9 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     switch (rf / 4) {
       case 1: TDR_LAUNCH_INIT(1) break;
       case 2: TDR_LAUNCH_INIT(2) break;
-      default: return fail(TDR_ERR_ARG, "score: init search supports up to 7 classes (record of %d floats)", rf);
+      case 3: TDR_LAUNCH_INIT(3) break;   // 8-11 classes
+      case 4: TDR_LAUNCH_INIT(4) break;   // 12-15 classes (TDR_MAX_CLASSES)
+      default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
     }
 #undef TDR_LAUNCH_INIT
     LAUNCH_CHECK("score_init");
@@ -1184,6 +1190,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   choose_chunks(n, cols, a.cpc, a.nchunks, TDR_CART_WAVE_MUL);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
+  a.libm_fma = tdr_libm_fma();
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
   {

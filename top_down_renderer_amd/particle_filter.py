@@ -115,9 +115,10 @@ class ParticleFilter:
         self.seed = int(seed)
         self.gen_ = self.k.rng_create(seed)
         self.step_ = 0
+        self.prop_calls_ = 0      # device RNG counter: every propagate call draws fresh noise
         self._maybe_uninit = True
         self._uniform_scale = 0.0
-        self._ml_state = None
+        self._ml_fields = None
         self.num_gaussians_ = 1   # :7
         self.gmm_means_ = np.zeros((0, 3), np.float32)
         self.gmm_covs_ = np.zeros((0, 3, 3), np.float32)
@@ -213,8 +214,9 @@ class ParticleFilter:
             z = self.k.propagate_normals(self.gen_, n, self.scale_frozen_)
             z_dev = self.k.to_device(z[self.comm.rank * nl:(self.comm.rank + 1) * nl])
         self.k.propagate(self.st, nl, self.last_dist, float(trans[0]), float(trans[1]), float(omega),
-                         self.scale_frozen_, p.pos_cov, p.theta_cov, z4=z_dev, seed=self.seed, step=self.step_,
+                         self.scale_frozen_, p.pos_cov, p.theta_cov, z4=z_dev, seed=self.seed, step=self.prop_calls_,
                          index_base=self.comm.rank * nl)
+        self.prop_calls_ += 1
 
     # ---- particle_filter.cpp:94-189 -----------------------------------------------------------------------------------
     def update(self, top_down_scan, top_down_geo=None, res=1.0, n_target=None, covs=None, shift=None):
@@ -305,8 +307,17 @@ class ParticleFilter:
         self.last_shift_ = float(shift)
 
     def _save_ml_state(self, st_all, nl):
-        """max_likelihood_particle_ (:145-147) points at the pre-resample particle; keep a copy of its state."""
-        self._ml_src = (st_all, nl, self.st)
+        """max_likelihood_particle_ (:145-147) points at the PRE-resample particle: copy its 7 fields into a small
+        tensor of the filter's own (device-side gather, no host round trip).  A view into st_all / self.st would be
+        overwritten by the next all-gather of the resampled states (meanLikelihood, computeMeanCov, computeCov,
+        computeGMM and freezeScale all gather) or by the next update."""
+        j = self.info[:1].view(torch.int32).to(torch.int64)          # argmax of update_weights, stays on the device
+        if st_all is not None:
+            r = torch.div(j, nl, rounding_mode="floor")
+            flat = st_all.view(self.comm.world, 7, nl)
+            self._ml_fields = flat[r, :, j - r * nl].reshape(7).clone()
+        else:
+            self._ml_fields = self.st.index_select(1, j).reshape(7).clone()
 
     def resample_indices(self):
         """Global source index of every particle of this rank's shard after the last update (for parity tests)."""
@@ -355,13 +366,9 @@ class ParticleFilter:
         return self.k.mean_cov(st, n)[4:20].cpu().numpy().reshape(4, 4).copy()
 
     def maxLikelihood(self):
-        st_all, nl, st_old = self._ml_src
-        j = self._argmax()
-        if st_all is not None:
-            r, l = divmod(j, nl)
-            s = st_all.view(-1, 7, nl)[r, :, l].cpu().numpy()
-        else:
-            s = st_old[:, j].cpu().numpy()
+        if self._ml_fields is None:
+            raise RuntimeError("maxLikelihood: no update yet, there is no max-likelihood particle")
+        s = self._ml_fields.cpu().numpy()
         sc = np.float32(s[5])
         return np.asarray([np.float32(s[2] * sc + s[0]), np.float32(s[3] * sc + s[1]), s[4], sc], np.float32)
 
