@@ -6,6 +6,9 @@ statistics + resample) on N MI355X GPUs of one node.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Workload: N = 1 -> BASELINE.json configs[1] ("c2", 100k particles).  N > 1 -> configs[2] ("c3": the same scan / map with
+1 M particles over 8 GPUs, i.e. 125 000 per GPU — weak scaling at that per-GPU load for every N > 1).
+
 A "step" is one full pass of the hot path over one synthetic scan: H2D of the packed scan points, raster kernel,
 propagate kernel (device counter-based RNG), scoring kernel over this rank's particles, weight statistics,
 order-exact prefix, resample + state gather (and, for N > 1, the scan broadcast and the weight/state all-gathers over
@@ -14,12 +17,18 @@ BASELINE.json configs[1] ("c2": 100k-pt scan, 6 classes, 256x256 polar render, 4
 for N > 1 every GPU holds the same number of particles (weak scaling; N = 8 with --particles-per-gpu 125000 is
 configs[2]).
 
-One JSON line on stdout (rank 0).  `roofline` prices the scoring kernel against HBM bandwidth with the ALGORITHMIC
-bytes of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update): particles sharing map cells are served by
-L1/L2/Infinity Cache, so the fraction can exceed 1 — the HBM traffic measured with rocprofv3 --pmc is reported
-beside it (`traffic`, from profiles/score_traffic.json when present).  `cpu_baseline` times the CPU oracle
-(oracle/oracle.cpp, OpenMP over particles like the reference's parallel for_each) on a bounded sample of the same
-workload on this host's cores.
+One JSON line on stdout (rank 0).  `roofline` prices the scoring kernel (its average launch duration measured live
+with HIP events on its launch stream) against the 8 TB/s HBM peak:
+  * `traffic` = HBM bytes per launch MEASURED with rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum in a pass
+    of its own over this same command (tools/traffic_from_pmc.py -> profiles/score_traffic.json).  The record carries a
+    hash of the kernel sources and the launch shape: when either differs from what runs now, `traffic` is null.
+  * `achieved` / `frac` = traffic / launch duration (/ peak) when traffic is known — the fraction of the HBM roofline the
+    kernel actually runs at;
+  * `algorithmic` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the same
+    duration.  Particles share map cells, so L1/L2 serve much of it and this figure can exceed the peak: it is a
+    work-rate, kept under its own key; it becomes `achieved` (flagged by `basis`) only when no measured traffic exists.
+`cpu_baseline` times the CPU oracle (oracle/oracle.cpp, OpenMP over particles like the reference's parallel for_each)
+on a bounded sample of the same workload on this host's cores.
 """
 import argparse
 import json
@@ -37,8 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2")
-    ap.add_argument("--particles-per-gpu", type=int, default=0, help="default: the config's particle count")
+    ap.add_argument("--config", default="", help="default: c2 on one GPU, c3 (125 000 particles per GPU) on several")
+    ap.add_argument("--particles-per-gpu", type=int, default=0, help="default: the config's particle count (c3, c5: / 8)")
     ap.add_argument("--locality-every", type=int, default=1, help="recompute the cache-locality order every k steps (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="particles in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -79,6 +88,30 @@ def cpu_baseline(sc, cfg, n_sample, threads):
                       f"O(N) resample, {dt:.1f} s on {threads} OpenMP threads"}
 
 
+def kernel_source_hash():
+    """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tdr_score.hip", "tdr_common.h", "tdr_sincosf.h"):
+        h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(cfg_name, kernel, n_local):
+    """(HBM bytes per launch from profiles/score_traffic.json, note) — None unless the record was made from the kernel
+    sources in this tree, for this kernel and this launch shape."""
+    tpath = os.path.join(ROOT, "profiles", "score_traffic.json")
+    try:
+        rec = json.load(open(tpath))["entries"][cfg_name]
+    except Exception:
+        return None, "no record"
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, "record is from other kernel sources"
+    if rec.get("particles_per_launch") != n_local or kernel not in rec.get("kernel", ""):
+        return None, "record is for another launch shape"
+    return float(rec["hbm_bytes_per_launch"]), rec.get("source", "")
+
+
 def main():
     a = parse()
     import numpy as np
@@ -110,8 +143,9 @@ def main():
     from top_down_renderer_amd.kernels import HipKernels
 
     k = HipKernels()
-    cfg = synth.CONFIGS[a.config]
-    per_gpu = a.particles_per_gpu or cfg.n_particles
+    cfg = synth.CONFIGS[a.config or ("c2" if world == 1 else "c3")]
+    # configs 3 and 5 name a total over 8 GPUs: every GPU holds an eighth of it, whatever N is (weak scaling)
+    per_gpu = a.particles_per_gpu or (cfg.n_particles // 8 if cfg.name in ("c3", "c5") else cfg.n_particles)
     n_global = per_gpu * world
     sc = synth.make_scene(cfg, n_particles=n_global)   # same seed on every rank -> identical scene
     if cfg.polar:
@@ -195,15 +229,12 @@ def main():
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "score_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("config") == cfg.name:
-                    traffic = tj["hbm_bytes_per_particle"] * n_local
-            except Exception:
-                traffic = None
+        alg_gbps = achieved
+        traffic, traffic_note = measured_traffic(cfg.name, kname, n_local)
+        if traffic is not None and avg_ms > 0:
+            achieved, basis = traffic / (avg_ms * 1e-3) / 1e9, "pmc_traffic"
+        else:
+            basis = "algorithmic (no measured traffic for this build / shape: " + traffic_note + ")"
         out = {
             "metric": "particle-updates/sec (render+score+resample)",
             "value": n_global * a.steps / dt,
@@ -219,9 +250,10 @@ def main():
                                                  if cfg.have_init else "8 Gaussian clusters (40 px) on road cells"),
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
                          "avg_launch_ms": avg_ms, "launches": launches.value,
-                         "algorithmic_bytes_per_launch": b_pu * n_local},
+                         "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
+                                         "frac": alg_gbps / 8000.0}},
         }
         if init_step_ms is not None:
             out["config"]["init_search_first_step_ms"] = init_step_ms

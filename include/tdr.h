@@ -62,6 +62,13 @@ typedef struct tdr_map_desc {
                            records; per cell {dist_0..dist_{ncls-1}, 0.., [known,] known} (see tdr_k_pack_map) */
   int32_t ncls, rows, cols, rec_floats;   /* rec_floats = 4*ceil((ncls+1)/4) */
   float resolution;     /* TopDownMap::Params::resolution (top_down_map.h:61) */
+  /* Optional compact form of the same records (tdr_k_compact_map; cwords == 0: absent).  A cell is cwords dwords of
+   * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 10*(k%3)), `known` in bit 31 of the last
+   * dword; records are tiled 4 rows x 32/(4*cwords) columns per 128-byte line.  Decoding reproduces `rec` bit for bit;
+   * the scoring kernels read it instead of `rec` for waves whose particles are spread over the map. */
+  int32_t cwords, dict_n;
+  const uint32_t* crec;
+  const float* dict;    /* [TDR_CMAP_MAX_DICT], entry 0 = +0.0f */
 } tdr_map_desc;
 
 const char* tdr_last_error(void);
@@ -77,6 +84,18 @@ int tdr_rec_floats(int ncls);
 size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
 int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
                    void* stream);
+
+/* Compact form of the cell records (csrc/tdr_cmap.hip).  Fills map->crec / dict / dict_n / cwords from map->rec;
+ * crec_out: tdr_cmap_words_total(ncls, rows, cols) dwords, dict_out: TDR_CMAP_MAX_DICT floats, workspace:
+ * TDR_CMAP_WORKSPACE_BYTES, all device memory.  Load-time work: synchronises with `stream`.  Maps with more than
+ * TDR_CMAP_MAX_DICT distinct distance values or more than 11 classes have no compact form: cwords stays 0, TDR_OK.
+ * tdr_k_unpack_compact_map decodes it back into dense records (rec_out like tdr_k_pack_map's output). */
+#define TDR_CMAP_MAX_DICT 1024
+#define TDR_CMAP_WORKSPACE_BYTES (8192 * 4 + 8192 * 2 + 256)
+int tdr_cmap_words(int ncls);
+size_t tdr_cmap_words_total(int ncls, int rows, int cols);
+int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream);
+int tdr_k_unpack_compact_map(const tdr_map_desc* map, float* rec_out, void* stream);
 
 /* Map ingest on the device: TopDownMap::loadCompressedRasterMap (src/top_down_map.cpp:116-144) +
  * computeDists (:289-326) for a class-index image, the work of TopDownMap::updateMap (:146-157) when a new aerial
@@ -111,6 +130,19 @@ int tdr_k_raster_polar(const float* pts, int stride, int ioff, int64_t n, float 
 /* ScanRenderer::renderSemanticTopDown (src/scan_renderer.cpp:55-78); img_out [ncls][rows*cols]. */
 int tdr_k_raster_cart(const float* pts, int stride, int ioff, int64_t n, float res, const int32_t* lut256, int ncls,
                       int rows, int cols, float* img_out, float* pk_out, void* workspace, void* stream);
+/* renderGeometricTopDown: the ground / obstacle images (dead at the reference's call site,
+ * src/top_down_render.cpp:540, but part of the class surface).  pts: the ORGANISED cloud, element idy*width + idx
+ * (cloud->at(idx, idy)), `stride` floats apart, x y z first; unorganised clouds have height 1.
+ *   polar     (src/scan_renderer_polar.cpp:6-81): img_out [2][nb*nr], [0] ground, [1] obstacles; per theta bin the
+ *             returns are walked by range descending — equal ranges in input order, the tie rule where the reference's
+ *             std::sort leaves the order open; workspace of tdr_raster_geo_workspace_bytes(width*height) bytes;
+ *   Cartesian (src/scan_renderer.cpp:7-53): img_out [2][rows*cols]; every column idx is one scan line walked upwards.
+ * Counts are exact.  Points with a non-finite x or y are dropped (the reference indexes with (int)NaN there). */
+int64_t tdr_raster_geo_workspace_bytes(int64_t n);
+int tdr_k_raster_geo_polar(const float* pts, int stride, int64_t width, int64_t height, float res, float ang_res, int nb,
+                           int nr, float* img_out, void* workspace, void* stream);
+int tdr_k_raster_geo_cart(const float* pts, int stride, int64_t width, int64_t height, float res, int rows, int cols,
+                          float* img_out, void* stream);
 /* Builds pk_out from caller-supplied images (ParticleFilter::update is handed images, particle_filter.cpp:94-95). */
 int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, void* stream);
 
@@ -295,6 +327,11 @@ void tdr_renderer_destroy(tdr_renderer* r);
  * device for tdr_filter_update. */
 int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride, int ioff, int64_t n, float res,
                         float ang_res, int ncls, int rows, int cols, float* imgs_out);
+
+/* renderGeometricTopDown (scan_renderer_polar.cpp:6-81 / scan_renderer.cpp:7-53): HOST organised cloud (element
+ * idy*width + idx; pcl clouds: width = cloud->width, height = cloud->height), imgs_out HOST [2][rows*cols]. */
+int tdr_renderer_render_geo(tdr_renderer* r, int polar, const float* pts, int stride, int64_t width, int64_t height,
+                            float res, float ang_res, int rows, int cols, float* imgs_out);
 
 /* seed: the reference seeds its std::mt19937 from std::random_device (src/particle_filter.cpp:4-5), i.e. not
  * reproducibly.  seed == 0 stands for that case: propagate's noise is then drawn on the device (counter-based, 4 us).

@@ -31,10 +31,10 @@ class ScanRenderer {
                              std::vector<Eigen::ArrayXXf>& imgs) {
     render(0, cloud, res, 1.f, imgs);
   }
-  // src/scan_renderer.cpp:7-53: disabled at the reference's call site (src/top_down_render.cpp:540) and unused by the
-  // score (src/state_particle.cpp:145-152); zero-fills like the reference's first lines and returns.
-  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr&, float, std::vector<Eigen::ArrayXXf>& imgs) {
-    for (auto& im : imgs) im.setZero();
+  // src/scan_renderer.cpp:7-53: ground (imgs[0]) / obstacle (imgs[1]) counts along the scan lines of the organised
+  // cloud.  (Commented out at the reference's call site, src/top_down_render.cpp:540; part of the class surface.)
+  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr& cloud, float res, std::vector<Eigen::ArrayXXf>& imgs) {
+    render_geo(0, cloud, res, 1.f, imgs);
   }
   const tdr_renderer* handle() const { return r_; }  // device-resident last render, for ParticleFilter::update
 
@@ -50,6 +50,23 @@ class ScanRenderer {
     if (tdr_renderer_render(r_, polar, pts, 8, 4, n, res, ang_res, ncls, rows, cols, buf.data()) != TDR_OK)
       throw std::runtime_error(std::string("renderSemanticTopDown: ") + tdr_last_error());
     for (int c = 0; c < ncls; c++) std::memcpy(imgs[c].data(), buf.data() + P * c, P * sizeof(float));
+  }
+  void render_geo(int polar, const pcl::PointCloud<PointType>::ConstPtr& cloud, float res, float ang_res,
+                  std::vector<Eigen::ArrayXXf>& imgs) {
+    if (imgs.size() < 2) return;                                   // scan_renderer.cpp:8
+    for (auto& im : imgs) im.setZero();                            // :12-14
+    const int rows = (int)imgs[0].rows(), cols = (int)imgs[0].cols();
+    const size_t P = (size_t)rows * cols;
+    if (P == 0 || (size_t)imgs[1].rows() * imgs[1].cols() != P) return;
+    const int64_t n = cloud ? (int64_t)cloud->points.size() : 0;
+    int64_t width = cloud ? (int64_t)cloud->width : 0, height = cloud ? (int64_t)cloud->height : 0;
+    if (width * height != n) { width = n; height = 1; }            // not organised: one line of returns
+    std::vector<float> buf(2 * P);
+    const float* pts = n ? reinterpret_cast<const float*>(cloud->points.data()) : nullptr;
+    if (tdr_renderer_render_geo(r_, polar, pts, 8, width, height, res, ang_res, rows, cols, buf.data()) != TDR_OK)
+      throw std::runtime_error(std::string("renderGeometricTopDown: ") + tdr_last_error());
+    std::memcpy(imgs[0].data(), buf.data(), P * sizeof(float));
+    std::memcpy(imgs[1].data(), buf.data() + P, P * sizeof(float));
   }
   tdr_renderer* r_ = nullptr;
 };

@@ -26,12 +26,14 @@ class ScanRendererPolar : public ScanRenderer {
     render(kPolar, cloud, res, ang_res, imgs);
   }
 
-  // The geometric render is commented out at its only call site (src/top_down_render.cpp:540) and its score term is
-  // commented out too (src/state_particle.cpp:145-152).  What survives of it is the zero-fill with which the reference
-  // function begins (src/scan_renderer_polar.cpp:11-13), so publishGeometricTopDown keeps receiving blank images.
-  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr& /*cloud*/, float /*res*/, float /*ang_res*/,
+  // Geometric render, polar (src/scan_renderer_polar.cpp:6-81): per theta bin the returns are sorted by range
+  // descending (equal ranges keep their input order) and walked: slope > 1 against the previous return counts an
+  // obstacle at its range bin, slope < 0.3 (and no obstacle just before) counts ground from the previous range bin up
+  // to this one.  imgs[0] ground, imgs[1] obstacles.  (Commented out at the reference's call site,
+  // src/top_down_render.cpp:540; part of the class surface.)
+  void renderGeometricTopDown(const pcl::PointCloud<PointType>::ConstPtr& cloud, float res, float ang_res,
                               std::vector<Eigen::ArrayXXf>& imgs) {
-    for (Eigen::ArrayXXf& im : imgs) im.setZero();
+    render_geo(1, cloud, res, ang_res, imgs);
   }
 };
 

@@ -121,6 +121,27 @@ def raster_cart(pts, res, lut256, ncls, rows, cols):
     return out
 
 
+def raster_geo_polar(pts, width, height, res, ang_res, nb, nr):
+    """renderGeometricTopDown (scan_renderer_polar.cpp:6-81): (2, nb*nr) ground / obstacle images.  pts is the organised
+    cloud in PCL order (element idy*width + idx)."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    assert pts.shape[0] == width * height
+    out = np.empty((2, nb * nr), np.float32)
+    lib().orc_raster_geo_polar(_p(pts), C.c_int(pts.shape[1]), C.c_long(width), C.c_long(height), C.c_float(res),
+                               C.c_float(ang_res), C.c_int(nb), C.c_int(nr), _p(out))
+    return out
+
+
+def raster_geo_cart(pts, width, height, res, rows, cols):
+    """renderGeometricTopDown (scan_renderer.cpp:7-53): (2, rows*cols) ground / obstacle images."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    assert pts.shape[0] == width * height
+    out = np.empty((2, rows * cols), np.float32)
+    lib().orc_raster_geo_cart(_p(pts), C.c_int(pts.shape[1]), C.c_long(width), C.c_long(height), C.c_float(res),
+                              C.c_int(rows), C.c_int(cols), _p(out))
+    return out
+
+
 def polar_table(nb, nr, ang_res, resolution=1.0):
     """Returns (P, 2) float32 (interleaved like Eigen::Array2Xf)."""
     tab = np.empty((nb * nr, 2), np.float32)

@@ -107,6 +107,102 @@ void orc_raster_cart(const float* pts, int stride, int ioff, long n, float res,
   }
 }
 
+// A3  ScanRendererPolar::renderGeometricTopDown   (src/scan_renderer_polar.cpp:6-81)
+// The cloud is read as cloud->at(idx, idy) with idx < width outer, idy < height inner (:27-29): element idy*width + idx.
+// imgs: [2][nb*nr] col-major: [0] ground, [1] obstacles.
+// x86 float -> int conversion (cvttss2si): NaN and out-of-range give INT_MIN.
+static inline int cvt_x86(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : INT32_MIN; }
+// Conventions where the reference leaves a choice (documented in DESIGN.md):
+//  * std::sort (:49-51) is not stable; ties in r keep their input order here (std::stable_sort);
+//  * a point whose x or y is not finite would index ang_bins with (int)NaN (undefined behaviour): it is dropped;
+//  * unqualified atan2 / sqrt / abs on floats are taken as the float overloads, like in A1.
+void orc_raster_geo_polar(const float* pts, int stride, long width, long height, float res, float ang_res, int nb,
+                          int nr, float* imgs) {
+  std::memset(imgs, 0, sizeof(float) * (size_t)2 * nb * nr);       // :11-13
+  struct P { float x, y, z, r; };
+  std::vector<std::vector<P>> bins((size_t)nb);                    // :17-21
+  for (long idx = 0; idx < width; idx++)
+    for (long idy = 0; idy < height; idy++) {
+      const float* p = pts + (size_t)(idy * width + idx) * stride;
+      const float x = p[0], y = p[1], z = p[2];
+      if (x == 0 && y == 0) continue;                              // :30
+      if (!std::isfinite(x) || !std::isfinite(y)) continue;
+      const float theta = atan2f(x, y);                            // :32
+      const float r = sqrtf(x * x + y * y);                        // :33
+      float t = roundf(theta / ang_res) + (float)(nb / 2);         // :36-37 std::clamp<float>(.., 0, rows-1)
+      t = t < 0.f ? 0.f : (t > (float)(nb - 1) ? (float)(nb - 1) : t);
+      bins[(size_t)(int)t].push_back(P{x, y, z, r});               // :39
+    }
+  for (int theta_ind = 0; theta_ind < nb; theta_ind++) {
+    std::vector<P>& bin = bins[(size_t)theta_ind];
+    std::stable_sort(bin.begin(), bin.end(), [](const P& a, const P& b) { return a.r > b.r; });   // :49-51
+    float lx = 0, ly = 0, lz = 0;                                  // :54
+    bool last_high_grad = false;
+    int last_r_ind = 0;
+    for (const P& pt : bin) {
+      const float dx = pt.x - lx, dy = pt.y - ly;
+      const float dist = sqrtf(dx * dx + dy * dy);                 // :58
+      const float slope = fabsf(pt.z - lz) / dist;                 // :59
+      const int r_ind = cvt_x86(roundf(pt.r / res));               // :60
+      if (slope > 1) {                                             // :62-66
+        if (r_ind >= 0 && r_ind < nr) imgs[(size_t)nb * nr + theta_ind + (size_t)nb * r_ind] += 1;
+        last_high_grad = true;
+      } else if ((double)slope < 0.3 && last_high_grad == false) { // :67-72
+        // (last_r_ind is negative only after a return 2^31 bins away, where the reference writes in front of its image)
+        for (long i = last_r_ind < 0 ? 0 : last_r_ind; i <= r_ind && i < nr; i++) imgs[theta_ind + (size_t)nb * i] += 1;
+      } else {
+        last_high_grad = false;                                    // :73-75
+      }
+      lx = pt.x; ly = pt.y; lz = pt.z;                             // :76-77
+      last_r_ind = r_ind;
+    }
+  }
+}
+
+// A3  ScanRenderer::renderGeometricTopDown   (src/scan_renderer.cpp:7-53): every column idx of the organised cloud is
+// one vertical scan line walked upwards; ground cells are filled along the line between consecutive returns.
+// imgs: [2][rows*cols] col-major, img_size = (cols, rows) (:10).  Non-finite x / y: dropped (their indices are INT_MIN
+// in the reference and the line interpolation then overflows: undefined behaviour).
+void orc_raster_geo_cart(const float* pts, int stride, long width, long height, float res, int rows, int cols,
+                         float* imgs) {
+  std::memset(imgs, 0, sizeof(float) * (size_t)2 * rows * cols);
+  for (long idx = 0; idx < width; idx++) {
+    float lx = 0, ly = 0, lz = 0;                                  // :17
+    int last_x = cols / 2, last_y = rows / 2;                      // :19
+    bool last_high_grad = false;
+    for (long idy = 0; idy < height; idy++) {                      // :23
+      const float* p = pts + (size_t)(idy * width + idx) * stride;
+      const float x = p[0], y = p[1], z = p[2];
+      if (x == 0 && y == 0) continue;                              // :26
+      if (!std::isfinite(x) || !std::isfinite(y)) continue;
+      const int x_ind = cvt_x86(roundf(x / res) + (float)(cols / 2));   // :27
+      const int y_ind = cvt_x86(roundf(y / res) + (float)(rows / 2));   // :28
+      // returns more than 2^24 cells away: the interpolation loop below overflows / does not terminate in the reference
+      const int lim = 1 << 24;
+      if (x_ind > lim || x_ind < -lim || y_ind > lim || y_ind < -lim) continue;
+      const float dx = x - lx, dy = y - ly;
+      const float dist = sqrtf(dx * dx + dy * dy);                 // :30
+      const float slope = fabsf(z - lz) / dist;                    // :31
+      if (slope > 1) {                                             // :32-36
+        if (x_ind >= 0 && x_ind < cols && y_ind >= 0 && y_ind < rows) imgs[(size_t)rows * cols + y_ind + (size_t)rows * x_ind] += 1;
+        last_high_grad = true;
+      } else if ((double)slope < 0.3 && last_high_grad == false) { // :37-45
+        const long long ddx = (long long)x_ind - last_x, ddy = (long long)y_ind - last_y;
+        const int nrm = (int)std::sqrt((double)(ddx * ddx + ddy * ddy));   // Vector2i::norm(): integer sqrt, truncated
+        for (float i = 0; i < 1; i = (float)((double)i + 1. / nrm)) {      // :39
+          const int ix = (int)roundf((float)last_x + i * (float)ddx);
+          const int iy = (int)roundf((float)last_y + i * (float)ddy);
+          if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) imgs[iy + (size_t)rows * ix] += 1;   // :41-44
+        }
+      } else {
+        last_high_grad = false;                                    // :46-48
+      }
+      lx = x; ly = y; lz = z;                                      // :49
+      last_x = x_ind; last_y = y_ind;                              // :50
+    }
+  }
+}
+
 // Eigen's LinSpaced<float>(n, low, high) coefficient i (linspaced_op_impl, non-integer branch).
 static inline float linspaced(int i, int n, float low, float high) {
   int size1 = (n == 1) ? 1 : n - 1;

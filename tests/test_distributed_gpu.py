@@ -28,7 +28,7 @@ def _free_port():
     return p
 
 
-def _run(group, out_path, six_classes):
+def _run(group, out_path, six_classes, force_collectives=False):
     import top_down_renderer_amd as pkg
     from top_down_renderer_amd import synth
     from top_down_renderer_amd.kernels import HipKernels
@@ -42,7 +42,9 @@ def _run(group, out_path, six_classes):
     m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
     m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
     f = pkg.ParticleFilter(N, m, pkg.FilterParams(fixed_scale=1.0), seed=7, group=group, kernels=k,
-                           parity_rng=False, locality_every=1, init_particles=False)
+                           parity_rng=False, locality_every=1, init_particles=False,
+                           force_collectives=force_collectives)
+    assert f.comm.active == (group is not None)
     f.set_states(st)
     r = pkg.ScanRendererPolar(sc.lut, kernels=k)
     r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
@@ -61,8 +63,12 @@ def _run(group, out_path, six_classes):
         log[f"w{step}"] = f.weights()
         log[f"idx{step}"] = f.resample_indices()
         log[f"st{step}"] = f.get_states().view(np.uint8).reshape(-1, 28)
-        log[f"ml{step}"] = f.maxLikelihood()
+        # the reference node's order (top_down_render.cpp:333,354): the pose statistics first (they all-gather the
+        # resampled states), then the max-likelihood particle, which is the PRE-resample one
         log[f"mean{step}"] = f.meanLikelihood()
+        log[f"cov{step}"] = f.computeMeanCov()
+        log[f"covml{step}"] = f.computeCov()
+        log[f"ml{step}"] = f.maxLikelihood()
     np.savez(out_path, **log)
 
 
@@ -91,5 +97,37 @@ def test_two_gpu_ranks_equal_one_rank_bit_for_bit(six_classes):
             both = np.concatenate([r0[f"{key}{step}"], r1[f"{key}{step}"]])
             assert np.array_equal(both, single[f"{key}{step}"], equal_nan=True), (key, step)
         assert np.array_equal(r0[f"ml{step}"], single[f"ml{step}"]) and np.array_equal(r1[f"ml{step}"], single[f"ml{step}"])
-        assert np.array_equal(r0[f"mean{step}"], single[f"mean{step}"])
+        for key in ("mean", "cov", "covml"):
+            assert np.array_equal(r0[f"{key}{step}"], single[f"{key}{step}"]), (key, step)
+            assert np.array_equal(r1[f"{key}{step}"], single[f"{key}{step}"]), (key, step)
     assert len(single["st2"]) == 4096 and len(r0["st2"]) == 2048
+
+
+def _rccl_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        _run(dist.group.WORLD, os.path.join(tmp, "rccl.npz"), True, force_collectives=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_world_size_one_equals_groupless_run():
+    """backend "nccl" IS RCCL on ROCm.  With the one GPU of this box the group has a single rank, but every collective
+    of the sharded filter goes through RCCL for real: the scan broadcast, the blocking all-gather of {raw weights,
+    last_dist}, the ASYNC all-gather of the state planes (its own stream, waited for at the gather) and the gathers
+    behind the pose statistics.  Results must equal the group-less filter bit for bit.  (The 8-GPU run is the driver's.)"""
+    import torch.multiprocessing as mp
+    tmp = tempfile.mkdtemp(prefix="tdr_rccl_")
+    _run(None, os.path.join(tmp, "single.npz"), True)
+    mp.spawn(_rccl_worker, args=(1, _free_port(), tmp), nprocs=1, join=True)
+    load = lambda n: np.load(os.path.join(tmp, n), allow_pickle=False)  # noqa: E731
+    single, rc = load("single.npz"), load("rccl.npz")
+    assert set(single.files) == set(rc.files)
+    for key in single.files:
+        assert np.array_equal(single[key], rc[key], equal_nan=True), key

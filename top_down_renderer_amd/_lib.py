@@ -25,7 +25,8 @@ class FilterParamsC(C.Structure):
 
 class MapDescC(C.Structure):
     _fields_ = [("rec", C.c_void_p), ("ncls", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("rec_floats", C.c_int32), ("resolution", C.c_float)]
+                ("rec_floats", C.c_int32), ("resolution", C.c_float),
+                ("cwords", C.c_int32), ("dict_n", C.c_int32), ("crec", C.c_void_p), ("dict", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/tdr.h declares
@@ -36,6 +37,10 @@ SIGNATURES = {
     "tdr_device_count": (_i, []),
     "tdr_rec_floats": (_i, [_i]),
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_cmap_words": (_i, [_i]),
+    "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
+    "tdr_k_unpack_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp]),
     "tdr_k_selftest_atan2": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tdr_libm_variant": (_i, []),
     "tdr_libm_force_variant": (_i, [_i]),
@@ -51,6 +56,9 @@ SIGNATURES = {
     "tdr_raster_workspace_bytes": (_i64, [_i64]),
     "tdr_k_raster_polar": (_i, [_vp, _i, _i, _i64, _f, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tdr_k_raster_cart": (_i, [_vp, _i, _i, _i64, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "tdr_raster_geo_workspace_bytes": (_i64, [_i64]),
+    "tdr_k_raster_geo_polar": (_i, [_vp, _i, _i64, _i64, _f, _f, _i, _i, _vp, _vp, _vp]),
+    "tdr_k_raster_geo_cart": (_i, [_vp, _i, _i64, _i64, _f, _i, _i, _vp, _vp]),
     "tdr_k_pack_scan": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
@@ -102,6 +110,7 @@ SIGNATURES = {
     "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
     "tdr_renderer_destroy": (None, [_vp]),
     "tdr_renderer_render": (_i, [_vp, _i, _vp, _i, _i, _i64, _f, _f, _i, _i, _i, _vp]),
+    "tdr_renderer_render_geo": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _f, _i, _i, _vp]),
     "tdr_filter_create": (_i, [_vp, _i, C.POINTER(FilterParamsC), _u32, C.POINTER(_vp)]),
     "tdr_filter_destroy": (None, [_vp]),
     "tdr_filter_configure": (_i, [_vp, _i, _i]),

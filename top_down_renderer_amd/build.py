@@ -7,10 +7,10 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", f) for f in
-       ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_filter.hip", "tdr_prefix.hip",
+       ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_filter.hip", "tdr_prefix.hip", "tdr_geo.hip", "tdr_cmap.hip",
         "tdr_host.cpp", "tdr_gmm.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h"), os.path.join(PKG, "csrc", "tdr_common.h"),
-       os.path.join(PKG, "csrc", "tdr_sincosf.h")]
+       os.path.join(PKG, "csrc", "tdr_sincosf.h"), os.path.join(PKG, "csrc", "tdr_atan2f.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 
 # -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)

@@ -1,0 +1,194 @@
+// tdr_cmap.hip — the COMPACT map: the same cell records as tdr_map.hip at a quarter of the bytes, exact by construction.
+//
+// Why.  A scoring wave whose 64 particles are spread over the map (particle initialisation, the uniform tenth of the
+// bench workload, multi-hypothesis clusters) touches one 128-byte line per lane and sample and uses 32 bytes of it: the
+// kernel then runs at the HBM rate and only fewer bytes make it faster.  Distance maps are
+// `min(50, resolution * sqrt(d2))` with integer d2 (src/top_down_map.cpp:312-317, cv::distanceTransform DIST_L2 /
+// MASK_PRECISE): a 4000 x 4000 six-class map holds < 800 DISTINCT float values.  So a cell is stored as 10-bit indices
+// into a dictionary of the map's own float values — three per dword, `known` in the top bit of the record's last dword —
+// and decoded through an LDS copy of the dictionary: bit-identical operands, 8 bytes instead of 32 for six classes.
+// Records are tiled 4 rows x (32 / record bytes) columns per 128-byte line, so a ray crosses (|sin| + |cos|) / 4 lines
+// per cell step instead of one (row direction) or a quarter (column direction) of a row-major layout.
+//
+// Built from the dense records, whoever produced them (tdr_k_pack_map, tdr_k_map_from_labels), once per map:
+//   cmap_collect_kernel  every distance value -> a hash set in device memory (distinct count capped at 1024)
+//   host                 the <= 1024 values, sorted, become the dictionary; slot -> index table for the hash set
+//   cmap_pack_kernel     one thread per compact record: look the cell's values up, pack, store tile-major (coalesced)
+// A map with more than 1024 distinct values (fine resolutions) or more than 11 classes has no compact form: the
+// scoring kernels then read the dense records for every wave, as before.
+#include <algorithm>
+
+#include "tdr_common.h"
+
+#define CMAP_HASH_BITS 13
+#define CMAP_HASH_SLOTS (1 << CMAP_HASH_BITS)
+#define CMAP_EMPTY 0xFFFFFFFFu
+
+__device__ __forceinline__ unsigned cmap_hash(unsigned v) { return (v * 2654435761u) >> (32 - CMAP_HASH_BITS); }
+
+// count[0] = distinct values inserted, count[1] = overflow flag
+__global__ __launch_bounds__(256) void cmap_collect_kernel(const float* __restrict__ rec, int64_t gcell, int rf, int ncls,
+                                                           unsigned* __restrict__ hash, int* __restrict__ count) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gcell) return;
+  unsigned last = CMAP_EMPTY;
+  for (int k = 0; k < ncls; k++) {
+    const unsigned v = __float_as_uint(rec[idx * rf + k]);
+    if (v == last) continue;   // runs of equal values (the truncation distance) cost one lookup
+    last = v;
+    if (v == CMAP_EMPTY) { atomicExch(&count[1], 1); return; }   // this NaN payload is the empty marker: not compactable
+    unsigned h = cmap_hash(v);
+    for (int probe = 0; probe < CMAP_HASH_SLOTS; probe++) {
+      const unsigned cur = hash[h];
+      if (cur == v) break;
+      if (cur == CMAP_EMPTY) {
+        if (count[1]) return;                                     // already overflowed: stop filling the table
+        const unsigned old = atomicCAS(&hash[h], CMAP_EMPTY, v);
+        if (old == CMAP_EMPTY) {
+          if (atomicAdd(&count[0], 1) >= TDR_CMAP_MAX_DICT) atomicExch(&count[1], 1);
+          break;
+        }
+        if (old == v) break;
+      }
+      h = (h + 1) & (CMAP_HASH_SLOTS - 1);
+    }
+  }
+}
+
+struct CmapGeom {
+  int cw;            // dwords per record: 1, 2 or 4
+  int lc;            // log2 of the tile's column count: tile = 4 rows x (1 << lc) columns = 128 bytes
+  int tiles_r, tiles_c;
+};
+static CmapGeom cmap_geom(int cw, int rows, int cols) {
+  CmapGeom g;
+  g.cw = cw;
+  g.lc = cw == 1 ? 3 : (cw == 2 ? 2 : 1);
+  // cell (r, c), r in [-1, rows], lives in tile ((r >> 2) + 1, (c >> lc) + 1): tile row / column 0 hold the guard ring
+  g.tiles_r = (rows >> 2) + 2;
+  g.tiles_c = (cols >> g.lc) + 2;
+  return g;
+}
+extern "C" int tdr_cmap_words(int ncls) {
+  const int rf = tdr_rec_floats(ncls);
+  const int nd = tdr_has_kslot(ncls, rf) ? rf - 2 : rf - 1;   // distance slots the scoring loop multiplies
+  const int dw = (nd + 2) / 3;                                // three 10-bit fields per dword
+  if (dw > 4) return 0;
+  return dw <= 1 ? 1 : (dw == 2 ? 2 : 4);
+}
+extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
+  const int cw = tdr_cmap_words(ncls);
+  if (!cw) return 0;
+  const CmapGeom g = cmap_geom(cw, rows, cols);
+  return (size_t)g.tiles_r * g.tiles_c * 32;   // 128 bytes per tile
+}
+
+__global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
+                                                        int ncls, const unsigned* __restrict__ hash,
+                                                        const uint16_t* __restrict__ hidx, CmapGeom g,
+                                                        uint32_t* __restrict__ crec) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_tile = 4 << g.lc;
+  const int64_t ntile = (int64_t)g.tiles_r * g.tiles_c;
+  if (t >= ntile * per_tile) return;
+  const int64_t tile = t / per_tile;
+  const int within = (int)(t - tile * per_tile);
+  const int tr = (int)(tile / g.tiles_c), tc = (int)(tile - (int64_t)tr * g.tiles_c);
+  const int r = ((tr - 1) << 2) + (within >> g.lc), c = ((tc - 1) << g.lc) + (within & ((1 << g.lc) - 1));
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  if (r >= 0 && r < rows && c >= 0 && c < cols) {
+    const float* src = rec + ((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf;
+    for (int k = 0; k < ncls; k++) {
+      const unsigned v = __float_as_uint(src[k]);
+      unsigned h = cmap_hash(v);
+      while (hash[h] != v) h = (h + 1) & (CMAP_HASH_SLOTS - 1);   // every map value is in the set
+      w[k / 3] |= (uint32_t)hidx[h] << (10 * (k % 3));
+    }
+    if (src[rf - 1] != 0.f) w[g.cw - 1] |= 0x80000000u;            // known
+  }
+  for (int d = 0; d < g.cw; d++) crec[t * g.cw + d] = w[d];
+}
+
+// Builds the compact form of map->rec into crec_out (tdr_cmap_words_total dwords) / dict_out (TDR_CMAP_MAX_DICT
+// floats), workspace = TDR_CMAP_WORKSPACE_BYTES of device scratch, and fills map->crec / dict / dict_n / cwords.
+// Load-time work: synchronises with `stream` in the middle (the dictionary is sorted on the host).  A map that has no
+// compact form leaves map->cwords = 0 and returns TDR_OK.
+extern "C" int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream) {
+  if (!map || !map->rec || !crec_out || !dict_out || !workspace) return fail(TDR_ERR_ARG, "compact_map: null pointer");
+  map->crec = nullptr; map->dict = nullptr; map->dict_n = 0; map->cwords = 0;
+  const int ncls = map->ncls, rf = map->rec_floats, rows = map->rows, cols = map->cols;
+  const int cw = tdr_cmap_words(ncls);
+  if (!cw) return TDR_OK;
+  const CmapGeom g = cmap_geom(cw, rows, cols);
+  if ((uint64_t)g.tiles_r * g.tiles_c * 128 > 0xFFFFFFF0ull || g.tiles_c >= (1 << 22)) return TDR_OK;   // 32-bit offsets
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* hash = reinterpret_cast<unsigned*>(workspace);
+  uint16_t* hidx = reinterpret_cast<uint16_t*>(hash + CMAP_HASH_SLOTS);
+  int* count = reinterpret_cast<int*>(hidx + CMAP_HASH_SLOTS);
+  HIP_TRY(hipMemsetAsync(hash, 0xFF, sizeof(unsigned) * CMAP_HASH_SLOTS, s));
+  HIP_TRY(hipMemsetAsync(count, 0, 2 * sizeof(int), s));
+  const int64_t gcell = (int64_t)(rows + 2) * (cols + 2);
+  hipLaunchKernelGGL(cmap_collect_kernel, dim3((unsigned)cdiv(gcell, 256)), dim3(256), 0, s, map->rec, gcell, rf, ncls,
+                     hash, count);
+  LAUNCH_CHECK("cmap_collect");
+  int hcount[2] = {0, 0};
+  std::vector<unsigned> hh(CMAP_HASH_SLOTS);
+  HIP_TRY(hipMemcpyAsync(hcount, count, sizeof(hcount), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hh.data(), hash, sizeof(unsigned) * CMAP_HASH_SLOTS, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (hcount[1] || hcount[0] > TDR_CMAP_MAX_DICT) return TDR_OK;   // too many distinct values: dense records only
+  // dictionary: +0.0f first (the guard record and unused fields are index 0), the rest ascending by bit pattern
+  std::vector<unsigned> vals;
+  vals.push_back(0u);
+  for (unsigned v : hh)
+    if (v != CMAP_EMPTY && v != 0u) vals.push_back(v);
+  std::sort(vals.begin() + 1, vals.end());
+  if ((int)vals.size() > TDR_CMAP_MAX_DICT) return TDR_OK;
+  std::vector<float> dict(TDR_CMAP_MAX_DICT, 0.f);
+  std::memcpy(dict.data(), vals.data(), vals.size() * sizeof(unsigned));
+  std::vector<uint16_t> hx(CMAP_HASH_SLOTS, 0);
+  for (int h = 0; h < CMAP_HASH_SLOTS; h++)
+    if (hh[h] != CMAP_EMPTY && hh[h] != 0u)
+      hx[h] = (uint16_t)(std::lower_bound(vals.begin() + 1, vals.end(), hh[h]) - vals.begin());
+  HIP_TRY(hipMemcpyAsync(dict_out, dict.data(), sizeof(float) * TDR_CMAP_MAX_DICT, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(hidx, hx.data(), sizeof(uint16_t) * CMAP_HASH_SLOTS, hipMemcpyHostToDevice, s));
+  const int64_t nrec = (int64_t)g.tiles_r * g.tiles_c * (4 << g.lc);
+  hipLaunchKernelGGL(cmap_pack_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, map->rec, rows, cols, rf, ncls,
+                     (const unsigned*)hash, (const uint16_t*)hidx, g, crec_out);
+  LAUNCH_CHECK("cmap_pack");
+  HIP_TRY(hipStreamSynchronize(s));   // dict / hx live on this stack frame until the copies are done
+  map->crec = crec_out;
+  map->dict = dict_out;
+  map->dict_n = (int)vals.size();
+  map->cwords = cw;
+  return TDR_OK;
+}
+
+// Compact records back to dense ones: rec_out [(rows+2)*(cols+2)][rf] exactly as tdr_k_pack_map writes them — the
+// round-trip check of the encoding (tests/test_gpu_parity.py::test_compact_map_round_trip).
+__global__ __launch_bounds__(256) void cmap_unpack_kernel(const uint32_t* __restrict__ crec, const float* __restrict__ dict,
+                                                          int rows, int cols, int rf, int ncls, CmapGeom g,
+                                                          float* __restrict__ rec) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gcols = cols + 2, gcell = (int64_t)(rows + 2) * gcols;
+  if (idx >= gcell) return;
+  const int r = (int)(idx / gcols) - 1, c = (int)(idx % gcols) - 1;
+  const int64_t tile = (int64_t)((r >> 2) + 1) * g.tiles_c + ((c >> g.lc) + 1);
+  const int within = ((r & 3) << g.lc) | (c & ((1 << g.lc) - 1));
+  const uint32_t* w = crec + (tile * (4 << g.lc) + within) * g.cw;
+  float* o = rec + idx * rf;
+  for (int k = 0; k < rf; k++) o[k] = 0.f;
+  for (int k = 0; k < ncls; k++) o[k] = dict[(w[k / 3] >> (10 * (k % 3))) & 1023u];
+  const float known = (w[g.cw - 1] >> 31) ? 1.f : 0.f;
+  o[rf - 1] = known;
+  if (tdr_has_kslot(ncls, rf)) o[rf - 2] = known;
+}
+extern "C" int tdr_k_unpack_compact_map(const tdr_map_desc* map, float* rec_out, void* stream) {
+  if (!map || !map->crec || !map->dict || !rec_out || !map->cwords) return fail(TDR_ERR_ARG, "unpack_compact_map: no compact map");
+  const CmapGeom g = cmap_geom(map->cwords, map->rows, map->cols);
+  const int64_t gcell = (int64_t)(map->rows + 2) * (map->cols + 2);
+  hipLaunchKernelGGL(cmap_unpack_kernel, dim3((unsigned)cdiv(gcell, 256)), dim3(256), 0, (hipStream_t)stream, map->crec,
+                     map->dict, map->rows, map->cols, map->rec_floats, map->ncls, g, rec_out);
+  LAUNCH_CHECK("cmap_unpack");
+  return TDR_OK;
+}

@@ -78,8 +78,9 @@ struct tdr_map {
 
 struct tdr_renderer {
   DevBuf<int32_t> lut;
-  DevBuf<float> pts, img, pk;
+  DevBuf<float> pts, img, pk, geo;
   DevBuf<uint8_t> keys;  // per-point bin keys of the two-phase raster
+  DevBuf<uint8_t> geo_ws;  // sort keys / scratch of the geometric render
   int ncls = 0, rows = 0, cols = 0;  // shape of the last render
   bool have_scan = false;
 };
@@ -310,6 +311,28 @@ int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride
   r->rows = rows;
   r->cols = cols;
   r->have_scan = true;
+  return TDR_OK;
+}
+
+// renderGeometricTopDown (scan_renderer_polar.cpp:6-81 when polar != 0, scan_renderer.cpp:7-53 otherwise).  pts: HOST
+// organised cloud (element idy*width + idx); imgs_out: HOST [2][rows*cols] column-major (ground, obstacles).
+int tdr_renderer_render_geo(tdr_renderer* r, int polar, const float* pts, int stride, int64_t width, int64_t height,
+                            float res, float ang_res, int rows, int cols, float* imgs_out) {
+  if (!r || !imgs_out) return failh(TDR_ERR_ARG, "render_geo: null pointer");
+  const int64_t n = width * height;
+  if (width < 0 || height < 0 || (n > 0 && !pts)) return failh(TDR_ERR_ARG, "render_geo: bad cloud");
+  if (rows < 1 || cols < 1) return TDR_OK;
+  const size_t P = (size_t)rows * cols;
+  TTRY(r->pts.resize((size_t)std::max<int64_t>(n, 1) * stride));
+  TTRY(r->geo.resize(2 * P));
+  if (n > 0) HTRY(hipMemcpy(r->pts.p, pts, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
+  if (polar) {
+    TTRY(r->geo_ws.resize((size_t)tdr_raster_geo_workspace_bytes(std::max<int64_t>(n, 1))));
+    TTRY(tdr_k_raster_geo_polar(r->pts.p, stride, width, height, res, ang_res, rows, cols, r->geo.p, r->geo_ws.p, nullptr));
+  } else {
+    TTRY(tdr_k_raster_geo_cart(r->pts.p, stride, width, height, res, rows, cols, r->geo.p, nullptr));
+  }
+  HTRY(hipMemcpy(imgs_out, r->geo.p, 2 * P * sizeof(float), hipMemcpyDeviceToHost));
   return TDR_OK;
 }
 

@@ -124,6 +124,18 @@ class HipKernels:
                                          _ptr(img), _ptr(pk), _ptr(self._raster_workspace(n)), self.stream()))
         return img, pk
 
+    def raster_geo(self, pts, stride, width, height, res, ang_res, rows, cols, polar):
+        """renderGeometricTopDown on a device cloud (organised: element idy*width + idx): (2, rows*cols) device images."""
+        img = self.empty((2, rows * cols))
+        if polar:
+            ws = self.empty((int(self.lib.tdr_raster_geo_workspace_bytes(max(1, width * height))),), torch.uint8)
+            check(self.lib.tdr_k_raster_geo_polar(_ptr(pts), stride, width, height, C.c_float(res), C.c_float(ang_res),
+                                                  rows, cols, _ptr(img), _ptr(ws), self.stream()))
+        else:
+            check(self.lib.tdr_k_raster_geo_cart(_ptr(pts), stride, width, height, C.c_float(res), rows, cols, _ptr(img),
+                                                 self.stream()))
+        return img
+
     # ---- getLocalMap materialised ----------------------------------------------------------------------------
     def local_map(self, m, polar, cx, cy, scale_or_rot, res, rows=None, cols=None):
         """(dists (ncls, rows*cols) float32, mask (rows*cols,) uint8) device tensors: the window of one pose

@@ -69,7 +69,7 @@ class FilterParams:
 class _Comm:
     """The collective steps of the sharded filter on top of torch.distributed (nccl == RCCL on ROCm, gloo on CPU)."""
 
-    def __init__(self, group):
+    def __init__(self, group, force_collectives=False):
         self.group = group
         if group is None:
             self.world, self.rank = 1, 0
@@ -77,33 +77,38 @@ class _Comm:
             import torch.distributed as dist
             self.dist = dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # `active`: the filter takes the sharded code path (collectives, global arrays).  A one-rank group normally
+        # does not — nothing to exchange — unless force_collectives asks for it (the RCCL test on a one-GPU box).
+        self.active = group is not None and (self.world > 1 or force_collectives)
 
     def all_gather(self, out, inp, async_op=False):
         """out: [world * len(inp)] contiguous, rank-major.  async_op: returns a handle whose wait() orders the current
         stream behind the collective (RCCL runs it on its own stream, so kernels launched meanwhile overlap it)."""
-        if self.world == 1:
+        if not self.active:
             out.copy_(inp)
             return None
         return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
     def broadcast(self, t, src=0):
-        if self.world > 1:
+        if self.active:
             self.dist.broadcast(t, src=src, group=self.group)
 
 
 class ParticleFilter:
     def __init__(self, N, map, params, seed=0, group=None, kernels=None, parity_rng=True, locality_every=0,
-                 init_particles=True):
+                 init_particles=True, force_collectives=False):
         """N: maximum (global) particle count; map: TopDownMapPolar; params: FilterParams.
         group: torch.distributed process group (None = single process); particles are sharded over its ranks.
         parity_rng: propagate consumes host-generated std::mt19937 normals in the reference's order (bit-parity with
         the CPU path); False = counter-based RNG on the device (throughput mode).
         locality_every: recompute the cache-locality processing order every k updates (0 = never).
-        init_particles: run initializeParticles() like the reference's constructor (False: call set_states())."""
+        init_particles: run initializeParticles() like the reference's constructor (False: call set_states()).
+        force_collectives: take the sharded code path (scan broadcast, both all-gathers) even when the group has one
+        rank — lets a one-GPU box exercise RCCL end to end."""
         self.map_ = map
         self.k = kernels if kernels is not None else map.k
         self.params_ = params
-        self.comm = _Comm(group)
+        self.comm = _Comm(group, force_collectives)
         self.max_num_particles_ = int(N)
         if self.max_num_particles_ % self.comm.world:
             raise ValueError("N must be a multiple of the number of ranks")
@@ -140,7 +145,7 @@ class ParticleFilter:
         self.info = k.zeros((65536,))   # TDR_UW_INFO_FLOATS
         self.weights_ = k.zeros((N,))
         self.runmax = k.zeros((N,))
-        if self.comm.world > 1:
+        if self.comm.active:
             self.xchg_in = k.zeros((2, cap))
             self.xchg_out = k.zeros((self.comm.world, 2, cap))
             self.raw_glob = k.zeros((N,))
@@ -253,7 +258,7 @@ class ParticleFilter:
             self._maybe_uninit = False
         self._n_raw = nl
 
-        if comm.world > 1:
+        if comm.active:
             self.xchg_in[0, :nl].copy_(self.raw_w[:nl])
             self.xchg_in[1, :nl].copy_(self.last_dist[:nl])
             xin = self.xchg_in[:, :nl].contiguous()
@@ -267,7 +272,7 @@ class ParticleFilter:
             raw_glob, ld_glob = self.raw_w, self.last_dist
         # the pre-resample states are final now: their all-gather (28 B x N) runs behind the statistics and the running sum
         st_work, sa = None, None
-        if comm.world > 1:
+        if comm.active:
             sa = self.st_all[: comm.world * 7 * nl]
             self._st_send = self.st[:, :nl].contiguous().view(-1)
             st_work = comm.all_gather(sa, self._st_send, async_op=True)
@@ -292,7 +297,7 @@ class ParticleFilter:
         nl_new = n_new // comm.world
         i0 = comm.rank * nl_new
         k.resample(self.runmax, n, n_new, float(shift), i0, i0 + nl_new, self.idx)
-        if comm.world > 1:
+        if comm.active:
             if st_work is not None:
                 st_work.wait()
             k.gather_states(sa, self.idx, nl_new, self.st_new, src_shard=nl)
@@ -329,7 +334,7 @@ class ParticleFilter:
     # ---- particle_filter.cpp:191-236 ----------------------------------------------------------------------------------
     def _global_states(self):
         nl = self.n_local
-        if self.comm.world == 1:
+        if not self.comm.active:
             return self.st, nl, 0
         sa = self.st_all[: self.comm.world * 7 * nl]
         self.comm.all_gather(sa, self.st[:, :nl].contiguous().view(-1))

@@ -46,6 +46,27 @@ class ScanRenderer:
         self._last = (img, pk)
         self._fill(imgs, img, rows, cols)
 
+    def _organised(self, cloud, width, height):
+        pts, n, stride, _ = self._points(cloud)
+        if width is None:
+            width, height = n, 1          # an unorganised cloud: pcl sets width = size, height = 1
+        if width * height != n:
+            raise ValueError("cloud has %d points, width x height = %d x %d" % (n, width, height))
+        return pts, stride, int(width), int(height)
+
+    def renderGeometricTopDown(self, cloud, res, imgs, width=None, height=None):
+        """src/scan_renderer.cpp:7-53: ground (imgs[0]) / obstacle (imgs[1]) counts; every column of the organised
+        cloud (cloud->at(idx, idy) = element idy*width + idx) is one scan line.  Returns the (2, rows*cols) device images."""
+        if len(imgs) < 2:
+            return None   # :8
+        pts, stride, width, height = self._organised(cloud, width, height)
+        rows, cols = imgs[0].shape
+        img = self.k.raster_geo(pts, stride, width, height, float(res), 0.0, rows, cols, polar=False)
+        self._fill(imgs[:2], img, rows, cols)
+        for im in imgs[2:]:
+            im[...] = 0          # `imgs[i].setZero()` for every image (:12-14)
+        return img
+
     def _shape(self, imgs):
         if imgs is None:
             return self.default_shape
@@ -73,3 +94,16 @@ class ScanRendererPolar(ScanRenderer):
         img, pk = self.k.raster_polar(pts, n, stride, ioff, float(res), float(ang_res), self.flatten_lut_, ncls, nb, nr)
         self._last = (img, pk)
         self._fill(imgs, img, nb, nr)
+
+    def renderGeometricTopDown(self, cloud, res, ang_res, imgs, width=None, height=None):
+        """src/scan_renderer_polar.cpp:6-81: per theta bin the returns sorted by range descending and walked (equal
+        ranges in input order).  imgs[0] ground, imgs[1] obstacles, (theta bins x range bins)."""
+        if len(imgs) < 2:
+            return None   # :8
+        pts, stride, width, height = self._organised(cloud, width, height)
+        nb, nr = imgs[0].shape
+        img = self.k.raster_geo(pts, stride, width, height, float(res), float(ang_res), nb, nr, polar=True)
+        self._fill(imgs[:2], img, nb, nr)
+        for im in imgs[2:]:
+            im[...] = 0
+        return img
