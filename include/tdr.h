@@ -253,6 +253,11 @@ int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, v
 int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t n, float* out12, void* stream);
 int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream);      /* updateMap :325-334 */
 
+/* The scoring kernels read the compact records whenever the map has them (tdr_k_compact_map); tdr_config_compact(0)
+ * forces the dense records (A/B measurements, tests), 1 restores the default, < 0 only queries.  Results never depend on
+ * it: both forms decode to the same operands.  Returns the value in force.  (Environment: TDR_COMPACT=0.) */
+int tdr_config_compact(int on);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* While enabled, every launch of the scoring kernel is bracketed by HIP events on its launch stream;
  * tdr_profile_score_ms synchronises on them, returns the summed duration and the launch count, and resets. */

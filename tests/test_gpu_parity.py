@@ -412,6 +412,88 @@ def test_local_map_polar_and_cartesian_bit_exact(tdr, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(d1, d2)) and np.array_equal(m1, m2)
 
 
+# ---- compact map records ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ncls,rows,cols", [(2, 97, 130), (3, 200, 150), (6, 301, 257), (7, 64, 64), (10, 90, 75)])
+def test_compact_map_round_trip(tdr, ncls, rows, cols):
+    """csrc/tdr_cmap.hip: the compact records (10-bit dictionary indices, tiled) decode to the dense records bit for bit,
+    for every record width (1, 2 and 4 dwords), non-square maps and maps whose sides are not multiples of the tile."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    import ctypes as C
+    cfg = synth.Config("cm", 100, ncls, 16, 8, max(rows, cols), 4, seed=300 + ncls)
+    sc = synth.make_scene(cfg, with_particles=False)
+    maps = np.ascontiguousarray(sc.class_maps[:, :rows, :cols])
+    mask = np.ascontiguousarray(sc.class_mask[:rows, :cols])
+    m = k.make_map(maps, mask, 1.0)
+    assert m.desc.cwords == k.lib.tdr_cmap_words(ncls) and m.desc.cwords in (1, 2, 4)
+    assert 1 < m.desc.dict_n <= 1024
+    dic = m.dict.cpu().numpy()
+    assert dic[0] == 0.0 and set(np.unique(maps)) <= set(dic[: m.desc.dict_n])
+    back = k.zeros((m.rec.numel(),))
+    assert k.lib.tdr_k_unpack_compact_map(C.byref(m.desc), C.c_void_p(back.data_ptr()), k.stream()) == 0
+    assert __import__("torch").equal(back, m.rec)
+
+
+def test_map_without_compact_form_falls_back_to_dense(tdr, oracle):
+    """More than 1024 distinct distance values (here: random floats) or more than 11 classes: no compact records, every
+    wave reads the dense ones; scoring is unaffected."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("nocm", 3000, 4, 32, 24, 160, 300, seed=71)
+    sc = synth.make_scene(cfg)
+    maps = sc.class_maps * np.random.default_rng(5).uniform(0.5, 1.0, sc.class_maps.shape).astype(np.float32)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), maps, sc.class_mask, kernels=k)
+    assert m.dev.desc.cwords == 0 and m.dev.crec is None
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref = oracle.compute_weights(oracle.OracleMap(maps, sc.class_mask, 1.0), oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res),
+                                 cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls), sc.states.copy())
+    f = pkg.ParticleFilter(len(sc.states), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False)
+    f.set_states(sc.states)
+    f.update(scan, None, cfg.res)
+    _assert_weights(f.raw_weights(), ref)
+    assert k.lib.tdr_cmap_words(12) == 0 and k.lib.tdr_cmap_words(11) == 4 and k.lib.tdr_cmap_words(6) == 2
+
+
+@pytest.mark.parametrize("ncls,nb,scale_fixed", [(3, 36, True), (6, 64, True), (6, 50, False), (7, 33, True), (9, 40, False)])
+def test_compact_and_dense_records_score_identically(tdr, oracle, ncls, nb, scale_fixed):
+    """A particle's raw weight does not depend on which record form the launch read: the dense-record kernel
+    (tdr_config_compact(0)) and the compact-record kernel give the same bits — and the oracle's weights to 1e-5."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("cmix", 4000, ncls, nb, 24, 260, 1500, seed=900 + ncls + nb)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    rng = np.random.default_rng(ncls)
+    if not scale_fixed:
+        st["scale"] = rng.uniform(0.6, 1.7, len(st)).astype(np.float32)
+    far = rng.random(len(st)) < 0.1
+    st["init_x_px"][far] = rng.uniform(-300, 600, int(far.sum())).astype(np.float32)   # partly outside the map
+    params = dict(fixed_scale=1.0 if scale_fixed else -1.0)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    assert m.dev.desc.cwords > 0
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0),
+                                 oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
+                                 oracle.make_params(cfg.ncls, **params), st.copy())
+    before = k.lib.tdr_config_compact(-1)
+    out = []
+    try:
+        for on in (0, 1):
+            k.lib.tdr_config_compact(on)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False,
+                                   locality_every=on)
+            f.set_states(st)
+            f.update(scan, None, cfg.res)
+            out.append(f.raw_weights())
+    finally:
+        k.lib.tdr_config_compact(before)
+    _assert_weights(out[0], ref)
+    for o in out[1:]:
+        assert np.array_equal(out[0], o, equal_nan=True)
+
+
 # ---- A10 propagate ------------------------------------------------------------------------------------------------------
 def test_propagate_golden(tdr, g):
     pkg, k = tdr

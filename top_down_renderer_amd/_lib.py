@@ -37,6 +37,7 @@ SIGNATURES = {
     "tdr_device_count": (_i, []),
     "tdr_rec_floats": (_i, [_i]),
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_config_compact": (_i, [_i]),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),

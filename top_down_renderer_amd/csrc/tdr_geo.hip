@@ -3,15 +3,15 @@
 //   Cartesian: src/scan_renderer.cpp:7-53         per scan line of the organised cloud: slope walk, ground cells filled
 //                                                 along the line between consecutive returns
 // The reference's node has the call commented out (src/top_down_render.cpp:540) and publishes zero images; the functions
-// themselves are part of the class surface and are reproduced here exactly (integer counts, bit-exact against the
-// oracle).  Both walks are serial per bin / per scan line by definition (every step depends on the previous return), so
+// themselves are part of the class surface and are reproduced here exactly (integer counts; tests/test_geo.py checks
+// them bit for bit).  Both walks are serial per bin / per scan line by definition (every step depends on the previous return), so
 // the parallel axis is the bin / the line:
 //   polar:     geo_keys_kernel (one thread per point: theta bin + range -> 64-bit key) -> rocPRIM radix sort (stable:
 //              equal ranges keep their input order — the documented tie rule where std::sort leaves it open) ->
 //              geo_walk_polar_kernel (one thread per theta bin walks its run of the sorted list; it owns its image row)
 //   Cartesian: geo_walk_cart_kernel (one thread per scan line; lines may cross, so cells are counted with atomics —
 //              the addends are all 1, the result is order-independent and exact below 2^24)
-// Conventions where the reference leaves a choice (same as the oracle): unqualified atan2 / sqrt / abs on
+// Conventions where the reference leaves a choice: unqualified atan2 / sqrt / abs on
 // floats are the float overloads; a point whose x or y is not finite is dropped (the reference would index a vector
 // with (int)NaN); float -> int conversions follow x86 (cvttss2si: NaN / out of range -> INT_MIN).
 #include <rocprim/device/device_radix_sort.hpp>

@@ -68,6 +68,9 @@ struct DevBuf {
 struct tdr_map {
   DevBuf<float> rec;
   DevBuf<float> tab;
+  DevBuf<uint32_t> crec;   // compact form of `rec` (tdr_k_compact_map), when the map has one
+  DevBuf<float> cdict;
+  DevBuf<uint8_t> cws;
   std::vector<float> maps_host;  // class_maps_ (column-major), kept for getClassesAtPoint / particle initialisation
   tdr_map_desc desc{};
   int nb = 0, nr = 0;
@@ -108,6 +111,17 @@ struct tdr_filter {
   hipStream_t stream = nullptr;
 };
 
+// the compact records of a freshly packed map (desc.rec etc. already set)
+static int map_compact(tdr_map* m) {
+  m->desc.crec = nullptr; m->desc.dict = nullptr; m->desc.dict_n = 0; m->desc.cwords = 0;
+  const size_t nw = tdr_cmap_words_total(m->desc.ncls, m->desc.rows, m->desc.cols);
+  if (nw == 0) return TDR_OK;
+  TTRY(m->crec.resize(nw));
+  TTRY(m->cdict.resize(TDR_CMAP_MAX_DICT));
+  TTRY(m->cws.resize(TDR_CMAP_WORKSPACE_BYTES));
+  return tdr_k_compact_map(&m->desc, m->crec.p, m->cdict.p, m->cws.p, nullptr);
+}
+
 extern "C" {
 
 // ---- TopDownMap(Polar) ------------------------------------------------------------------------------------------------
@@ -145,6 +159,7 @@ int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, 
   m->desc.resolution = resolution;
   m->center_x = center_x;
   m->center_y = center_y;
+  TTRY(map_compact(m));
   m->have_map = true;
   if (m->nb > 0) return tdr_map_sample_pts_polar(m, m->nb, m->nr, m->ang_res);
   return TDR_OK;
@@ -183,6 +198,7 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
   m->desc.resolution = resolution;
   m->center_x = center_x;
   m->center_y = center_y;
+  TTRY(map_compact(m));
   // `if (!class_maps_[1].isZero(0)) have_map_ = true; else "Received map with no road"` (:150-154)
   bool road = false;
   if (ncls > 1)

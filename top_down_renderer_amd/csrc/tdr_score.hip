@@ -25,6 +25,10 @@ struct ScoreArgs {
   int rpc, nchunks;     // rings per chunk
   int64_t npad;         // slots padded to a multiple of 64
   float* part;          // [nchunks][rf+1][npad]
+  // compact form of the records (tdr_cmap.hip), read by the COMPACT instantiations
+  const uint32_t* crec;
+  const float* dict;
+  int ctiles_c;         // tiles per tile row
 };
 
 __device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
@@ -47,6 +51,49 @@ __device__ __forceinline__ int round_half_away_clamped(float x) {
   return r;
 }
 
+// ---- compact records (tdr_cmap.hip): geometry, load, decode — shared by the polar and the Cartesian kernel ------------
+template <int RF, bool KSLOT>
+struct CmapShape {
+  static constexpr int ND = KSLOT ? RF - 2 : RF - 1;                               // distance slots of a record
+  static constexpr int CW = (ND + 2) / 3 <= 1 ? 1 : ((ND + 2) / 3 == 2 ? 2 : 4);   // dwords of a compact record
+  static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = 4 rows x (1 << LC) columns
+};
+// byte offset of cell (ri, ci) — it lives in tile ((ri >> 2) + 1, (ci >> LC) + 1), ckconst = (tiles_c + 1) * 128 — or of
+// record 0 of tile 0 (a guard record: distances 0, unknown) when the cell is outside the map
+template <int CW, int LC>
+__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, bool inb, int ctiles_c, int ckconst) {
+  const int tile = __mul24(ri >> 2, ctiles_c) + (ci >> LC);
+  const int within = ((ri & 3) << LC) | (ci & ((1 << LC) - 1));
+  return inb ? (unsigned)(tile * 128 + within * (4 * CW) + ckconst) : 0u;
+}
+template <int CW>
+__device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsigned off, uint32_t (&w)[CW]) {
+  if constexpr (CW == 1) {
+    w[0] = *reinterpret_cast<const uint32_t*>(crecb + off);
+  } else if constexpr (CW == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(crecb + off);
+    w[0] = v.x; w[1] = v.y;
+  } else {
+    const uint4 v = *reinterpret_cast<const uint4*>(crecb + off);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  }
+}
+// one compact record -> the RF operands the dense record would have delivered, bit for bit (ldict: the dictionary in LDS)
+template <int RF, bool KSLOT>
+__device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KSLOT>::CW], const float* ldict, float (&m)[RF]) {
+  constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const uint32_t ww = w[k / 3];
+    const int sh = 10 * (k % 3);
+    const uint32_t boff = sh >= 2 ? ((ww >> (sh - 2)) & 0xFFCu) : ((ww << 2) & 0xFFCu);   // index * 4
+    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+  }
+  const float kf = (float)(w[CW - 1] >> 31);
+  if (KSLOT) m[RF - 2] = kf;
+  m[RF - 1] = kf;
+}
+
 #ifdef TDR_SCORE_TIMELINE   // diagnostic build: start / end time stamp (100 MHz) of every workgroup
 #define TDR_TL_MAX (1 << 17)
 __device__ unsigned long long g_timeline[2 * TDR_TL_MAX];
@@ -54,9 +101,15 @@ extern "C" int tdr_debug_read_timeline(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int NV4, int U, bool KSLOT, bool USCALE>
-__global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
+// COMPACT: this instantiation reads the compact records (10-bit dictionary indices, decoded through LDS; bit-identical
+// operands) instead of the dense ones — a quarter of the bytes through L1 / L2 / HBM for six classes.  It is the one
+// that runs whenever the map has a compact form (A/B on MI355X, config 2, 100 k particles, ms per launch dense ->
+// compact: bench mix 15.5 -> 9.6, 100 % Gaussian 30 px 7.3 -> 5.9, Gaussian 5 px 6.2 -> 5.8, 100 % uniform 97 -> 67,
+// 8 clusters 20.3 -> 6.6); the dense instantiation remains for maps without one (> 1024 distinct values, > 11 classes).
+template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT>
+__global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
+  constexpr int CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
 #ifdef TDR_SCORE_TIMELINE
   const unsigned tl_id = blockIdx.y * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0 && tl_id < TDR_TL_MAX) g_timeline[2 * tl_id] = wall_clock64();
@@ -90,7 +143,13 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
   const int kbase = (a.cols + 3) * (RF * 4);                // byte offset of cell (0,0)
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
-  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  // The sample table is read-only for the whole launch and every lane of a wave reads the same entry: it is addressed
+  // through the CONSTANT address space so that these are scalar loads whatever else the kernel contains.  (Left to its
+  // own no-clobber analysis the compiler gives up in the compact kernel — the dictionary staging is one store too many —
+  // and emits vector loads with a full wait in front of every address computation.)
+  typedef const float __attribute__((address_space(4))) * tdr_const_f;
+  const tdr_const_f tabc = (tdr_const_f)(USCALE ? a.utab : a.tab);
+  auto tab_at = [&](int64_t k) { return make_float2(tabc[2 * k], tabc[2 * k + 1]); };
   const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
   const int nb2 = 2 * a.nb;
 
@@ -125,6 +184,30 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
 #endif
   };
 
+  // ---- compact records: the dictionary in LDS, the tiled address, the decode -----------------------------------------
+  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
+  if constexpr (COMPACT)
+    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  const int ckconst = (a.ctiles_c + 1) * 128;   // cell (r, c) lives in tile ((r >> 2) + 1, (c >> LC) + 1)
+  auto ccell_offset = [&](float2 t) -> unsigned {
+    float p0, p1;
+    if constexpr (USCALE) {
+      p0 = t.x;
+      p1 = t.y;
+    } else {
+      p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
+      p1 = (t.y * scale) * a.res;
+    }
+    p0 = p0 + off0;
+    p1 = p1 + off1;
+    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
+    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
+    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
+    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+    return cmap_offset<CW, LC>(ri, ci, inb, a.ctiles_c, ckconst);
+  };
+
   for (int j = j0; j < j1; j++) {
     __syncthreads();
     for (int t = threadIdx.x; t < a.nb * NV4; t += 256) {
@@ -134,11 +217,66 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
       ring[pl * nb2 + row + a.nb] = v;
     }
     __syncthreads();
+    if constexpr (COMPACT) {
+      // the same samples in the same order with the same operands as the dense loop below: identical bits
+      float acc[RF];
+#pragma unroll
+      for (int k = 0; k < RF; k++) acc[k] = 0.f;
+      float known = 0.f;
+      const int64_t trow = (int64_t)j * a.nb;
+      const float4* rl = ring + shift;
+      int i = 0;
+      for (; i + U <= a.nb; i += U) {
+        unsigned boff[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) boff[u] = ccell_offset(tab_at(trow + i + u));
+        uint32_t w[U][CW];
+        float4 s[U][NV4];
+#pragma unroll
+        for (int u = 0; u < U; u++) cmap_load<CW>(crecb, boff[u], w[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int v = 0; v < NV4; v++) s[u][v] = rl[v * nb2 + i + u];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          float m[RF];
+          cmap_decode<RF, KSLOT>(w[u], ldict, m);
+#pragma unroll
+          for (int v = 0; v < NV4; v++) {
+            acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[4 * v + 0], acc[4 * v + 0]);
+            acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[4 * v + 1], acc[4 * v + 1]);
+            acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[4 * v + 2], acc[4 * v + 2]);
+            acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[4 * v + 3], acc[4 * v + 3]);
+          }
+          if (!KSLOT) known += m[RF - 1];
+        }
+      }
+      for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
+        const unsigned bo = ccell_offset(tab_at(trow + i));
+        uint32_t w[CW];
+        cmap_load<CW>(crecb, bo, w);
+        float m[RF];
+        cmap_decode<RF, KSLOT>(w, ldict, m);
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          const float4 sv = rl[v * nb2 + i];
+          acc[4 * v + 0] = __builtin_fmaf(sv.x, m[4 * v + 0], acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(sv.y, m[4 * v + 1], acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(sv.z, m[4 * v + 2], acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(sv.w, m[4 * v + 3], acc[4 * v + 3]);
+        }
+        if (!KSLOT) known += m[RF - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < RF; k++) acc2[k] += acc[k];
+      known2 += known;
+    } else {
     float acc[RF];
 #pragma unroll
     for (int k = 0; k < RF; k++) acc[k] = 0.f;
     float known = 0.f;
-    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const int64_t trow = (int64_t)j * a.nb;
     const float4* rl = ring + shift;
     int i = 0;
     // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together,
@@ -146,7 +284,7 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
     for (; i + U <= a.nb; i += U) {
       unsigned boff[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) boff[u] = cell_offset(trow[i + u]);
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(tab_at(trow + i + u));
       float4 m[U][NV4], s[U][NV4];
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -169,7 +307,7 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
       }
     }
     for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
-      const unsigned bo = cell_offset(trow[i]);
+      const unsigned bo = cell_offset(tab_at(trow + i));
 #pragma unroll
       for (int v = 0; v < NV4; v++) {
         const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
@@ -184,6 +322,7 @@ __global__ __launch_bounds__(256) void score_polar_kernel(ScoreArgs a) {
 #pragma unroll
     for (int k = 0; k < RF; k++) acc2[k] += acc[k];
     known2 += known;
+    }   // dense records
   }
   if (slot < a.npad) {
     float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
@@ -217,6 +356,9 @@ struct CartArgs {
   int64_t npad;
   float* part;
   int libm_fma;          // which build of sinf / cosf the host's libm runs (tdr_sincosf.h)
+  const uint32_t* crec;  // compact form of the records (COMPACT instantiations)
+  const float* dict;
+  int ctiles_c;
 };
 
 __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
@@ -224,9 +366,15 @@ __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, floa
   return (i == size1) ? high : (low + (float)i * step);
 }
 
-template <int NV4, int U, bool KSLOT>
+template <int NV4, int U, bool KSLOT, bool COMPACT>
 __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   constexpr int RF = 4 * NV4;
+  constexpr int CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
+  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
+  if constexpr (COMPACT) {
+    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
   if ((int64_t)blockIdx.x * 256 >= a.n) return;
@@ -253,7 +401,12 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   const int kbase = (a.map_cols + 3) * (RF * 4);
   const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
-  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  const int ckconst = (a.ctiles_c + 1) * 128;
+  // the scan record of sample (i, j) is the same for every lane: read through the CONSTANT address space = scalar loads
+  // whatever else the kernel contains (see score_polar_kernel)
+  typedef const float __attribute__((address_space(4))) * tdr_const_f;
+  const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
 
   float acc2[RF];
 #pragma unroll
@@ -273,48 +426,49 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
       p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
       const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);  // :437
       const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
-      return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+      if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, inb, a.ctiles_c, ckconst);
+      else return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+    };
+    // the record of one sample as RF operands: dense records as they are, compact ones decoded (bit-identical)
+    auto fetch = [&](unsigned off, float (&m)[RF]) {
+      if constexpr (COMPACT) {
+        uint32_t w[CW];
+        cmap_load<CW>(crecb, off, w);
+        cmap_decode<RF, KSLOT>(w, ldict, m);
+      } else {
+#pragma unroll
+        for (int v = 0; v < NV4; v++) {
+          const float4 q = *reinterpret_cast<const float4*>(recb + off + 16 * v);
+          m[4 * v + 0] = q.x; m[4 * v + 1] = q.y; m[4 * v + 2] = q.z; m[4 * v + 3] = q.w;
+        }
+      }
     };
     float acc[RF];
 #pragma unroll
     for (int k = 0; k < RF; k++) acc[k] = 0.f;
     float known = 0.f;
-    const float4* srow = scan4 + (int64_t)j * a.rows * NV4;  // wave-uniform: scalar loads
+    const int64_t sbase = (int64_t)j * a.rows * RF;  // wave-uniform
     int i = 0;
     for (; i + U <= a.rows; i += U) {
       unsigned boff[U];
 #pragma unroll
       for (int u = 0; u < U; u++) boff[u] = cell_offset(i + u);
-      float4 m[U][NV4];
+      float m[U][RF];
 #pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
+      for (int u = 0; u < U; u++) fetch(boff[u], m[u]);
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int v = 0; v < NV4; v++) {
-          const float4 sv = srow[(i + u) * NV4 + v];
-          acc[4 * v + 0] = __builtin_fmaf(sv.x, m[u][v].x, acc[4 * v + 0]);
-          acc[4 * v + 1] = __builtin_fmaf(sv.y, m[u][v].y, acc[4 * v + 1]);
-          acc[4 * v + 2] = __builtin_fmaf(sv.z, m[u][v].z, acc[4 * v + 2]);
-          acc[4 * v + 3] = __builtin_fmaf(sv.w, m[u][v].w, acc[4 * v + 3]);
-        }
-        if (!KSLOT) known += m[u][NV4 - 1].w;
+        for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + (int64_t)(i + u) * RF + k], m[u][k], acc[k]);
+        if (!KSLOT) known += m[u][RF - 1];
       }
     }
     for (; i < a.rows; i++) {
-      const unsigned bo = cell_offset(i);
+      float m[RF];
+      fetch(cell_offset(i), m);
 #pragma unroll
-      for (int v = 0; v < NV4; v++) {
-        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
-        const float4 sv = srow[i * NV4 + v];
-        acc[4 * v + 0] = __builtin_fmaf(sv.x, m.x, acc[4 * v + 0]);
-        acc[4 * v + 1] = __builtin_fmaf(sv.y, m.y, acc[4 * v + 1]);
-        acc[4 * v + 2] = __builtin_fmaf(sv.z, m.z, acc[4 * v + 2]);
-        acc[4 * v + 3] = __builtin_fmaf(sv.w, m.w, acc[4 * v + 3]);
-        if (!KSLOT && v == NV4 - 1) known += m.w;
-      }
+      for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + (int64_t)i * RF + k], m[k], acc[k]);
+      if (!KSLOT) known += m[RF - 1];
     }
 #pragma unroll
     for (int k = 0; k < RF; k++) acc2[k] += acc[k];
@@ -1028,27 +1182,53 @@ static int check_map_addressing(const tdr_map_desc* map, int rf, const char* who
   return TDR_OK;
 }
 
-static int launch_score(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
+// The compact records are used whenever the map has them; tdr_config_compact(0) forces the dense ones (A/B, tests).
+static int g_use_compact = [] {
+  const char* e = getenv("TDR_COMPACT");
+  return e ? atoi(e) : 1;
+}();
+extern "C" int tdr_config_compact(int on) {   // < 0: query only
+  if (on >= 0) g_use_compact = on ? 1 : 0;
+  return g_use_compact;
+}
+extern "C" int tdr_cmap_words(int ncls);
+
+template <bool CM>
+static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
-  size_t lds = (size_t)2 * a.nb * rf * 4;
+  size_t lds = (size_t)2 * a.nb * rf * 4;   // + the static dictionary array of the compact kernels (4 KB)
   const bool ks = tdr_has_kslot(ncls, rf);
-  ScoreProfScope prof(s);
   const bool us = a.utab != nullptr;
-#define TDR_LAUNCH_SCORE(NV4)                                                                                   \
-  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true>), grid, block, lds, s, a);   \
-  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false>), grid, block, lds, s, a);   \
-  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true>), grid, block, lds, s, a);   \
-  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false>), grid, block, lds, s, a);
+#define TDR_LAUNCH_SCORE(NV4)                                                                                       \
+  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true, CM>), grid, block, lds, s, a);   \
+  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false, CM>), grid, block, lds, s, a);   \
+  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true, CM>), grid, block, lds, s, a);   \
+  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false, CM>), grid, block, lds, s, a);
   switch (rf / 4) {
     case 1: TDR_LAUNCH_SCORE(1) break;
     case 2: TDR_LAUNCH_SCORE(2) break;
     case 3: TDR_LAUNCH_SCORE(3) break;
-    case 4: TDR_LAUNCH_SCORE(4) break;
+    case 4:
+      if constexpr (!CM) { TDR_LAUNCH_SCORE(4) }   // 12-15 classes have no compact form
+      break;
     default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
   }
 #undef TDR_LAUNCH_SCORE
   LAUNCH_CHECK("score_polar");
   return TDR_OK;
+}
+static bool map_has_compact(const tdr_map_desc* map, int rf) {
+  return g_use_compact && map->cwords > 0 && map->crec && map->dict && map->cwords == tdr_cmap_words(map->ncls) && rf <= 12;
+}
+static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s) {
+  a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
+  ScoreProfScope prof(s);
+  if (!map_has_compact(map, rf)) return launch_score_form<false>(a, rf, ncls, s);
+  const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
+  a.crec = map->crec;
+  a.dict = map->dict;
+  a.ctiles_c = (map->cols >> lc) + 2;
+  return launch_score_form<true>(a, rf, ncls, s);
 }
 
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
@@ -1143,7 +1323,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
                        (const float*)res_flag, n, st, cap);
     LAUNCH_CHECK("init_apply");
   }
-  rc = launch_score(a, rf, map->ncls, s);
+  rc = launch_score(a, map, rf, map->ncls, s);
   if (rc) return rc;
 
   FinalizeArgs f;
@@ -1193,19 +1373,29 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   a.libm_fma = tdr_libm_fma();
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
+  const bool cm = map_has_compact(map, rf);
+  a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
+  if (cm) {
+    const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
+    a.crec = map->crec; a.dict = map->dict; a.ctiles_c = (map->cols >> lc) + 2;
+  }
   {
     ScoreProfScope prof(s);
-#define TDR_LAUNCH_CART(NV4)                                                                        \
-  if (ks) hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, true>), grid, block, 0, s, a);    \
-  else hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, false>), grid, block, 0, s, a);
+#define TDR_LAUNCH_CART2(NV4, CM)                                                                       \
+  if (ks) hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, true, CM>), grid, block, 0, s, a);    \
+  else hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, false, CM>), grid, block, 0, s, a);
+#define TDR_LAUNCH_CART(NV4)               \
+  if (cm) { TDR_LAUNCH_CART2(NV4, true) }  \
+  else { TDR_LAUNCH_CART2(NV4, false) }
     switch (rf / 4) {
       case 1: TDR_LAUNCH_CART(1) break;
       case 2: TDR_LAUNCH_CART(2) break;
       case 3: TDR_LAUNCH_CART(3) break;
-      case 4: TDR_LAUNCH_CART(4) break;
+      case 4: TDR_LAUNCH_CART2(4, false) break;
       default: return fail(TDR_ERR_ARG, "score_cart: unsupported record size %d", rf);
     }
 #undef TDR_LAUNCH_CART
+#undef TDR_LAUNCH_CART2
   }
   LAUNCH_CHECK("score_cart");
   FinalizeArgs f;

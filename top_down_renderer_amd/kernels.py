@@ -29,6 +29,22 @@ class DeviceMap:
         self.tab_host = None  # numpy (P,2) f32
         self.nb = self.nr = 0
         self.ang_res = 0.0
+        self.crec = self.dict = None   # compact form of the records (tdr_k_compact_map), when the map has one
+
+    def compact(self, kernels):
+        """Builds the compact records (csrc/tdr_cmap.hip): 10-bit dictionary indices instead of floats, exact by
+        construction; read by scoring waves whose particles are spread over the map.  No-op for maps without one."""
+        lib = kernels.lib
+        nw = int(lib.tdr_cmap_words_total(self.ncls, self.rows, self.cols))
+        if nw == 0:
+            return False
+        crec = kernels.empty((nw,), torch.int32)
+        dic = kernels.empty((1024,))                    # TDR_CMAP_MAX_DICT
+        ws = kernels.empty((8192 * 4 + 8192 * 2 + 256,), torch.uint8)   # TDR_CMAP_WORKSPACE_BYTES
+        check(lib.tdr_k_compact_map(C.byref(self.desc), _ptr(crec), _ptr(dic), _ptr(ws), kernels.stream()))
+        if self.desc.cwords:
+            self.crec, self.dict = crec, dic            # keep the device memory alive with the descriptor
+        return bool(self.desc.cwords)
 
 
 class HipKernels:
@@ -70,7 +86,9 @@ class HipKernels:
         check(self.lib.tdr_k_pack_map(_ptr(maps_cm), _ptr(mask_cm), ncls, H, W, _ptr(rec), self.stream()))
         self.synchronize()
         del maps_cm, mask_cm
-        return DeviceMap(rec, ncls, H, W, resolution)
+        m = DeviceMap(rec, ncls, H, W, resolution)
+        m.compact(self)
+        return m
 
     def make_map_from_labels(self, label_img, flatten_lut, ncls, resolution):
         """label_img: (img_h, img_w) uint8 class-index image (cv::Mat layout, row 0 = top).  Runs
@@ -87,7 +105,9 @@ class HipKernels:
         check(self.lib.tdr_k_map_from_labels(_ptr(img_d), img_h, img_w, _ptr(lut_d), len(lut), ncls,
                                              C.c_float(resolution), _ptr(rec), _ptr(ws), self.stream()))
         self.synchronize()
-        return DeviceMap(rec, ncls, rows, cols, resolution)
+        m = DeviceMap(rec, ncls, rows, cols, resolution)
+        m.compact(self)
+        return m
 
     def unpack_map(self, m):
         """Device map -> the reference's host layout: class maps (ncls, cols, rows) i.e. column-major, mask (cols, rows)."""
