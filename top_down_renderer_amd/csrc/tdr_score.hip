@@ -1,4 +1,6 @@
 // tdr_score.hip — per-particle window gather + class-wise score: polar, Cartesian, finalize, the 40-rotation init search.
+#include <type_traits>
+
 #include "tdr_common.h"
 #include "tdr_sincosf.h"
 
@@ -22,7 +24,7 @@ struct ScoreArgs {
   const int32_t* count; // optional device count limiting the active slots (init search)
   int use_theta_override;
   float theta_override;
-  int rpc, nchunks;     // rings per chunk
+  int group, nchunks;   // rings per workgroup (score_group_rings), number of groups
   int64_t npad;         // slots padded to a multiple of 64
   float* part;          // [nchunks][rf+1][npad]
   // compact form of the records (tdr_cmap.hip), read by the COMPACT instantiations
@@ -58,13 +60,16 @@ struct CmapShape {
   static constexpr int CW = (ND + 2) / 3 <= 1 ? 1 : ((ND + 2) / 3 == 2 ? 2 : 4);   // dwords of a compact record
   static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = 4 rows x (1 << LC) columns
 };
-// byte offset of cell (ri, ci) — it lives in tile ((ri >> 2) + 1, (ci >> LC) + 1), ckconst = (tiles_c + 1) * 128 — or of
-// record 0 of tile 0 (a guard record: distances 0, unknown) when the cell is outside the map
+// Byte offset of cell (ri, ci), ri in [-1, rows], ci in [-1, cols] (the clamped sample coordinate): it lives in tile
+// ((ri >> 2) + 1, (ci >> LC) + 1) at (ri & 3, ci & (2^LC - 1)); ckconst = (tiles_c + 1) * 128.  Cells outside the map are
+// guard records (distance 0, unknown).  Written separably — 128 * tile + 32 * (ri & 3) + RB * (ci & ..) =
+// [32 ri + (ri >> 2)(128 tiles_c - 128)] + [RB ci + 96 (ci >> LC)] with RB = 4 CW record bytes — it is six integer ops.
 template <int CW, int LC>
-__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, bool inb, int ctiles_c, int ckconst) {
-  const int tile = __mul24(ri >> 2, ctiles_c) + (ci >> LC);
-  const int within = ((ri & 3) << LC) | (ci & ((1 << LC) - 1));
-  return inb ? (unsigned)(tile * 128 + within * (4 * CW) + ckconst) : 0u;
+__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ctiles_c, int ckconst) {
+  const int t1 = __mul24(ri >> 2, ctiles_c * 128 - 128) + ckconst;   // v_mad_i32_i24
+  const int t2 = __mul24(ci >> LC, 96) + t1;
+  const int t3 = (ri << 5) + t2;                                   // v_lshl_add_u32
+  return (unsigned)((ci << (CW == 1 ? 2 : (CW == 2 ? 3 : 4))) + t3);
 }
 template <int CW>
 __device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsigned off, uint32_t (&w)[CW]) {
@@ -106,6 +111,14 @@ extern "C" int tdr_debug_read_timeline(unsigned long long* out, int n) {
 // that runs whenever the map has a compact form (A/B on MI355X, config 2, 100 k particles, ms per launch dense ->
 // compact: bench mix 15.5 -> 9.6, 100 % Gaussian 30 px 7.3 -> 5.9, Gaussian 5 px 6.2 -> 5.8, 100 % uniform 97 -> 67,
 // 8 clusters 20.3 -> 6.6); the dense instantiation remains for maps without one (> 1024 distinct values, > 11 classes).
+//
+// Work decomposition: grid.y = GROUP of a.group consecutive range rings (a constant of the image shape, see
+// score_group_rings), so the summation tree of a particle's score is a pure function of the configuration — never of the
+// number of particles in the launch or of the rank count.  Inside a group the samples are visited RAY-major: for each
+// window row i (a direction) the group's rings in turn, i.e. up to a.group consecutive cells along one ray.  Compact
+// records are tiled 4 x 4 cells per 128-byte line, so a ray stays in a tile for ~3 steps: a lane whose neighbours are far
+// away (scattered particles) fetches ~0.5 lines per sample instead of one.  The scan rows of the whole group sit in LDS
+// ([ring][plane][row], not doubled: the row (i + shift) mod nb is computed once per direction).
 template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT>
 __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
@@ -114,7 +127,8 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
   const unsigned tl_id = blockIdx.y * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0 && tl_id < TDR_TL_MAX) g_timeline[2 * tl_id] = wall_clock64();
 #endif
-  extern __shared__ float4 ring[];  // [NV4 planes][2*nb rows]: row r and r+nb hold scan row r (no wrap arithmetic)
+  extern __shared__ float4 ring[];  // [nb rows][rs]: a row's (ring, plane) records side by side, rs = group * NV4 | 1
+  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if TDR_XCD_SWIZZLE
   // Workgroups are dealt round-robin over the 8 XCDs; remap so that each XCD (its own L2) gets a contiguous run of
@@ -138,11 +152,13 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
   const float theta = a.use_theta_override ? a.theta_override : a.st[TDR_ST_THETA * a.cap + p];
   const int shift = rot_shift_dev(theta, a.nb);  // scan row paired with window row i is (i + shift) mod nb
 
-  const int j0 = blockIdx.y * a.rpc, j1 = min(a.nr, j0 + a.rpc);
+  const int j0 = blockIdx.y * a.group, gn = min(a.nr - j0, a.group);   // this workgroup's rings: [j0, j0 + gn)
   const int rowstride = (a.cols + 2) * (RF * 4);            // bytes per guarded map row
   const int kbase = (a.cols + 3) * (RF * 4);                // byte offset of cell (0,0)
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  const int ckconst = (a.ctiles_c + 1) * 128;
   // The sample table is read-only for the whole launch and every lane of a wave reads the same entry: it is addressed
   // through the CONSTANT address space so that these are scalar loads whatever else the kernel contains.  (Left to its
   // own no-clobber analysis the compiler gives up in the compact kernel — the dictionary staging is one store too many —
@@ -151,184 +167,163 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
   const tdr_const_f tabc = (tdr_const_f)(USCALE ? a.utab : a.tab);
   auto tab_at = [&](int64_t k) { return make_float2(tabc[2 * k], tabc[2 * k + 1]); };
   const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
-  const int nb2 = 2 * a.nb;
+  const int nb = a.nb;
 
-  float acc2[RF];
-#pragma unroll
-  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
-  float known2 = 0.f;
+  // stage the group's scan rows and (compact) the dictionary
+  if constexpr (COMPACT)
+    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
+  // One row of the LDS image = the scan records (ring, plane) of one direction, 16 bytes each, side by side: a step
+  // reads them with ONE address per lane and immediate offsets.  The row stride is an ODD number of 16-byte slots, so
+  // lanes on different rows (different headings) fall on different banks.
+  const int rs = (a.group * NV4) | 1;
+  for (int jj = 0; jj < gn; jj++)
+    for (int t = threadIdx.x; t < nb * NV4; t += 256) {
+      const float4 v = scan4[(int64_t)(j0 + jj) * nb * NV4 + t];
+      const int row = t / NV4, pl = t - row * NV4;
+      ring[row * rs + jj * NV4 + pl] = v;
+    }
+  __syncthreads();
 
   // USCALE: every particle has the same scale, so (tab*scale)*res was evaluated once per step into a.utab and is
   // wave-uniform here; otherwise it is evaluated per lane.  Identical float operations either way.
+  // Returns the byte offset of the sample's record (dense: guarded row-major grid; compact: tiled).
+  typedef float tdr_v2f __attribute__((ext_vector_type(2)));   // both coordinates in one v_pk_add_f32 / v_pk_mul_f32
+  const tdr_v2f offv = {off0, off1};
   auto cell_offset = [&](float2 t) -> unsigned {
-    float p0, p1;
-    if constexpr (USCALE) {
-      p0 = t.x;
-      p1 = t.y;
-    } else {
-      p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
-      p1 = (t.y * scale) * a.res;
-    }
-    p0 = p0 + off0;
-    p1 = p1 + off1;
-    // clamp into the guard ring, then round like `pts.round().cast<int>()` (:31)
-    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
-    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
-    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
-#if TDR_OOB_ALIAS
-    // every out-of-bounds sample reads the SAME guard record (always cache-resident) instead of a distinct one
-    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
-    return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
-#else
-    return (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase));  // v_mad_i32_i24 + v_lshl_add
-#endif
-  };
-
-  // ---- compact records: the dictionary in LDS, the tiled address, the decode -----------------------------------------
-  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
-  if constexpr (COMPACT)
-    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
-  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
-  const int ckconst = (a.ctiles_c + 1) * 128;   // cell (r, c) lives in tile ((r >> 2) + 1, (c >> LC) + 1)
-  auto ccell_offset = [&](float2 t) -> unsigned {
-    float p0, p1;
-    if constexpr (USCALE) {
-      p0 = t.x;
-      p1 = t.y;
-    } else {
-      p0 = (t.x * scale) * a.res;  // top_down_map_polar.cpp:28
-      p1 = (t.y * scale) * a.res;
-    }
-    p0 = p0 + off0;
-    p1 = p1 + off1;
-    p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
-    p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
-    const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);
-    const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
-    return cmap_offset<CW, LC>(ri, ci, inb, a.ctiles_c, ckconst);
-  };
-
-  for (int j = j0; j < j1; j++) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < a.nb * NV4; t += 256) {
-      const float4 v = scan4[(int64_t)j * a.nb * NV4 + t];
-      const int row = t / NV4, pl = t - row * NV4;
-      ring[pl * nb2 + row] = v;
-      ring[pl * nb2 + row + a.nb] = v;
-    }
-    __syncthreads();
+    tdr_v2f pv = {t.x, t.y};
+    if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
+    pv = pv + offv;                                     // :29-30
+    // clamp into the guard ring, then round like `pts.round().cast<int>()` (:31): roundf(x) == floor(fl(x + (0.5 - 2^-25)))
+    // on [-1, 2^23] (round_half_away_clamped), the addition done for both coordinates at once
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;
+    int ri, ci;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
     if constexpr (COMPACT) {
-      // the same samples in the same order with the same operands as the dense loop below: identical bits
-      float acc[RF];
+      // cells of the guard ring are zero records in their own right (distance 0, unknown): no select needed
+      return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
+    } else {
+#if TDR_OOB_ALIAS
+      // every out-of-bounds sample reads the SAME guard record (always cache-resident) instead of a distinct one
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+#else
+      return (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase));  // v_mad_i32_i24 + v_lshl_add
+#endif
+    }
+  };
+  // the record at `off` as the RF operands of the product sums (compact: decoded, bit-identical to the dense record)
+  struct Raw { uint32_t w[COMPACT ? CW : 1]; float4 q[COMPACT ? 1 : NV4]; };
+  auto load_raw = [&](unsigned off, Raw& r) {
+    if constexpr (COMPACT) cmap_load<CW>(crecb, off, r.w);
+    else {
 #pragma unroll
-      for (int k = 0; k < RF; k++) acc[k] = 0.f;
-      float known = 0.f;
-      const int64_t trow = (int64_t)j * a.nb;
-      const float4* rl = ring + shift;
-      int i = 0;
-      for (; i + U <= a.nb; i += U) {
-        unsigned boff[U];
+      for (int v = 0; v < NV4; v++) r.q[v] = *reinterpret_cast<const float4*>(recb + off + 16 * v);
+    }
+  };
+  auto operands = [&](const Raw& r, float (&m)[RF]) {
+    if constexpr (COMPACT) cmap_decode<RF, KSLOT>(r.w, ldict, m);
+    else {
 #pragma unroll
-        for (int u = 0; u < U; u++) boff[u] = ccell_offset(tab_at(trow + i + u));
-        uint32_t w[U][CW];
-        float4 s[U][NV4];
+      for (int v = 0; v < NV4; v++) { m[4 * v] = r.q[v].x; m[4 * v + 1] = r.q[v].y; m[4 * v + 2] = r.q[v].z; m[4 * v + 3] = r.q[v].w; }
+    }
+  };
+
+  float acc[RF];
 #pragma unroll
-        for (int u = 0; u < U; u++) cmap_load<CW>(crecb, boff[u], w[u]);
+  for (int k = 0; k < RF; k++) acc[k] = 0.f;
+  float known = 0.f;
+  // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together, then
+  // the FMAs.  The order of the FMAs — direction i ascending, ring ascending within it — is the same in every
+  // instantiation and independent of U and of the launch: results are a pure function of the inputs.
+  auto step = [&](auto full_step, const unsigned (&boff)[U], const float4* const (&sp)[U], int cnt) {
+    constexpr bool FULL = decltype(full_step)::value;   // all U samples are real: no per-sample predicate
+    Raw raw[U];
+    float4 s[U][NV4];
 #pragma unroll
-        for (int u = 0; u < U; u++)
+    for (int u = 0; u < U; u++)
+      if (FULL || u < cnt) load_raw(boff[u], raw[u]);
 #pragma unroll
-          for (int v = 0; v < NV4; v++) s[u][v] = rl[v * nb2 + i + u];
+    for (int u = 0; u < U; u++)
+      if (FULL || u < cnt) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          float m[RF];
-          cmap_decode<RF, KSLOT>(w[u], ldict, m);
-#pragma unroll
-          for (int v = 0; v < NV4; v++) {
-            acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[4 * v + 0], acc[4 * v + 0]);
-            acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[4 * v + 1], acc[4 * v + 1]);
-            acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[4 * v + 2], acc[4 * v + 2]);
-            acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[4 * v + 3], acc[4 * v + 3]);
-          }
-          if (!KSLOT) known += m[RF - 1];
-        }
+        for (int v = 0; v < NV4; v++) s[u][v] = sp[u][v];
       }
-      for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
-        const unsigned bo = ccell_offset(tab_at(trow + i));
-        uint32_t w[CW];
-        cmap_load<CW>(crecb, bo, w);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (FULL || u < cnt) {
         float m[RF];
-        cmap_decode<RF, KSLOT>(w, ldict, m);
+        operands(raw[u], m);
 #pragma unroll
         for (int v = 0; v < NV4; v++) {
-          const float4 sv = rl[v * nb2 + i];
-          acc[4 * v + 0] = __builtin_fmaf(sv.x, m[4 * v + 0], acc[4 * v + 0]);
-          acc[4 * v + 1] = __builtin_fmaf(sv.y, m[4 * v + 1], acc[4 * v + 1]);
-          acc[4 * v + 2] = __builtin_fmaf(sv.z, m[4 * v + 2], acc[4 * v + 2]);
-          acc[4 * v + 3] = __builtin_fmaf(sv.w, m[4 * v + 3], acc[4 * v + 3]);
+          acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[4 * v + 0], acc[4 * v + 0]);
+          acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[4 * v + 1], acc[4 * v + 1]);
+          acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[4 * v + 2], acc[4 * v + 2]);
+          acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[4 * v + 3], acc[4 * v + 3]);
         }
         if (!KSLOT) known += m[RF - 1];
       }
+  };
+  if (gn >= U) {
+    // ray-major: consecutive samples of a lane are consecutive cells along one ray
+    const int gfull = gn - gn % U;
+    for (int i = 0; i < nb; i++) {
+      int row = i + shift;
+      row -= row >= nb ? nb : 0;
+      const float4* const rl = ring + __mul24(row, rs);
+      for (int jj = 0; jj < gfull; jj += U) {
+        unsigned boff[U];
+        const float4* sp[U];
+        const float4* const rj = rl + jj * NV4;
 #pragma unroll
-      for (int k = 0; k < RF; k++) acc2[k] += acc[k];
-      known2 += known;
-    } else {
-    float acc[RF];
-#pragma unroll
-    for (int k = 0; k < RF; k++) acc[k] = 0.f;
-    float known = 0.f;
-    const int64_t trow = (int64_t)j * a.nb;
-    const float4* rl = ring + shift;
-    int i = 0;
-    // U samples per step: all addresses first, then all loads (map records + LDS scan records) in flight together,
-    // then the FMAs — the wave keeps 2*U*NV4 16-byte loads outstanding instead of waiting per sample.
-    for (; i + U <= a.nb; i += U) {
-      unsigned boff[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) boff[u] = cell_offset(tab_at(trow + i + u));
-      float4 m[U][NV4], s[U][NV4];
-#pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int v = 0; v < NV4; v++) m[u][v] = *reinterpret_cast<const float4*>(recb + boff[u] + 16 * v);
-#pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int v = 0; v < NV4; v++) s[u][v] = rl[v * nb2 + i + u];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-#pragma unroll
-        for (int v = 0; v < NV4; v++) {
-          acc[4 * v + 0] = __builtin_fmaf(s[u][v].x, m[u][v].x, acc[4 * v + 0]);
-          acc[4 * v + 1] = __builtin_fmaf(s[u][v].y, m[u][v].y, acc[4 * v + 1]);
-          acc[4 * v + 2] = __builtin_fmaf(s[u][v].z, m[u][v].z, acc[4 * v + 2]);
-          acc[4 * v + 3] = __builtin_fmaf(s[u][v].w, m[u][v].w, acc[4 * v + 3]);
+        for (int u = 0; u < U; u++) {
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj + u) * nb + i));
+          sp[u] = rj + u * NV4;
         }
-        if (!KSLOT) known += m[u][NV4 - 1].w;
+        step(std::true_type{}, boff, sp, U);
       }
     }
-    for (; i < a.nb; i++) {  // remainder when nb is not a multiple of U
-      const unsigned bo = cell_offset(tab_at(trow + i));
+    if (gfull < gn) {   // the group's last rings when gn is not a multiple of U: a pass of their own over the directions
+      for (int i = 0; i < nb; i++) {
+        int row = i + shift;
+        row -= row >= nb ? nb : 0;
+        const float4* const rl = ring + __mul24(row, rs);
+        unsigned boff[U];
+        const float4* sp[U];
 #pragma unroll
-      for (int v = 0; v < NV4; v++) {
-        const float4 m = *reinterpret_cast<const float4*>(recb + bo + 16 * v);
-        const float4 s = rl[v * nb2 + i];
-        acc[4 * v + 0] = __builtin_fmaf(s.x, m.x, acc[4 * v + 0]);
-        acc[4 * v + 1] = __builtin_fmaf(s.y, m.y, acc[4 * v + 1]);
-        acc[4 * v + 2] = __builtin_fmaf(s.z, m.z, acc[4 * v + 2]);
-        acc[4 * v + 3] = __builtin_fmaf(s.w, m.w, acc[4 * v + 3]);
-        if (!KSLOT && v == NV4 - 1) known += m.w;
+        for (int u = 0; u < U; u++) {
+          const int jc = min(gfull + u, gn - 1);
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jc) * nb + i));
+          sp[u] = rl + jc * NV4;
+        }
+        step(std::false_type{}, boff, sp, gn - gfull);
       }
     }
+  } else {
+    // fewer rings than loads to keep in flight (very long rows): U consecutive directions of one ring at a time
+    for (int jj = 0; jj < gn; jj++) {
+      const float4* const rj = ring + jj * NV4;
+      for (int i = 0; i < nb; i += U) {
+        unsigned boff[U];
+        const float4* sp[U];
 #pragma unroll
-    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
-    known2 += known;
-    }   // dense records
+        for (int u = 0; u < U; u++) {
+          const int ic = min(i + u, nb - 1);
+          int row = ic + shift;
+          row -= row >= nb ? nb : 0;
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj) * nb + ic));
+          sp[u] = rj + __mul24(row, rs);
+        }
+        step(std::false_type{}, boff, sp, min(U, nb - i));
+      }
+    }
   }
   if (slot < a.npad) {
     float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
 #pragma unroll
-    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
-    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc[k];
+    o[(int64_t)RF * a.npad] = KSLOT ? acc[RF - 2] : known;
   }
 #ifdef TDR_SCORE_TIMELINE
   __syncthreads();
@@ -426,7 +421,7 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
       p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
       const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);  // :437
       const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
-      if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, inb, a.ctiles_c, ckconst);
+      if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
       else return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
     };
     // the record of one sample as RF operands: dense records as they are, compact ones decoded (bit-identical)
@@ -1106,9 +1101,23 @@ __global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float sca
   if (k < n2) utab[k] = (tab[k] * scale) * res;  // `ang_sample_pts_*scale*res` (top_down_map_polar.cpp:28)
 }
 
+// Rings per workgroup of score_polar_kernel: as many as fit the LDS budget (the group's scan rows are staged together;
+// 32 KB keeps four workgroups per CU), at most 8, whole steps of TDR_SCORE_U.  A function of the image shape only: the
+// partition of a particle's score into partial sums must not depend on the launch.  TDR_SCORE_GROUP overrides (tuning).
+static int score_group_rings(int nb, int rf) {
+  static const int forced = [] {
+    const char* e = getenv("TDR_SCORE_GROUP");
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t ring_bytes = (int64_t)nb * rf * 4;
+  int g = forced > 0 ? forced : (int)std::min<int64_t>(8, (32 * 1024) / std::max<int64_t>(ring_bytes, 1));
+  g = std::max(1, std::min<int>(g, (int)((60 * 1024) / std::max<int64_t>(ring_bytes, 1))));
+  if (g >= TDR_SCORE_U) g -= g % TDR_SCORE_U;
+  return std::max(g, 1);
+}
 extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n) {
-  int rpc, nchunks;
-  choose_chunks(n, nr, rpc, nchunks);
+  const int group = score_group_rings(nb, tdr_rec_floats(ncls));
+  const int nchunks = (int)cdiv(nr, group);
   int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   int rf = tdr_rec_floats(ncls);
   // partials + best_cost + best_theta + list + count(64) + uniform-scale table
@@ -1196,7 +1205,7 @@ extern "C" int tdr_cmap_words(int ncls);
 template <bool CM>
 static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
-  size_t lds = (size_t)2 * a.nb * rf * 4;   // + the static dictionary array of the compact kernels (4 KB)
+  size_t lds = (size_t)a.nb * ((a.group * (rf / 4)) | 1) * 16;   // [row][group * planes | 1] float4 (+ 4 KB dictionary)
   const bool ks = tdr_has_kslot(ncls, rf);
   const bool us = a.utab != nullptr;
 #define TDR_LAUNCH_SCORE(NV4)                                                                                       \
@@ -1218,7 +1227,10 @@ static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s
   return TDR_OK;
 }
 static bool map_has_compact(const tdr_map_desc* map, int rf) {
-  return g_use_compact && map->cwords > 0 && map->crec && map->dict && map->cwords == tdr_cmap_words(map->ncls) && rf <= 12;
+  if (!(g_use_compact && map->cwords > 0 && map->crec && map->dict && map->cwords == tdr_cmap_words(map->ncls) && rf <= 12))
+    return false;
+  const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
+  return (int64_t)((map->cols >> lc) + 2) * 128 < (1 << 23);   // cmap_offset multiplies with 24-bit operands
 }
 static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s) {
   a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
@@ -1254,7 +1266,8 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
   a.use_theta_override = 0; a.theta_override = 0.f;
-  choose_chunks(n, nr, a.rpc, a.nchunks);
+  a.group = score_group_rings(nb, rf);
+  a.nchunks = (int)cdiv(nr, a.group);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
   int rc = fill_utab(a, workspace, rf, uniform_scale, s);
