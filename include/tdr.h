@@ -229,6 +229,13 @@ int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, i
 int tdr_k_gather_states(const float* src, int64_t src_cap, int64_t src_shard, const int32_t* idx, int64_t n_new,
                         float* dst, int64_t dst_cap, void* stream);
 
+/* Buffers of a sharded filter (one rank per GPU): {a, b}[nl] -> one send buffer [2][nl]; the gathered
+ * [world][2][nl] -> a_glob / b_glob [world*nl] in global particle order; the gathered state planes [world][7][nl] ->
+ * a plain SoA [7][cap]. */
+int tdr_k_shard_pack2(const float* a, const float* b, int64_t nl, float* out, void* stream);
+int tdr_k_shard_unpack2(const float* in, int world, int64_t nl, float* a_glob, float* b_glob, void* stream);
+int tdr_k_unshard_states(const float* in, int world, int64_t nl, float* st, int64_t cap, void* stream);
+
 /* ---- getLocalMap materialised (src/top_down_map_polar.cpp:21-53, src/top_down_map.cpp:429-459) ----------------- */
 /* The window of ONE pose as the reference's arrays: dists_out (device) [ncls][rows*cols] column-major images,
  * mask_out (device) [rows*cols], 1 = unknown or outside the map.  Polar: rows = nb, cols = nr, `tab` from
@@ -250,7 +257,8 @@ int tdr_k_set_scale(float* st, int64_t cap, int64_t n, const float* scale_dev, v
 /* max_likelihood_particle_ (:145-147): out12 (device) = the 7 SoA fields of particle argmax (info[0] of
  * tdr_k_update_weights), one spare, then its mlState {x, y, theta, scale} (state_particle.cpp:98-102).  Call before the
  * resampled set replaces `st`. */
-int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t n, float* out12, void* stream);
+int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t src_shard, int64_t n, float* out12,
+                        void* stream);   /* src_shard > 0: st is the all-gathered [rank][7][src_shard] buffer */
 int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void* stream);      /* updateMap :325-334 */
 
 /* The scoring kernels read the compact records whenever the map has them (tdr_k_compact_map); tdr_config_compact(0)
@@ -337,6 +345,40 @@ int tdr_renderer_render(tdr_renderer* r, int polar, const float* pts, int stride
  * idy*width + idx; pcl clouds: width = cloud->width, height = cloud->height), imgs_out HOST [2][rows*cols]. */
 int tdr_renderer_render_geo(tdr_renderer* r, int polar, const float* pts, int stride, int64_t width, int64_t height,
                             float res, float ang_res, int rows, int cols, float* imgs_out);
+
+/* ---- several GPUs: one process (rank) per GPU, particles partitioned contiguously by rank -------------
+ * A tdr_comm carries the three exchange steps of a sharded filter — broadcast of the rasterised scan from rank 0,
+ * all-gather of {raw weight, last_dist}, all-gather of the state planes — over RCCL (xGMI), called directly on the
+ * filter's stream, or over functions the caller supplies (MPI, a test double).  Every rank then computes the weight
+ * statistics and the order-exact running sum on the same gathered arrays, so an N-rank filter equals the 1-rank filter
+ * bit for bit (tests/test_sharded_handle.py).  The reference has no counterpart: it is one CPU process. */
+#define TDR_COMM_ID_BYTES 128
+typedef struct tdr_comm tdr_comm;
+typedef struct tdr_comm_ops {   /* device pointers; enqueue on `stream` (a hipStream_t) or complete before returning */
+  void* ctx;
+  int (*all_gather)(void* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+  int (*broadcast)(void* ctx, void* buf_dev, size_t bytes, int root, void* stream);
+} tdr_comm_ops;
+/* RCCL transport: rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by any means; every
+ * rank then calls create_rccl with its HIP device current (ncclCommInitRank).  librccl.so is loaded on first use. */
+int tdr_comm_rccl_unique_id(void* id_out128);
+int tdr_comm_create_rccl(int world_size, int rank, const void* unique_id128, tdr_comm** out);
+int tdr_comm_create(int world_size, int rank, const tdr_comm_ops* ops, tdr_comm** out);
+void tdr_comm_destroy(tdr_comm* c);
+int tdr_comm_world(const tdr_comm* c);
+int tdr_comm_rank(const tdr_comm* c);
+int tdr_comm_all_gather(tdr_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int tdr_comm_broadcast(tdr_comm* c, void* buf_dev, size_t bytes, int root, void* stream);
+/* A filter whose particles are sharded over comm's ranks: n_max (the GLOBAL maximum) and every particle count must be
+ * multiples of the world size; every rank makes the same calls with the same arguments (same seed: the host generator
+ * is replicated), each on its own map handle holding the same map.  set_states takes the GLOBAL array and keeps this
+ * rank's slice; get_states / get_raw_weights / get_last_dist / get_resample_indices return this rank's slice
+ * (tdr_filter_num_local entries, indices global); get_weights, mean_cov, scale, num_particles are global and identical
+ * on every rank.  tdr_filter_update: ranks other than 0 may pass scan_imgs == NULL and renderer == NULL — the packed scan
+ * of rank 0 is broadcast. */
+int tdr_filter_create_sharded(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_comm* comm,
+                              tdr_filter** out);
+int64_t tdr_filter_num_local(const tdr_filter* f);
 
 /* seed: the reference seeds its std::mt19937 from std::random_device (src/particle_filter.cpp:4-5), i.e. not
  * reproducibly.  seed == 0 stands for that case: propagate's noise is then drawn on the device (counter-based, 4 us).

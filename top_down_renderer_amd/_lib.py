@@ -87,7 +87,20 @@ SIGNATURES = {
     "tdr_filter_compute_gmm": (_i, [_vp]),
     "tdr_filter_get_gmm": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tdr_filter_adaptive_count": (_i64, [_vp]),
-    "tdr_k_save_ml_state": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "tdr_k_save_ml_state": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "tdr_k_shard_pack2": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "tdr_k_shard_unpack2": (_i, [_vp, _i, _i64, _vp, _vp, _vp]),
+    "tdr_k_unshard_states": (_i, [_vp, _i, _i64, _vp, _i64, _vp]),
+    "tdr_comm_rccl_unique_id": (_i, [_vp]),
+    "tdr_comm_create_rccl": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    "tdr_comm_create": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    "tdr_comm_destroy": (None, [_vp]),
+    "tdr_comm_world": (_i, [_vp]),
+    "tdr_comm_rank": (_i, [_vp]),
+    "tdr_comm_all_gather": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tdr_comm_broadcast": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
+    "tdr_filter_create_sharded": (_i, [_vp, _i, C.POINTER(FilterParamsC), _u32, _vp, C.POINTER(_vp)]),
+    "tdr_filter_num_local": (_i64, [_vp]),
     "tdr_k_set_scale": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_k_shift_init": (_i, [_vp, _i64, _i64, _f, _f, _vp]),
     "tdr_k_states_aos_to_soa": (_i, [_vp, _i64, _vp, _i64, _vp]),

@@ -1,21 +1,26 @@
-"""Builds libtdr_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No GPU is needed to compile."""
+"""Builds libtdr_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No GPU is needed to compile.
+
+Every translation unit is compiled to an object of its own (in parallel; only those whose source or headers changed) and
+the objects are linked into the shared library."""
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", f) for f in
-       ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_filter.hip", "tdr_prefix.hip", "tdr_geo.hip", "tdr_cmap.hip",
-        "tdr_host.cpp", "tdr_gmm.cpp")]
-HDR = [os.path.join(ROOT, "include", "tdr.h"), os.path.join(PKG, "csrc", "tdr_common.h"),
-       os.path.join(PKG, "csrc", "tdr_sincosf.h"), os.path.join(PKG, "csrc", "tdr_atan2f.h")]
+       ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_filter.hip", "tdr_prefix.hip",
+        "tdr_geo.hip", "tdr_cmap.hip", "tdr_host.cpp", "tdr_comm.cpp", "tdr_gmm.cpp")]
+HDR = [os.path.join(ROOT, "include", "tdr.h")] + \
+      [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
+OBJ_DIR = os.path.join(PKG, "_obj")
 
 # -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-I", os.path.join(ROOT, "include")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include")]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 
 
 def hipcc():
@@ -25,17 +30,37 @@ def hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in SRC + HDR + [os.path.abspath(__file__)])
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(OUT, SRC + HDR + [os.path.abspath(__file__)])
 
 
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-o", OUT, "-x", "hip"] + SRC
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    todo = [s for s in SRC if force or extra_flags or _stale(_obj(s), [s] + HDR + [os.path.abspath(__file__)])]
+
+    def compile_one(src):
+        cmd = [cc] + CFLAGS + list(extra_flags) + ["-c", "-x", "hip", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [cc] + LDFLAGS + ["-o", OUT] + [_obj(s) for s in SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -43,4 +68,4 @@ def build(force=False, verbose=False, extra_flags=()):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -682,23 +682,31 @@ extern "C" int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, flo
 // max_likelihood_particle_ = particles_[argmax] (particle_filter.cpp:145-147) points at the PRE-resample particle:
 // keep its fields and its mlState (state_particle.cpp:98-102) on the device, so the update needs no host round trip.
 __global__ void save_ml_state_kernel(const float* __restrict__ info, const float* __restrict__ st, int64_t cap,
-                                     int64_t n, float* __restrict__ out) {
+                                     int64_t src_shard, int64_t n, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int64_t best = (int64_t)__float_as_int(info[0]);
   if (best < 0 || best >= n) best = 0;
   float f[TDR_ST_FIELDS];
+  if (src_shard > 0) {   // all-gathered source [rank][field][src_shard], `best` is a global particle index
+    const int64_t r = best / src_shard, l = best - r * src_shard;
 #pragma unroll
-  for (int k = 0; k < TDR_ST_FIELDS; k++) { f[k] = st[(int64_t)k * cap + best]; out[k] = f[k]; }
+    for (int k = 0; k < TDR_ST_FIELDS; k++) { f[k] = st[(r * TDR_ST_FIELDS + k) * src_shard + l]; out[k] = f[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < TDR_ST_FIELDS; k++) { f[k] = st[(int64_t)k * cap + best]; out[k] = f[k]; }
+  }
   out[7] = 0.f;
   out[8] = f[TDR_ST_DX] * f[TDR_ST_SCALE] + f[TDR_ST_INIT_X];
   out[9] = f[TDR_ST_DY] * f[TDR_ST_SCALE] + f[TDR_ST_INIT_Y];
   out[10] = f[TDR_ST_THETA];
   out[11] = f[TDR_ST_SCALE];
 }
-extern "C" int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t n, float* out12,
-                                   void* stream) {
-  if (!info || !st || !out12 || n < 1 || cap < n) return fail(TDR_ERR_ARG, "save_ml_state: bad arguments");
-  hipLaunchKernelGGL(save_ml_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info, st, cap, n, out12);
+extern "C" int tdr_k_save_ml_state(const float* info, const float* st, int64_t cap, int64_t src_shard, int64_t n,
+                                   float* out12, void* stream) {
+  if (!info || !st || !out12 || n < 1 || src_shard < 0 || (src_shard == 0 && cap < n))
+    return fail(TDR_ERR_ARG, "save_ml_state: bad arguments");
+  hipLaunchKernelGGL(save_ml_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info, st, cap, src_shard, n,
+                     out12);
   LAUNCH_CHECK("save_ml_state");
   return TDR_OK;
 }
@@ -719,6 +727,56 @@ extern "C" int tdr_k_sample_ml_states(const float* st, int64_t cap, int64_t n, i
   hipLaunchKernelGGL(sample_ml_states_kernel, dim3((unsigned)cdiv(num, 256)), dim3(256), 0, (hipStream_t)stream, st,
                      cap, n, num, out);
   LAUNCH_CHECK("sample_ml_states");
+  return TDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sharded filter (one rank per GPU, tdr_host.cpp): the buffers the two all-gathers move.
+//   pack2   : {a[nl], b[nl]} -> one contiguous send buffer [2][nl]
+//   unpack2 : the gathered [world][2][nl] -> a_glob[world*nl], b_glob[world*nl] in global particle order
+//   unshard : the gathered state planes [world][7][nl] -> a plain SoA [7][cap] (pose statistics run on that)
+__global__ void shard_pack2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t nl,
+                                   float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nl) { out[i] = a[i]; out[nl + i] = b[i]; }
+}
+__global__ void shard_unpack2_kernel(const float* __restrict__ in, int world, int64_t nl, float* __restrict__ a,
+                                     float* __restrict__ b) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)world * nl) return;
+  const int64_t r = g / nl, l = g - r * nl;
+  a[g] = in[(2 * r) * nl + l];
+  b[g] = in[(2 * r + 1) * nl + l];
+}
+__global__ void unshard_states_kernel(const float* __restrict__ in, int world, int64_t nl, float* __restrict__ st,
+                                      int64_t cap) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)world * nl) return;
+  const int64_t r = g / nl, l = g - r * nl;
+#pragma unroll
+  for (int f = 0; f < TDR_ST_FIELDS; f++) st[f * cap + g] = in[(r * TDR_ST_FIELDS + f) * nl + l];
+}
+extern "C" int tdr_k_shard_pack2(const float* a, const float* b, int64_t nl, float* out, void* stream) {
+  if (!a || !b || !out || nl < 0) return fail(TDR_ERR_ARG, "shard_pack2: bad arguments");
+  if (nl == 0) return TDR_OK;
+  hipLaunchKernelGGL(shard_pack2_kernel, dim3((unsigned)cdiv(nl, 256)), dim3(256), 0, (hipStream_t)stream, a, b, nl, out);
+  LAUNCH_CHECK("shard_pack2");
+  return TDR_OK;
+}
+extern "C" int tdr_k_shard_unpack2(const float* in, int world, int64_t nl, float* a_glob, float* b_glob, void* stream) {
+  if (!in || !a_glob || !b_glob || world < 1 || nl < 0) return fail(TDR_ERR_ARG, "shard_unpack2: bad arguments");
+  if (nl == 0) return TDR_OK;
+  hipLaunchKernelGGL(shard_unpack2_kernel, dim3((unsigned)cdiv((int64_t)world * nl, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, world, nl, a_glob, b_glob);
+  LAUNCH_CHECK("shard_unpack2");
+  return TDR_OK;
+}
+extern "C" int tdr_k_unshard_states(const float* in, int world, int64_t nl, float* st, int64_t cap, void* stream) {
+  if (!in || !st || world < 1 || nl < 0 || cap < (int64_t)world * nl) return fail(TDR_ERR_ARG, "unshard_states: bad arguments");
+  if (nl == 0) return TDR_OK;
+  hipLaunchKernelGGL(unshard_states_kernel, dim3((unsigned)cdiv((int64_t)world * nl, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, world, nl, st, cap);
+  LAUNCH_CHECK("unshard_states");
   return TDR_OK;
 }
 

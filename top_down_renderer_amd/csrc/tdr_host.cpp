@@ -4,7 +4,8 @@
 //     tdr_map       TopDownMapPolar   (include/top_down_render/top_down_map_polar.h:6-22)
 //     tdr_renderer  ScanRendererPolar (include/top_down_render/scan_renderer_polar.h:15-22)
 //     tdr_filter    ParticleFilter    (include/top_down_render/particle_filter.h:22-73)
-// Single GPU, one caller thread per handle (the reference calls everything from the ROS spinner thread).
+// One caller thread per handle (the reference calls everything from the ROS spinner thread).  A filter lives on one GPU
+// or is sharded over the ranks of a tdr_comm (one process per GPU, tdr_comm.cpp: RCCL or caller-supplied transport).
 // No CPU fallback: every entry point fails with TDR_ERR_HIP when no device is present.
 #include <hip/hip_runtime.h>
 
@@ -109,6 +110,14 @@ struct tdr_filter {
   DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
   bool have_ml = false;
   hipStream_t stream = nullptr;
+  // Sharded over the ranks of `comm` (one process per GPU; NULL = the whole filter lives here).  n / n_max stay the
+  // GLOBAL counts; this rank holds particles [rank * nl, (rank + 1) * nl), nl = n / world, in st[7][cap] with
+  // cap = n_max / world.  raw_glob / ld_glob / w / runmax are global arrays, identical on every rank.
+  tdr_comm* comm = nullptr;
+  int world = 1, rank = 0;
+  int64_t cap = 0;
+  DevBuf<float> xchg_in, xchg_out, raw_glob, ld_glob, st_send, st_all, st_glob, pk_recv;
+  int64_t nl() const { return n / world; }
 };
 
 // the compact records of a freshly packed map (desc.rec etc. already set)
@@ -353,32 +362,48 @@ int tdr_renderer_render_geo(tdr_renderer* r, int polar, const float* pts, int st
 }
 
 // ---- ParticleFilter ------------------------------------------------------------------------------------------------------
-int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_filter** out) {
+static int filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_comm* comm,
+                         tdr_filter** out) {
   if (!map || !fp || !out || n_max < 1) return failh(TDR_ERR_ARG, "filter_create: bad arguments");
+  const int world = comm ? tdr_comm_world(comm) : 1;
+  if (n_max % world) return failh(TDR_ERR_ARG, "filter_create: n_max = %d is not a multiple of the %d ranks", n_max, world);
   tdr_filter* f = new tdr_filter();
   f->map = map;
   f->fp = *fp;
   f->n_max = n_max;
+  f->comm = comm;
+  f->world = world;
+  f->rank = comm ? tdr_comm_rank(comm) : 0;
+  f->cap = n_max / world;
   f->seed = seed;
   f->rng = tdr_rng_create(seed);  // explicit seed instead of std::random_device (particle_filter.cpp:4-5)
   // seed 0 = "unseeded", like the reference's std::random_device: nothing to reproduce, so propagate draws its noise on
   // the device; a non-zero seed asks for the reference-ordered std::mt19937 stream (tdr_filter_configure overrides)
   f->parity_rng = seed != 0;
   int rc = TDR_OK;
-  const size_t cap = (size_t)n_max;
+  const size_t cap = (size_t)f->cap, N = (size_t)n_max;
   if (rc == TDR_OK) rc = f->st.resize(TDR_ST_FIELDS * cap);
   if (rc == TDR_OK) rc = f->st_new.resize(TDR_ST_FIELDS * cap);
   if (rc == TDR_OK) rc = f->last_dist.resize(cap);
   if (rc == TDR_OK) rc = f->raw_w.resize(cap);
-  if (rc == TDR_OK) rc = f->w.resize(cap);
-  if (rc == TDR_OK) rc = f->runmax.resize(cap);
-  if (rc == TDR_OK) rc = f->pfx_ws.resize((size_t)tdr_prefix_workspace_bytes((int64_t)cap));
+  if (rc == TDR_OK) rc = f->w.resize(N);
+  if (rc == TDR_OK) rc = f->runmax.resize(N);
+  if (rc == TDR_OK) rc = f->pfx_ws.resize((size_t)tdr_prefix_workspace_bytes((int64_t)N));
   if (rc == TDR_OK) rc = f->idx.resize(cap);
   if (rc == TDR_OK) rc = f->perm.resize(cap);
   if (rc == TDR_OK) rc = f->info.resize(TDR_UW_INFO_FLOATS);
   if (rc == TDR_OK) rc = f->stats.resize(TDR_MEAN_COV_FLOATS);
-  if (rc == TDR_OK) rc = f->aos.resize(cap);
+  if (rc == TDR_OK) rc = f->aos.resize(N);
   if (rc == TDR_OK) rc = f->z4.resize(4 * cap);
+  if (rc == TDR_OK && comm) {
+    rc = f->xchg_in.resize(2 * cap);
+    if (rc == TDR_OK) rc = f->xchg_out.resize(2 * N);
+    if (rc == TDR_OK) rc = f->raw_glob.resize(N);
+    if (rc == TDR_OK) rc = f->ld_glob.resize(N);
+    if (rc == TDR_OK) rc = f->st_send.resize(TDR_ST_FIELDS * cap);
+    if (rc == TDR_OK) rc = f->st_all.resize(TDR_ST_FIELDS * N);
+    if (rc == TDR_OK) rc = f->st_glob.resize(TDR_ST_FIELDS * N);
+  }
   if (rc == TDR_OK && hipMemset(f->last_dist.p, 0, cap * sizeof(float)) != hipSuccess) rc = failh(TDR_ERR_HIP, "memset");
   if (rc != TDR_OK) {
     tdr_filter_destroy(f);
@@ -387,6 +412,16 @@ int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint
   *out = f;
   return TDR_OK;
 }
+int tdr_filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_filter** out) {
+  return filter_create(map, n_max, fp, seed, nullptr, out);
+}
+// particles sharded over the ranks of `comm` (not owned; must outlive the filter)
+int tdr_filter_create_sharded(tdr_map* map, int n_max, const tdr_filter_params* fp, uint32_t seed, tdr_comm* comm,
+                              tdr_filter** out) {
+  if (!comm) return failh(TDR_ERR_ARG, "filter_create_sharded: null comm");
+  return filter_create(map, n_max, fp, seed, comm, out);
+}
+int64_t tdr_filter_num_local(const tdr_filter* f) { return f ? f->nl() : 0; }
 void tdr_filter_destroy(tdr_filter* f) {
   if (!f) return;
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
@@ -408,11 +443,14 @@ static void note_uniform_scale(tdr_filter* f, const tdr_state* s, int64_t n) {
   f->uniform_scale = s[0].scale;
 }
 
+// states: the GLOBAL particle array; a sharded filter keeps this rank's slice
 int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n) {
   if (!f || (n > 0 && !states) || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_set_states: bad arguments");
-  if (n > 0) {
-    HTRY(hipMemcpy(f->aos.p, states, (size_t)n * sizeof(tdr_state), hipMemcpyHostToDevice));
-    TTRY(tdr_k_states_aos_to_soa(f->aos.p, n, f->st.p, f->n_max, f->stream));
+  if (n % f->world) return failh(TDR_ERR_ARG, "filter_set_states: %lld particles over %d ranks", (long long)n, f->world);
+  const int64_t nl = n / f->world;
+  if (nl > 0) {
+    HTRY(hipMemcpy(f->aos.p, states + (size_t)f->rank * nl, (size_t)nl * sizeof(tdr_state), hipMemcpyHostToDevice));
+    TTRY(tdr_k_states_aos_to_soa(f->aos.p, nl, f->st.p, f->cap, f->stream));
     HTRY(hipDeviceSynchronize());
   }
   f->n = n;
@@ -423,10 +461,11 @@ int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n) {
   return TDR_OK;
 }
 
+// this rank's particles (all of them when the filter is not sharded): n <= tdr_filter_num_local
 int tdr_filter_get_states(tdr_filter* f, tdr_state* out, int64_t n) {
-  if (!f || !out || n < 0 || n > f->n) return failh(TDR_ERR_ARG, "filter_get_states: bad arguments");
+  if (!f || !out || n < 0 || n > f->nl()) return failh(TDR_ERR_ARG, "filter_get_states: bad arguments");
   if (n == 0) return TDR_OK;
-  TTRY(tdr_k_states_soa_to_aos(f->st.p, f->n_max, n, f->aos.p, f->stream));
+  TTRY(tdr_k_states_soa_to_aos(f->st.p, f->cap, n, f->aos.p, f->stream));
   HTRY(hipMemcpy(out, f->aos.p, (size_t)n * sizeof(tdr_state), hipMemcpyDeviceToHost));
   return TDR_OK;
 }
@@ -458,22 +497,27 @@ int tdr_filter_initialize_particles(tdr_filter* f) {
   TTRY(tdr_init_particles_host(f->rng, m->maps_host.data(), m->desc.ncls, m->desc.rows, m->desc.cols,
                                m->desc.resolution, &p, (int)f->n_max, states.data(), &n));
   n = std::min<int64_t>(n, f->n_max);
+  n -= n % f->world;
   return tdr_filter_set_states(f, states.data(), n);
 }
 
 // ParticleFilter::propagate (particle_filter.cpp:86-92)
 static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool scale_freeze) {
   if (f->n == 0) return TDR_OK;
+  const int64_t nl = f->nl();
   const float* z = nullptr;
   if (f->parity_rng) {
+    // the reference draws serially in GLOBAL particle order from one generator: every rank replays the whole stream
+    // (same seed) and uploads its own slice
     std::vector<float> zh((size_t)4 * f->n);
     TTRY(tdr_propagate_normals_host(f->rng, f->n, scale_freeze ? 1 : 0, zh.data()));
-    HTRY(hipMemcpyAsync(f->z4.p, zh.data(), zh.size() * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    HTRY(hipMemcpyAsync(f->z4.p, zh.data() + (size_t)4 * f->rank * nl, (size_t)4 * nl * sizeof(float),
+                        hipMemcpyHostToDevice, f->stream));
     HTRY(hipStreamSynchronize(f->stream));
     z = f->z4.p;
   }
-  return tdr_k_propagate(f->st.p, f->n_max, f->n, f->last_dist.p, tx, ty, omega, scale_freeze ? 1 : 0, f->fp.pos_cov,
-                         f->fp.theta_cov, z, f->seed, f->prop_calls++, 0, f->stream);
+  return tdr_k_propagate(f->st.p, f->cap, nl, f->last_dist.p, tx, ty, omega, scale_freeze ? 1 : 0, f->fp.pos_cov,
+                         f->fp.theta_cov, z, f->seed, f->prop_calls++, (int64_t)f->rank * nl, f->stream);
 }
 int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega) {
   if (!f) return failh(TDR_ERR_ARG, "filter_propagate: null filter");
@@ -514,8 +558,19 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
   if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_update: no map");
   if (f->n == 0) return TDR_OK;  // :96-99
   TTRY(filter_score(f, scan_imgs, renderer, res));
-  const int64_t n = f->n;
-  TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
+  const int64_t n = f->n, nl = f->nl();
+  const float *raw = f->raw_w.p, *ld = f->last_dist.p;
+  if (f->comm) {
+    // ONE all-gather of {raw weight, last_dist}: afterwards every rank computes the same statistics and the same
+    // order-exact running sum on the same global arrays (replaces the north star's all-reduce, whose result
+    // would depend on the reduction tree)
+    TTRY(tdr_k_shard_pack2(f->raw_w.p, f->last_dist.p, nl, f->xchg_in.p, f->stream));
+    TTRY(tdr_comm_all_gather(f->comm, f->xchg_in.p, f->xchg_out.p, (size_t)2 * nl * sizeof(float), f->stream));
+    TTRY(tdr_k_shard_unpack2(f->xchg_out.p, f->world, nl, f->raw_glob.p, f->ld_glob.p, f->stream));
+    raw = f->raw_glob.p;
+    ld = f->ld_glob.p;
+  }
+  TTRY(tdr_k_update_weights(raw, ld, n, f->w.p, f->info.p, f->stream));
   return filter_resample(f, n_target);
 }
 // StateParticle::computeWeight for every particle (state_particle.cpp:157-219): raw weights only, no statistics, no
@@ -526,12 +581,12 @@ int tdr_filter_compute_weights(tdr_filter* f, const float* scan_imgs, const tdr_
   return filter_score(f, scan_imgs, renderer, res);
 }
 int tdr_filter_get_raw_weights(tdr_filter* f, float* out, int64_t n) {
-  if (!f || !out || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_get_raw_weights: bad arguments");
+  if (!f || !out || n < 0 || n > f->cap) return failh(TDR_ERR_ARG, "filter_get_raw_weights: bad arguments");
   HTRY(hipMemcpy(out, f->raw_w.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return TDR_OK;
 }
 int tdr_filter_get_last_dist(tdr_filter* f, float* out, int64_t n) {
-  if (!f || !out || n < 0 || n > f->n_max) return failh(TDR_ERR_ARG, "filter_get_last_dist: bad arguments");
+  if (!f || !out || n < 0 || n > f->cap) return failh(TDR_ERR_ARG, "filter_get_last_dist: bad arguments");
   HTRY(hipMemcpy(out, f->last_dist.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return TDR_OK;
 }
@@ -541,29 +596,39 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
   f->fp.num_classes = m->desc.ncls;
   const int ncls = m->desc.ncls, nb = m->nb, nr = m->nr;
   const size_t P = (size_t)nb * nr;
+  const size_t pk_floats = P * tdr_rec_floats(ncls);
   const float* pk = nullptr;
   if (scan_imgs) {
     TTRY(f->scan_img.resize(P * ncls));
-    TTRY(f->scan_pk.resize(P * tdr_rec_floats(ncls)));
+    TTRY(f->scan_pk.resize(pk_floats));
     HTRY(hipMemcpyAsync(f->scan_img.p, scan_imgs, P * ncls * sizeof(float), hipMemcpyHostToDevice, f->stream));
     TTRY(tdr_k_pack_scan(f->scan_img.p, ncls, nb, nr, f->scan_pk.p, f->stream));
     pk = f->scan_pk.p;
-  } else {
-    if (!renderer || !renderer->have_scan) return failh(TDR_ERR_ARG, "filter_update: no scan");
+  } else if (renderer) {
+    if (!renderer->have_scan) return failh(TDR_ERR_ARG, "filter_update: no scan");
     if (renderer->ncls != ncls || renderer->rows != nb || renderer->cols != nr)
       return failh(TDR_ERR_ARG, "filter_update: render shape %dx%dx%d does not match the map's %dx%dx%d",
                    renderer->ncls, renderer->rows, renderer->cols, ncls, nb, nr);
     pk = renderer->pk.p;
+  } else if (!(f->comm && f->rank != 0)) {
+    return failh(TDR_ERR_ARG, "filter_update: no scan");
   }
-  const int64_t n = f->n;
+  if (f->comm) {
+    // the rasterised scan is produced once, on rank 0, and broadcast (north star): 2 MB at config 2
+    TTRY(f->pk_recv.resize(pk_floats));
+    if (f->rank == 0) HTRY(hipMemcpyAsync(f->pk_recv.p, pk, pk_floats * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+    TTRY(tdr_comm_broadcast(f->comm, f->pk_recv.p, pk_floats * sizeof(float), 0, f->stream));
+    pk = f->pk_recv.p;
+  }
+  const int64_t n = f->nl();   // this rank's particles
   const int32_t* perm = nullptr;
   if (f->locality_every > 0) {
     TTRY(f->loc_tmp.resize(tdr_locality_tmp_ints(n, m->desc.rows, m->desc.cols)));
-    TTRY(tdr_k_locality_order(f->st.p, f->n_max, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
+    TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
     perm = f->perm.p;
   }
   TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n)));
-  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->n_max, n, perm, f->uniform_scale,
+  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, perm, f->uniform_scale,
                          f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised
   if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
@@ -571,21 +636,52 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
 }
 // statistics are done: running sum, resample, gather, bookkeeping (particle_filter.cpp:151-188)
 static int filter_resample(tdr_filter* f, int64_t n_target) {
-  const int64_t n = f->n;
+  const int64_t n = f->n, nl = f->nl();
   int64_t n_new = n;
   if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));
-  const float shift = tdr_rng_uniform_host(f->rng);  // :172-173
-  TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
-  TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, 0, n_new, f->idx.p, f->stream));
-  TTRY(tdr_k_gather_states(f->st.p, f->n_max, 0, f->idx.p, n_new, f->st_new.p, f->n_max, f->stream));
-  // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state (on the device:
-  // the update returns without waiting for the GPU)
+  n_new = std::max<int64_t>(f->world, n_new - n_new % f->world);   // whole shards
+  const int64_t nl_new = n_new / f->world, i0 = (int64_t)f->rank * nl_new;
+  const float shift = tdr_rng_uniform_host(f->rng);  // :172-173 (every rank owns an identically seeded generator)
   TTRY(f->ml_dev.resize(12));
-  TTRY(tdr_k_save_ml_state(f->info.p, f->st.p, f->n_max, n, f->ml_dev.p, f->stream));
+  TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
+  // each rank draws its own slice [i0, i0 + nl_new) of the new set; idx holds GLOBAL source indices
+  TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, i0, i0 + nl_new, f->idx.p, f->stream));
+  if (f->comm) {
+    // the second all-gather: the pre-resample state planes, [rank][7][nl] (28 B x N)
+    for (int k = 0; k < TDR_ST_FIELDS; k++)
+      HTRY(hipMemcpyAsync(f->st_send.p + (size_t)k * nl, f->st.p + (size_t)k * f->cap, (size_t)nl * sizeof(float),
+                          hipMemcpyDeviceToDevice, f->stream));
+    TTRY(tdr_comm_all_gather(f->comm, f->st_send.p, f->st_all.p, (size_t)TDR_ST_FIELDS * nl * sizeof(float), f->stream));
+    TTRY(tdr_k_gather_states(f->st_all.p, 0, nl, f->idx.p, nl_new, f->st_new.p, f->cap, f->stream));
+    TTRY(tdr_k_save_ml_state(f->info.p, f->st_all.p, 0, nl, n, f->ml_dev.p, f->stream));
+  } else {
+    TTRY(tdr_k_gather_states(f->st.p, f->cap, 0, f->idx.p, n_new, f->st_new.p, f->cap, f->stream));
+    // max_likelihood_particle_ = particles_[argmax] (:145-147): keep that particle's pre-resample state (on the device:
+    // the update returns without waiting for the GPU)
+    TTRY(tdr_k_save_ml_state(f->info.p, f->st.p, f->cap, 0, n, f->ml_dev.p, f->stream));
+  }
   f->have_ml = true;
   std::swap(f->st.p, f->st_new.p);  // :187
   f->n = n_new;
   f->step++;
+  return TDR_OK;
+}
+// The current particle set of ALL ranks as a plain SoA (pose statistics, the mixture fit): the filter's own arrays when
+// it is not sharded, else one all-gather of the state planes.
+static int filter_global_states(tdr_filter* f, const float** st, int64_t* cap) {
+  if (!f->comm) {
+    *st = f->st.p;
+    *cap = f->cap;
+    return TDR_OK;
+  }
+  const int64_t nl = f->nl();
+  for (int k = 0; k < TDR_ST_FIELDS; k++)
+    HTRY(hipMemcpyAsync(f->st_send.p + (size_t)k * nl, f->st.p + (size_t)k * f->cap, (size_t)nl * sizeof(float),
+                        hipMemcpyDeviceToDevice, f->stream));
+  TTRY(tdr_comm_all_gather(f->comm, f->st_send.p, f->st_all.p, (size_t)TDR_ST_FIELDS * nl * sizeof(float), f->stream));
+  TTRY(tdr_k_unshard_states(f->st_all.p, f->world, nl, f->st_glob.p, f->n_max, f->stream));
+  *st = f->st_glob.p;
+  *cap = f->n_max;
   return TDR_OK;
 }
 
@@ -595,7 +691,7 @@ int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n) {
   return TDR_OK;
 }
 int tdr_filter_get_resample_indices(tdr_filter* f, int32_t* out, int64_t n) {
-  if (!f || !out || n < 0 || n > f->n) return failh(TDR_ERR_ARG, "filter_get_resample_indices: bad arguments");
+  if (!f || !out || n < 0 || n > f->nl()) return failh(TDR_ERR_ARG, "filter_get_resample_indices: bad arguments");
   HTRY(hipMemcpy(out, f->idx.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   return TDR_OK;
 }
@@ -607,14 +703,17 @@ int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[
   if (state) std::memset(state, 0, 4 * sizeof(float));
   if (f->n < 1) return TDR_OK;  // :207-209
   float out[24];
+  const float* gst = nullptr;
+  int64_t gcap = 0;
+  TTRY(filter_global_states(f, &gst, &gcap));
   if (!about_max) {
-    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, nullptr, f->stats.p, f->stream));
+    TTRY(tdr_k_mean_cov(gst, gcap, f->n, nullptr, f->stats.p, f->stream));
     HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
     if (state) std::memcpy(state, out, 4 * sizeof(float));
   } else {
     float ref[4] = {0, 0, 0, 0};
     if (!f->have_ml) return failh(TDR_ERR_ARG, "filter_mean_cov: no update yet, there is no max-likelihood particle");
-    TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, f->ml_dev.p + 8, f->stats.p, f->stream));
+    TTRY(tdr_k_mean_cov(gst, gcap, f->n, f->ml_dev.p + 8, f->stats.p, f->stream));
     HTRY(hipMemcpyAsync(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost, f->stream));
     HTRY(hipMemcpyAsync(ref, f->ml_dev.p + 8, sizeof(ref), hipMemcpyDeviceToHost, f->stream));
     HTRY(hipStreamSynchronize(f->stream));
@@ -628,8 +727,11 @@ int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[
 int tdr_filter_freeze_scale(tdr_filter* f) {
   if (!f) return failh(TDR_ERR_ARG, "filter_freeze_scale: null filter");
   if (f->scale_frozen || f->n < 1) return TDR_OK;
-  TTRY(tdr_k_mean_cov(f->st.p, f->n_max, f->n, nullptr, f->stats.p, f->stream));
-  TTRY(tdr_k_set_scale(f->st.p, f->n_max, f->n, f->stats.p + 20, f->stream));
+  const float* gst = nullptr;
+  int64_t gcap = 0;
+  TTRY(filter_global_states(f, &gst, &gcap));
+  TTRY(tdr_k_mean_cov(gst, gcap, f->n, nullptr, f->stats.p, f->stream));
+  TTRY(tdr_k_set_scale(f->st.p, f->cap, f->nl(), f->stats.p + 20, f->stream));
   float gm = 0;
   HTRY(hipMemcpy(&gm, f->stats.p + 20, sizeof(float), hipMemcpyDeviceToHost));
   f->scale_frozen = true;
@@ -643,7 +745,7 @@ float tdr_filter_scale(tdr_filter* f) {
   if (f->fp.fixed_scale > 0) return f->fp.fixed_scale;
   if (f->scale_frozen && f->n > 0) {
     float s = -1.f;
-    if (hipMemcpy(&s, f->st.p + (size_t)TDR_ST_SCALE * f->n_max, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    if (hipMemcpy(&s, f->st.p + (size_t)TDR_ST_SCALE * f->cap, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
     return s;
   }
   return -1.f;
@@ -656,7 +758,10 @@ int tdr_filter_compute_gmm(tdr_filter* f) {
   if (f->n < 1) return TDR_OK;
   const int num = (int)std::min<int64_t>(1000, f->n);   // :262
   TTRY(f->gmm_samples.resize((size_t)3 * num));
-  TTRY(tdr_k_sample_ml_states(f->st.p, f->n_max, f->n, num, f->gmm_samples.p, f->stream));
+  const float* gst = nullptr;
+  int64_t gcap = 0;
+  TTRY(filter_global_states(f, &gst, &gcap));
+  TTRY(tdr_k_sample_ml_states(gst, gcap, f->n, num, f->gmm_samples.p, f->stream));
   std::vector<float> h((size_t)3 * num);
   HTRY(hipMemcpyAsync(h.data(), f->gmm_samples.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
   HTRY(hipStreamSynchronize(f->stream));
@@ -698,7 +803,7 @@ int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int im
   if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map_labels: null filter");
   const int ox = f->map->center_x, oy = f->map->center_y;
   TTRY(tdr_map_set_labels(f->map, label_img, img_h, img_w, flatten_lut, lut_size, ncls, resolution, center_x, center_y));
-  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->n_max, f->n, (float)(center_x - ox), (float)(center_y - oy), f->stream);
+  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->cap, f->nl(), (float)(center_x - ox), (float)(center_y - oy), f->stream);
   if (f->map->have_map) return tdr_filter_initialize_particles(f);  // :337-340
   return TDR_OK;
 }
@@ -709,7 +814,7 @@ int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t*
   if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map: null filter");
   const int ox = f->map->center_x, oy = f->map->center_y;
   TTRY(tdr_map_set(f->map, class_maps, class_mask, ncls, rows, cols, resolution, center_x, center_y));
-  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->n_max, f->n, (float)(center_x - ox), (float)(center_y - oy), f->stream);
+  if (f->n > 0) return tdr_k_shift_init(f->st.p, f->cap, f->nl(), (float)(center_x - ox), (float)(center_y - oy), f->stream);
   return tdr_filter_initialize_particles(f);  // :337-340
 }
 
