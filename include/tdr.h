@@ -107,6 +107,11 @@ size_t tdr_map_ingest_workspace_bytes(int ncls, int rows, int cols);
 int tdr_map_ingest_shape(int img_h, int img_w, float resolution, int* rows, int* cols);
 int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut, int lut_size,
                           int ncls, float resolution, float* rec_out, void* workspace, void* stream);
+/* geo_maps_ (top_down_map.h:79) as a 2-class record map {d_without, d_with, 1, 1}, derived from the class records
+ * (getGeoRasterMap top_down_map.cpp:410-427 + computeDists :58; exact distance transform), or — constant_one != 0 — the
+ * constant 1 of the dynamic-map path (:126-133).  geo_rec_out: tdr_map_rec_floats_total(2, rows, cols) floats;
+ * workspace: tdr_map_ingest_workspace_bytes(2, rows, cols) bytes (may be NULL with constant_one). */
+int tdr_k_geo_map_from_map(const tdr_map_desc* map, int constant_one, float* geo_rec_out, void* workspace, void* stream);
 /* Cell records back to the reference's layout: class_maps_out [ncls][rows*cols] column-major, class_mask_out u8. */
 int tdr_k_unpack_map(const float* rec, int ncls, int rows, int cols, float* class_maps_out, uint8_t* class_mask_out,
                      void* stream);
@@ -166,6 +171,19 @@ size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n);
 int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
                       const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
                       float uniform_scale, int init_search, float* raw_w, float* workspace, void* stream);
+
+/* Scoring WITH the geometric term of getCostForRot (src/state_particle.cpp:145-152: commented out in the reference, whose
+ * geometric images are all-zero anyway; opt-in here): cost += (geo_i . shifted geo_cls_i).sum() * 0.01 and
+ * normalization += geo_i.sum() for the two geometric layers.  geo_map: the 2-layer map of tdr_k_geo_map_from_map;
+ * geo_pk: the two geometric scan images packed by tdr_k_pack_scan(img, 2, nb, nr); geo_sum0/1: the sums of those images.
+ * Everything else as tdr_k_score_polar; the init search prices the geometric term for every candidate rotation (one
+ * scoring pass per rotation over the batches that hold an un-initialised particle).
+ * workspace: tdr_score_geo_workspace_floats. */
+size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n);
+int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc* geo_map, const float* tab, const float* scan_pk,
+                          const float* geo_pk, float geo_sum0, float geo_sum1, int nb, int nr, float res,
+                          const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
+                          float uniform_scale, int init_search, float* raw_w, float* workspace, void* stream);
 
 /* Cartesian scoring (BASELINE config 4).  The reference's StateParticle only reaches the polar overloads
  * (state_particle.h:61), so there is no reference function to match; the score is DEFINED as the window of
@@ -332,6 +350,20 @@ int tdr_map_center(const tdr_map* m, int* center_x, int* center_y);             
 int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
                       float* dists_out, uint8_t* mask_out);
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
+/* getLocalGeoMap (top_down_map_polar.cpp:55-76 / top_down_map.cpp:461-481): the same window gathered from the two
+ * geometric layers geo_maps_ — [0] distance to the nearest cell WITHOUT a geometric class (flattened class >= 3), [1]
+ * to the nearest cell WITH one (getGeoRasterMap :410-427 + computeDists), as tdr_map_set derives them; after
+ * tdr_map_set_labels both layers are the constant 1 the reference's updateMap path leaves them at (:126-133).
+ * dists_out HOST [2][rows*cols]. */
+int tdr_map_local_geo_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
+                          float* dists_out);
+/* The reference's on-disk map cache (src/top_down_map.cpp:226-286; .eig = 2 x int64 shape + column-major scalars,
+ * top_down_map.h:29-50): cached_data.txt, class_map<i>.eig, geo_map<i>.eig, class_mask.eig under cache_dir (NULL =
+ * $HOME/.ros/xview_cache).  load: *loaded = 1 and the map is set when the cache's (map_path, num_classes, resolution)
+ * match like loadCacheMetaData, else *loaded = 0.  save writes the files of the map the handle holds. */
+int tdr_map_load_cache(tdr_map* m, const char* cache_dir, const char* map_path, int num_classes, float resolution,
+                       int center_x, int center_y, int* loaded);
+int tdr_map_save_cache(tdr_map* m, const char* cache_dir, const char* map_path);
 
 int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out);              /* scan_renderer.cpp:3-5 */
 void tdr_renderer_destroy(tdr_renderer* r);
@@ -397,6 +429,9 @@ int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega);       
  * trip), (nb, nr) = tdr_map_polar_shape — the caller checks its images against it, ncls*nb*nr floats are read;
  * n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
 int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target);
+/* The same with the geometric images top_down_geo (HOST [2][nb*nr]) entering the score (tdr_k_score_polar_geo); the
+ * reference passes them to update() too but its score ignores them.  Not available on a sharded filter. */
+int tdr_filter_update_geo(tdr_filter* f, const float* scan_imgs, const float* geo_imgs, float res, int64_t n_target);
 int tdr_filter_get_weights(tdr_filter* f, float* out, int64_t n);
 /* The per-particle surface of StateParticle (include/top_down_render/state_particle.h:42-53) on a filter:
  * computeWeight for every particle without statistics / resampling (state_particle.cpp:157-219) and its result

@@ -10,7 +10,8 @@
 //     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides;
 //   * visualize(cv::Mat&) (:373-423) is drawing code: with OpenCV present it draws the particles / mixture / best
 //     particle from a host copy of the states; without OpenCV it is a no-op (there is nothing to draw with);
-//   * top_down_geo is accepted and ignored like in the reference's score (src/state_particle.cpp:145-152).
+//   * top_down_geo is accepted and ignored like in the reference's score, whose geometric block is commented out
+//     (src/state_particle.cpp:145-152); setGeometricCost(true) switches that block on.
 #ifndef PARTICLE_FILTER_H_
 #define PARTICLE_FILTER_H_
 
@@ -36,6 +37,24 @@ class ParticleFilter {
       throw std::runtime_error(msg);
     }
   }
+  // Several GPUs, one process per GPU: the particles are sharded over the ranks of `comm` (tdr_comm_create_rccl: RCCL over
+  // xGMI; or tdr_comm_create with the host's own transport).  N is the GLOBAL particle count, a multiple of the world
+  // size; every rank constructs the filter with the same arguments and makes the same calls; update() on ranks other
+  // than 0 may be given empty images — rank 0's rasterised scan is broadcast.  Results equal the one-GPU filter bit for
+  // bit; statistics (computeMeanCov, meanLikelihood, maxLikelihood, scale, numParticles) are global on every rank,
+  // states() returns this rank's slice.
+  ParticleFilter(int N, TopDownMapPolar* map, FilterParams& params, uint32_t seed, tdr_comm* comm) : map_(map), params_(params) {
+    if (!map || !comm) throw std::invalid_argument("ParticleFilter: null map / comm");
+    max_num_particles_ = N;
+    tdr_filter_params c = to_tdr_params(params_, map_->numClasses());
+    if (tdr_filter_create_sharded(map_->handle(), N, &c, seed, comm, &f_) != TDR_OK) fail("ParticleFilter");
+    sharded_rank_ = tdr_comm_rank(comm);
+    if (map_->haveMap() && tdr_filter_initialize_particles(f_) != TDR_OK) {
+      const std::string msg = std::string("initializeParticles: ") + tdr_last_error();
+      tdr_filter_destroy(f_);
+      throw std::runtime_error(msg);
+    }
+  }
   ~ParticleFilter() { tdr_filter_destroy(f_); }
   ParticleFilter(const ParticleFilter&) = delete;
   ParticleFilter& operator=(const ParticleFilter&) = delete;
@@ -43,7 +62,11 @@ class ParticleFilter {
   void propagate(Eigen::Vector2f& trans, float omega) {                                   // :86-92
     check(tdr_filter_propagate(f_, trans[0], trans[1], omega), "propagate");
   }
-  void update(std::vector<Eigen::ArrayXXf>& top_down_scan, std::vector<Eigen::ArrayXXf>& /*top_down_geo*/, float res) {  // :94-189
+  void update(std::vector<Eigen::ArrayXXf>& top_down_scan, std::vector<Eigen::ArrayXXf>& top_down_geo, float res) {  // :94-189
+    if (sharded_rank_ > 0 && top_down_scan.empty()) {   // not rank 0 of a sharded filter: the scan arrives by broadcast
+      if (numParticles() > 0) check(tdr_filter_update(f_, nullptr, nullptr, res, next_count()), "update");
+      return;
+    }
     if (top_down_scan.empty() || numParticles() == 0) return;
     const int ncls = map_->numClasses();
     if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("update: fewer scan images than map classes");
@@ -58,8 +81,17 @@ class ParticleFilter {
                                     std::to_string(shape[0]) + "x" + std::to_string(shape[1]));
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
+    if (geometric_cost_ && top_down_geo.size() >= 2 && (size_t)top_down_geo[0].size() == P && (size_t)top_down_geo[1].size() == P) {
+      std::vector<float> geo(2 * P);
+      for (int i = 0; i < 2; i++) std::memcpy(geo.data() + P * i, top_down_geo[i].data(), P * sizeof(float));
+      check(tdr_filter_update_geo(f_, buf.data(), geo.data(), res, next_count()), "update");
+      return;
+    }
     check(tdr_filter_update(f_, buf.data(), nullptr, res, next_count()), "update");
   }
+  // Extension: let top_down_geo enter the score — getCostForRot's geometric block (src/state_particle.cpp:145-152), which
+  // the reference has commented out.  Off by default = the reference's behaviour.
+  void setGeometricCost(bool on) { geometric_cost_ = on; }
   // Extension: score against the renderer's last render without copying the images through the host.
   void update(const ScanRenderer& renderer, float res) {
     check(tdr_filter_update(f_, nullptr, renderer.handle(), res, next_count()), "update");
@@ -170,8 +202,8 @@ class ParticleFilter {
   void setStates(const std::vector<State>& s) {
     check(tdr_filter_set_states(f_, reinterpret_cast<const tdr_state*>(s.data()), (int64_t)s.size()), "setStates");
   }
-  std::vector<State> states() {
-    std::vector<State> s((size_t)numParticles());
+  std::vector<State> states() {   // this rank's particles (all of them unless the filter is sharded)
+    std::vector<State> s((size_t)tdr_filter_num_local(f_));
     if (!s.empty()) check(tdr_filter_get_states(f_, reinterpret_cast<tdr_state*>(s.data()), (int64_t)s.size()), "states");
     return s;
   }
@@ -181,7 +213,7 @@ class ParticleFilter {
     return w;
   }
   std::vector<int32_t> resampleIndices() {
-    std::vector<int32_t> idx((size_t)numParticles());
+    std::vector<int32_t> idx((size_t)tdr_filter_num_local(f_));
     if (!idx.empty()) check(tdr_filter_get_resample_indices(f_, idx.data(), (int64_t)idx.size()), "resampleIndices");
     return idx;
   }
@@ -201,8 +233,10 @@ class ParticleFilter {
   [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + tdr_last_error()); }
 
   int max_num_particles_ = 0;
+  int sharded_rank_ = -1;   // >= 0: rank of this process in a sharded filter
   int target_count_ = -1;
   bool adaptive_ = false;
+  bool geometric_cost_ = false;
   TopDownMapPolar* map_;
   FilterParams params_;
   tdr_filter* f_ = nullptr;

@@ -24,8 +24,27 @@ class TopDownMap {
     float resolution = 1;
     float out_of_bounds_const = 5;  // unused by the reference too: every out-of-bounds write is a literal 0
   };
-  explicit TopDownMap(const Params& params) : params_(params) {
+  // src/top_down_map.cpp:9-64.  An empty map_path is the dynamic-map case (the map arrives through updateMap).  A static
+  // map is taken from the reference's own cache — ~/.ros/xview_cache, written by the reference or by saveCachedMaps() —
+  // when its (map_path, num_classes, resolution) match (:18-20, :226-261).  Parsing SVG / decoding PNG (nanosvg, OpenCV:
+  // load-time work outside the per-scan path) is not done here: without a matching cache the map stays empty until
+  // setDistanceMaps() / updateMap() provide it.
+  explicit TopDownMap(const Params& params, const char* cache_dir = nullptr) : params_(params) {
     if (tdr_map_create(&m_) != TDR_OK) throw std::runtime_error(std::string("TopDownMap: ") + tdr_last_error());
+    if (!params_.map_path.empty() && params_.num_classes > 0) {
+      int loaded = 0;
+      if (tdr_map_load_cache(m_, cache_dir, params_.map_path.c_str(), params_.num_classes, params_.resolution, 0, 0,
+                             &loaded) != TDR_OK) {
+        const std::string msg = std::string("TopDownMap: ") + tdr_last_error();
+        tdr_map_destroy(m_);
+        throw std::runtime_error(msg);
+      }
+    }
+  }
+  // saveCachedMaps (:263-286): the cache the constructor above (and the reference) reads
+  void saveCachedMaps(const std::string& map_path, const char* cache_dir = nullptr) {
+    if (tdr_map_save_cache(m_, cache_dir, map_path.c_str()) != TDR_OK)
+      throw std::runtime_error(std::string("saveCachedMaps: ") + tdr_last_error());
   }
   virtual ~TopDownMap() { tdr_map_destroy(m_); }
   TopDownMap(const TopDownMap&) = delete;
@@ -78,10 +97,11 @@ class TopDownMap {
     if (dists.size() < 1) return;
     local_map(0, center, rot, res, (int)dists[0].rows(), (int)dists[0].cols(), dists, mask);
   }
-  // getLocalGeoMap (:461-490): the geometric layers have no consumer (src/state_particle.cpp:145-152 is commented out)
-  // and are not carried here: the outputs are zeroed.
-  void getLocalGeoMap(Eigen::Vector2f, float, float, std::vector<Eigen::ArrayXXf>& dists) {
-    for (Eigen::ArrayXXf& d : dists) d.setZero();
+  // getLocalGeoMap (:461-481): the same window gathered from the two geometric layers geo_maps_ ([0] distance to the
+  // nearest cell without a geometric class, [1] with one); dists.size() < 1 -> nothing happens (:464).
+  void getLocalGeoMap(Eigen::Vector2f center, float rot, float res, std::vector<Eigen::ArrayXXf>& dists) {
+    if (dists.size() < 1) return;
+    local_geo_map(0, center, rot, res, (int)dists[0].rows(), (int)dists[0].cols(), dists);
   }
   void getClassesAtPoint(const Eigen::Vector2f& center, std::vector<int>& classes) {      // :172-175
     getClassesAtPoint(Eigen::Vector2i((int)(center[0] / params_.resolution), (int)(center[1] / params_.resolution)), classes);
@@ -117,6 +137,14 @@ class TopDownMap {
       throw std::runtime_error(std::string("getLocalMap: ") + tdr_last_error());
     for (int c = 0; c < ncls; c++) std::memcpy(dists[c].data(), d.data() + P * c, P * sizeof(float));
     std::memcpy(mask.data(), k.data(), P);
+  }
+  void local_geo_map(int polar, const Eigen::Vector2f& center, float scale_or_rot, float res, int rows, int cols,
+                     std::vector<Eigen::ArrayXXf>& dists) {
+    const size_t P = (size_t)rows * cols;
+    std::vector<float> d(P * 2);
+    if (tdr_map_local_geo_map(m_, polar, center[0], center[1], scale_or_rot, res, rows, cols, d.data()) != TDR_OK)
+      throw std::runtime_error(std::string("getLocalGeoMap: ") + tdr_last_error());
+    for (size_t c = 0; c < dists.size() && c < 2; c++) std::memcpy(dists[c].data(), d.data() + P * c, P * sizeof(float));
   }
   Params params_;
   Eigen::Vector2i map_center_;

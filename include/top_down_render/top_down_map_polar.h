@@ -10,7 +10,7 @@
 
 class TopDownMapPolar : public TopDownMap {
  public:
-  explicit TopDownMapPolar(const Params& params) : TopDownMap(params) {
+  explicit TopDownMapPolar(const Params& params, const char* cache_dir = nullptr) : TopDownMap(params, cache_dir) {
     samplePtsPolar(Eigen::Vector2i(100, 50), (float)(2 * 3.14159265358979323846 / 100));  // top_down_map_polar.cpp:3-5
   }
   void samplePtsPolar(Eigen::Vector2i shape, float ang_res) {                              // :7-19
@@ -29,10 +29,12 @@ class TopDownMapPolar : public TopDownMap {
   void getLocalMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists, Eigen::ArrayXXc& mask) {
     getLocalMap(center, 1.f, res, dists, mask);                                           // :78-81
   }
-  // The geometric layers are never filled in the reference either (geo_maps_ stays empty unless getGeoRasterMap is
-  // called, which nothing does; the consumer is commented out, src/state_particle.cpp:145-152): the outputs are zeroed.
-  void getLocalGeoMap(Eigen::Vector2f, float, float, std::vector<Eigen::ArrayXXf>& dists) {
-    for (Eigen::ArrayXXf& d : dists) d.setZero();
+  // :55-76: the polar window gathered from the two geometric layers geo_maps_ (see TopDownMap::getLocalGeoMap)
+  void getLocalGeoMap(Eigen::Vector2f center, float scale, float res, std::vector<Eigen::ArrayXXf>& dists) {
+    if (dists.size() < 1) return;   // :58
+    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1])
+      throw std::invalid_argument("getLocalGeoMap: output arrays do not have the shape given to samplePtsPolar");
+    local_geo_map(1, center, scale, res, shape_[0], shape_[1], dists);
   }
   void getLocalGeoMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists) {
     getLocalGeoMap(center, 1.f, res, dists);

@@ -121,6 +121,38 @@ def raster_cart(pts, res, lut256, ncls, rows, cols):
     return out
 
 
+def geo_maps_from_class_maps(class_maps, class_mask, resolution=1.0):
+    """geo_maps_ as the static-map constructor builds them (src/top_down_map.cpp:48-58): getGeoRasterMap (:410-427) on the
+    class presence, then computeDists.  Returns an OracleMap with two "classes": [0] distance to the nearest cell WITHOUT
+    a geometric class (flattened class >= 3), [1] to the nearest cell WITH one; nothing is masked."""
+    from scipy.ndimage import distance_transform_edt
+    class_maps = np.asarray(class_maps, np.float32)
+    known = np.asarray(class_mask) == 0
+    geo = np.zeros(class_maps.shape[1:], bool)
+    for c in range(3, class_maps.shape[0]):
+        geo |= (class_maps[c] == 0) & known                        # :417-419
+    out = np.empty((2,) + geo.shape, np.float32)
+    for i, zero_where in enumerate((~geo, geo)):                   # layer i is 0 exactly on `zero_where`
+        if not zero_where.any():
+            d = np.full(geo.shape, 3.0e38, np.float32)
+        else:
+            d = distance_transform_edt(~zero_where).astype(np.float32)
+        out[i] = np.minimum(d * np.float32(resolution), np.float32(50))
+    return OracleMap(out, np.zeros(geo.shape, np.uint8), resolution)
+
+
+def compute_weights_geo(om, geo_om, tab, nb, nr, scan, geo_scan, res, fp, states, nthreads=0):
+    """computeWeight with getCostForRot's geometric block (state_particle.cpp:145-152) switched on."""
+    scan = np.ascontiguousarray(scan, np.float32)
+    geo_scan = np.ascontiguousarray(geo_scan, np.float32)
+    tab = np.ascontiguousarray(tab, np.float32)
+    w = np.empty(len(states), np.float32)
+    lib().orc_compute_weights_geo(C.byref(om.c), C.byref(geo_om.c), _p(tab), C.c_int(nb), C.c_int(nr), _p(scan),
+                                  _p(geo_scan), C.c_float(res), C.byref(fp), _p(states), C.c_long(len(states)), _p(w),
+                                  C.c_int(nthreads if nthreads > 0 else lib().orc_max_threads()))
+    return w
+
+
 def raster_geo_polar(pts, width, height, res, ang_res, nb, nr):
     """renderGeometricTopDown (scan_renderer_polar.cpp:6-81): (2, nb*nr) ground / obstacle images.  pts is the organised
     cloud in PCL order (element idy*width + idx)."""

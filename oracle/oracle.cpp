@@ -385,6 +385,97 @@ void orc_compute_weights(const orc_map* m, const float* tab, int nb, int nr, con
   }
 }
 
+// N4  getCostForRot WITH its geometric block (src/state_particle.cpp:145-152, commented out in the reference) and
+// computeWeight around it: geo_scan [2][nb*nr] are the images of renderGeometricTopDown, geo (an orc_map with 2 "classes"
+// = geo_maps_[0..1], mask all zero) is gathered by getLocalGeoMap (src/top_down_map_polar.cpp:55-76) — the same addressing
+// as getLocalMap.
+float orc_cost_for_rot_geo(const float* scan, const float* geo_scan, const float* classes, const float* geo_cls,
+                           const float* maskf, int ncls, int nb, int nr, const float* class_weights, float rot) {
+  long P = (long)nb * nr;
+  double msum = 0;
+  for (long k = 0; k < P; k++) msum += maskf[k];
+  if ((float)msum / (float)P < 0.5) return std::numeric_limits<float>::quiet_NaN();   // :117-120
+  int s = orc_rot_shift(rot, nb);
+  float cost = 0, normalization = 0;
+  for (int c = 0; c < ncls; c++) {                                             // :132-143
+    const float* sc = scan + (size_t)c * P;
+    const float* cl = classes + (size_t)c * P;
+    double top = 0, bot = 0, ntop = 0, nbot = 0;
+    for (int j = 0; j < nr; j++) {
+      for (int a = 0; a < s; a++) {
+        top += (double)(sc[a + (size_t)nb * j] * cl[(nb - s + a) + (size_t)nb * j]);
+        ntop += (double)(sc[a + (size_t)nb * j] * maskf[(nb - s + a) + (size_t)nb * j]);
+      }
+      for (int a = s; a < nb; a++) {
+        bot += (double)(sc[a + (size_t)nb * j] * cl[(a - s) + (size_t)nb * j]);
+        nbot += (double)(sc[a + (size_t)nb * j] * maskf[(a - s) + (size_t)nb * j]);
+      }
+    }
+    cost = (float)((double)cost + (double)(float)top * 0.01 * (double)class_weights[c]);
+    cost = (float)((double)cost + (double)(float)bot * 0.01 * (double)class_weights[c]);
+    normalization += (float)ntop;
+    normalization += (float)nbot;
+  }
+  for (int i = 0; i < 2; i++) {                                                // :146-151
+    const float* sc = geo_scan + (size_t)i * P;
+    const float* cl = geo_cls + (size_t)i * P;
+    double top = 0, bot = 0, total = 0;
+    for (int j = 0; j < nr; j++) {
+      for (int a = 0; a < s; a++) top += (double)(sc[a + (size_t)nb * j] * cl[(nb - s + a) + (size_t)nb * j]);
+      for (int a = s; a < nb; a++) bot += (double)(sc[a + (size_t)nb * j] * cl[(a - s) + (size_t)nb * j]);
+    }
+    for (long k = 0; k < P; k++) total += sc[k];
+    cost = (float)((double)cost + (double)(float)top * 0.01);                 // :148
+    cost = (float)((double)cost + (double)(float)bot * 0.01);                 // :149
+    normalization += (float)total;                                             // :150
+  }
+  return cost / normalization;
+}
+void orc_compute_weights_geo(const orc_map* m, const orc_map* geo, const float* tab, int nb, int nr, const float* scan,
+                             const float* geo_scan, float res, const orc_filter_params* fp, orc_state* states, long n,
+                             float* weights, int nthreads) {
+  long P = (long)nb * nr;
+  int ncls = m->ncls;
+  float width = (float)m->cols * m->resolution, height = (float)m->rows * m->resolution;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    std::vector<float> classes((size_t)ncls * P), geo_cls(2 * (size_t)P), maskf(P);
+    std::vector<uint8_t> mask(P), gmask(P);
+#pragma omp for schedule(dynamic, 16)
+    for (long p = 0; p < n; p++) {
+      orc_state& st = states[p];
+      float cx = st.dx_m * st.scale + st.init_x_px;
+      float cy = st.dy_m * st.scale + st.init_y_px;
+      if (fp->force_on_map) {
+        if (cx < 0 || cy < 0 || cx > width || cy > height) { weights[p] = 0; continue; }
+      }
+      if (fp->fixed_scale < 0) {
+        if ((double)st.scale < std::pow(10., (double)fp->scale_log_min) ||
+            (double)st.scale > std::pow(10., (double)fp->scale_log_max)) { weights[p] = 0; continue; }
+      }
+      orc_local_map_polar(m, tab, P, cx, cy, st.scale, res, classes.data(), mask.data());      // :188
+      orc_local_map_polar(geo, tab, P, cx, cy, st.scale, res, geo_cls.data(), gmask.data());   // :189 getLocalGeoMap
+      for (long k = 0; k < P; k++) maskf[k] = 1.f - (float)mask[k];
+      float best_cost = std::numeric_limits<float>::max();
+      float best_theta = 0;
+      if (!st.have_init) {
+        for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {
+          float cost = orc_cost_for_rot_geo(scan, geo_scan, classes.data(), geo_cls.data(), maskf.data(), ncls, nb, nr,
+                                            fp->class_weights, t);
+          if (cost < best_cost) { best_cost = cost; best_theta = t; }
+        }
+        st.theta = best_theta;
+        st.have_init = 1;
+      } else {
+        best_cost = orc_cost_for_rot_geo(scan, geo_scan, classes.data(), geo_cls.data(), maskf.data(), ncls, nb, nr,
+                                         fp->class_weights, st.theta);
+      }
+      weights[p] = (float)(1. / (double)(best_cost + fp->regularization));
+    }
+  }
+}
+
 // Cartesian score used for BASELINE config 4: the reference has no Cartesian score function;
 // defined as A9 with shift 0 on a window sampled by A7 with rot = theta, res as given (scale folded by caller).
 void orc_compute_weights_cart(const orc_map* m, int rows, int cols, const float* scan, float res,

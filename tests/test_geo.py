@@ -162,3 +162,170 @@ def test_geo_render_edge_cases(tdr, oracle):
     assert np.array_equal(dev.cpu().numpy(), oracle.raster_geo_cart(pts, 1, 3, 1.0, 9, 9))
     with pytest.raises(ValueError):
         rc.renderGeometricTopDown(pts, 1.0, _imgs(2, 9, 9), width=2, height=3)
+
+
+# ---- N4: geometric layers of the map, getLocalGeoMap, the geometric score term -------------------------------------------
+def _geo_scene(seed=0, ncls=6, nb=48, nr=32, size=260, n=600):
+    from top_down_renderer_amd import synth
+    cfg = synth.Config("geo", 4000, ncls, nb, nr, size, n, seed=4100 + seed)
+    return cfg, synth.make_scene(cfg)
+
+
+def test_oracle_geo_maps_definition(oracle):
+    """geo_maps_ (src/top_down_map.cpp:48-58, 410-427): layer 1 = distance to the nearest cell of a flattened class >= 3,
+    layer 0 = distance to the nearest cell without one, truncated at 50, nothing masked."""
+    maps = np.full((5, 6, 9), 50.0, np.float32)
+    mask = np.zeros((6, 9), np.uint8)
+    maps[3][2, 4] = 0.0                 # one cell of geometric class 3 ...
+    maps[1][0, 0] = 0.0                 # ... and a road cell (class 1 is not geometric)
+    maps[4][5, 8] = 0.0
+    mask[5, 8] = 1                      # class 4 "present" on an unknown cell does not count (its 0 is the mask's)
+    g = oracle.geo_maps_from_class_maps(maps, mask, 1.0)
+    g0, g1 = g.maps_cm[0].T, g.maps_cm[1].T           # back to [row, col]
+    assert g1[2, 4] == 0 and g1[2, 5] == 1 and np.isclose(g1[0, 0], np.hypot(2, 4))
+    assert g0[2, 4] == 1 and g0[0, 0] == 0 and g0[5, 8] == 0
+    assert not g.mask_cm.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,resolution", [(0, 1.0), (1, 0.5), (2, 2.0)])
+def test_geo_layers_and_local_geo_map_match_oracle(tdr, oracle, seed, resolution):
+    pkg, k = tdr
+    from top_down_renderer_amd import synth
+    cfg = synth.Config("geo", 3000, 6, 40, 24, 220, 8, seed=4200 + seed, map_resolution=resolution)
+    sc = synth.make_scene(cfg, with_particles=False)
+    rows, cols = 200, 170
+    maps = np.ascontiguousarray(sc.class_maps[:, :rows, :cols])
+    mask = np.ascontiguousarray(sc.class_mask[:rows, :cols])
+    geo_o = oracle.geo_maps_from_class_maps(maps, mask, resolution)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=resolution), maps, mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    gm, gk = k.unpack_map(m.geo_dev())                       # (2, cols, rows) column-major like the oracle's
+    assert np.array_equal(gm, geo_o.maps_cm) and not gk.any()
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, resolution)
+    rng = np.random.default_rng(seed)
+    for _ in range(6):
+        cx, cy = rng.uniform(-20, cols * resolution + 20), rng.uniform(-20, rows * resolution + 20)
+        scale, res = float(rng.uniform(0.5, 2.5)), float(rng.choice([0.5, 1.0, 1.5]))
+        d_o, _ = oracle.local_map_polar(geo_o, tab, cx, cy, scale, res)
+        d = m.getLocalGeoMap((cx, cy), scale, res)
+        assert np.array_equal(np.stack([x.T.ravel() for x in d]), d_o)
+    mc = pkg.TopDownMap(pkg.Params(resolution=resolution), maps, mask, kernels=k)
+    d_o, _ = oracle.local_map_cart(geo_o, 60.0, 70.0, 0.7, 1.0, 21, 17)
+    d = mc.getLocalGeoMap((60.0, 70.0), 0.7, 1.0, (21, 17))
+    assert np.array_equal(np.stack([x.T.ravel() for x in d]), d_o)
+    # the dynamic-map path (updateMap with a label image) leaves both layers at 1 (src/top_down_map.cpp:126-133)
+    lab = np.where(sc.lab[:rows, :cols] >= 0, sc.lab[:rows, :cols], 200).astype(np.uint8)[::-1].copy()
+    md = pkg.TopDownMapPolar(pkg.Params(resolution=1.0, flatten_lut=list(sc.lut), num_classes=6), kernels=k)
+    md.updateMap(lab, None, (0, 0))
+    md.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    d = md.getLocalGeoMap((cols / 2, rows / 2), 1.0, 1.0)
+    inside = np.stack(d)[:, :, :8]
+    assert (inside == 1.0).all() and set(np.unique(np.stack(d))) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,uninit", [(0, False), (1, True), (2, True)])
+def test_geometric_cost_term_matches_oracle(tdr, oracle, seed, uninit):
+    """getCostForRot with its geometric block (src/state_particle.cpp:145-152) switched on: weights within 1e-5 of the
+    oracle; with un-initialised particles the 40-rotation search prices the geometric term too."""
+    pkg, k = tdr
+    cfg, sc = _geo_scene(seed, ncls=[6, 5, 7][seed])
+    rng = np.random.default_rng(seed)
+    st = sc.states.copy()
+    st["dx_m"] = rng.normal(0, 2, len(st)).astype(np.float32)
+    far = rng.random(len(st)) < 0.1
+    st["init_x_px"][far] = rng.uniform(-300, 600, int(far.sum())).astype(np.float32)
+    if uninit:
+        st["have_init"][rng.random(len(st)) < 0.4] = 0
+    # geometric images of an organised scan of the same scene
+    pts, w, h = _lidar(rng, 256, 16, bumps=0.3)
+    ang = cfg.ang_res
+    geo = oracle.raster_geo_polar(pts, w, h, cfg.res, ang, cfg.nb, cfg.nr)
+    assert geo[0].sum() > 0 and geo[1].sum() > 0
+    scan = oracle.raster_polar(sc.pts, cfg.res, ang, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
+    geo_o = oracle.geo_maps_from_class_maps(sc.class_maps, sc.class_mask, 1.0)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, ang, 1.0)
+    cw = [float(x) for x in rng.uniform(0.3, 2.0, cfg.ncls)]
+    params = dict(fixed_scale=1.0, class_weights=cw, regularization=0.3)
+    st_o = st.copy()
+    ref = oracle.compute_weights_geo(om, geo_o, tab, cfg.nb, cfg.nr, scan, geo, cfg.res, oracle.make_params(cfg.ncls, **params),
+                                     st_o)
+    plain = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls, **params), st.copy())
+    ok = ~np.isnan(ref)
+    assert np.abs(ref[ok] - plain[ok]).max() > 1e-3            # the term does change the weights
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), ang)
+    geo_imgs = [geo[i].reshape(cfg.nr, cfg.nb).T.copy() for i in range(2)]
+    f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False, locality_every=1,
+                           use_geometric_cost=True)
+    f.set_states(st)
+    f.update(scan, geo_imgs, cfg.res)
+    got = f.raw_weights()
+    pre = k.states_to_host(f.st_new, len(st), pkg.STATE_DTYPE)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    same = pre["theta"] == st_o["theta"]
+    assert same.mean() > 0.9
+    err = np.abs(got[ok & same] - ref[ok & same]) / np.abs(ref[ok & same])
+    assert err.max(initial=0.0) <= 1e-5, err.max()
+    if not same.all():   # another candidate of the search: the weight is the oracle's at that rotation, which is a near-tie
+        st2 = st_o.copy()
+        st2["theta"], st2["have_init"] = pre["theta"], 1
+        ref2 = oracle.compute_weights_geo(om, geo_o, tab, cfg.nb, cfg.nr, scan, geo, cfg.res,
+                                          oracle.make_params(cfg.ncls, **params), st2)
+        d = ok & ~same
+        assert (np.abs(got[d] - ref2[d]) / np.abs(ref2[d])).max() <= 1e-5
+        assert (np.abs(ref2[d] - ref[d]) / np.abs(ref[d])).max() <= 2e-5
+    # without the switch top_down_geo is ignored like in the reference
+    f0 = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False)
+    f0.set_states(st)
+    f0.update(scan, geo_imgs, cfg.res)
+    w0 = f0.raw_weights()
+    assert np.allclose(w0[ok], plain[ok], rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+def test_map_cache_round_trip_in_the_reference_format(tdr, oracle, tmp_path):
+    """saveCachedMaps / loadCachedMaps (src/top_down_map.cpp:226-286) through the C ABI: cached_data.txt + class_map<i>.eig
+    + geo_map<i>.eig + class_mask.eig, readable by the Python reader of the same format; a cache for other parameters is
+    not loaded."""
+    import ctypes as C
+    pkg, k = tdr
+    from top_down_renderer_amd import eig_io, synth
+    from top_down_renderer_amd._lib import check
+    L = k.lib
+    cfg = synth.Config("cache", 100, 4, 16, 8, 90, 4, seed=77)
+    sc = synth.make_scene(cfg, with_particles=False)
+    ncls, H, W = sc.class_maps.shape
+    maps_cm = np.ascontiguousarray(np.transpose(sc.class_maps, (0, 2, 1)), np.float32)
+    mask_cm = np.ascontiguousarray(sc.class_mask.T, np.uint8)
+    vp = C.c_void_p
+    m = vp()
+    check(L.tdr_map_create(C.byref(m)))
+    check(L.tdr_map_set(m, maps_cm.ctypes.data_as(vp), mask_cm.ctypes.data_as(vp), ncls, H, W, C.c_float(1.0), 3, 4))
+    d = str(tmp_path).encode()
+    check(L.tdr_map_save_cache(m, d, b"/maps/site.svg"))
+    got_maps, got_mask = eig_io.load_cached_maps(str(tmp_path), ncls)
+    assert np.array_equal(got_maps, sc.class_maps) and np.array_equal(got_mask, sc.class_mask)
+    geo_o = oracle.geo_maps_from_class_maps(sc.class_maps, sc.class_mask, 1.0)
+    for i in range(2):
+        assert np.array_equal(eig_io.read_eig(str(tmp_path / f"geo_map{i}.eig"), np.float32).T, geo_o.maps_cm[i])
+    m2, loaded = vp(), C.c_int(-1)
+    check(L.tdr_map_create(C.byref(m2)))
+    check(L.tdr_map_load_cache(m2, d, b"/maps/other.svg", ncls, C.c_float(1.0), 0, 0, C.byref(loaded)))
+    assert loaded.value == 0
+    check(L.tdr_map_load_cache(m2, d, b"/maps/site.svg", ncls + 1, C.c_float(1.0), 0, 0, C.byref(loaded)))
+    assert loaded.value == 0
+    check(L.tdr_map_load_cache(m2, d, b"/maps/site.svg", ncls, C.c_float(1.0), 3, 4, C.byref(loaded)))
+    assert loaded.value == 1
+    dist = np.zeros(ncls * 12 * 10, np.float32)
+    msk = np.zeros(12 * 10, np.uint8)
+    ref_d = np.zeros_like(dist)
+    ref_m = np.zeros_like(msk)
+    for handle, dd, mm in ((m, ref_d, ref_m), (m2, dist, msk)):
+        check(L.tdr_map_local_map(handle, 0, C.c_float(40.0), C.c_float(35.0), C.c_float(0.4), C.c_float(1.0), 12, 10,
+                                  dd.ctypes.data_as(vp), mm.ctypes.data_as(vp)))
+    assert np.array_equal(dist, ref_d) and np.array_equal(msk, ref_m)
+    L.tdr_map_destroy(m)
+    L.tdr_map_destroy(m2)

@@ -64,6 +64,9 @@ SIGNATURES = {
     "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
                                _vp, _f, _i, _vp, _vp, _vp]),
+    "tdr_score_geo_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
+    "tdr_k_score_polar_geo": (_i, [C.POINTER(MapDescC), C.POINTER(MapDescC), _vp, _vp, _vp, _f, _f, _i, _i, _f,
+                                   C.POINTER(FilterParamsC), _vp, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),
     "tdr_score_cart_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_cart": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64, _vp,
                               _vp, _vp, _vp]),
@@ -120,6 +123,10 @@ SIGNATURES = {
     "tdr_map_local_map": (_i, [_vp, _i, _f, _f, _f, _f, _i, _i, _vp, _vp]),
     "tdr_k_local_map_polar": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     "tdr_k_local_map_cart": (_i, [_vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "tdr_map_local_geo_map": (_i, [_vp, _i, _f, _f, _f, _f, _i, _i, _vp]),
+    "tdr_map_load_cache": (_i, [_vp, C.c_char_p, C.c_char_p, _i, _f, _i, _i, C.POINTER(_i)]),
+    "tdr_map_save_cache": (_i, [_vp, C.c_char_p, C.c_char_p]),
+    "tdr_k_geo_map_from_map": (_i, [C.POINTER(MapDescC), _i, _vp, _vp, _vp]),
     "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),
     "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
     "tdr_renderer_destroy": (None, [_vp]),
@@ -133,6 +140,7 @@ SIGNATURES = {
     "tdr_filter_get_states": (_i, [_vp, _vp, _i64]),
     "tdr_filter_propagate": (_i, [_vp, _f, _f, _f]),
     "tdr_filter_update": (_i, [_vp, _vp, _vp, _f, _i64]),
+    "tdr_filter_update_geo": (_i, [_vp, _vp, _vp, _f, _i64]),
     "tdr_filter_compute_weights": (_i, [_vp, _vp, _vp, _f]),
     "tdr_filter_get_raw_weights": (_i, [_vp, _vp, _i64]),
     "tdr_filter_get_last_dist": (_i, [_vp, _vp, _i64]),

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <string>
 #include <vector>
 
 #include "tdr.h"
@@ -73,7 +74,10 @@ struct tdr_map {
   DevBuf<float> cdict;
   DevBuf<uint8_t> cws;
   std::vector<float> maps_host;  // class_maps_ (column-major), kept for getClassesAtPoint / particle initialisation
+  std::vector<uint8_t> mask_host;  // class_mask_ (column-major), kept for the map cache
   tdr_map_desc desc{};
+  DevBuf<float> geo_rec;         // geo_maps_[0..1] as a 2-class record map (tdr_k_geo_map_from_map)
+  tdr_map_desc geo_desc{};
   int nb = 0, nr = 0;
   float ang_res = 0;
   int center_x = 0, center_y = 0;
@@ -117,8 +121,59 @@ struct tdr_filter {
   int world = 1, rank = 0;
   int64_t cap = 0;
   DevBuf<float> xchg_in, xchg_out, raw_glob, ld_glob, st_send, st_all, st_glob, pk_recv;
+  DevBuf<float> geo_pk;   // packed geometric scan (tdr_filter_update_geo)
   int64_t nl() const { return n / world; }
 };
+
+// .eig files of the reference's map cache (top_down_map.h:29-50)
+static std::string cache_dir_or_default(const char* cache_dir) {
+  if (cache_dir && *cache_dir) return cache_dir;
+  const char* home = getenv("HOME");
+  return std::string(home ? home : ".") + "/.ros/xview_cache";
+}
+template <class T>
+static int read_eig(const std::string& path, std::vector<T>& out, int64_t& rows, int64_t& cols) {
+  FILE* fh = fopen(path.c_str(), "rb");
+  if (!fh) return failh(TDR_ERR_ARG, "map cache: cannot open %s", path.c_str());
+  int64_t hdr[2] = {0, 0};
+  bool ok = fread(hdr, sizeof(int64_t), 2, fh) == 2 && hdr[0] > 0 && hdr[1] > 0 && hdr[0] < (1 << 24) && hdr[1] < (1 << 24);
+  if (ok) {
+    out.resize((size_t)hdr[0] * hdr[1]);
+    ok = fread(out.data(), sizeof(T), out.size(), fh) == out.size() && fgetc(fh) == EOF;
+  }
+  fclose(fh);
+  if (!ok) return failh(TDR_ERR_ARG, "map cache: %s is not a well-formed .eig file of this scalar type", path.c_str());
+  rows = hdr[0];
+  cols = hdr[1];
+  return TDR_OK;
+}
+template <class T>
+static int write_eig(const std::string& path, const T* data, int64_t rows, int64_t cols) {
+  FILE* fh = fopen(path.c_str(), "wb");
+  if (!fh) return failh(TDR_ERR_ARG, "map cache: cannot write %s", path.c_str());
+  const int64_t hdr[2] = {rows, cols};
+  const bool ok = fwrite(hdr, sizeof(int64_t), 2, fh) == 2 && fwrite(data, sizeof(T), (size_t)rows * cols, fh) == (size_t)rows * cols;
+  fclose(fh);
+  return ok ? TDR_OK : failh(TDR_ERR_ARG, "map cache: short write to %s", path.c_str());
+}
+// geo_maps_ for a freshly packed map: computed from the class maps like the static-map constructor does
+// (src/top_down_map.cpp:48-58), or the constant 1 the dynamic-map path leaves them at (:126-133)
+static int map_make_geo(tdr_map* m, bool constant_one) {
+  const int rows = m->desc.rows, cols = m->desc.cols;
+  TTRY(m->geo_rec.resize(tdr_map_rec_floats_total(2, rows, cols)));
+  DevBuf<uint8_t> ws;
+  if (!constant_one) TTRY(ws.resize(tdr_map_ingest_workspace_bytes(2, rows, cols)));
+  TTRY(tdr_k_geo_map_from_map(&m->desc, constant_one ? 1 : 0, m->geo_rec.p, ws.p, nullptr));
+  HTRY(hipDeviceSynchronize());
+  m->geo_desc = tdr_map_desc{};
+  m->geo_desc.rec = m->geo_rec.p;
+  m->geo_desc.ncls = 2;
+  m->geo_desc.rows = rows;
+  m->geo_desc.cols = cols;
+  m->geo_desc.rec_floats = tdr_rec_floats(2);
+  m->geo_desc.resolution = m->desc.resolution;
+  return TDR_OK;
+}
 
 // the compact records of a freshly packed map (desc.rec etc. already set)
 static int map_compact(tdr_map* m) {
@@ -160,6 +215,7 @@ int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, 
   TTRY(tdr_k_pack_map(d_maps.p, d_mask.p, ncls, rows, cols, m->rec.p, nullptr));
   HTRY(hipDeviceSynchronize());
   m->maps_host.assign(class_maps, class_maps + ncell * ncls);
+  m->mask_host.assign(class_mask, class_mask + ncell);
   m->desc.rec = m->rec.p;
   m->desc.ncls = ncls;
   m->desc.rows = rows;
@@ -169,6 +225,7 @@ int tdr_map_set(tdr_map* m, const float* class_maps, const uint8_t* class_mask, 
   m->center_x = center_x;
   m->center_y = center_y;
   TTRY(map_compact(m));
+  TTRY(map_make_geo(m, false));
   m->have_map = true;
   if (m->nb > 0) return tdr_map_sample_pts_polar(m, m->nb, m->nr, m->ang_res);
   return TDR_OK;
@@ -198,7 +255,9 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
   TTRY(d_mask.resize(ncell));
   TTRY(tdr_k_unpack_map(m->rec.p, ncls, rows, cols, d_maps.p, d_mask.p, nullptr));
   m->maps_host.resize(ncell * ncls);
+  m->mask_host.resize(ncell);
   HTRY(hipMemcpy(m->maps_host.data(), d_maps.p, ncell * ncls * sizeof(float), hipMemcpyDeviceToHost));
+  HTRY(hipMemcpy(m->mask_host.data(), d_mask.p, ncell, hipMemcpyDeviceToHost));
   m->desc.rec = m->rec.p;
   m->desc.ncls = ncls;
   m->desc.rows = rows;
@@ -208,6 +267,7 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
   m->center_x = center_x;
   m->center_y = center_y;
   TTRY(map_compact(m));
+  TTRY(map_make_geo(m, true));   // updateMap leaves geo_maps_ at their constant 1 (:126-133)
   // `if (!class_maps_[1].isZero(0)) have_map_ = true; else "Received map with no road"` (:150-154)
   bool road = false;
   if (ncls > 1)
@@ -277,6 +337,106 @@ int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_
   else TTRY(tdr_k_local_map_cart(&m->desc, rows, cols, cx, cy, scale_or_rot, res, d.p, k.p, nullptr));
   HTRY(hipMemcpy(dists_out, d.p, P * m->desc.ncls * sizeof(float), hipMemcpyDeviceToHost));
   HTRY(hipMemcpy(mask_out, k.p, P, hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
+// getLocalGeoMap (top_down_map_polar.cpp:55-76, top_down_map.cpp:461-481): the window of one pose gathered from the two
+// geometric layers; dists_out HOST [2][rows*cols]
+int tdr_map_local_geo_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
+                          float* dists_out) {
+  if (!m || !m->have_map || !dists_out || !m->geo_rec.p) return failh(TDR_ERR_ARG, "map_local_geo_map: no map / null output");
+  if (polar) {
+    if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "map_local_geo_map: samplePtsPolar was never called");
+    rows = m->nb;
+    cols = m->nr;
+  }
+  if (rows < 1 || cols < 1) return failh(TDR_ERR_ARG, "map_local_geo_map: bad window shape");
+  const size_t P = (size_t)rows * cols;
+  DevBuf<float> d;
+  DevBuf<uint8_t> k;
+  TTRY(d.resize(P * 2));
+  TTRY(k.resize(P));
+  if (polar) TTRY(tdr_k_local_map_polar(&m->geo_desc, m->tab.p, rows, cols, cx, cy, scale_or_rot, res, d.p, k.p, nullptr));
+  else TTRY(tdr_k_local_map_cart(&m->geo_desc, rows, cols, cx, cy, scale_or_rot, res, d.p, k.p, nullptr));
+  HTRY(hipMemcpy(dists_out, d.p, P * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  return TDR_OK;
+}
+
+// ---- the reference's on-disk map cache (src/top_down_map.cpp:226-286) ------------------------------------------------
+// ~/.ros/xview_cache/{cached_data.txt, class_map<i>.eig, geo_map<i>.eig, class_mask.eig}; an .eig file is
+// `Index rows, Index cols` (2 x int64) followed by the column-major scalars (top_down_map.h:29-50).
+// loadCacheMetaData + loadCachedMaps (:226-261).  *loaded = 0 (and TDR_OK) when no cache matches (map_path, num_classes,
+// resolution) — the caller then builds the map by other means; a matching but damaged cache is an error.
+int tdr_map_load_cache(tdr_map* m, const char* cache_dir, const char* map_path, int num_classes, float resolution,
+                       int center_x, int center_y, int* loaded) {
+  if (!m || !map_path || !loaded) return failh(TDR_ERR_ARG, "map_load_cache: bad arguments");
+  *loaded = 0;
+  const std::string dir = cache_dir_or_default(cache_dir);
+  FILE* fh = fopen((dir + "/cached_data.txt").c_str(), "r");
+  if (!fh) return TDR_OK;
+  char line[4096];
+  bool match = fgets(line, sizeof(line), fh) != nullptr;
+  if (match) {
+    line[strcspn(line, "\r\n")] = 0;
+    match = std::string(line) == map_path;                                        // :234-235
+  }
+  if (match) match = fgets(line, sizeof(line), fh) && atoi(line) == num_classes;  // :236-237
+  if (match) match = fgets(line, sizeof(line), fh) && std::fabs((float)atof(line) - resolution) <= 0.01f;   // :238-239
+  fclose(fh);
+  if (!match) return TDR_OK;
+  if (num_classes < 1 || num_classes > TDR_MAX_CLASSES) return failh(TDR_ERR_ARG, "map_load_cache: bad class count");
+  std::vector<float> maps, one;
+  std::vector<uint8_t> mask;
+  int64_t rows = 0, cols = 0, r2 = 0, c2 = 0;
+  for (int c = 0; c < num_classes; c++) {
+    TTRY(read_eig(dir + "/class_map" + std::to_string(c) + ".eig", one, r2, c2));
+    if (c == 0) { rows = r2; cols = c2; }
+    if (r2 != rows || c2 != cols) return failh(TDR_ERR_ARG, "map_load_cache: class maps differ in shape");
+    maps.insert(maps.end(), one.begin(), one.end());
+  }
+  TTRY(read_eig(dir + "/class_mask.eig", mask, r2, c2));
+  if (r2 != rows || c2 != cols) return failh(TDR_ERR_ARG, "map_load_cache: mask shape differs from the class maps");
+  TTRY(tdr_map_set(m, maps.data(), mask.data(), num_classes, (int)rows, (int)cols, resolution, center_x, center_y));
+  // the cached geometric layers replace the ones tdr_map_set derived (they are the same for a cache this library wrote)
+  std::vector<float> g0, g1;
+  if (read_eig(dir + "/geo_map0.eig", g0, r2, c2) == TDR_OK && r2 == rows && c2 == cols &&
+      read_eig(dir + "/geo_map1.eig", g1, r2, c2) == TDR_OK && r2 == rows && c2 == cols) {
+    g0.insert(g0.end(), g1.begin(), g1.end());
+    std::vector<uint8_t> zero((size_t)rows * cols, 0);
+    DevBuf<float> d_maps;
+    DevBuf<uint8_t> d_mask;
+    TTRY(d_maps.resize(g0.size()));
+    TTRY(d_mask.resize(zero.size()));
+    HTRY(hipMemcpy(d_maps.p, g0.data(), g0.size() * sizeof(float), hipMemcpyHostToDevice));
+    HTRY(hipMemcpy(d_mask.p, zero.data(), zero.size(), hipMemcpyHostToDevice));
+    TTRY(tdr_k_pack_map(d_maps.p, d_mask.p, 2, (int)rows, (int)cols, m->geo_rec.p, nullptr));
+    HTRY(hipDeviceSynchronize());
+  }
+  *loaded = 1;
+  return TDR_OK;
+}
+// saveCachedMaps (:263-286)
+int tdr_map_save_cache(tdr_map* m, const char* cache_dir, const char* map_path) {
+  if (!m || !m->have_map || !map_path) return failh(TDR_ERR_ARG, "map_save_cache: no map");
+  const std::string dir = cache_dir_or_default(cache_dir);
+  const int ncls = m->desc.ncls, rows = m->desc.rows, cols = m->desc.cols;
+  const size_t ncell = (size_t)rows * cols;
+  FILE* fh = fopen((dir + "/cached_data.txt").c_str(), "w");
+  if (!fh) return failh(TDR_ERR_ARG, "map_save_cache: cannot write into %s (the directory must exist)", dir.c_str());
+  fprintf(fh, "%s\n%d\n%g\n", map_path, ncls, (double)m->desc.resolution);
+  fclose(fh);
+  for (int c = 0; c < ncls; c++)
+    TTRY(write_eig(dir + "/class_map" + std::to_string(c) + ".eig", m->maps_host.data() + ncell * c, rows, cols));
+  TTRY(write_eig(dir + "/class_mask.eig", m->mask_host.data(), rows, cols));
+  DevBuf<float> d_maps;
+  DevBuf<uint8_t> d_mask;
+  TTRY(d_maps.resize(ncell * 2));
+  TTRY(d_mask.resize(ncell));
+  TTRY(tdr_k_unpack_map(m->geo_rec.p, 2, rows, cols, d_maps.p, d_mask.p, nullptr));
+  std::vector<float> g(ncell * 2);
+  HTRY(hipMemcpy(g.data(), d_maps.p, g.size() * sizeof(float), hipMemcpyDeviceToHost));
+  TTRY(write_eig(dir + "/geo_map0.eig", g.data(), rows, cols));
+  TTRY(write_eig(dir + "/geo_map1.eig", g.data() + ncell, rows, cols));
   return TDR_OK;
 }
 
@@ -571,6 +731,42 @@ int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer*
     ld = f->ld_glob.p;
   }
   TTRY(tdr_k_update_weights(raw, ld, n, f->w.p, f->info.p, f->stream));
+  return filter_resample(f, n_target);
+}
+// ParticleFilter::update with the geometric images entering the score (state_particle.cpp:145-152, opt-in)
+int tdr_filter_update_geo(tdr_filter* f, const float* scan_imgs, const float* geo_imgs, float res, int64_t n_target) {
+  if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_update_geo: no map");
+  if (!scan_imgs || !geo_imgs) return failh(TDR_ERR_ARG, "filter_update_geo: null images");
+  if (f->comm) return failh(TDR_ERR_ARG, "filter_update_geo: not available on a sharded filter");
+  if (f->n == 0) return TDR_OK;
+  tdr_map* m = f->map;
+  if (m->nb < 1 || !m->tab.p || !m->geo_rec.p) return failh(TDR_ERR_ARG, "filter_update_geo: samplePtsPolar was never called");
+  f->fp.num_classes = m->desc.ncls;
+  const int ncls = m->desc.ncls, nb = m->nb, nr = m->nr;
+  const size_t P = (size_t)nb * nr;
+  TTRY(f->scan_img.resize(P * std::max(ncls, 2)));
+  TTRY(f->scan_pk.resize(P * tdr_rec_floats(ncls)));
+  TTRY(f->geo_pk.resize(P * 4));
+  HTRY(hipMemcpyAsync(f->scan_img.p, scan_imgs, P * ncls * sizeof(float), hipMemcpyHostToDevice, f->stream));
+  TTRY(tdr_k_pack_scan(f->scan_img.p, ncls, nb, nr, f->scan_pk.p, f->stream));
+  HTRY(hipMemcpyAsync(f->scan_img.p, geo_imgs, P * 2 * sizeof(float), hipMemcpyHostToDevice, f->stream));
+  TTRY(tdr_k_pack_scan(f->scan_img.p, 2, nb, nr, f->geo_pk.p, f->stream));
+  double gs[2] = {0, 0};   // top_down_geo[i].sum(): Eigen's order is unspecified; counts are small integers, any order is exact
+  for (int i = 0; i < 2; i++)
+    for (size_t k = 0; k < P; k++) gs[i] += (double)geo_imgs[P * i + k];
+  const int64_t n = f->n;
+  const int32_t* perm = nullptr;
+  if (f->locality_every > 0) {
+    TTRY(f->loc_tmp.resize(tdr_locality_tmp_ints(n, m->desc.rows, m->desc.cols)));
+    TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
+    perm = f->perm.p;
+  }
+  TTRY(f->ws.resize(tdr_score_geo_workspace_floats(ncls, nb, nr, n)));
+  TTRY(tdr_k_score_polar_geo(&m->desc, &m->geo_desc, m->tab.p, f->scan_pk.p, f->geo_pk.p, (float)gs[0], (float)gs[1], nb, nr,
+                             res, &f->fp, f->st.p, f->cap, n, perm, f->uniform_scale, f->maybe_uninit ? 1 : 0,
+                             f->raw_w.p, f->ws.p, f->stream));
+  if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
+  TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
   return filter_resample(f, n_target);
 }
 // StateParticle::computeWeight for every particle (state_particle.cpp:157-219): raw weights only, no statistics, no

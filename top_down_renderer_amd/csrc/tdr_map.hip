@@ -173,6 +173,64 @@ extern "C" int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int im
   return TDR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// N4: the geometric layers geo_maps_[0..1] (top_down_map.h:79).  The static-map constructor derives them from the class
+// images — getGeoRasterMap (src/top_down_map.cpp:410-427): layer 1 marks the cells of any "geometric" class (flattened
+// class >= 3), layer 0 its complement — and runs computeDists on them (:58): geo_maps_[1] = distance to the nearest cell
+// WITH a geometric class, geo_maps_[0] = distance to the nearest cell WITHOUT one, times the resolution, truncated at 50;
+// no cell is masked (the two binary layers sum to 1 everywhere, :294-299).  Here the class presence is read off the cell
+// records (distance 0 on a known cell) and the two layers go through the same exact distance transform as the class
+// maps, into records of their own: a 2-class map {d_without, d_with, 1, 1}.
+__global__ void geo_labels_kernel(const float* __restrict__ rec, int ncls, int rows, int cols, int rf,
+                                  int8_t* __restrict__ cls_map) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx % cols);
+  const float* o = rec + ((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf;
+  bool geo = false;
+  if (o[rf - 1] != 0.f)
+    for (int k = 3; k < ncls; k++) geo |= o[k] == 0.f;                          // :417-419
+  cls_map[idx] = geo ? 1 : 0;
+}
+// the dynamic-map path leaves both layers at their initial constant 1 (loadCompressedRasterMap :126-133, "Not actually
+// used at the moment"; updateMap never recomputes them): records {1, 1, 1, 1} inside the map, the zero guard ring outside
+__global__ void geo_ones_kernel(int rows, int cols, float* __restrict__ rec) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gcols = cols + 2;
+  if (idx >= (int64_t)(rows + 2) * gcols) return;
+  const int r = (int)(idx / gcols) - 1, c = (int)(idx % gcols) - 1;
+  const float v = (r >= 0 && r < rows && c >= 0 && c < cols) ? 1.f : 0.f;
+  for (int k = 0; k < 4; k++) rec[idx * 4 + k] = v;
+}
+// geo_rec_out: tdr_map_rec_floats_total(2, rows, cols) floats; workspace: tdr_map_ingest_workspace_bytes(2, rows, cols)
+// (unused when constant_one != 0).
+extern "C" int tdr_k_geo_map_from_map(const tdr_map_desc* map, int constant_one, float* geo_rec_out, void* workspace,
+                                      void* stream) {
+  if (!map || !map->rec || !geo_rec_out) return fail(TDR_ERR_ARG, "geo_map_from_map: null pointer");
+  const int rows = map->rows, cols = map->cols;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t ncell = (int64_t)rows * cols, nrec = (int64_t)tdr_map_rec_floats_total(2, rows, cols);
+  if (constant_one) {
+    hipLaunchKernelGGL(geo_ones_kernel, dim3((unsigned)cdiv(nrec / 4, 256)), dim3(256), 0, s, rows, cols, geo_rec_out);
+    LAUNCH_CHECK("geo_ones");
+    return TDR_OK;
+  }
+  if (!workspace) return fail(TDR_ERR_ARG, "geo_map_from_map: workspace required");
+  const int R = (int)std::ceil(50.0 / (double)map->resolution);
+  if (R > 250) return fail(TDR_ERR_ARG, "geo_map_from_map: resolution %g needs a %d-cell window (max 250)", map->resolution, R);
+  int8_t* cls_map = reinterpret_cast<int8_t*>(workspace);
+  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)ncell + 255) & ~(size_t)255);
+  hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, geo_rec_out, nrec);
+  hipLaunchKernelGGL(geo_labels_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, map->rec, map->ncls, rows, cols,
+                     map->rec_floats, cls_map);
+  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map, 2,
+                     rows, cols, R, g);
+  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map,
+                     (const uint8_t*)g, 2, rows, cols, R, map->resolution, 4, geo_rec_out);
+  LAUNCH_CHECK("geo_map_from_map");
+  return TDR_OK;
+}
+
 // Back to the reference's layout (class_maps_ / class_mask_: column-major per class), e.g. for the host copy that
 // getClassesAtPoint and the particle initialisation read.
 __global__ void unpack_map_kernel(const float* __restrict__ rec, int ncls, int rows, int cols, int rf,

@@ -24,6 +24,7 @@ struct ScoreArgs {
   const int32_t* count; // optional device count limiting the active slots (init search)
   int use_theta_override;
   float theta_override;
+  int only_uninit;      // score only workgroups that hold a particle without a heading (the geometric init search)
   int group, nchunks;   // rings per workgroup (score_group_rings), number of groups
   int64_t npad;         // slots padded to a multiple of 64
   float* part;          // [nchunks][rf+1][npad]
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
   if ((int64_t)bx * 256 >= nact) return;  // whole workgroup idle (uniform)
   const bool valid = slot < nact;
   const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  if (a.only_uninit && !__syncthreads_or(valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f)) return;
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
   const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];  // :162
@@ -594,6 +596,12 @@ struct FinalizeArgs {
   float* raw_w;
   float* best_cost;
   float* best_theta;
+  // the geometric term of getCostForRot (state_particle.cpp:145-152, commented out in the reference; opt-in here):
+  // partial sums of a second scoring launch over the 2-layer geometric map and the sums of the two geometric scan images
+  const float* gpart;   // [gnchunks][5][npad], NULL = no geometric term
+  int gnchunks;
+  float gsum0, gsum1;
+  int only_uninit;      // mode 1: slots whose particle already has a heading are left alone
 };
 
 __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
@@ -608,6 +616,7 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
     a.raw_w[p] = 0.f;
     return;
   }
+  if (a.mode == 1 && a.only_uninit && a.st[TDR_ST_HAVE_INIT * a.cap + p] != 0.f) return;
   // Per-chunk partial sums -> double totals, chunk order ascending for every slot.  The loads of FIN_B chunks x all
   // slots are issued together (independent addresses, coalesced over the particles) before the dependent additions.
   constexpr int FIN_B = 4, FIN_S = TDR_MAX_CLASSES + 2;   // slots: ncls class dots, normalisation, known count
@@ -650,7 +659,20 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
 #pragma unroll
     for (int k = 0; k < TDR_MAX_CLASSES; k++)
       if (k < a.ncls) cost = (float)((double)cost + (double)(float)tot[k] * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
-    cost = cost / (float)norm;  // :154
+    float normf = (float)norm;
+    if (a.gpart) {   // :145-152: cost += (geo_i . geo_cls_i) * 0.01; normalization += geo_i.sum()
+      double g[2] = {0, 0};
+      const int64_t gstride = (int64_t)5 * a.npad;
+      for (int c0g = 0; c0g < a.gnchunks; c0g++) {
+        g[0] += (double)a.gpart[(int64_t)c0g * gstride + slot];
+        g[1] += (double)a.gpart[(int64_t)c0g * gstride + a.npad + slot];
+      }
+      cost = (float)((double)cost + (double)(float)g[0] * 0.01);
+      normf = normf + a.gsum0;
+      cost = (float)((double)cost + (double)(float)g[1] * 0.01);
+      normf = normf + a.gsum1;
+    }
+    cost = cost / normf;  // :154
   }
   if (a.mode == 0) {
     a.raw_w[p] = (float)(1. / (double)(cost + a.fp.regularization));  // :212
@@ -1265,7 +1287,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
-  a.use_theta_override = 0; a.theta_override = 0.f;
+  a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
   a.group = score_group_rings(nb, rf);
   a.nchunks = (int)cdiv(nr, a.group);
   a.npad = cdiv(n, 64) * 64;
@@ -1345,11 +1367,122 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   f.gate = make_gate(fp, map);
   f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
   hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
   LAUNCH_CHECK("score_finalize");
   if (init_search) {
     hipLaunchKernelGGL(init_fixup_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_flag, n,
                        fp->regularization, raw_w);
+    LAUNCH_CHECK("init_fixup");
+  }
+  return TDR_OK;
+}
+
+// ---- scoring WITH the geometric term -------------------------------------------------------------------
+// getCostForRot's geometric block — cost += (top_down_geo[i] . shifted geo_cls[i]).sum() * 0.01 for the two layers,
+// normalization += top_down_geo[i].sum() — is commented out in the reference (src/state_particle.cpp:145-152) and its
+// inputs are zero images there (src/top_down_render.cpp:533-540).  It is available here as an opt-in: a second scoring
+// launch over the 2-layer geometric map (tdr_k_geo_map_from_map) against the packed geometric scan, combined in the
+// finalize step.  The 40-rotation search then has to price the geometric term for every candidate too: it runs as one
+// scoring pass per rotation over the workgroups that hold a particle without a heading (the window-gathered-once
+// kernels only know the semantic term).
+__global__ void init_from_best_kernel(const float* __restrict__ best_cost, const float* __restrict__ best_theta,
+                                      const int32_t* __restrict__ order, int64_t n, float* __restrict__ st, int64_t cap,
+                                      GateArgs gate, float* __restrict__ res_flag) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const int64_t p = order ? (int64_t)order[slot] : slot;
+  res_flag[p] = 0.f;
+  if (st[TDR_ST_HAVE_INIT * cap + p] != 0.f) return;
+  const float scale = st[TDR_ST_SCALE * cap + p];
+  const float cx = st[TDR_ST_DX * cap + p] * scale + st[TDR_ST_INIT_X * cap + p];
+  const float cy = st[TDR_ST_DY * cap + p] * scale + st[TDR_ST_INIT_Y * cap + p];
+  if (particle_gated(gate, cx, cy, scale)) return;          // computeWeight returns before the search (:163-176)
+  const bool none = !(best_cost[slot] < 3.402823466e+38f);  // every candidate scored NaN: best_theta stays 0 (:193-194)
+  st[TDR_ST_THETA * cap + p] = none ? 0.f : best_theta[slot];   // :205
+  st[TDR_ST_HAVE_INIT * cap + p] = 1.f;                         // :206
+  res_flag[p] = none ? 2.f : 1.f;
+}
+extern "C" size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n) {
+  const int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  const int ggroup = score_group_rings(nb, 4);
+  return tdr_score_workspace_floats(ncls, nb, nr, n) + (size_t)(cdiv(nr, ggroup) * 5 * npad);
+}
+extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc* geo_map, const float* tab,
+                                     const float* scan_pk, const float* geo_pk, float geo_sum0, float geo_sum1, int nb,
+                                     int nr, float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
+                                     const int32_t* perm, float uniform_scale, int init_search, float* raw_w,
+                                     float* workspace, void* stream) {
+  if (!map || !map->rec || !geo_map || !geo_map->rec || !tab || !scan_pk || !geo_pk || !fp || !st || !raw_w || !workspace)
+    return fail(TDR_ERR_ARG, "score_geo: null pointer");
+  if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_geo: n exceeds capacity");
+  if (n == 0) return TDR_OK;
+  if (nb < 1 || nr < 1) return fail(TDR_ERR_ARG, "score_geo: bad image shape");
+  if (map->ncls < 1 || map->ncls > TDR_MAX_CLASSES || fp->num_classes != map->ncls)
+    return fail(TDR_ERR_ARG, "score_geo: class count mismatch");
+  if (geo_map->ncls != 2 || geo_map->rec_floats != 4 || geo_map->rows != map->rows || geo_map->cols != map->cols)
+    return fail(TDR_ERR_ARG, "score_geo: the geometric map must be the 2-layer map of the same grid");
+  const int rf = tdr_rec_floats(map->ncls);
+  if (map->rec_floats != rf) return fail(TDR_ERR_ARG, "score_geo: map record size mismatch");
+  if ((size_t)nb * rf * 4 > 60 * 1024) return fail(TDR_ERR_ARG, "score_geo: nb too large for the LDS scan ring");
+  if (int rc0 = check_map_addressing(map, rf, "score_geo")) return rc0;
+  hipStream_t s = (hipStream_t)stream;
+  ScoreArgs a;
+  a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
+  a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
+  a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
+  a.group = score_group_rings(nb, rf);
+  a.nchunks = (int)cdiv(nr, a.group);
+  a.npad = cdiv(n, 64) * 64;
+  a.part = workspace;
+  int rc = fill_utab(a, workspace, rf, uniform_scale, s);
+  if (rc) return rc;
+  float* best_cost = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;   // npad floats (res_flag's place)
+  float* best_theta = best_cost + a.npad;                                 // npad floats
+  float* res_flag = best_theta + a.npad;                                  // npad floats ("list" region)
+  ScoreArgs g = a;   // the geometric launch: same particles, same table, the 2-layer map and scan
+  g.rec = geo_map->rec; g.scan_pk = geo_pk;
+  g.group = score_group_rings(nb, 4);
+  g.nchunks = (int)cdiv(nr, g.group);
+  g.part = workspace + tdr_score_workspace_floats(map->ncls, nb, nr, n);
+  FinalizeArgs f;
+  f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
+  f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
+  f.gate = make_gate(fp, map);
+  f.P = (int64_t)nb * nr; f.ncls = map->ncls;
+  f.raw_w = raw_w; f.best_cost = best_cost; f.best_theta = best_theta;
+  f.gpart = g.part; f.gnchunks = g.nchunks; f.gsum0 = geo_sum0; f.gsum1 = geo_sum1;
+  const dim3 fgrid((unsigned)cdiv(n, 256)), fblock(256);
+  if (init_search) {
+    // state_particle.cpp:195-206 with the geometric term: one pass per candidate rotation, workgroups without an
+    // un-initialised particle return at once
+    a.only_uninit = g.only_uninit = 1;
+    a.use_theta_override = g.use_theta_override = 1;
+    f.mode = 1; f.only_uninit = 1;
+    int k = 0;
+    for (float t = 0; t < 2 * M_PI; t += 2 * M_PI / 40) {   // :197 (float t, double increment)
+      a.theta_override = g.theta_override = t;
+      if ((rc = launch_score(a, map, rf, map->ncls, s))) return rc;
+      if ((rc = launch_score(g, geo_map, 4, 2, s))) return rc;
+      f.first = k == 0; f.theta_override = t;
+      hipLaunchKernelGGL(score_finalize_kernel, fgrid, fblock, 0, s, f);
+      LAUNCH_CHECK("score_finalize(geo init)");
+      k++;
+    }
+    hipLaunchKernelGGL(init_from_best_kernel, fgrid, fblock, 0, s, (const float*)best_cost, (const float*)best_theta, perm,
+                       n, st, cap, f.gate, res_flag);
+    LAUNCH_CHECK("init_from_best");
+    a.only_uninit = g.only_uninit = 0;
+    a.use_theta_override = g.use_theta_override = 0;
+  }
+  if ((rc = launch_score(a, map, rf, map->ncls, s))) return rc;
+  if ((rc = launch_score(g, geo_map, 4, 2, s))) return rc;
+  f.mode = 0; f.first = 0; f.theta_override = 0.f; f.only_uninit = 0;
+  hipLaunchKernelGGL(score_finalize_kernel, fgrid, fblock, 0, s, f);
+  LAUNCH_CHECK("score_finalize(geo)");
+  if (init_search) {
+    hipLaunchKernelGGL(init_fixup_kernel, fgrid, fblock, 0, s, (const float*)res_flag, n, fp->regularization, raw_w);
     LAUNCH_CHECK("init_fixup");
   }
   return TDR_OK;
@@ -1419,6 +1552,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   f.gate.scale_unknown = 0;
   f.P = (int64_t)rows * cols; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
+  f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
   hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
   LAUNCH_CHECK("score_finalize(cart)");
   return TDR_OK;

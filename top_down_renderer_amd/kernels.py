@@ -31,6 +31,23 @@ class DeviceMap:
         self.ang_res = 0.0
         self.crec = self.dict = None   # compact form of the records (tdr_k_compact_map), when the map has one
 
+    def geo_map(self, kernels, constant_one=False):
+        """geo_maps_[0..1] as a 2-class DeviceMap (tdr_k_geo_map_from_map): distance to the nearest cell without / with
+        a geometric class, derived from the class records; constant_one: what the reference's updateMap path leaves."""
+        key = bool(constant_one)
+        if getattr(self, "_geo", None) is None or self._geo[0] != key:
+            lib = kernels.lib
+            rec = kernels.empty((int(lib.tdr_map_rec_floats_total(2, self.rows, self.cols)),))
+            ws = kernels.empty((int(lib.tdr_map_ingest_workspace_bytes(2, self.rows, self.cols)),), torch.uint8)
+            check(lib.tdr_k_geo_map_from_map(C.byref(self.desc), int(key), _ptr(rec), _ptr(ws), kernels.stream()))
+            kernels.synchronize()
+            g = DeviceMap(rec, 2, self.rows, self.cols, self.resolution)
+            g.tab, g.tab_host, g.nb, g.nr, g.ang_res = self.tab, self.tab_host, self.nb, self.nr, self.ang_res
+            self._geo = (key, g)
+        g = self._geo[1]
+        g.tab, g.tab_host, g.nb, g.nr, g.ang_res = self.tab, self.tab_host, self.nb, self.nr, self.ang_res
+        return g
+
     def compact(self, kernels):
         """Builds the compact records (csrc/tdr_cmap.hip): 10-bit dictionary indices instead of floats, exact by
         construction; read by scoring waves whose particles are spread over the map.  No-op for maps without one."""
@@ -190,6 +207,18 @@ class HipKernels:
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
                                          C.byref(fp), _ptr(st), cap, n, _ptr(perm), C.c_float(uniform_scale),
                                          int(bool(init_search)), _ptr(raw_w), _ptr(ws), self.stream()))
+
+    def score_geo(self, m, gm, scan_pk, geo_pk, geo_sums, res, fp, st, n, raw_w, perm=None, init_search=False,
+                  uniform_scale=0.0):
+        """Scoring with the geometric term (tdr_k_score_polar_geo): gm = m.geo_map(...), geo_pk = pack_scan of the two
+        geometric images, geo_sums = their sums."""
+        need = int(self.lib.tdr_score_geo_workspace_floats(m.ncls, m.nb, m.nr, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.empty((need,))
+        check(self.lib.tdr_k_score_polar_geo(C.byref(m.desc), C.byref(gm.desc), _ptr(m.tab), _ptr(scan_pk), _ptr(geo_pk),
+                                             C.c_float(geo_sums[0]), C.c_float(geo_sums[1]), m.nb, m.nr, C.c_float(res),
+                                             C.byref(fp), _ptr(st), st.shape[1], n, _ptr(perm), C.c_float(uniform_scale),
+                                             int(bool(init_search)), _ptr(raw_w), _ptr(self._ws), self.stream()))
 
     def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None):
         need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n))

@@ -18,7 +18,8 @@ Deliberate, documented deviations from the reference
   * the three `for (int i; ...)` loops (:110,120,138) start at 0;
   * the adaptive particle count (:151-157) takes the GMM covariances / target count as an explicit input instead of
     racing an OpenCV EM thread; default keeps N;
-  * top_down_geo is accepted and ignored: its score term is commented out in the reference (state_particle.cpp:145-152).
+  * top_down_geo is accepted and ignored like in the reference, whose geometric score term is commented out
+    (state_particle.cpp:145-152); use_geometric_cost=True switches that term on.
 """
 import math
 from dataclasses import dataclass, field
@@ -96,19 +97,24 @@ class _Comm:
 
 class ParticleFilter:
     def __init__(self, N, map, params, seed=0, group=None, kernels=None, parity_rng=True, locality_every=0,
-                 init_particles=True, force_collectives=False):
+                 init_particles=True, force_collectives=False, use_geometric_cost=False):
         """N: maximum (global) particle count; map: TopDownMapPolar; params: FilterParams.
         group: torch.distributed process group (None = single process); particles are sharded over its ranks.
         parity_rng: propagate consumes host-generated std::mt19937 normals in the reference's order (bit-parity with
         the CPU path); False = counter-based RNG on the device (throughput mode).
         locality_every: recompute the cache-locality processing order every k updates (0 = never).
         init_particles: run initializeParticles() like the reference's constructor (False: call set_states()).
+        use_geometric_cost: let top_down_geo enter the score (getCostForRot's geometric block, state_particle.cpp:145-152,
+        commented out in the reference; single-rank filters only).
         force_collectives: take the sharded code path (scan broadcast, both all-gathers) even when the group has one
         rank — lets a one-GPU box exercise RCCL end to end."""
         self.map_ = map
         self.k = kernels if kernels is not None else map.k
         self.params_ = params
         self.comm = _Comm(group, force_collectives)
+        self.use_geometric_cost = bool(use_geometric_cost)
+        if self.use_geometric_cost and self.comm.active:
+            raise ValueError("the geometric cost term is not available on a sharded filter")
         self.max_num_particles_ = int(N)
         if self.max_num_particles_ % self.comm.world:
             raise ValueError("N must be a multiple of the number of ranks")
@@ -244,7 +250,15 @@ class ParticleFilter:
             else:   # Cartesian windows rotate with the particle: heading belongs in the key
                 wr, wc = m.window_shape()
                 k.locality_order_pose(self.st, nl, m.rows, m.cols, self.perm, theta_radius=(wr + wc) / 16.0)
-        if getattr(m, "polar", True):
+        if getattr(m, "polar", True) and self.use_geometric_cost and top_down_geo is not None:
+            geo = np.stack([np.asarray(g, np.float32).reshape(m.nb, m.nr, order="A").ravel(order="F")
+                            for g in top_down_geo[:2]])
+            geo_pk = k.pack_scan(k.to_device(geo), 2, m.nb, m.nr)
+            sums = (float(np.float32(geo[0].astype(np.float64).sum())), float(np.float32(geo[1].astype(np.float64).sum())))
+            k.score_geo(m.dev, m.geo_dev(), scan_pk, geo_pk, sums, float(res), self.fp_c, self.st, nl, self.raw_w,
+                        perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
+                        uniform_scale=self._uniform_scale)
+        elif getattr(m, "polar", True):
             k.score(m.dev, scan_pk, float(res), self.fp_c, self.st, nl, self.raw_w,
                     perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
                     uniform_scale=self._uniform_scale)

@@ -33,6 +33,7 @@ class TopDownMap:
         self.map_center_ = (0, 0)
         self.have_map_ = False
         self.dev = None
+        self.geo_constant_one_ = False   # True after updateMap(label image): the reference leaves geo_maps_ at 1 there
         if class_maps is not None:
             self._load(class_maps, class_mask)
 
@@ -59,6 +60,7 @@ class TopDownMap:
             return self.loadCompressedRasterMap(class_maps, map_center)
         self.map_center_ = (int(map_center[0]), int(map_center[1]))
         old = self.dev
+        self.geo_constant_one_ = False
         self._load(class_maps, class_mask)
         if old is not None and getattr(old, "nb", 0):
             self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
@@ -72,6 +74,7 @@ class TopDownMap:
         if not p.num_classes or not len(p.flatten_lut):
             raise ValueError("Params.num_classes and Params.flatten_lut are needed to ingest a label image")
         old = self.dev
+        self.geo_constant_one_ = True            # loadCompressedRasterMap :126-133, never recomputed by updateMap
         self.dev = self.k.make_map_from_labels(label_img, p.flatten_lut, p.num_classes, p.resolution)
         self.rows, self.cols = self.dev.rows, self.dev.cols
         maps_cm, _ = self.k.unpack_map(self.dev)
@@ -105,6 +108,20 @@ class TopDownMap:
         d, k = self.k.local_map(self.dev, False, float(center[0]), float(center[1]), float(rot), float(res), rows, cols)
         d = d.cpu().numpy().reshape(self.dev.ncls, cols, rows)
         return [d[c].T.copy() for c in range(self.dev.ncls)], k.cpu().numpy().reshape(cols, rows).T.copy()
+
+    # top_down_map.cpp:461-481
+    def getLocalGeoMap(self, center, rot, res, shape):
+        """The Cartesian window gathered from the two geometric layers geo_maps_: list of two (rows, cols) arrays."""
+        rows, cols = int(shape[0]), int(shape[1])
+        g = self.geo_dev()
+        d, _ = self.k.local_map(g, False, float(center[0]), float(center[1]), float(rot), float(res), rows, cols)
+        d = d.cpu().numpy().reshape(2, cols, rows)
+        return [d[c].T.copy() for c in range(2)]
+
+    def geo_dev(self):
+        """geo_maps_ on the device (built on first use): derived from the class maps like the static-map constructor does
+        (src/top_down_map.cpp:48-58), or the constant 1 the updateMap path leaves (:126-133)."""
+        return self.dev.geo_map(self.k, self.geo_constant_one_)
 
     # --- window (image) shape of the scan the filter scores against -------------------------------------------------
     polar = False
@@ -171,6 +188,13 @@ class TopDownMapPolar(TopDownMap):
         nb, nr = self.nb, self.nr
         d = d.cpu().numpy().reshape(self.dev.ncls, nr, nb)
         return [d[c].T.copy() for c in range(self.dev.ncls)], k.cpu().numpy().reshape(nr, nb).T.copy()
+
+    # top_down_map_polar.cpp:55-76 (and the 3-argument overload, :83-86)
+    def getLocalGeoMap(self, center, scale_or_res, res=None):   # noqa: D401
+        scale, res = (1.0, scale_or_res) if res is None else (scale_or_res, res)
+        d, _ = self.k.local_map(self.geo_dev(), True, float(center[0]), float(center[1]), float(scale), float(res))
+        d = d.cpu().numpy().reshape(2, self.nr, self.nb)
+        return [d[c].T.copy() for c in range(2)]
 
     polar = True
 
