@@ -155,7 +155,7 @@ int tdr_k_pack_scan(const float* img, int ncls, int nb, int nr, float* pk_out, v
  *      TopDownMapPolar::getLocalMap src/top_down_map_polar.cpp:21-53 + getCostForRot src/state_particle.cpp:112-155,
  *      driven by ParticleFilter::update src/particle_filter.cpp:104-105) ------------------------------------- */
 /* workspace floats needed by tdr_k_score_polar for n particles */
-size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n);
+size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total);
 /* Scores particles [0,n) of st (plane stride cap) against the packed scan at each particle's own theta; writes raw
  * weights raw_w[n] (NaN = "too much unknown", 0 = gated by force_on_map / scale range, state_particle.cpp:163-176).
  * perm (optional, int32[n]): processing order (a permutation of 0..n-1, e.g. from tdr_k_locality_order) for cache
@@ -167,10 +167,15 @@ size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n);
  * state_particle.cpp:195-206 — one pass over their window scoring all candidate rotations — which sets their theta
  * and have_init in st; they are then scored at that rotation like everyone else (all-NaN searches keep the
  * reference's 1/(FLT_MAX + regularization)).  Batches without such particles exit immediately; nothing synchronises
- * with the host.  Pass 0 when the caller knows every particle is initialised. */
+ * with the host.  Pass 0 when the caller knows every particle is initialised.
+ * n_total: the particle count of the WHOLE filter (all ranks of a sharded filter; <= 0 means n).  The kernel splits a
+ * particle's score into partial sums over groups of range rings, sized from the image shape and n_total — a small filter
+ * gets many short workgroups — so a shard scored on its own gives the same bits as the same particles inside the
+ * one-rank filter. */
 int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
-                      const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                      float uniform_scale, int init_search, float* raw_w, float* workspace, void* stream);
+                      const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
+                      const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,
+                      void* stream);
 
 /* Scoring WITH the geometric term of getCostForRot (src/state_particle.cpp:145-152: commented out in the reference, whose
  * geometric images are all-zero anyway; opt-in here): cost += (geo_i . shifted geo_cls_i).sum() * 0.01 and
@@ -179,11 +184,12 @@ int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* sc
  * Everything else as tdr_k_score_polar; the init search prices the geometric term for every candidate rotation (one
  * scoring pass per rotation over the batches that hold an un-initialised particle).
  * workspace: tdr_score_geo_workspace_floats. */
-size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n);
+size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total);
 int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc* geo_map, const float* tab, const float* scan_pk,
                           const float* geo_pk, float geo_sum0, float geo_sum1, int nb, int nr, float res,
-                          const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                          float uniform_scale, int init_search, float* raw_w, float* workspace, void* stream);
+                          const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
+                          const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,
+                          void* stream);
 
 /* Cartesian scoring (BASELINE config 4).  The reference's StateParticle only reaches the polar overloads
  * (state_particle.h:61), so there is no reference function to match; the score is DEFINED as the window of

@@ -224,6 +224,42 @@ int main(int argc, char** argv) {
     misc[6] = after[0].init_y_px - before[0].init_y_px;
     misc[7] = (float)map_->mapCenter()[0] * 1000.f + (float)map_->mapCenter()[1];
     dump(dir + "/out_misc.bin", misc, 8);
+
+    // ---- the rest of the class surface the node touches (src/top_down_render.cpp:431, 540, 591) -------------------------
+    float extra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {   // the reference's two-argument updateMap(cv::Mat, centre): the LUT comes from the map's Params
+      cv::Mat img(rows, cols, labels.data());
+      before = filter_->states();
+      filter_->updateMap(img, Eigen::Vector2i(9, -1));
+      after = filter_->states();
+      extra[0] = after[0].init_x_px - before[0].init_x_px;      // +2 against the centre (7, -3) set above
+      extra[1] = after[0].init_y_px - before[0].init_y_px;      // +2
+      cv::Mat canvas(rows, cols, labels.data());
+      filter_->visualize(canvas);                                // drawing code: a no-op without OpenCV, must not throw
+    }
+    {   // update() refuses images that do not have the shape given to samplePtsPolar instead of reading past them
+      std::vector<Eigen::ArrayXXf> wrong, geo2;
+      for (int c = 0; c < ncls; c++) wrong.push_back(Eigen::ArrayXXf(nb, nr + 1));
+      try {
+        filter_->update(wrong, geo2, res);
+      } catch (const std::invalid_argument&) {
+        extra[2] = 1.f;
+      }
+    }
+    {   // renderGeometricTopDown + getLocalGeoMap (dead at the node's call site, part of the surface)
+      std::vector<Eigen::ArrayXXf> geo_imgs;
+      for (int i = 0; i < 2; i++) geo_imgs.push_back(Eigen::ArrayXXf(nb, nr));
+      renderer_->renderGeometricTopDown(cloud_ptr, res, ang_res, geo_imgs);
+      dump(dir + "/out_geo_render.bin", geo_imgs[0].data(), (size_t)nb * nr);
+      dump(dir + "/out_geo_render1.bin", geo_imgs[1].data(), (size_t)nb * nr);
+      std::vector<Eigen::ArrayXXf> gwin;
+      for (int i = 0; i < 2; i++) gwin.push_back(Eigen::ArrayXXf(nb, nr));
+      map_->getLocalGeoMap(Eigen::Vector2f(60.f, 70.f), 1.f, res, gwin);
+      float mx = 0.f;
+      for (int k = 0; k < nb * nr; k++) mx = std::max(mx, std::max(gwin[0](k), gwin[1](k)));
+      extra[3] = mx;   // the updateMap path leaves both geometric layers at 1 (src/top_down_map.cpp:126-133)
+    }
+    dump(dir + "/out_extra.bin", extra, 8);
     delete renderer_;
     delete filter_;
     delete map_;

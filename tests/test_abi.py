@@ -64,7 +64,7 @@ def test_argument_validation_happens_before_any_launch(lib):
     fp = _lib.FilterParamsC()
     fp.num_classes = 6
     dummy = C.c_void_p(8)
-    assert lib.tdr_k_score_polar(C.byref(desc), dummy, dummy, 64, 16, C.c_float(1.0), C.byref(fp), dummy, 10, 10, None,
+    assert lib.tdr_k_score_polar(C.byref(desc), dummy, dummy, 64, 16, C.c_float(1.0), C.byref(fp), dummy, 10, 10, 0, None,
                                  C.c_float(0.0), 0, dummy, dummy, None) == -1
     assert b"4 GiB" in lib.tdr_last_error()
     assert lib.tdr_prefix_workspace_bytes(0) == 0 and lib.tdr_prefix_workspace_bytes(4097) == 64

@@ -250,3 +250,10 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     assert int(misc[4]) == oracle.adaptive_count(covs[:, :2, :2], n, n)
     # updateMap with a moved centre (:325-334)
     assert misc[5] == 7.0 and misc[6] == -3.0 and misc[7] == 6997.0
+    # the two-argument updateMap(cv::Mat, centre) of the reference, update()'s shape check, visualize() not throwing,
+    # renderGeometricTopDown against the oracle, getLocalGeoMap after the dynamic-map path (constant 1 inside the map)
+    extra = rd("out_extra.bin", np.float32)
+    assert extra[0] == 2.0 and extra[1] == 2.0 and extra[2] == 1.0 and extra[3] == 1.0
+    geo = np.stack([rd("out_geo_render.bin", np.float32), rd("out_geo_render1.bin", np.float32)])
+    pts4 = np.ascontiguousarray(sc.pts[:, :4])
+    assert np.array_equal(geo, oracle.raster_geo_polar(pts4, len(pts4), 1, cfg.res, cfg.ang_res, cfg.nb, cfg.nr))

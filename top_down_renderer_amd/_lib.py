@@ -61,12 +61,12 @@ SIGNATURES = {
     "tdr_k_raster_geo_polar": (_i, [_vp, _i, _i64, _i64, _f, _f, _i, _i, _vp, _vp, _vp]),
     "tdr_k_raster_geo_cart": (_i, [_vp, _i, _i64, _i64, _f, _i, _i, _vp, _vp]),
     "tdr_k_pack_scan": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
+    "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
-                               _vp, _f, _i, _vp, _vp, _vp]),
-    "tdr_score_geo_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
+                               _i64, _vp, _f, _i, _vp, _vp, _vp]),
+    "tdr_score_geo_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar_geo": (_i, [C.POINTER(MapDescC), C.POINTER(MapDescC), _vp, _vp, _vp, _f, _f, _i, _i, _f,
-                                   C.POINTER(FilterParamsC), _vp, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),
+                                   C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),
     "tdr_score_cart_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
     "tdr_k_score_cart": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64, _vp,
                               _vp, _vp, _vp]),

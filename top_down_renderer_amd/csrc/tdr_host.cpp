@@ -761,9 +761,9 @@ int tdr_filter_update_geo(tdr_filter* f, const float* scan_imgs, const float* ge
     TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
     perm = f->perm.p;
   }
-  TTRY(f->ws.resize(tdr_score_geo_workspace_floats(ncls, nb, nr, n)));
+  TTRY(f->ws.resize(tdr_score_geo_workspace_floats(ncls, nb, nr, n, n)));
   TTRY(tdr_k_score_polar_geo(&m->desc, &m->geo_desc, m->tab.p, f->scan_pk.p, f->geo_pk.p, (float)gs[0], (float)gs[1], nb, nr,
-                             res, &f->fp, f->st.p, f->cap, n, perm, f->uniform_scale, f->maybe_uninit ? 1 : 0,
+                             res, &f->fp, f->st.p, f->cap, n, n, perm, f->uniform_scale, f->maybe_uninit ? 1 : 0,
                              f->raw_w.p, f->ws.p, f->stream));
   if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
   TTRY(tdr_k_update_weights(f->raw_w.p, f->last_dist.p, n, f->w.p, f->info.p, f->stream));
@@ -823,8 +823,8 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
     TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
     perm = f->perm.p;
   }
-  TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n)));
-  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, perm, f->uniform_scale,
+  TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n, f->n)));
+  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, f->n, perm, f->uniform_scale,
                          f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised
   if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;

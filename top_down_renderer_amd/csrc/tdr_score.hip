@@ -1123,22 +1123,28 @@ __global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float sca
   if (k < n2) utab[k] = (tab[k] * scale) * res;  // `ang_sample_pts_*scale*res` (top_down_map_polar.cpp:28)
 }
 
-// Rings per workgroup of score_polar_kernel: as many as fit the LDS budget (the group's scan rows are staged together;
-// 32 KB keeps four workgroups per CU), at most 8, whole steps of TDR_SCORE_U.  A function of the image shape only: the
-// partition of a particle's score into partial sums must not depend on the launch.  TDR_SCORE_GROUP overrides (tuning).
-static int score_group_rings(int nb, int rf) {
+// Rings per workgroup of score_polar_kernel.  Larger groups give a ray more consecutive cells (tile reuse) and fewer,
+// longer workgroups; a small filter needs many short ones to fill 256 CUs.  So the group is sized from the image shape
+// (the group's scan rows must fit the LDS budget; 32 KB keeps four workgroups per CU; at most 8 rings; whole steps of
+// TDR_SCORE_U) and from the TOTAL particle count of the filter — n_total, the same on every rank of a sharded filter,
+// never the size of one launch or shard: the partition of a particle's score into partial sums is then the same in an
+// N-rank run as in the 1-rank run.  Aim: >= 2048 workgroups.  TDR_SCORE_GROUP overrides (tuning).
+static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
   static const int forced = [] {
     const char* e = getenv("TDR_SCORE_GROUP");
     return e ? atoi(e) : 0;
   }();
-  const int64_t ring_bytes = (int64_t)nb * rf * 4;
-  int g = forced > 0 ? forced : (int)std::min<int64_t>(8, (32 * 1024) / std::max<int64_t>(ring_bytes, 1));
-  g = std::max(1, std::min<int>(g, (int)((60 * 1024) / std::max<int64_t>(ring_bytes, 1))));
+  const int64_t ring_bytes = std::max<int64_t>((int64_t)nb * rf * 4, 1);
+  int g = (int)std::min<int64_t>(8, (32 * 1024) / ring_bytes);
+  const int64_t chunks_wanted = cdiv(2048, cdiv(std::max<int64_t>(n_total, 1), 256));
+  g = (int)std::min<int64_t>(g, std::max<int64_t>(1, nr / std::max<int64_t>(chunks_wanted, 1)));
+  if (forced > 0) g = forced;
+  g = std::max(1, std::min<int>(g, (int)((60 * 1024) / ring_bytes)));
   if (g >= TDR_SCORE_U) g -= g % TDR_SCORE_U;
   return std::max(g, 1);
 }
-extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n) {
-  const int group = score_group_rings(nb, tdr_rec_floats(ncls));
+extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
+  const int group = score_group_rings(nb, nr, tdr_rec_floats(ncls), n_total > 0 ? n_total : n);
   const int nchunks = (int)cdiv(nr, group);
   int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   int rf = tdr_rec_floats(ncls);
@@ -1267,10 +1273,11 @@ static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, 
 
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                  float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                 const int32_t* perm, float uniform_scale, int init_search, float* raw_w,
-                                 float* workspace, void* stream) {
+                                 int64_t n_total, const int32_t* perm, float uniform_scale, int init_search,
+                                 float* raw_w, float* workspace, void* stream) {
   if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score: null pointer");
+  if (n_total <= 0) n_total = n;
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score: n=%lld exceeds capacity %lld", (long long)n, (long long)cap);
   if (n == 0) return TDR_OK;
   if (nb < 1 || nr < 1) return fail(TDR_ERR_ARG, "score: bad image shape");
@@ -1288,7 +1295,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
-  a.group = score_group_rings(nb, rf);
+  a.group = score_group_rings(nb, nr, rf, n_total);
   a.nchunks = (int)cdiv(nr, a.group);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
@@ -1403,20 +1410,21 @@ __global__ void init_from_best_kernel(const float* __restrict__ best_cost, const
   st[TDR_ST_HAVE_INIT * cap + p] = 1.f;                         // :206
   res_flag[p] = none ? 2.f : 1.f;
 }
-extern "C" size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n) {
+extern "C" size_t tdr_score_geo_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   const int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
-  const int ggroup = score_group_rings(nb, 4);
-  return tdr_score_workspace_floats(ncls, nb, nr, n) + (size_t)(cdiv(nr, ggroup) * 5 * npad);
+  const int ggroup = score_group_rings(nb, nr, 4, n_total > 0 ? n_total : n);
+  return tdr_score_workspace_floats(ncls, nb, nr, n, n_total) + (size_t)(cdiv(nr, ggroup) * 5 * npad);
 }
 extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc* geo_map, const float* tab,
                                      const float* scan_pk, const float* geo_pk, float geo_sum0, float geo_sum1, int nb,
                                      int nr, float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
-                                     const int32_t* perm, float uniform_scale, int init_search, float* raw_w,
-                                     float* workspace, void* stream) {
+                                     int64_t n_total, const int32_t* perm, float uniform_scale, int init_search,
+                                     float* raw_w, float* workspace, void* stream) {
   if (!map || !map->rec || !geo_map || !geo_map->rec || !tab || !scan_pk || !geo_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score_geo: null pointer");
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_geo: n exceeds capacity");
   if (n == 0) return TDR_OK;
+  if (n_total <= 0) n_total = n;
   if (nb < 1 || nr < 1) return fail(TDR_ERR_ARG, "score_geo: bad image shape");
   if (map->ncls < 1 || map->ncls > TDR_MAX_CLASSES || fp->num_classes != map->ncls)
     return fail(TDR_ERR_ARG, "score_geo: class count mismatch");
@@ -1432,7 +1440,7 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
-  a.group = score_group_rings(nb, rf);
+  a.group = score_group_rings(nb, nr, rf, n_total);
   a.nchunks = (int)cdiv(nr, a.group);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
@@ -1443,9 +1451,9 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   float* res_flag = best_theta + a.npad;                                  // npad floats ("list" region)
   ScoreArgs g = a;   // the geometric launch: same particles, same table, the 2-layer map and scan
   g.rec = geo_map->rec; g.scan_pk = geo_pk;
-  g.group = score_group_rings(nb, 4);
+  g.group = score_group_rings(nb, nr, 4, n_total);
   g.nchunks = (int)cdiv(nr, g.group);
-  g.part = workspace + tdr_score_workspace_floats(map->ncls, nb, nr, n);
+  g.part = workspace + tdr_score_workspace_floats(map->ncls, nb, nr, n, n_total);
   FinalizeArgs f;
   f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
   f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;

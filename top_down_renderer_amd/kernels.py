@@ -195,30 +195,32 @@ class HipKernels:
         return pk
 
     # ---- filter ---------------------------------------------------------------------------------------------
-    def _workspace(self, ncls, nb, nr, n):
-        need = int(self.lib.tdr_score_workspace_floats(ncls, nb, nr, n))
+    def _workspace(self, ncls, nb, nr, n, n_total=0):
+        need = int(self.lib.tdr_score_workspace_floats(ncls, nb, nr, n, n_total))
         if self._ws is None or self._ws.numel() < need:
             self._ws = self.empty((need,))
         return self._ws
 
-    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0):
-        ws = self._workspace(m.ncls, m.nb, m.nr, n)
+    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0):
+        """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_polar; 0 = n."""
+        ws = self._workspace(m.ncls, m.nb, m.nr, n, n_total)
         cap = st.shape[1]
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
-                                         C.byref(fp), _ptr(st), cap, n, _ptr(perm), C.c_float(uniform_scale),
+                                         C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
                                          int(bool(init_search)), _ptr(raw_w), _ptr(ws), self.stream()))
 
     def score_geo(self, m, gm, scan_pk, geo_pk, geo_sums, res, fp, st, n, raw_w, perm=None, init_search=False,
                   uniform_scale=0.0):
         """Scoring with the geometric term (tdr_k_score_polar_geo): gm = m.geo_map(...), geo_pk = pack_scan of the two
         geometric images, geo_sums = their sums."""
-        need = int(self.lib.tdr_score_geo_workspace_floats(m.ncls, m.nb, m.nr, n))
+        need = int(self.lib.tdr_score_geo_workspace_floats(m.ncls, m.nb, m.nr, n, 0))
         if self._ws is None or self._ws.numel() < need:
             self._ws = self.empty((need,))
         check(self.lib.tdr_k_score_polar_geo(C.byref(m.desc), C.byref(gm.desc), _ptr(m.tab), _ptr(scan_pk), _ptr(geo_pk),
                                              C.c_float(geo_sums[0]), C.c_float(geo_sums[1]), m.nb, m.nr, C.c_float(res),
-                                             C.byref(fp), _ptr(st), st.shape[1], n, _ptr(perm), C.c_float(uniform_scale),
-                                             int(bool(init_search)), _ptr(raw_w), _ptr(self._ws), self.stream()))
+                                             C.byref(fp), _ptr(st), st.shape[1], n, 0, _ptr(perm),
+                                             C.c_float(uniform_scale), int(bool(init_search)), _ptr(raw_w),
+                                             _ptr(self._ws), self.stream()))
 
     def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None):
         need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n))

@@ -261,7 +261,7 @@ class ParticleFilter:
         elif getattr(m, "polar", True):
             k.score(m.dev, scan_pk, float(res), self.fp_c, self.st, nl, self.raw_w,
                     perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
-                    uniform_scale=self._uniform_scale)
+                    uniform_scale=self._uniform_scale, n_total=n)
         else:   # Cartesian window (BASELINE config 4; definition in include/tdr.h:tdr_k_score_cart)
             rows, cols = m.window_shape()
             k.score_cart(m.dev, scan_pk, rows, cols, float(res), self.fp_c, self.st, nl, self.raw_w,
