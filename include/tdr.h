@@ -63,7 +63,7 @@ typedef struct tdr_map_desc {
   int32_t ncls, rows, cols, rec_floats;   /* rec_floats = 4*ceil((ncls+1)/4) */
   float resolution;     /* TopDownMap::Params::resolution (top_down_map.h:61) */
   /* Optional compact form of the same records (tdr_k_compact_map; cwords == 0: absent).  A cell is cwords dwords of
-   * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 10*(k%3)), `known` in bit 31 of the last
+   * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 2 + 10*(k%3)), `known` in bit 0 of the last
    * dword; records are tiled 4 rows x 32/(4*cwords) columns per 128-byte line.  Decoding reproduces `rec` bit for bit;
    * the scoring kernels read it instead of `rec` for waves whose particles are spread over the map. */
   int32_t cwords, dict_n;

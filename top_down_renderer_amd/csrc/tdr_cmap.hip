@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict_
       const unsigned v = __float_as_uint(src[k]);
       unsigned h = cmap_hash(v);
       while (hash[h] != v) h = (h + 1) & (CMAP_HASH_SLOTS - 1);   // every map value is in the set
-      w[k / 3] |= (uint32_t)hidx[h] << (10 * (k % 3));
+      w[k / 3] |= (uint32_t)hidx[h] << (2 + 10 * (k % 3));
     }
-    if (src[rf - 1] != 0.f) w[g.cw - 1] |= 0x80000000u;            // known
+    if (src[rf - 1] != 0.f) w[g.cw - 1] |= 1u;                     // known
   }
   for (int d = 0; d < g.cw; d++) crec[t * g.cw + d] = w[d];
 }
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void cmap_unpack_kernel(const uint32_t* __rest
   const uint32_t* w = crec + (tile * (4 << g.lc) + within) * g.cw;
   float* o = rec + idx * rf;
   for (int k = 0; k < rf; k++) o[k] = 0.f;
-  for (int k = 0; k < ncls; k++) o[k] = dict[(w[k / 3] >> (10 * (k % 3))) & 1023u];
-  const float known = (w[g.cw - 1] >> 31) ? 1.f : 0.f;
+  for (int k = 0; k < ncls; k++) o[k] = dict[(w[k / 3] >> (2 + 10 * (k % 3))) & 1023u];
+  const float known = (w[g.cw - 1] & 1u) ? 1.f : 0.f;
   o[rf - 1] = known;
   if (tdr_has_kslot(ncls, rf)) o[rf - 2] = known;
 }

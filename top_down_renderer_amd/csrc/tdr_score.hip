@@ -67,10 +67,14 @@ struct CmapShape {
 // [32 ri + (ri >> 2)(128 tiles_c - 128)] + [RB ci + 96 (ci >> LC)] with RB = 4 CW record bytes — it is six integer ops.
 template <int CW, int LC>
 __device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ctiles_c, int ckconst) {
-  const int t1 = __mul24(ri >> 2, ctiles_c * 128 - 128) + ckconst;   // v_mad_i32_i24
-  const int t2 = __mul24(ci >> LC, 96) + t1;
-  const int t3 = (ri << 5) + t2;                                   // v_lshl_add_u32
-  return (unsigned)((ci << (CW == 1 ? 2 : (CW == 2 ? 3 : 4))) + t3);
+  // spelled out: the compiler would otherwise emit the two products and the two shifts as separate instructions (8)
+  int t1, t2, t3, off;
+  const int rq = ri >> 2, cq = ci >> LC, krow = ctiles_c * 128 - 128, kcol = 96;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(rq), "s"(krow), "v"(ckconst));   // one SGPR operand at most
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t2) : "v"(cq), "v"(kcol), "v"(t1));
+  asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(t3) : "v"(ri), "v"(t2));
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t3));
+  return (unsigned)off;
 }
 template <int CW>
 __device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsigned off, uint32_t (&w)[CW]) {
@@ -91,11 +95,11 @@ __device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KS
 #pragma unroll
   for (int k = 0; k < ND; k++) {
     const uint32_t ww = w[k / 3];
-    const int sh = 10 * (k % 3);
-    const uint32_t boff = sh >= 2 ? ((ww >> (sh - 2)) & 0xFFCu) : ((ww << 2) & 0xFFCu);   // index * 4
+    const int sh = 10 * (k % 3);                        // field at bits [2 + sh, 12 + sh): (ww >> sh) & 0xFFC = index * 4
+    const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
     m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
   }
-  const float kf = (float)(w[CW - 1] >> 31);
+  const float kf = (float)(w[CW - 1] & 1u);
   if (KSLOT) m[RF - 2] = kf;
   m[RF - 1] = kf;
 }
