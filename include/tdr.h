@@ -65,10 +65,16 @@ typedef struct tdr_map_desc {
   /* Optional compact form of the same records (tdr_k_compact_map; cwords == 0: absent).  A cell is cwords dwords of
    * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 2 + 10*(k%3)), `known` in bit 0 of the last
    * dword; records are tiled 4 rows x 32/(4*cwords) columns per 128-byte line.  Decoding reproduces `rec` bit for bit;
-   * the scoring kernels read it instead of `rec` for waves whose particles are spread over the map. */
+   * the scoring kernels read it instead of `rec` whenever it is present (tdr_config_compact(0) forces `rec`). */
   int32_t cwords, dict_n;
   const uint32_t* crec;
   const float* dict;    /* [TDR_CMAP_MAX_DICT], entry 0 = +0.0f */
+  /* Optional SCRATCH of tdr_map_rec16_bytes(ncls, rows, cols) bytes of device memory (NULL: none).  The 40-rotation
+   * search of tdr_k_score_polar(init_search != 0) writes the map's records there as pre-split f16 pairs with the
+   * filter's class weights folded in and gathers those (twice as fast as splitting the f32 records per sample; same
+   * bits).  Its contents mean nothing between calls; two searches that share one map on different streams need a
+   * scratch each. */
+  void* rec16;
 } tdr_map_desc;
 
 const char* tdr_last_error(void);
@@ -82,6 +88,11 @@ int tdr_rec_floats(int ncls);
  * at r + rows*c) and the unknown mask `class_mask_` (u8, 1 = unknown) into cell records (tdr_map_desc.rec).
  * rec_out must hold tdr_map_rec_floats_total(ncls, rows, cols) floats. */
 size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
+/* bytes behind tdr_map_desc.rec16; 0 when the record size has no matrix-core search (fewer than 4 / more than 7 classes) */
+size_t tdr_map_rec16_bytes(int ncls, int rows, int cols);
+/* Launches of fewer particles than this ignore rec16 (rebuilding it costs one pass over the map); default 8192.
+ * n >= 0 sets the threshold, n < 0 only returns it. */
+int64_t tdr_config_rec16_min_particles(int64_t n);
 int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
                    void* stream);
 

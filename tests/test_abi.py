@@ -32,7 +32,7 @@ def test_struct_layouts_match_reference_state():
     from top_down_renderer_amd import STATE_DTYPE, _lib
     assert STATE_DTYPE.itemsize == 28                      # state_particle.h:9-17
     assert C.sizeof(_lib.FilterParamsC) == 15 * 4 + 16 * 4
-    assert C.sizeof(_lib.MapDescC) == 8 + 4 * 4 + 4 + 2 * 4 + 4 + 2 * 8   # ptr, 4 ints, float, 2 ints, pad, 2 ptrs
+    assert C.sizeof(_lib.MapDescC) == 8 + 4 * 4 + 4 + 2 * 4 + 4 + 3 * 8   # ptr, 4 ints, float, 2 ints, pad, 3 ptrs
     assert _lib.MapDescC.crec.offset == 40 and _lib.MapDescC.dict.offset == 48
 
 

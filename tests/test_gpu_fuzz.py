@@ -136,26 +136,39 @@ def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
     m.samplePtsPolar((nb, nr), cfg.ang_res)
     f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), seed=seed, kernels=k, init_particles=False)
     f.set_states(st)
-    # score only: read the states back before the resample shuffles them
-    k.score(m.dev, m.scan_handle(scan_o), cfg.res, f.fp_c, f.st, len(st), f.raw_w, init_search=True)
-    raw_g = f.raw_w[: len(st)].cpu().numpy()
-    got = k.states_to_host(f.st, len(st), st.dtype)
-    assert np.array_equal(got["have_init"], st_o["have_init"])
-    same = got["theta"] == st_o["theta"]
-    assert same.mean() > 0.9
-    _assert_weights(raw_g[same], raw_o[same], 1e-5)
-    # Where another candidate was chosen: the weight is the oracle's AT THAT rotation (1e-5), and that rotation ties
-    # with the oracle's minimum to within the rounding of the candidates' float sums (the reference's own Eigen sums
-    # have unspecified order) — a margin on the search's choice, not on any weight.
-    diff = np.nonzero(~same)[0]
-    if len(diff):
-        st2 = st_o.copy()
-        st2["theta"][diff] = got["theta"][diff]
-        st2["have_init"] = 1
-        raw2 = oracle.compute_weights(om, tab, nb, nr, scan_o, cfg.res, fpo, st2)
-        _assert_weights(raw_g[diff], raw2[diff], 1e-5)
-        tie = np.abs(raw2[diff] - raw_o[diff]) / np.maximum(np.abs(raw_o[diff]), 1e-30)
-        assert np.nanmax(tie, initial=0.0) <= 2e-5, f"chosen rotation is not a near-tie: {np.nanmax(tie):.2e}"
+    def search_and_check():
+        # score only: read the states back before the resample shuffles them
+        f.set_states(st)
+        k.score(m.dev, m.scan_handle(scan_o), cfg.res, f.fp_c, f.st, len(st), f.raw_w, init_search=True)
+        raw_g = f.raw_w[: len(st)].cpu().numpy()
+        got = k.states_to_host(f.st, len(st), st.dtype)
+        assert np.array_equal(got["have_init"], st_o["have_init"])
+        same = got["theta"] == st_o["theta"]
+        assert same.mean() > 0.9
+        _assert_weights(raw_g[same], raw_o[same], 1e-5)
+        # Where another candidate was chosen: the weight is the oracle's AT THAT rotation (1e-5), and that rotation ties
+        # with the oracle's minimum to within the rounding of the candidates' float sums (the reference's own Eigen sums
+        # have unspecified order) — a margin on the search's choice, not on any weight.
+        diff = np.nonzero(~same)[0]
+        if len(diff):
+            st2 = st_o.copy()
+            st2["theta"][diff] = got["theta"][diff]
+            st2["have_init"] = 1
+            raw2 = oracle.compute_weights(om, tab, nb, nr, scan_o, cfg.res, fpo, st2)
+            _assert_weights(raw_g[diff], raw2[diff], 1e-5)
+            tie = np.abs(raw2[diff] - raw_o[diff]) / np.maximum(np.abs(raw_o[diff]), 1e-30)
+            assert np.nanmax(tie, initial=0.0) <= 2e-5, f"chosen rotation is not a near-tie: {np.nanmax(tie):.2e}"
+
+    search_and_check()
+    # The same search on pre-split half records (score_init_half_kernel through tdr_map_desc.rec16; by default only
+    # launches of thousands of particles take it): same f16 operands, summed four rings of one direction at a time.
+    old_min = int(k.lib.tdr_config_rec16_min_particles(-1))
+    try:
+        k.lib.tdr_config_rec16_min_particles(0)
+        search_and_check()
+    finally:
+        k.lib.tdr_config_rec16_min_particles(old_min)
+    assert (m.dev.rec16 is not None) == (4 <= ncls <= 7)
 
 
 @pytest.mark.parametrize("seed", range(max(8, N_SEEDS // 6)))

@@ -969,6 +969,24 @@ def test_c5_shard_full_size_init_search(tdr, oracle, big_polar):
     # a second update starts from initialised particles: the steady-state path on the same shard
     f.update(r.last_scan(), None, cfg.res)
     _resample_properties(f.weights(), f.resample_indices(), n)
+    # the search above gathered pre-split half records (tdr_map_desc.rec16); splitting the f32 records on the fly
+    # (score_init_mfma_kernel, what small launches and maps without the scratch use) sums the same f16 products in
+    # another order: the same rotations up to near-ties
+    assert m.dev.rec16 is not None
+    m.dev.use_rec16 = False
+    try:
+        f.set_states(st)
+        k.score(m.dev, m.scan_handle(r.last_scan()), cfg.res, f.fp_c, f.st, n, f.raw_w, init_search=True,
+                uniform_scale=f._uniform_scale)
+    finally:
+        m.dev.use_rec16 = True
+    again = k.states_to_host(f.st, n, pkg.STATE_DTYPE)
+    differ = again["theta"] != pre["theta"]
+    assert differ.mean() < 1e-3
+    raw2 = f.raw_w[:n].cpu().numpy()
+    assert np.array_equal(raw2[~differ], raw[~differ], equal_nan=True)
+    if differ.any():
+        assert np.nanmax(np.abs(raw2[differ] - raw[differ]) / np.abs(raw[differ])) <= 2e-5
 
 
 def test_c4_full_size_cartesian(tdr, oracle):

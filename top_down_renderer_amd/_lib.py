@@ -26,7 +26,8 @@ class FilterParamsC(C.Structure):
 class MapDescC(C.Structure):
     _fields_ = [("rec", C.c_void_p), ("ncls", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("rec_floats", C.c_int32), ("resolution", C.c_float),
-                ("cwords", C.c_int32), ("dict_n", C.c_int32), ("crec", C.c_void_p), ("dict", C.c_void_p)]
+                ("cwords", C.c_int32), ("dict_n", C.c_int32), ("crec", C.c_void_p), ("dict", C.c_void_p),
+                ("rec16", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/tdr.h declares
@@ -37,6 +38,8 @@ SIGNATURES = {
     "tdr_device_count": (_i, []),
     "tdr_rec_floats": (_i, [_i]),
     "tdr_map_rec_floats_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_map_rec16_bytes": (C.c_size_t, [_i, _i, _i]),
+    "tdr_config_rec16_min_particles": (_i64, [_i64]),
     "tdr_config_compact": (_i, [_i]),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),

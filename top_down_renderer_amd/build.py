@@ -21,6 +21,10 @@ OBJ_DIR = os.path.join(PKG, "_obj")
 # -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include")]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
+# per-file flags.  tdr_score.hip: matrix-core accumulators in VGPRs — with AGPR accumulators the register allocator rotates
+# the six accumulator tiles of the init-search loop through ~36 v_accvgpr moves per step (there is no register pressure:
+# 112 VGPRs at 4 waves per SIMD)
+FILE_FLAGS = {"tdr_score.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():
@@ -53,7 +57,8 @@ def build(force=False, verbose=False, extra_flags=()):
     todo = [s for s in SRC if force or extra_flags or _stale(_obj(s), [s] + HDR + [os.path.abspath(__file__)])]
 
     def compile_one(src):
-        cmd = [cc] + CFLAGS + list(extra_flags) + ["-c", "-x", "hip", src, "-o", _obj(src)]
+        cmd = [cc] + CFLAGS + FILE_FLAGS.get(os.path.basename(src), []) + list(extra_flags) + \
+              ["-c", "-x", "hip", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

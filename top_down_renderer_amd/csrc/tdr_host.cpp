@@ -73,6 +73,7 @@ struct tdr_map {
   DevBuf<uint32_t> crec;   // compact form of `rec` (tdr_k_compact_map), when the map has one
   DevBuf<float> cdict;
   DevBuf<uint8_t> cws;
+  DevBuf<uint8_t> rec16;   // scratch of the 40-rotation search (tdr_map_desc.rec16), allocated by the first large search
   std::vector<float> maps_host;  // class_maps_ (column-major), kept for getClassesAtPoint / particle initialisation
   std::vector<uint8_t> mask_host;  // class_mask_ (column-major), kept for the map cache
   tdr_map_desc desc{};
@@ -824,6 +825,15 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
     perm = f->perm.p;
   }
   TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n, f->n)));
+  if (f->maybe_uninit && !m->desc.rec16 && n >= tdr_config_rec16_min_particles(-1)) {
+    // the search over this many particles pays for pre-split half records (filters on one map share the scratch: their
+    // searches must not overlap in time)
+    const size_t b16 = tdr_map_rec16_bytes(ncls, m->desc.rows, m->desc.cols);
+    if (b16) {
+      TTRY(m->rec16.resize(b16));
+      m->desc.rec16 = m->rec16.p;
+    }
+  }
   TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, f->n, perm, f->uniform_scale,
                          f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised

@@ -1062,6 +1062,239 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
   }
 }
 
+// ---- the matrix-core search on pre-split half records ------------------------------------------------------------------
+// score_init_mfma_kernel spends most of its vector instructions turning a gathered f32 record into the f16 hi / lo
+// operands (weights, two conversions and a subtraction per pair, the zeroing of ragged lanes), per sample per particle.
+// That work depends on the cell alone.  half_records_kernel does it ONCE per cell into a 32-byte record
+//     H = {hi_0 .. hi_5, hi_6 | 0, 0}   L = {lo_0 .. lo_5, lo_6 | 0, unknown}      (f16; hi + lo = w_c * 0.01 * d_c)
+// laid out like the dense records (guarded row-major grid, guard cells = distance 0, unknown; one all-zero record behind
+// the grid for lanes without a sample), so that a lane's two 16-byte loads ARE the B fragments: H as it is, L with its
+// last half cleared.  The scan side is ONE LDS image per ring, {c_0 .. c_5, c_6 | 0, sum c}: its slot 7 meets a zero in H
+// and in the cleared L.  The normalisation  sum_samples (sum c) * known  is taken as  S - sum_samples (sum c) * unknown
+// with S the sum of the whole scan (the same for every candidate): the third product, {0 .. 0, unknown}, is issued only
+// in steps where some lane of the wave met an unknown cell — none, for a window inside the mapped area.
+// Same f16 operands as score_init_mfma_kernel, summed in another order (four rings of one direction per instruction).
+// The records carry the class weights, so they are rebuilt at every search (one pass over the map, ~0.35 ms for 4000^2
+// cells) into scratch memory the map's owner provides (tdr_map_desc.rec16).
+template <bool SEVEN>
+__global__ __launch_bounds__(256) void half_records_kernel(const float4* __restrict__ rec, int64_t ncells, int unitw,
+                                                           tdr_filter_params fp, int ncls, uint4* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const float4 m0 = rec[2 * c], m1 = rec[2 * c + 1];
+  float v[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, SEVEN ? m1.z : 0.f, 0.f};
+  if (!unitw) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) v[k] *= k < ncls ? (float)(0.01 * (double)fp.class_weights[k]) : 0.f;
+  }
+  union { tdr_h2 h[4]; uint4 u; } H, L;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]);
+    H.h[k] = hi;
+    L.h[k] = __builtin_amdgcn_cvt_pkrtz(v[2 * k] - (float)hi[0], v[2 * k + 1] - (float)hi[1]);
+  }
+  {
+    const tdr_h2 h6 = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v[6] : 0.f, 0.f);
+    H.h[3] = h6;
+    L.h[3] = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v[6] - (float)h6[0] : 0.f, 1.f - m1.w);
+  }
+  out[2 * c] = H.u;
+  out[2 * c + 1] = L.u;
+  if (c == 0) {   // the record behind the grid: nothing at all (what lanes without a sample read)
+    out[2 * ncells] = make_uint4(0u, 0u, 0u, 0u);
+    out[2 * ncells + 1] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// Work of one MFMA (k = 4 samples x 8 slots): the SAME direction i on 4 consecutive range rings — four neighbouring cells
+// along a ray for each of the wave's 16 (neighbouring) particles, so that one gather instruction touches few cache
+// lines (the L1 looks up one line per clock: with four samples a quarter ring apart the counters showed 42 line
+// accesses per instruction and the L1, not the matrix or the vector units, setting the pace).  Rings are staged four at
+// a time (one LDS image per ring).
+// AHEAD: record loads in flight — those of step t + AHEAD are issued before the matrix work of step t.  The step loop is
+// unrolled AHEAD + 1 times so that the buffers rotate by name (no register copies); the step count is padded to a multiple
+// of that, the padding steps read the zero guard record.
+template <bool USCALE, bool SEVEN, int AHEAD>
+__global__ __launch_bounds__(256) void score_init_half_kernel(InitArgs a, const uint4* __restrict__ rec16,
+                                                              int* __restrict__ inexact, int img) {
+  constexpr int R = AHEAD + 1;
+  // LDS: [4 rings][img] scan records {c0..c5, c6|0, sum c} as 8 x f16, row r and r + nb of an image hold scan row r; the
+  // img - 2 nb >= R rows behind them stay zero (padding steps; the exact count is chosen on the host so that the four
+  // images sit on the banks with the fewest conflicts, init_half_image_rows) — followed by the rings' sample-table rows,
+  // [4][nb + 2 R] float2
+  extern __shared__ uint4 ringh[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  // (an XCD-contiguous order of the workgroups and 1, 2 or 3 record loads in flight all run within 1 %: A/B on MI355X)
+  const int64_t slot = (int64_t)blockIdx.x * 64 + wave * 16 + col;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  if (!__syncthreads_or(want)) return;   // nothing to initialise in this batch of 64 particles
+  typedef float tdr_v2f __attribute__((ext_vector_type(2)));
+  const tdr_v2f offv = {cy / a.resolution, cx / a.resolution};
+  const int rowstride = (a.cols + 2) * 32;
+  const int kbase = (a.cols + 3) * 32;
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(rec16);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  const int nb = a.nb;
+  const int ntab = nb + 2 * R;    // entries per table row in LDS
+  float2* const ltab = reinterpret_cast<float2*>(ringh + 4 * img);
+  // LDS byte address of this lane's candidate row at direction 0, per tile (the lane's ring image); candidates past nrot
+  // read row 0 (their results are ignored)
+  int arow[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) {
+    const int m = 16 * T + col;
+    arow[T] = (q * img + (m < nrot ? a.shift[m] : 0)) * 16;
+  }
+  const int npad = img - 2 * nb;
+  for (int t = threadIdx.x; t < 4 * npad; t += 256) ringh[(t / npad) * img + 2 * nb + t % npad] = make_uint4(0u, 0u, 0u, 0u);
+  tdr_f4 accC[INITM_TILES], accN[INITM_TILES];   // accN: the normalisation's deficit, sum (sum c) * unknown
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) { accC[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; accN[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; }
+  unsigned ucount = 0;   // 60 per unknown cell met
+  float ssum = 0.f;      // this thread's share of S, the sum of the whole scan
+  const int rounds = (nb + R - 1) / R;   // R directions each
+  const char* const ringb = reinterpret_cast<const char*>(ringh);
+  const float2* const ltq = ltab + q * ntab;
+  const unsigned none_off = (unsigned)(a.rows + 2) * (unsigned)(a.cols + 2) * 32u;   // the all-zero record behind the grid
+
+  // byte offset of the half record of table entry tv; a lane without a sample (ring >= nr, padding step) gets `none`
+  auto rec_off = [&](float2 tv, bool in) -> unsigned {
+    tdr_v2f pv = {tv.x, tv.y};
+    if constexpr (!USCALE) pv = (pv * scale) * a.res;   // top_down_map_polar.cpp:28
+    pv = pv + offv;                                      // :29-30
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;                               // :31, see round_half_away_clamped
+    int ri, ci;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+    const unsigned off = (unsigned)(__mul24(ri, rowstride) + (ci * 32 + kbase));   // guard cells: distance 0, unknown
+    return in ? off : none_off;
+  };
+
+  for (int j0 = 0; j0 < a.nr; j0 += 4) {
+    __syncthreads();
+    bool big = false;
+    for (int t = threadIdx.x; t < 4 * nb; t += 256) {
+      const int kb = t / nb, r = t - kb * nb;
+      union { tdr_h2 h[4]; uint4 u; } pc;
+      pc.u = make_uint4(0u, 0u, 0u, 0u);
+      if (j0 + kb < a.nr) {
+        const float4* srow = scan4 + ((int64_t)(j0 + kb) * nb + r) * 2;
+        const float4 v0 = srow[0], v1 = srow[1];
+        big |= v0.x > 2048.f || v0.y > 2048.f || v0.z > 2048.f || v0.w > 2048.f || v1.x > 2048.f || v1.y > 2048.f ||
+               v1.z > 2048.f || v1.w > 2048.f;
+        pc.h[0] = __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y);
+        pc.h[1] = __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w);
+        pc.h[2] = __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y);
+        pc.h[3] = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v1.z : 0.f, v1.w);
+        ssum += v1.w;
+      }
+      ringh[kb * img + r] = pc.u;
+      ringh[kb * img + r + nb] = pc.u;
+    }
+    for (int t = threadIdx.x; t < 4 * ntab; t += 256) {
+      const int kb = t / ntab, r = t - kb * ntab;
+      ltab[t] = tab2[(int64_t)min(j0 + kb, a.nr - 1) * nb + min(r, nb - 1)];
+    }
+    if (big) atomicOr(inexact, 1);
+    __syncthreads();
+    const bool ring_ok = j0 + q < a.nr;
+    // Software pipeline: the two record loads of step t + AHEAD are issued before the matrix work of step t (the table
+    // entry comes from LDS, so the address costs no trip to memory).  The scheduling barriers keep the compiler from
+    // sinking the loads next to their use, which would expose a full memory latency in every step.
+    uint4 h[R], l[R];
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+      const char* r = recb + rec_off(ltq[k], ring_ok && k < nb);
+      h[k] = *reinterpret_cast<const uint4*>(r);
+      l[k] = *reinterpret_cast<const uint4*>(r + 16);
+    }
+    int ar[INITM_TILES];
+#pragma unroll
+    for (int T = 0; T < INITM_TILES; T++) ar[T] = arow[T];
+    int inext = AHEAD;   // direction of the loads issued next
+    for (int rd = 0; rd < rounds; rd++) {
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        {
+          const char* r = recb + rec_off(ltq[inext], ring_ok && inext < nb);
+          h[(u + AHEAD) % R] = *reinterpret_cast<const uint4*>(r);
+          l[(u + AHEAD) % R] = *reinterpret_cast<const uint4*>(r + 16);
+          inext++;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rd * R + u < nb) {   // (uniform) not a padding step
+          union { uint4 u4; tdr_h8 v8; } bh, bl, bn;
+          bh.u4 = h[u];
+          bl.u4 = l[u];
+          bn.u4 = make_uint4(0u, 0u, 0u, bl.u4.w & 0xFFFF0000u);   // {0 .. 0, unknown}
+          bl.u4.w &= 0x0000FFFFu;
+          ucount += bn.u4.w >> 24;   // f16 1.0 = 0x3C00: its high byte, 60 per unknown cell
+          union { uint4 u4; tdr_h8 v8; } ac[INITM_TILES];
+#pragma unroll
+          for (int T = 0; T < INITM_TILES; T++) ac[T].u4 = *reinterpret_cast<const uint4*>(ringb + ar[T]);
+#pragma unroll
+          for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[T].v8, bh.v8, accC[T], 0, 0, 0);
+          if (__builtin_amdgcn_ballot_w64(bn.u4.w != 0u) != 0) {   // (uniform) some lane met an unknown cell
+#pragma unroll
+            for (int T = 0; T < INITM_TILES; T++) accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[T].v8, bn.v8, accN[T], 0, 0, 0);
+          }
+#pragma unroll
+          for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[T].v8, bl.v8, accC[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int T = 0; T < INITM_TILES; T++) ar[T] += 16;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // S: every thread staged its share of every ring
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(ringh);
+  red[threadIdx.x] = ssum;
+  __syncthreads();
+  float stotal = 0.f;
+  for (int t = 0; t < 256; t++) stotal += red[t];   // same order in every lane
+  // samples this lane went through: nb directions on each of its rings j = q, q + 4, ...
+  const int my_rings = (a.nr - q + 3) / 4;
+  float known = (float)(my_rings * nb - (int)(ucount / 60u));
+  known += __shfl_xor(known, 16, 64);
+  known += __shfl_xor(known, 32, 64);
+  const bool unknown = (known / (float)a.P) < 0.5;   // state_particle.cpp:117-120
+  float best = 3.402823466e+38f;
+  int bm = -1;
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * T + 4 * q + r;
+      float cost = accC[T][r] / (stotal - accN[T][r]);  // :154
+      if (unknown) cost = __builtin_nanf("");
+      if (m < nrot && cost < best) { best = cost; bm = m; }   // :200-203 (NaN never wins)
+    }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {   // first minimum in rotation order over the particle's four lanes
+    const float oc = __shfl_xor(best, o, 64);
+    const int om = __shfl_xor(bm, o, 64);
+    const bool take = om >= 0 && (bm < 0 || oc < best || (oc == best && om < bm));
+    if (take) { best = oc; bm = om; }
+  }
+  if (q == 0 && want) {
+    a.res_theta[p] = bm >= 0 ? a.theta[bm] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bm < 0 ? 2.f : 1.f;
+  }
+}
+
 // candidate rotations of the search, generated exactly like the reference's loop (state_particle.cpp:197: float t,
 // double increment) together with their bin shifts (:124-128)
 __global__ void init_rot_kernel(int nb, int* __restrict__ shift, float* __restrict__ theta, int* __restrict__ nrot) {
@@ -1146,6 +1379,67 @@ static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
   g = std::max(1, std::min<int>(g, (int)((60 * 1024) / ring_bytes)));
   if (g >= TDR_SCORE_U) g -= g % TDR_SCORE_U;
   return std::max(g, 1);
+}
+// bytes of the scratch behind tdr_map_desc.rec16 (0: this record size has no matrix-core search)
+extern "C" size_t tdr_map_rec16_bytes(int ncls, int rows, int cols) {
+  if (ncls < 1 || rows < 1 || cols < 1 || tdr_rec_floats(ncls) != 8) return 0;
+  return (size_t)(rows + 2) * (size_t)(cols + 2) * 32 + 32;   // + the all-zero record behind the grid
+}
+// Rebuilding the half records is one pass over the whole map: it pays from a few thousand particles on (4000^2 cells:
+// 0.35 ms, the price of searching ~2000 particles with 256 x 256 windows on the fly).  Launches below the threshold
+// ignore the scratch.  TDR_INIT_HALF=0 turns the path off (A/B).
+static int64_t g_rec16_min = [] {
+  const char* e = getenv("TDR_INIT_HALF");
+  return (e && atoi(e) == 0) ? INT64_MAX : (int64_t)8192;
+}();
+extern "C" int64_t tdr_config_rec16_min_particles(int64_t n) {   // < 0: query only
+  if (n >= 0) g_rec16_min = n;
+  return g_rec16_min;
+}
+// Rows per LDS scan image of score_init_half_kernel: 2 nb + R + c with the c in [0, 16) that gives the ds_read_b128 of
+// the candidates' rows the fewest bank conflicts.  A lane (candidate m, ring q) reads row q * img + i + shift_m; the LDS
+// serves the instruction in four groups of 16 lanes (MI355X_MICROARCH.md, LDS) and two lanes of a group collide when
+// their rows differ by a multiple of 16.  The shifts are multiples of nb / 40, so only a few residues occur and the
+// image stride decides how the rings' residues interleave (nb = 256: 3.7 LDS cycles per read at the worst stride, 2.0 at
+// the best).
+static int init_half_image_rows(int nb, int R) {
+  int sh[48] = {0};
+  int k = 0;
+  for (float t = 0; t < 2 * M_PI && k < 48; t += 2 * M_PI / 40) {   // as init_rot_kernel / rot_shift_dev
+    int s = (int)round((double)(t * (float)nb / 2) / M_PI);
+    s %= nb;
+    if (s < 0) s += nb;
+    sh[k++] = s;
+  }
+  static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                 {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                 {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                 {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  int best_c = 0;
+  long best = -1;
+  for (int c = 0; c < 16; c++) {
+    const int img = 2 * nb + R + c;
+    long tot = 0;
+    for (int T = 0; T < 3; T++)
+      for (int i = 0; i < 16; i++)   // the pattern repeats with i mod 16
+        for (int g = 0; g < 4; g++) {
+          int rows[16], worst = 1;
+          for (int l = 0; l < 16; l++) rows[l] = (grp[g][l] >> 4) * img + i + sh[16 * T + (grp[g][l] & 15)];
+          for (int x = 0; x < 16; x++) {
+            int distinct = 1;   // distinct rows on the bank quad of rows[x]
+            for (int y = 0; y < x; y++)
+              if ((rows[y] - rows[x]) % 16 == 0 && rows[y] != rows[x]) {
+                bool seen = false;
+                for (int z = 0; z < y; z++) seen |= rows[z] == rows[y];
+                if (!seen) distinct++;
+              }
+            if (distinct > worst) worst = distinct;
+          }
+          tot += worst;
+        }
+    if (best < 0 || tot < best) { best = tot; best_c = c; }
+  }
+  return 2 * nb + R + best_c;
 }
 extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   const int group = score_group_rings(nb, nr, tdr_rec_floats(ncls), n_total > 0 ? n_total : n);
@@ -1335,6 +1629,32 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
       for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
       unitw &= fp->class_weights[0] > 0.f;
       const int variant = (us ? 4 : 0) | (unitw ? 2 : 0) | (ks ? 0 : 1);
+      if (map->rec16 && n >= g_rec16_min && (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024) {
+        // pre-split half records (weights folded in) into the map owner's scratch, then the search that reads them
+        const int64_t ncells = (int64_t)(map->rows + 2) * (map->cols + 2);
+        const dim3 hgrid((unsigned)cdiv(ncells, 256)), hblock(256);
+        const float4* rec4 = reinterpret_cast<const float4*>(map->rec);
+        uint4* r16 = reinterpret_cast<uint4*>(map->rec16);
+        if (ks) hipLaunchKernelGGL((half_records_kernel<false>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
+        else hipLaunchKernelGGL((half_records_kernel<true>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
+        LAUNCH_CHECK("half_records");
+        static const int ahead = [] {
+          const char* e = getenv("TDR_INIT_AHEAD");   // tuning: record loads kept in flight per wave (1..3)
+          const int v = e ? atoi(e) : 1;
+          return v < 1 ? 1 : (v > 3 ? 3 : v);
+        }();
+        const int R = ahead + 1;
+        const int img = init_half_image_rows(nb, R);
+        const size_t ldsh = (size_t)4 * img * 16 + (size_t)4 * (nb + 2 * R) * 8;
+        const uint4* r16c = r16;
+#define TDR_LAUNCH_HALF(AH)                                                                                              \
+  if (us && ks) hipLaunchKernelGGL((score_init_half_kernel<true, false, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);   \
+  else if (us) hipLaunchKernelGGL((score_init_half_kernel<true, true, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);     \
+  else if (ks) hipLaunchKernelGGL((score_init_half_kernel<false, false, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);   \
+  else hipLaunchKernelGGL((score_init_half_kernel<false, true, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);
+        if (ahead == 1) { TDR_LAUNCH_HALF(1) } else if (ahead == 2) { TDR_LAUNCH_HALF(2) } else { TDR_LAUNCH_HALF(3) }
+#undef TDR_LAUNCH_HALF
+      } else
       switch (variant) {
 #define TDR_LAUNCH_MFMA(US, UW, SV) \
   hipLaunchKernelGGL((score_init_mfma_kernel<US, UW, SV>), grid, dim3(256), lds16, s, ia, d_inexact); break;

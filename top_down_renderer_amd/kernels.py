@@ -30,6 +30,20 @@ class DeviceMap:
         self.nb = self.nr = 0
         self.ang_res = 0.0
         self.crec = self.dict = None   # compact form of the records (tdr_k_compact_map), when the map has one
+        self.rec16 = None              # scratch of the 40-rotation search (tdr_map_desc.rec16), allocated on first use
+        self.use_rec16 = True          # False: the search splits the f32 records on the fly (A/B, tests)
+
+    def init_scratch(self, kernels):
+        """Gives the descriptor the scratch the matrix-core init search writes its pre-split f16 records to."""
+        if not self.use_rec16:
+            self.desc.rec16 = None
+            return
+        if self.rec16 is None:
+            nbytes = int(kernels.lib.tdr_map_rec16_bytes(self.ncls, self.rows, self.cols))
+            if nbytes == 0:
+                return
+            self.rec16 = kernels.empty((nbytes,), torch.uint8)
+        self.desc.rec16 = self.rec16.data_ptr()
 
     def geo_map(self, kernels, constant_one=False):
         """geo_maps_[0..1] as a 2-class DeviceMap (tdr_k_geo_map_from_map): distance to the nearest cell without / with
@@ -205,6 +219,8 @@ class HipKernels:
         """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_polar; 0 = n."""
         ws = self._workspace(m.ncls, m.nb, m.nr, n, n_total)
         cap = st.shape[1]
+        if init_search and n >= int(self.lib.tdr_config_rec16_min_particles(-1)):
+            m.init_scratch(self)
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
                                          C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
                                          int(bool(init_search)), _ptr(raw_w), _ptr(ws), self.stream()))
