@@ -480,16 +480,30 @@ __device__ __forceinline__ PfxPair pfx_element_pair(unsigned f, bool tie) {
 }
 // inclusive scan of per-thread pairs over a workgroup of NT threads; returns the EXCLUSIVE pair of this thread and the
 // workgroup total.  `sh` holds one slot per wave; safe to call repeatedly (leading barrier).
+// Inclusive wave scan of pairs with data-parallel-primitive moves instead of LDS permutes (each __shfl_up is a
+// ds_bpermute: ~100 clocks of latency, twelve of them in a row per scan).  Lanes without a source lane receive the
+// identity pair {0, 0} (compose({0,0}, v) == v), so no lane predicate is needed.  Steps: shift right by 1, 2, 4, 8
+// within rows of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ PfxPair pfx_pair_dpp(PfxPair v) {
+  PfxPair t;
+  t.a0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.a0, CTRL, ROW_MASK, 0xF, false);
+  t.a1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.a1, CTRL, ROW_MASK, 0xF, false);
+  return t;
+}
+__device__ __forceinline__ PfxPair pfx_pair_wave_scan(PfxPair v) {
+  v = pfx_compose(pfx_pair_dpp<0x111, 0xF>(v), v);   // row_shr:1
+  v = pfx_compose(pfx_pair_dpp<0x112, 0xF>(v), v);   // row_shr:2
+  v = pfx_compose(pfx_pair_dpp<0x114, 0xF>(v), v);   // row_shr:4
+  v = pfx_compose(pfx_pair_dpp<0x118, 0xF>(v), v);   // row_shr:8
+  v = pfx_compose(pfx_pair_dpp<0x142, 0xA>(v), v);   // row_bcast:15 into rows 1 and 3
+  v = pfx_compose(pfx_pair_dpp<0x143, 0xC>(v), v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
 template <int NT>
 __device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh, PfxPair& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    PfxPair t;
-    t.a0 = __shfl_up(v.a0, o, 64);
-    t.a1 = __shfl_up(v.a1, o, 64);
-    if (lane >= o) v = pfx_compose(t, v);
-  }
+  v = pfx_pair_wave_scan(v);
   pfx_sync();
   if (lane == 63) sh[wave] = v;
   pfx_sync();
@@ -501,10 +515,8 @@ __device__ __forceinline__ PfxPair pfx_pair_scan(PfxPair v, PfxPair* sh, PfxPair
     tot = pfx_compose(tot, x);
   }
   total = tot;
-  PfxPair ex;
-  ex.a0 = __shfl_up(v.a0, 1, 64);
-  ex.a1 = __shfl_up(v.a1, 1, 64);
-  if (lane == 0) { ex.a0 = 0u; ex.a1 = 0u; }
+  // exclusive: the inclusive value of the lane before (wave_shr:1; lane 0 gets the identity)
+  PfxPair ex = pfx_pair_dpp<0x138, 0xF>(v);
   return pfx_compose(pre, ex);
 }
 template <int K>
@@ -904,6 +916,26 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_summary_kernel(ChainSrc s,
   }
 }
 // one chunk on the spot: like pfx_walk_chunk, without outputs and with the real additions done in double
+#ifdef TDR_UW_TIMELINE   // diagnostic build: 100 MHz time stamps at the phase boundaries of uw_small_kernel
+__device__ unsigned long long g_uw_tl[16];
+extern "C" int tdr_debug_read_uw_timeline(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uw_tl), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#define UW_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) g_uw_tl[k] = wall_clock64(); } while (0)
+#else
+#define UW_STAMP(k) do { } while (0)
+#endif
+// FROM_LDS: the raw weights sit in the kernel's dynamic LDS array (uw_small_kernel) instead of global memory
+__device__ __forceinline__ int uws_idx(int e) { return e + (e >> 5); }   // one pad word per 32: bank spread for strided runs
+__device__ __forceinline__ double uws_addend(int kind, int e, float mean) {
+  extern __shared__ float uws_lraw[];
+  const float v = uws_lraw[uws_idx(e)];
+  if (kind == 0) return (v != v) ? 0.0 : (double)v;                         // :111-115
+  if (v != v || !(v < mean)) return 0.0;                                    // :120
+  const double d = (double)(v - mean);                                      // float subtraction, then pow(double, 2)
+  return d * d;
+}
+template <bool FROM_LDS = false>
 __device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo, int cnt, float mean, float& r,
                                                  int pos_start) {
   __shared__ PfxPair shp[PFXW_THREADS / 64];
@@ -912,14 +944,23 @@ __device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo
   __shared__ double s_xstop;
   const int tid = threadIdx.x, t0 = tid * CHAIN_K;
   double xv[CHAIN_K];
-  chain_load(s, lo, cnt, mean, xv);
+  if constexpr (FROM_LDS) {
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) xv[k] = (t0 + k < cnt) ? uws_addend(s.kind, (int)lo + t0 + k, mean) : 0.0;
+  } else {
+    chain_load(s, lo, cnt, mean, xv);
+  }
   int pos = pos_start;
   while (pos < cnt) {
+#ifdef TDR_UW_TIMELINE
+    if (FROM_LDS && tid == 0) g_uw_tl[10 + s.kind]++;
+#endif
     const unsigned rb = __float_as_uint(r);
     const unsigned re = rb >> 23;   // sign included
     pfx_sync();
     if (tid == 0) { s_bad = cnt; s_cross = cnt; s_nz = cnt; s_xstop = 0.0; s_state = 0u; }
     pfx_sync();
+
     if (!(re >= PFXM_RE_MIN && re <= PFXM_RE_MAX)) {
       // zero / tiny / huge / inf / NaN running sum: zero addends change nothing, the next other one is really added
       int first = cnt;
@@ -953,6 +994,7 @@ __device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo
       tiebits |= tie ? (1u << k) : 0u;
       mine = pfx_compose(mine, pfx_element_pair(f[k], tie));
     }
+
     PfxPair total;
     const PfxPair ex = pfx_pair_scan<PFXW_THREADS>(mine, shp, total);
     unsigned st[CHAIN_K];
@@ -977,6 +1019,7 @@ __device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo
       if (li == stop) s_xstop = xv[k];
     }
     pfx_sync();
+
     if (stop > pos) r = __uint_as_float((re << 23) | (s_state & 0x7FFFFFu));
     if (stop < cnt) {
       r = (float)((double)r + s_xstop);   // one real addition, in the reference's types
@@ -1046,113 +1089,166 @@ int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n
 
 // ---- ParticleFilter::update's statistics for small particle sets, in ONE launch ------------------------------------
 // src/particle_filter.cpp:107-147 for n <= TDR_UW_SMALL_MAX_N — the reference's own operating point (20 000 particles,
-// src/top_down_render.cpp:53): one workgroup evaluates both serial float chains exactly (head one by one, then chunk by
-// chunk with chain_walk_chunk; no prediction pass, there are at most 8 chunks) and runs the fill / normalise / argmax
-// passes behind them.  Same results as the multi-workgroup path of tdr_filter.hip, bit for bit in `sum`, `mean`,
-// `bottom_stddev` (tests/test_gpu_parity.py::test_update_weights_serial_chains_bit_exact).
-__device__ __forceinline__ float chain_total_block(const ChainSrc& s, int64_t n, float mean) {
+// src/top_down_render.cpp:53).  One workgroup; the raw weights are staged into LDS once (n floats, at most 128 KB) and
+// every pass — the two exact serial chains, the counts, fill / normalise / argmax — runs out of LDS; the weights are
+// written to memory once, at the end.  Same results as the multi-workgroup path of tdr_filter.hip, bit for bit in
+// `sum`, `mean`, `bottom_stddev` (tests/test_gpu_parity.py::test_update_weights_serial_chains_bit_exact).
+//
+// The chains: head one by one, then chunk by chunk with chain_walk_chunk (no prediction pass: at most 8 chunks).  (One
+// stretch over the whole array instead of chunks re-classifies every remaining addend at each binade crossing: 80 us
+// against 48 at 20 000 weights.)
+__device__ __forceinline__ float uws_chain_total(int kind, int n, float mean) {
   __shared__ double head[CHAIN_HEAD];
   __shared__ float s_head_r;
-  const int hn = (int)min((long long)CHAIN_HEAD, (long long)n);
+  const int hn = min(CHAIN_HEAD, n);
   pfx_sync();
-  for (int t = threadIdx.x; t < hn; t += PFXW_THREADS) head[t] = chain_addend(s, t, mean);
+  for (int t = threadIdx.x; t < hn; t += PFXW_THREADS) head[t] = uws_addend(kind, t, mean);
   pfx_sync();
   if (threadIdx.x == 0) {
     float run = 0.f;
-    for (int t = 0; t < hn; t++) run = (float)((double)run + head[t]);
+    if (kind == 0) {
+      // float + float: (float)((double)a + (double)b) == a + b for every pair of floats (53 >= 2 * 24 + 2 bits: the
+      // double sum rounds to the same float), and a float add is a third of the dependent latency
+      for (int t = 0; t < hn; t++) run += (float)head[t];
+    } else {
+      for (int t = 0; t < hn; t++) run = (float)((double)run + head[t]);
+    }
     s_head_r = run;
   }
   pfx_sync();
+  UW_STAMP(kind ? 5 : 2);
   float r = s_head_r;   // workgroup-uniform
-  const int nch = (int)((n + PFXM_CHUNK - 1) / PFXM_CHUNK);
+  const ChainSrc s{nullptr, nullptr, kind};
+  const int nch = (n + PFXM_CHUNK - 1) / PFXM_CHUNK;
   for (int c = 0; c < nch; c++) {
-    const long long lo = (long long)c * PFXM_CHUNK;
-    const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
+    const int lo = c * PFXM_CHUNK;
+    const int cnt = min((int)PFXM_CHUNK, n - lo);
     if (c == 0 && hn >= cnt) continue;
-    chain_walk_chunk(s, lo, cnt, mean, r, c == 0 ? hn : 0);
+    chain_walk_chunk<true>(s, lo, cnt, mean, r, c == 0 ? hn : 0);
   }
   return r;
 }
 __device__ __forceinline__ double uws_sum_d(double v, double* sh) {   // block sum, fixed order: a pure function of the inputs
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  __syncthreads();
+  pfx_sync();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
+  pfx_sync();
   double t = 0;
   for (int w = 0; w < PFXW_THREADS / 64; w++) t += sh[w];
   return t;
 }
 __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __restrict__ raw,
-                                                                const float* __restrict__ last_dist, int64_t n,
+                                                                const float* __restrict__ last_dist, int n,
                                                                 float* __restrict__ w, float* __restrict__ info) {
+  extern __shared__ float uws_lraw[];   // [uws_idx(n)]: the raw weights, later the weights being normalised
+  float* const lraw = uws_lraw;
   __shared__ double shd[PFXW_THREADS / 64];
   __shared__ float sh_best[PFXW_THREADS / 64];
-  __shared__ long long sh_besti[PFXW_THREADS / 64];
+  __shared__ int sh_besti[PFXW_THREADS / 64];
   const int tid = threadIdx.x;
   constexpr int nt = PFXW_THREADS;
-  // :108-116  sum (serial float chain, exact) and the count of valid weights
+#ifdef TDR_UW_TIMELINE
+  if (tid == 0) { for (int k = 10; k < 16; k++) g_uw_tl[k] = 0; }
+#endif
+  UW_STAMP(0);
+  // stage (four loads in flight per thread), count the valid weights on the way (:108-116)
   double cnt = 0;
-  for (int64_t i = tid; i < n; i += nt) cnt += (raw[i] == raw[i]) ? 1.0 : 0.0;
-  const long long num_valid = (long long)uws_sum_d(cnt, shd);
-  ChainSrc s0{raw, nullptr, 0};
-  const float sum = chain_total_block(s0, n, 0.f);
+  {
+    int i = tid;
+    for (; i + 3 * nt < n; i += 4 * nt) {
+      const float v0 = raw[i], v1 = raw[i + nt], v2 = raw[i + 2 * nt], v3 = raw[i + 3 * nt];
+      lraw[uws_idx(i)] = v0; lraw[uws_idx(i + nt)] = v1; lraw[uws_idx(i + 2 * nt)] = v2; lraw[uws_idx(i + 3 * nt)] = v3;
+      cnt += (v0 == v0 ? 1.0 : 0.0) + (v1 == v1 ? 1.0 : 0.0) + (v2 == v2 ? 1.0 : 0.0) + (v3 == v3 ? 1.0 : 0.0);
+    }
+    for (; i < n; i += nt) {
+      const float v = raw[i];
+      lraw[uws_idx(i)] = v;
+      cnt += (v == v) ? 1.0 : 0.0;
+    }
+  }
+  const long long num_valid = (long long)uws_sum_d(cnt, shd);   // (its barriers also publish the staged weights)
+  UW_STAMP(1);
+  const float sum = uws_chain_total(0, n, 0.f);   // serial float chain, exact
+  UW_STAMP(3);
   const float mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
   // :118-126  bottom_stddev (serial float chain with double addends, exact) and the count below the mean
   double cu = 0;
-  for (int64_t i = tid; i < n; i += nt) {
-    const float v = raw[i];
+  for (int i = tid; i < n; i += nt) {
+    const float v = lraw[uws_idx(i)];
     cu += (v == v && v < mean) ? 1.0 : 0.0;
   }
   const long long num_under = (long long)uws_sum_d(cu, shd);
-  ChainSrc s1{raw, nullptr, 1};
-  const float bsum = chain_total_block(s1, n, mean);
+  UW_STAMP(4);
+  const float bsum = uws_chain_total(1, n, mean);
+  UW_STAMP(6);
   const float bottom = sqrtf(bsum / (float)num_under);
   const bool fallback = (sum == 0.f || num_under < 1);  // :129
   const float fill = mean - bottom;                      // :133
+  pfx_sync();                                            // every thread is done reading the raw weights
   double s1a = 0;
-  for (int64_t i = tid; i < n; i += nt) {
-    float v = raw[i];
+  for (int i = tid; i < n; i += nt) {
+    float v = lraw[uws_idx(i)];
     v = fallback ? 1.f : (v != v ? fill : v);
-    w[i] = v;
+    lraw[uws_idx(i)] = v;
     s1a += (double)v;
   }
   const float fs1 = (float)uws_sum_d(s1a, shd);
+  UW_STAMP(7);
   const float fn = (float)n;
   double s2 = 0;
-  for (int64_t i = tid; i < n; i += nt) {  // :135, :138-141
-    float v = w[i] / fs1;
-    const float d = fminf(last_dist[i] * 5.f, 1.f);
-    v = d * v + (1.f - d) / fn;
-    w[i] = v;
-    s2 += (double)v;
+  {
+    auto one = [&](int i, float ld) {   // :135, :138-141
+      float v = lraw[uws_idx(i)] / fs1;
+      const float d = fminf(ld * 5.f, 1.f);
+      v = d * v + (1.f - d) / fn;
+      lraw[uws_idx(i)] = v;
+      s2 += (double)v;
+    };
+    int i = tid;
+    for (; i + 3 * nt < n; i += 4 * nt) {
+      const float l0 = last_dist[i], l1 = last_dist[i + nt], l2 = last_dist[i + 2 * nt], l3 = last_dist[i + 3 * nt];
+      one(i, l0); one(i + nt, l1); one(i + 2 * nt, l2); one(i + 3 * nt, l3);   // same order as one by one
+    }
+    for (; i < n; i += nt) one(i, last_dist[i]);
   }
   const float fs2 = (float)uws_sum_d(s2, shd);
+  UW_STAMP(8);
   float best = -INFINITY;
-  long long besti = 0x7fffffffffffffffll;
-  for (int64_t i = tid; i < n; i += nt) {  // :142, :145-147 (first maximum)
-    const float v = w[i] / fs2;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < n; i += nt) {  // :142, :145-147 (first maximum)
+    const float v = lraw[uws_idx(i)] / fs2;
     w[i] = v;
     if (v > best || (v == best && i < besti)) { best = v; besti = i; }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_down(best, o, 64);
-    const long long oi = __shfl_down(besti, o, 64);
+    const int oi = __shfl_down(besti, o, 64);
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
-  __syncthreads();
+  pfx_sync();
   if ((tid & 63) == 0) { sh_best[tid >> 6] = best; sh_besti[tid >> 6] = besti; }
-  __syncthreads();
+  pfx_sync();
   if (tid == 0) {
     for (int k = 1; k < nt / 64; k++)
       if (sh_best[k] > best || (sh_best[k] == best && sh_besti[k] < besti)) { best = sh_best[k]; besti = sh_besti[k]; }
-    if (besti == 0x7fffffffffffffffll) besti = 0;
-    info[0] = __int_as_float((int)besti);
+    if (besti == 0x7fffffff) besti = 0;
+    info[0] = __int_as_float(besti);
     info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = fallback ? 1.f : 0.f;
     info[5] = (float)num_valid; info[6] = (float)num_under; info[7] = 0.f;
   }
+  UW_STAMP(9);
 }
 int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st) {
-  hipLaunchKernelGGL(uw_small_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, raw, last_dist, n, w, info);
+  if (n < 1 || n > 32768) return fail(TDR_ERR_ARG, "uw_small: n out of range");
+  const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(uw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess)
+      return fail(TDR_ERR_HIP, "uw_small: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(uw_small_kernel, dim3(1), dim3(PFXW_THREADS), lds, st, raw, last_dist, (int)n, w, info);
   return TDR_OK;
 }
 
