@@ -179,6 +179,7 @@ static int map_make_geo(tdr_map* m, bool constant_one) {
 // the compact records of a freshly packed map (desc.rec etc. already set)
 static int map_compact(tdr_map* m) {
   m->desc.crec = nullptr; m->desc.dict = nullptr; m->desc.dict_n = 0; m->desc.cwords = 0;
+  m->desc.rec16 = nullptr;   // sized for the previous grid: the next large init search allocates it again
   const size_t nw = tdr_cmap_words_total(m->desc.ncls, m->desc.rows, m->desc.cols);
   if (nw == 0) return TDR_OK;
   TTRY(m->crec.resize(nw));
