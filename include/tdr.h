@@ -206,11 +206,13 @@ int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc* geo_map, 
  * (state_particle.h:61), so there is no reference function to match; the score is DEFINED as the window of
  * TopDownMap::getLocalMap(center, rot = theta, res = res*scale) (src/top_down_map.cpp:429-459) scored by
  * getCostForRot with shift 0 (src/state_particle.cpp:132-143), weight = 1/(cost + regularization), no gates.
- * scan_pk: packed [cols][rows][rf] Cartesian render (tdr_k_raster_cart / tdr_k_pack_scan with nb=rows, nr=cols). */
-size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n);
+ * scan_pk: packed [cols][rows][rf] Cartesian render (tdr_k_raster_cart / tdr_k_pack_scan with nb=rows, nr=cols).
+ * n_total: particle count of the whole (possibly sharded) filter, as in tdr_k_score_polar (0 = n): it fixes the split
+ * of the window into partial sums, so that a shard scores its particles to the same bits as the one-rank filter. */
+size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n, int64_t n_total);
 int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
-                     const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                     float* raw_w, float* workspace, void* stream);
+                     const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
+                     const int32_t* perm, float* raw_w, float* workspace, void* stream);
 
 /* ---- StateParticle::propagate for all particles (src/state_particle.cpp:57-78 via particle_filter.cpp:86-92) -- */
 /* z4: optional DEVICE array [n][4] of standard normals {theta, dx, dy, scale} in the reference's consumption

@@ -33,30 +33,41 @@ def _run(group, out_path, six_classes, force_collectives=False):
     from top_down_renderer_amd import synth
     from top_down_renderer_amd.kernels import HipKernels
     k = HipKernels()
+    cart = six_classes == "cart"
     # six classes: records of 8 floats, the init search runs on the matrix cores (16 particles per MFMA tile)
-    cfg = synth.Config("dist6", 20000, 6, 64, 48, 700, N, seed=77) if six_classes else synth.CONFIGS["c1"]
+    if cart:     # BASELINE config 4's path: Cartesian render + Cartesian window score (definition in include/tdr.h)
+        cfg = synth.Config("distc", 20000, 6, 40, 64, 700, N, polar=False, seed=79)
+    else:
+        cfg = synth.Config("dist6", 20000, 6, 64, 48, 700, N, seed=77) if six_classes else synth.CONFIGS["c1"]
     sc = synth.make_scene(cfg, n_particles=N)
     st = sc.states.copy()
-    st["have_init"][100:140] = 0            # init search on the first shard
-    st["have_init"][4000:4040] = 0          # ... and on the second
-    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
-    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    if not cart:
+        st["have_init"][100:140] = 0            # init search on the first shard
+        st["have_init"][4000:4040] = 0          # ... and on the second
+    if cart:
+        m = pkg.TopDownMap(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+        m.setWindow(cfg.nb, cfg.nr)
+    else:
+        m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+        m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
     f = pkg.ParticleFilter(N, m, pkg.FilterParams(fixed_scale=1.0), seed=7, group=group, kernels=k,
                            parity_rng=False, locality_every=1, init_particles=False,
                            force_collectives=force_collectives)
     assert f.comm.active == (group is not None)
     f.set_states(st)
-    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r = (pkg.ScanRenderer if cart else pkg.ScanRendererPolar)(sc.lut, kernels=k)
     r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
     log = {}
     n_targets = [None, 4096, None]
+    render = (lambda pts: r.renderSemanticTopDown(pts, cfg.res)) if cart else \
+        (lambda pts: r.renderSemanticTopDown(pts, cfg.res, cfg.ang_res))
     for step in range(STEPS):
         f.propagate((1.0, 0.2), 0.02)
         if f.comm.rank == 0:
-            r.renderSemanticTopDown(sc.pts, cfg.res, cfg.ang_res)
+            render(sc.pts)
             scan = r.last_scan()
         else:   # receives the render through the broadcast inside update()
-            r.renderSemanticTopDown(sc.pts[:1], cfg.res, cfg.ang_res)
+            render(sc.pts[:1])
             scan = r.last_scan()
         f.update(scan, None, cfg.res, n_target=n_targets[step])
         log[f"raw{step}"] = f.raw_weights()
@@ -74,6 +85,13 @@ def _run(group, out_path, six_classes, force_collectives=False):
 
 def _worker(rank, world, port, tmp, six_classes):
     import torch.distributed as dist
+    if six_classes == "cart":
+        # few window chunks, so that their number depends on the particle count: a shard must still split the window
+        # like the whole filter does (tdr_k_score_cart's n_total).  Read once per process by the library.
+        os.environ["TDR_SCORE_WAVES"] = "256"
+    if world == 1:
+        _run(None, os.path.join(tmp, "single.npz"), six_classes)
+        return
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,11 +101,11 @@ def _worker(rank, world, port, tmp, six_classes):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("six_classes", [False, True])
+@pytest.mark.parametrize("six_classes", [False, True, "cart"])
 def test_two_gpu_ranks_equal_one_rank_bit_for_bit(six_classes):
     import torch.multiprocessing as mp
     tmp = tempfile.mkdtemp(prefix="tdr_dist_gpu_")
-    _run(None, os.path.join(tmp, "single.npz"), six_classes)
+    mp.spawn(_worker, args=(1, _free_port(), tmp, six_classes), nprocs=1, join=True)   # the one-rank filter
     mp.spawn(_worker, args=(2, _free_port(), tmp, six_classes), nprocs=2, join=True)
     load = lambda n: np.load(os.path.join(tmp, n), allow_pickle=False)  # noqa: E731
     single, r0, r1 = load("single.npz"), load("rank0.npz"), load("rank1.npz")

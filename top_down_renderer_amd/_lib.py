@@ -71,8 +71,8 @@ SIGNATURES = {
     "tdr_k_score_polar_geo": (_i, [C.POINTER(MapDescC), C.POINTER(MapDescC), _vp, _vp, _vp, _f, _f, _i, _i, _f,
                                    C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),
     "tdr_score_cart_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
-    "tdr_k_score_cart": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64, _vp,
-                              _vp, _vp, _vp]),
+    "tdr_k_score_cart": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64,
+                              _vp, _vp, _vp, _vp]),
     "tdr_k_propagate": (_i, [_vp, _i64, _i64, _vp, _f, _f, _f, _i, _f, _f, _vp, _u64, _u64, _i64, _vp]),
     "tdr_rng_create": (_vp, [_u32]),
     "tdr_rng_destroy": (None, [_vp]),

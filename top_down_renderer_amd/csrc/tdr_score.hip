@@ -391,6 +391,8 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   // cos(rot), sin(rot) of top_down_map.cpp:381-385 = the host libm's cosf / sinf, bit for bit (tdr_sincosf.h)
   const float c = tdr_libm::cosf_v(theta, a.libm_fma), s = tdr_libm::sinf_v(theta, a.libm_fma);
   const float ns = -s;
+  typedef float tdr_v2f __attribute__((ext_vector_type(2)));
+  const tdr_v2f cs = {c, s}, offv = {off0, off1};
   const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
   const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
   const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
@@ -409,77 +411,83 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   typedef const float __attribute__((address_space(4))) * tdr_const_f;
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
 
-  float acc2[RF];
+  float acc[RF];
 #pragma unroll
-  for (int k = 0; k < RF; k++) acc2[k] = 0.f;
-  float known2 = 0.f;
-
-  for (int j = j0; j < j1; j++) {
-    const float xj = linspaced_dev(j, c1, lo_c, hi_c, step_c);
-    const float A = ns * xj, B = c * xj;  // rotm * pts (:383-385): q0 = c*y + (-s)*x, q1 = s*y + c*x
-    auto cell_offset = [&](int i) -> unsigned {
-      const float yi = linspaced_dev(i, r1, lo_r, hi_r, step_r);
-      float p0 = c * yi + A;
-      float p1 = s * yi + B;
-      p0 = p0 + off0;
-      p1 = p1 + off1;
-      p0 = __builtin_amdgcn_fmed3f(p0, -1.f, rmaxf);
-      p1 = __builtin_amdgcn_fmed3f(p1, -1.f, cmaxf);
-      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);  // :437
-      const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
-      if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
-      else return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
-    };
-    // the record of one sample as RF operands: dense records as they are, compact ones decoded (bit-identical)
-    auto fetch = [&](unsigned off, float (&m)[RF]) {
-      if constexpr (COMPACT) {
-        uint32_t w[CW];
-        cmap_load<CW>(crecb, off, w);
-        cmap_decode<RF, KSLOT>(w, ldict, m);
-      } else {
+  for (int k = 0; k < RF; k++) acc[k] = 0.f;
+  float known = 0.f;
+  // the record of one sample as RF operands: dense records as they are, compact ones decoded (bit-identical)
+  auto fetch = [&](unsigned off, float (&m)[RF]) {
+    if constexpr (COMPACT) {
+      uint32_t w[CW];
+      cmap_load<CW>(crecb, off, w);
+      cmap_decode<RF, KSLOT>(w, ldict, m);
+    } else {
 #pragma unroll
-        for (int v = 0; v < NV4; v++) {
-          const float4 q = *reinterpret_cast<const float4*>(recb + off + 16 * v);
-          m[4 * v + 0] = q.x; m[4 * v + 1] = q.y; m[4 * v + 2] = q.z; m[4 * v + 3] = q.w;
-        }
+      for (int v = 0; v < NV4; v++) {
+        const float4 q = *reinterpret_cast<const float4*>(recb + off + 16 * v);
+        m[4 * v + 0] = q.x; m[4 * v + 1] = q.y; m[4 * v + 2] = q.z; m[4 * v + 3] = q.w;
       }
-    };
-    float acc[RF];
+    }
+  };
+  // rotm * pts (:383-385) for window sample (row value yi, column terms AB = {-s * xj, c * xj}), centre added (:387-388),
+  // rounded (:437): both coordinates in packed instructions — the same float operations, two at a time
+  auto cell_offset = [&](tdr_v2f cyi, tdr_v2f AB) -> unsigned {
+    tdr_v2f pv = cyi + AB;         // p0 = c * yi + (-s * xj), p1 = s * yi + c * xj
+    pv = pv + offv;
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;         // see round_half_away_clamped
+    int ri, ci;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+    const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
+    if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
+    else return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
+  };
+  auto column_terms = [&](int j) -> tdr_v2f {
+    const float xj = linspaced_dev(j, c1, lo_c, hi_c, step_c);
+    return (tdr_v2f){ns * xj, c * xj};
+  };
+  // Order: blocks of U window rows, and within a block the chunk's columns one after the other — a patch of U x cpc
+  // neighbouring cells (rotated), so that a lane whose neighbours are far away meets each 4 x 4-cell tile of the compact
+  // records once per patch instead of once per column.  (Fixed by the configuration: the sums are a pure function of it.)
+  int i = 0;
+  for (; i + U <= a.rows - 1; i += U) {   // LinSpaced without the select of its last element; the last row: below
+    tdr_v2f cyi[U];
 #pragma unroll
-    for (int k = 0; k < RF; k++) acc[k] = 0.f;
-    float known = 0.f;
-    const int64_t sbase = (int64_t)j * a.rows * RF;  // wave-uniform
-    int i = 0;
-    for (; i + U <= a.rows; i += U) {
+    for (int u = 0; u < U; u++) cyi[u] = cs * (lo_r + (float)(i + u) * step_r);
+    for (int j = j0; j < j1; j++) {
+      const tdr_v2f AB = column_terms(j);
       unsigned boff[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) boff[u] = cell_offset(i + u);
+      for (int u = 0; u < U; u++) boff[u] = cell_offset(cyi[u], AB);
       float m[U][RF];
 #pragma unroll
       for (int u = 0; u < U; u++) fetch(boff[u], m[u]);
+      const int64_t sbase = ((int64_t)j * a.rows + i) * RF;  // wave-uniform
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + (int64_t)(i + u) * RF + k], m[u][k], acc[k]);
+        for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + u * RF + k], m[u][k], acc[k]);
         if (!KSLOT) known += m[u][RF - 1];
       }
     }
-    for (; i < a.rows; i++) {
+  }
+  for (; i < a.rows; i++) {   // the remaining rows (the last one among them), column by column
+    const tdr_v2f cyi = cs * linspaced_dev(i, r1, lo_r, hi_r, step_r);
+    for (int j = j0; j < j1; j++) {
       float m[RF];
-      fetch(cell_offset(i), m);
+      fetch(cell_offset(cyi, column_terms(j)), m);
+      const int64_t sbase = ((int64_t)j * a.rows + i) * RF;
 #pragma unroll
-      for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + (int64_t)i * RF + k], m[k], acc[k]);
+      for (int k = 0; k < RF; k++) acc[k] = __builtin_fmaf(scanc[sbase + k], m[k], acc[k]);
       if (!KSLOT) known += m[RF - 1];
     }
-#pragma unroll
-    for (int k = 0; k < RF; k++) acc2[k] += acc[k];
-    known2 += known;
   }
   if (slot < a.npad) {
     float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
 #pragma unroll
-    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc2[k];
-    o[(int64_t)RF * a.npad] = KSLOT ? acc2[RF - 2] : known2;
+    for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc[k];
+    o[(int64_t)RF * a.npad] = KSLOT ? acc[RF - 2] : known;
   }
 }
 
@@ -1820,19 +1828,20 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   return TDR_OK;
 }
 
-extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n) {
+extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n, int64_t n_total) {
   (void)rows;
   int cpc, nchunks;
-  choose_chunks(n, cols, cpc, nchunks, TDR_CART_WAVE_MUL);
+  choose_chunks(n_total > 0 ? n_total : n, cols, cpc, nchunks, TDR_CART_WAVE_MUL);
   int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   return (size_t)((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64);
 }
 
 extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
-                                const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, const int32_t* perm,
-                                float* raw_w, float* workspace, void* stream) {
+                                const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
+                                const int32_t* perm, float* raw_w, float* workspace, void* stream) {
   if (!map || !map->rec || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score_cart: null pointer");
+  if (n_total <= 0) n_total = n;
   if (n < 0 || cap < n) return fail(TDR_ERR_ARG, "score_cart: n exceeds capacity");
   if (n == 0) return TDR_OK;
   if (rows < 1 || cols < 1) return fail(TDR_ERR_ARG, "score_cart: bad window shape");
@@ -1845,7 +1854,9 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   a.rec = map->rec; a.map_rows = map->rows; a.map_cols = map->cols; a.resolution = map->resolution;
   a.scan_pk = scan_pk; a.rows = rows; a.cols = cols; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm;
-  choose_chunks(n, cols, a.cpc, a.nchunks, TDR_CART_WAVE_MUL);
+  // chunks of window columns from the filter's TOTAL particle count (the same on every rank of a sharded filter, like
+  // score_group_rings): a particle's partial sums are then the same in an N-rank run as in the 1-rank run
+  choose_chunks(n_total, cols, a.cpc, a.nchunks, TDR_CART_WAVE_MUL);
   a.npad = cdiv(n, 64) * 64;
   a.part = workspace;
   a.libm_fma = tdr_libm_fma();

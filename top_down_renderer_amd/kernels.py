@@ -238,12 +238,13 @@ class HipKernels:
                                              C.c_float(uniform_scale), int(bool(init_search)), _ptr(raw_w),
                                              _ptr(self._ws), self.stream()))
 
-    def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None):
-        need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n))
+    def score_cart(self, m, scan_pk, rows, cols, res, fp, st, n, raw_w, perm=None, n_total=0):
+        """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_cart; 0 = n."""
+        need = int(self.lib.tdr_score_cart_workspace_floats(m.ncls, rows, cols, n, n_total))
         if self._ws is None or self._ws.numel() < need:
             self._ws = self.empty((need,))
         check(self.lib.tdr_k_score_cart(C.byref(m.desc), _ptr(scan_pk), rows, cols, C.c_float(res), C.byref(fp),
-                                        _ptr(st), st.shape[1], n, _ptr(perm), _ptr(raw_w), _ptr(self._ws),
+                                        _ptr(st), st.shape[1], n, n_total, _ptr(perm), _ptr(raw_w), _ptr(self._ws),
                                         self.stream()))
 
     def propagate(self, st, n, last_dist, tx, ty, omega, scale_freeze, pos_cov, theta_cov, z4=None, seed=0, step=0,

@@ -265,7 +265,7 @@ class ParticleFilter:
         else:   # Cartesian window (BASELINE config 4; definition in include/tdr.h:tdr_k_score_cart)
             rows, cols = m.window_shape()
             k.score_cart(m.dev, scan_pk, rows, cols, float(res), self.fp_c, self.st, nl, self.raw_w,
-                         perm=self.perm if self.locality_every else None)
+                         perm=self.perm if self.locality_every else None, n_total=n)
         # the init search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay
         # un-initialised, and gates exist only with force_on_map or an unknown scale
         if not (self.params_.force_on_map or self.params_.fixed_scale < 0):
