@@ -90,8 +90,8 @@ int tdr_rec_floats(int ncls);
 size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
 /* bytes behind tdr_map_desc.rec16; 0 when the record size has no matrix-core search (fewer than 4 / more than 7 classes) */
 size_t tdr_map_rec16_bytes(int ncls, int rows, int cols);
-/* Launches of fewer particles than this ignore rec16 (rebuilding it costs one pass over the map); default 8192.
- * n >= 0 sets the threshold, n < 0 only returns it. */
+/* Filters of fewer particles than this (n_total of tdr_k_score_polar) ignore rec16 (rebuilding it costs one pass over
+ * the map); default 8192.  n >= 0 sets the threshold, n < 0 only returns it. */
 int64_t tdr_config_rec16_min_particles(int64_t n);
 int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls, int rows, int cols, float* rec_out,
                    void* stream);

@@ -51,9 +51,10 @@ def _run(comm_kind, rank, world, out_path, dist=None):
     from top_down_renderer_amd._lib import FilterParamsC, check
     L = _lib.load()
     torch.cuda.set_device(0)
-    # the un-initialised particles' 40-rotation search through the handle's half-record scratch (by default only
-    # launches of >= 8192 particles take it): allocated by the first update, on the map
-    L.tdr_config_rec16_min_particles(1024)
+    # the un-initialised particles' 40-rotation search through the handle's half-record scratch (by default only filters
+    # of >= 8192 particles take it): allocated by the first update, on the map.  3000 lies between a shard (2048) and the
+    # filter (4096): the filter's total decides, so the shards take the same kernel as the plain handle
+    L.tdr_config_rec16_min_particles(3000)
     cfg, sc, st = _scene()
     ncls, H, W = sc.class_maps.shape
     vp = C.c_void_p

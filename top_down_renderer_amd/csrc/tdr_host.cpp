@@ -826,7 +826,7 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
     perm = f->perm.p;
   }
   TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n, f->n)));
-  if (f->maybe_uninit && !m->desc.rec16 && n >= tdr_config_rec16_min_particles(-1)) {
+  if (f->maybe_uninit && !m->desc.rec16 && f->n >= tdr_config_rec16_min_particles(-1)) {
     // the search over this many particles pays for pre-split half records (filters on one map share the scratch: their
     // searches must not overlap in time)
     const size_t b16 = tdr_map_rec16_bytes(ncls, m->desc.rows, m->desc.cols);

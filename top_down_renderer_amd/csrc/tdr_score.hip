@@ -1394,8 +1394,10 @@ extern "C" size_t tdr_map_rec16_bytes(int ncls, int rows, int cols) {
   return (size_t)(rows + 2) * (size_t)(cols + 2) * 32 + 32;   // + the all-zero record behind the grid
 }
 // Rebuilding the half records is one pass over the whole map: it pays from a few thousand particles on (4000^2 cells:
-// 0.35 ms, the price of searching ~2000 particles with 256 x 256 windows on the fly).  Launches below the threshold
-// ignore the scratch.  TDR_INIT_HALF=0 turns the path off (A/B).
+// 0.35 ms, the price of searching ~2000 particles with 256 x 256 windows on the fly).  Filters below the threshold
+// ignore the scratch — the filter's TOTAL particle count decides (n_total, the same on every rank), so that the ranks of
+// a sharded filter take the kernel the one-rank filter takes and choose the same rotations where candidates tie.
+// TDR_INIT_HALF=0 turns the path off (A/B).
 static int64_t g_rec16_min = [] {
   const char* e = getenv("TDR_INIT_HALF");
   return (e && atoi(e) == 0) ? INT64_MAX : (int64_t)8192;
@@ -1637,7 +1639,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
       for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
       unitw &= fp->class_weights[0] > 0.f;
       const int variant = (us ? 4 : 0) | (unitw ? 2 : 0) | (ks ? 0 : 1);
-      if (map->rec16 && n >= g_rec16_min && (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024) {
+      if (map->rec16 && n_total >= g_rec16_min && (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024) {
         // pre-split half records (weights folded in) into the map owner's scratch, then the search that reads them
         const int64_t ncells = (int64_t)(map->rows + 2) * (map->cols + 2);
         const dim3 hgrid((unsigned)cdiv(ncells, 256)), hblock(256);

@@ -219,7 +219,7 @@ class HipKernels:
         """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_polar; 0 = n."""
         ws = self._workspace(m.ncls, m.nb, m.nr, n, n_total)
         cap = st.shape[1]
-        if init_search and n >= int(self.lib.tdr_config_rec16_min_particles(-1)):
+        if init_search and max(n, n_total) >= int(self.lib.tdr_config_rec16_min_particles(-1)):
             m.init_scratch(self)
         check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
                                          C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
