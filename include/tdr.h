@@ -88,7 +88,7 @@ int tdr_rec_floats(int ncls);
  * at r + rows*c) and the unknown mask `class_mask_` (u8, 1 = unknown) into cell records (tdr_map_desc.rec).
  * rec_out must hold tdr_map_rec_floats_total(ncls, rows, cols) floats. */
 size_t tdr_map_rec_floats_total(int ncls, int rows, int cols);
-/* bytes behind tdr_map_desc.rec16; 0 when the record size has no matrix-core search (fewer than 4 / more than 7 classes) */
+/* bytes behind tdr_map_desc.rec16; 0 when the class count has no matrix-core search (more than 7 classes) */
 size_t tdr_map_rec16_bytes(int ncls, int rows, int cols);
 /* Filters of fewer particles than this (n_total of tdr_k_score_polar) ignore rec16 (rebuilding it costs one pass over
  * the map); default 8192.  n >= 0 sets the threshold, n < 0 only returns it. */

@@ -107,12 +107,14 @@ def test_random_shapes_against_oracle(env, oracle, seed):
 @pytest.mark.parametrize("seed,ncls,pile", [(s, None, 0) for s in range(8)] +
                          [(20 + s, 4 + s % 4, 0) for s in range(max(12, N_SEEDS // 4))] +
                          [(40, 6, 3000), (41, 5, 2049)] +
-                         [(50, 8, 0), (51, 11, 0), (52, 12, 0), (53, 15, 0)])   # 12- and 16-float records: vector kernel
+                         [(50, 8, 0), (51, 11, 0), (52, 12, 0), (53, 15, 0)] +   # 12- and 16-float records: vector kernel
+                         [(60, 3, 0), (61, 2, 0), (62, 1, 0)])                    # 4-float records
 def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
     """have_init = false: the 40-rotation search on random shapes; the chosen rotation is verified through the oracle's
     cost at the GPU's theta (candidates can tie to within rounding).  4-7 classes take the matrix-core kernel
-    (score_init_mfma_kernel); `pile` points in one bin push a scan count past what f16 holds exactly, which must send the
-    search back to the vector kernel."""
+    (score_init_mfma_kernel), and up to 7 classes the one on half records (score_init_half_kernel, second pass below);
+    `pile` points in one bin push a scan count past what f16 holds exactly, which must send the search back to the
+    vector kernel."""
     pkg, k = env
     cfg, sc, maps, mask, st, params, rng = _case(100 + seed, ncls)
     if pile:
@@ -168,7 +170,7 @@ def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
         search_and_check()
     finally:
         k.lib.tdr_config_rec16_min_particles(old_min)
-    assert (m.dev.rec16 is not None) == (4 <= ncls <= 7)
+    assert (m.dev.rec16 is not None) == (ncls <= 7)     # 1-3 classes (4-float records) take the same search
 
 
 @pytest.mark.parametrize("seed", range(max(8, N_SEEDS // 6)))

@@ -1084,13 +1084,22 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
 // Same f16 operands as score_init_mfma_kernel, summed in another order (four rings of one direction per instruction).
 // The records carry the class weights, so they are rebuilt at every search (one pass over the map, ~0.35 ms for 4000^2
 // cells) into scratch memory the map's owner provides (tdr_map_desc.rec16).
-template <bool SEVEN>
+// RF: floats of the dense record read (4: up to 3 classes, 8: 4 to 7) — the half record is the same 32 bytes for both
+template <int RF>
 __global__ __launch_bounds__(256) void half_records_kernel(const float4* __restrict__ rec, int64_t ncells, int unitw,
                                                            tdr_filter_params fp, int ncls, uint4* __restrict__ out) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= ncells) return;
-  const float4 m0 = rec[2 * c], m1 = rec[2 * c + 1];
-  float v[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, SEVEN ? m1.z : 0.f, 0.f};
+  float m[RF];
+#pragma unroll
+  for (int q = 0; q < RF / 4; q++) {
+    const float4 t = rec[(RF / 4) * c + q];
+    m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
+  }
+  const float known = m[RF - 1];
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = (k < RF - 1 && k < 7 && k < ncls) ? m[k < RF ? k : 0] : 0.f;   // the distances
   if (!unitw) {
 #pragma unroll
     for (int k = 0; k < 7; k++) v[k] *= k < ncls ? (float)(0.01 * (double)fp.class_weights[k]) : 0.f;
@@ -1098,14 +1107,9 @@ __global__ __launch_bounds__(256) void half_records_kernel(const float4* __restr
   union { tdr_h2 h[4]; uint4 u; } H, L;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]);
+    const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]);   // v[7] == 0
     H.h[k] = hi;
-    L.h[k] = __builtin_amdgcn_cvt_pkrtz(v[2 * k] - (float)hi[0], v[2 * k + 1] - (float)hi[1]);
-  }
-  {
-    const tdr_h2 h6 = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v[6] : 0.f, 0.f);
-    H.h[3] = h6;
-    L.h[3] = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v[6] - (float)h6[0] : 0.f, 1.f - m1.w);
+    L.h[k] = __builtin_amdgcn_cvt_pkrtz(v[2 * k] - (float)hi[0], k == 3 ? 1.f - known : v[2 * k + 1] - (float)hi[1]);
   }
   out[2 * c] = H.u;
   out[2 * c + 1] = L.u;
@@ -1123,9 +1127,9 @@ __global__ __launch_bounds__(256) void half_records_kernel(const float4* __restr
 // AHEAD: record loads in flight — those of step t + AHEAD are issued before the matrix work of step t.  The step loop is
 // unrolled AHEAD + 1 times so that the buffers rotate by name (no register copies); the step count is padded to a multiple
 // of that, the padding steps read the zero guard record.
-template <bool USCALE, bool SEVEN, int AHEAD>
+template <bool USCALE, int AHEAD>
 __global__ __launch_bounds__(256) void score_init_half_kernel(InitArgs a, const uint4* __restrict__ rec16,
-                                                              int* __restrict__ inexact, int img) {
+                                                              int* __restrict__ inexact, int img, int rfs) {
   constexpr int R = AHEAD + 1;
   // LDS: [4 rings][img] scan records {c0..c5, c6|0, sum c} as 8 x f16, row r and r + nb of an image hold scan row r; the
   // img - 2 nb >= R rows behind them stay zero (padding steps; the exact count is chosen on the host so that the four
@@ -1150,7 +1154,6 @@ __global__ __launch_bounds__(256) void score_init_half_kernel(InitArgs a, const 
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(rec16);
   const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
-  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
   const int nrot = *a.nrot;
   const int nb = a.nb;
   const int ntab = nb + 2 * R;    // entries per table row in LDS
@@ -1197,15 +1200,17 @@ __global__ __launch_bounds__(256) void score_init_half_kernel(InitArgs a, const 
       union { tdr_h2 h[4]; uint4 u; } pc;
       pc.u = make_uint4(0u, 0u, 0u, 0u);
       if (j0 + kb < a.nr) {
-        const float4* srow = scan4 + ((int64_t)(j0 + kb) * nb + r) * 2;
-        const float4 v0 = srow[0], v1 = srow[1];
-        big |= v0.x > 2048.f || v0.y > 2048.f || v0.z > 2048.f || v0.w > 2048.f || v1.x > 2048.f || v1.y > 2048.f ||
-               v1.z > 2048.f || v1.w > 2048.f;
-        pc.h[0] = __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y);
-        pc.h[1] = __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w);
-        pc.h[2] = __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y);
-        pc.h[3] = __builtin_amdgcn_cvt_pkrtz(SEVEN ? v1.z : 0.f, v1.w);
-        ssum += v1.w;
+        // packed scan record of rfs floats: the class counts first, the sum of the counts last
+        const float* srow = a.scan_pk + ((int64_t)(j0 + kb) * nb + r) * rfs;
+        float cnt[8];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cnt[k] = k < a.ncls ? srow[k] : 0.f;
+        cnt[7] = srow[rfs - 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++) big |= cnt[k] > 2048.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pc.h[k] = __builtin_amdgcn_cvt_pkrtz(cnt[2 * k], cnt[2 * k + 1]);
+        ssum += cnt[7];
       }
       ringh[kb * img + r] = pc.u;
       ringh[kb * img + r + nb] = pc.u;
@@ -1390,7 +1395,7 @@ static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
 }
 // bytes of the scratch behind tdr_map_desc.rec16 (0: this record size has no matrix-core search)
 extern "C" size_t tdr_map_rec16_bytes(int ncls, int rows, int cols) {
-  if (ncls < 1 || rows < 1 || cols < 1 || tdr_rec_floats(ncls) != 8) return 0;
+  if (ncls < 1 || ncls > 7 || rows < 1 || cols < 1) return 0;
   return (size_t)(rows + 2) * (size_t)(cols + 2) * 32 + 32;   // + the all-zero record behind the grid
 }
 // Rebuilding the half records is one pass over the whole map: it pays from a few thousand particles on (4000^2 cells:
@@ -1631,40 +1636,44 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     const size_t lds = TDR_INIT_SCAN_LDS ? (size_t)2 * nb * rf * 4 : 0;
     const bool ks = tdr_has_kslot(map->ncls, rf), us = a.utab != nullptr;
     ia.only_if = nullptr;
-    if (rf == 8 && (ks || map->ncls == 7) && init_use_mfma()) {
-      // matrix-core pass first; the vector kernel below then runs only if a scan count did not fit f16
-      int* d_inexact = d_nrot + 1;
-      const size_t lds16 = ((size_t)2 * nb + 1) * 16;
-      bool unitw = true;
-      for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
-      unitw &= fp->class_weights[0] > 0.f;
-      const int variant = (us ? 4 : 0) | (unitw ? 2 : 0) | (ks ? 0 : 1);
-      if (map->rec16 && n_total >= g_rec16_min && (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024) {
-        // pre-split half records (weights folded in) into the map owner's scratch, then the search that reads them
-        const int64_t ncells = (int64_t)(map->rows + 2) * (map->cols + 2);
-        const dim3 hgrid((unsigned)cdiv(ncells, 256)), hblock(256);
-        const float4* rec4 = reinterpret_cast<const float4*>(map->rec);
-        uint4* r16 = reinterpret_cast<uint4*>(map->rec16);
-        if (ks) hipLaunchKernelGGL((half_records_kernel<false>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
-        else hipLaunchKernelGGL((half_records_kernel<true>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
-        LAUNCH_CHECK("half_records");
-        static const int ahead = [] {
-          const char* e = getenv("TDR_INIT_AHEAD");   // tuning: record loads kept in flight per wave (1..3)
-          const int v = e ? atoi(e) : 1;
-          return v < 1 ? 1 : (v > 3 ? 3 : v);
-        }();
-        const int R = ahead + 1;
-        const int img = init_half_image_rows(nb, R);
-        const size_t ldsh = (size_t)4 * img * 16 + (size_t)4 * (nb + 2 * R) * 8;
-        const uint4* r16c = r16;
+    bool unitw = true;
+    for (int c = 1; c < map->ncls; c++) unitw &= fp->class_weights[c] == fp->class_weights[0];
+    unitw &= fp->class_weights[0] > 0.f;
+    int* d_inexact = d_nrot + 1;
+    const bool half_path = (rf == 4 || rf == 8) && map->ncls <= 7 && init_use_mfma() && map->rec16 &&
+                           n_total >= g_rec16_min &&
+                           (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024;
+    if (half_path) {
+      // matrix-core pass on pre-split half records (weights folded in), built into the map owner's scratch first; the
+      // vector kernel below then runs only if a scan count did not fit f16
+      const int64_t ncells = (int64_t)(map->rows + 2) * (map->cols + 2);
+      const dim3 hgrid((unsigned)cdiv(ncells, 256)), hblock(256);
+      const float4* rec4 = reinterpret_cast<const float4*>(map->rec);
+      uint4* r16 = reinterpret_cast<uint4*>(map->rec16);
+      if (rf == 4) hipLaunchKernelGGL((half_records_kernel<4>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
+      else hipLaunchKernelGGL((half_records_kernel<8>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
+      LAUNCH_CHECK("half_records");
+      static const int ahead = [] {
+        const char* e = getenv("TDR_INIT_AHEAD");   // tuning: record loads kept in flight per wave (1..3)
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 3 ? 3 : v);
+      }();
+      const int R = ahead + 1;
+      const int img = init_half_image_rows(nb, R);
+      const size_t ldsh = (size_t)4 * img * 16 + (size_t)4 * (nb + 2 * R) * 8;
+      const uint4* r16c = r16;
 #define TDR_LAUNCH_HALF(AH)                                                                                              \
-  if (us && ks) hipLaunchKernelGGL((score_init_half_kernel<true, false, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);   \
-  else if (us) hipLaunchKernelGGL((score_init_half_kernel<true, true, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);     \
-  else if (ks) hipLaunchKernelGGL((score_init_half_kernel<false, false, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);   \
-  else hipLaunchKernelGGL((score_init_half_kernel<false, true, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img);
-        if (ahead == 1) { TDR_LAUNCH_HALF(1) } else if (ahead == 2) { TDR_LAUNCH_HALF(2) } else { TDR_LAUNCH_HALF(3) }
+  if (us) hipLaunchKernelGGL((score_init_half_kernel<true, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img, rf);   \
+  else hipLaunchKernelGGL((score_init_half_kernel<false, AH>), grid, dim3(256), ldsh, s, ia, r16c, d_inexact, img, rf);
+      if (ahead == 1) { TDR_LAUNCH_HALF(1) } else if (ahead == 2) { TDR_LAUNCH_HALF(2) } else { TDR_LAUNCH_HALF(3) }
 #undef TDR_LAUNCH_HALF
-      } else
+      LAUNCH_CHECK("score_init_half");
+      ia.only_if = d_inexact;
+    } else if (rf == 8 && (ks || map->ncls == 7) && init_use_mfma()) {
+      // matrix-core pass splitting the f32 records per sample (small filters, maps without the scratch); the vector
+      // kernel below then runs only if a scan count did not fit f16
+      const size_t lds16 = ((size_t)2 * nb + 1) * 16;
+      const int variant = (us ? 4 : 0) | (unitw ? 2 : 0) | (ks ? 0 : 1);
       switch (variant) {
 #define TDR_LAUNCH_MFMA(US, UW, SV) \
   hipLaunchKernelGGL((score_init_mfma_kernel<US, UW, SV>), grid, dim3(256), lds16, s, ia, d_inexact); break;
