@@ -785,6 +785,42 @@ def test_full_step_c1_vs_oracle(tdr, oracle):
                             s["theta"], s["scale"]], rtol=1e-5, atol=1e-4)
 
 
+def test_full_step_with_an_empty_scan_vs_oracle(tdr, oracle):
+    """A scan without a single usable return: every class image is zero, every cost is 0/0, every weight NaN — the
+    statistics take the reference's `sum == 0 || num_under_mean < 1` branch (src/particle_filter.cpp:129-131: all weights
+    1, then normalised) and the resampling draws from equal weights.  Same result as the oracle, indices included."""
+    pkg, k = tdr
+    sc, cfg, om, _, tab = _c1_scene(oracle)
+    pts = sc.pts.copy()
+    pts[:, 0:2] = 0.0          # every point is the sensor origin: skipped by the renderer (scan_renderer_polar.cpp:96)
+    seed = 5
+    fpo = oracle.make_params(cfg.ncls)
+    st_o = sc.states.copy()
+    rng_o = oracle.Rng(seed)
+    last_o = oracle.propagate(st_o, 0.5, 0.1, 0.02, True, fpo, rng_o)
+    scan_o = oracle.raster_polar(pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    assert not scan_o.any()
+    raw_o = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan_o, cfg.res, fpo, st_o)
+    assert np.isnan(raw_o).all()
+    w_o, best_o, _ = oracle.update_weights(raw_o, last_o)
+    idx_o = oracle.resample_prefix(w_o, len(st_o), rng_o.uniform())
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    f = pkg.ParticleFilter(len(sc.states), m, pkg.FilterParams(fixed_scale=1.0), seed=seed, kernels=k,
+                           init_particles=False)
+    f.set_states(sc.states)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    f.propagate((0.5, 0.1), 0.02)
+    r.renderSemanticTopDown(pts, cfg.res, cfg.ang_res)
+    assert not r.last_images().cpu().numpy().any()
+    f.update(r.last_scan(), None, cfg.res)
+    assert np.isnan(f.raw_weights()).all()
+    assert np.array_equal(f.weights(), w_o)
+    assert f._argmax() == best_o
+    assert np.array_equal(f.resample_indices(), idx_o)
+
+
 def test_init_search_c1(tdr, oracle):
     pkg, k = tdr
     sc, cfg, om, scan, tab = _c1_scene(oracle)
