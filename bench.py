@@ -260,8 +260,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
                          "note": "with the compact map records the kernel moves a quarter of the bytes and is bound by "
                                  "vector-instruction issue for clustered particles (SQ_ACTIVE_INST_VALU = 85 % of the SIMD "
-                                 "cycles, profiles/r02_pmc_score_compact_gaussian5_v1.txt); `frac` is what it still takes "
-                                 "of the HBM roofline (DESIGN.md 5.1)",
+                                 "cycles, profiles/r02_pmc_score_compact_gaussian5_v1.txt; 68 % for this bench's 90/10 mix, "
+                                 "..._mix_v1.txt; memory-bound at 0.73 of the peak only when all particles are scattered, "
+                                 "..._uniform_v1.txt); `frac` is what it still takes of the HBM roofline (DESIGN.md 5.1)",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
                                          "frac": alg_gbps / 8000.0}},

@@ -12,6 +12,6 @@ for G in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" 
          "TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" \
          "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $G -d $OUT/p$i -o pmc --output-format csv -- python3 tools/tune_compact.py c2 "$DIST" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
+  echo "pass $i: $G"; rocprofv3 --pmc $G -d $OUT/p$i -o pmc --output-format csv -- python3 tools/tune_compact.py c2 "$DIST" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done
 python3 tools/pmc_summary.py score_polar $(find $OUT -name '*counter_collection.csv' | sort) | tee $OUT/summary.txt
