@@ -5,10 +5,12 @@
 //   an unknown scale -> getClassesAtPoint -> two steps -> freezeScale -> computeGMM + adaptive particle count ->
 //   updateMap with a moved centre.
 // Inputs / outputs: raw files in argv[1], like facade_step.cpp (tests/test_facade.py compares with the CPU oracle).
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <random>
+#include <stdexcept>
 #include <string>
 
 #include "top_down_render/particle_filter.h"
@@ -258,6 +260,36 @@ int main(int argc, char** argv) {
       float mx = 0.f;
       for (int k = 0; k < nb * nr; k++) mx = std::max(mx, std::max(gwin[0](k), gwin[1](k)));
       extra[3] = mx;   // the updateMap path leaves both geometric layers at 1 (src/top_down_map.cpp:126-133)
+    }
+    {   // several GPUs behind the class surface: the sharded constructor on a one-rank RCCL communicator (every exchange
+        // really goes through RCCL) must reproduce the plain filter bit for bit; and the opt-in geometric cost
+        // (state_particle.cpp:145-152) with all-zero geometric images adds exact zeros
+      unsigned char id[TDR_COMM_ID_BYTES];
+      tdr_comm* comm = nullptr;
+      if (tdr_comm_rccl_unique_id(id) != TDR_OK || tdr_comm_create_rccl(1, 0, id, &comm) != TDR_OK)
+        throw std::runtime_error(std::string("rccl communicator: ") + tdr_last_error());
+      const int n2 = 768;
+      FilterParams fp2 = fp;
+      fp2.fixed_scale = 1.f;
+      ParticleFilter plain(n2, map_, fp2, 77), shard(n2, map_, fp2, 77, comm), geo(n2, map_, fp2, 77);
+      geo.setGeometricCost(true);
+      for (int i = 0; i < 2; i++) top_down_geo[i].setZero();
+      renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, top_down);
+      for (ParticleFilter* f : {&plain, &shard, &geo}) {
+        f->propagate(motion, 0.01f);
+        f->update(top_down, top_down_geo, res);
+      }
+      const auto wp = plain.weights(n2), ws = shard.weights(n2), wg = geo.weights(n2);
+      const auto sp2 = plain.states(), ss = shard.states();
+      bool same = wp.size() == ws.size() && sp2.size() == ss.size() &&
+                  std::memcmp(wp.data(), ws.data(), wp.size() * sizeof(float)) == 0 &&
+                  std::memcmp(sp2.data(), ss.data(), sp2.size() * sizeof(State)) == 0;
+      extra[4] = same ? 1.f : 0.f;
+      float worst = 0.f;
+      for (size_t i = 0; i < wp.size(); i++) worst = std::max(worst, std::fabs(wg[i] - wp[i]) / std::max(std::fabs(wp[i]), 1e-30f));
+      extra[5] = worst;
+      extra[6] = (float)wp.size();
+      tdr_comm_destroy(comm);
     }
     dump(dir + "/out_extra.bin", extra, 8);
     delete renderer_;
