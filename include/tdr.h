@@ -65,10 +65,13 @@ typedef struct tdr_map_desc {
   /* Optional compact form of the same records (tdr_k_compact_map; cwords == 0: absent).  A cell is cwords dwords of
    * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 2 + 10*(k%3)), `known` in bit 0 of the last
    * dword; records are tiled 4 rows x 32/(4*cwords) columns per 128-byte line.  Decoding reproduces `rec` bit for bit;
-   * the scoring kernels read it instead of `rec` whenever it is present (tdr_config_compact(0) forces `rec`). */
+   * the scoring kernels read it instead of `rec` whenever it is present (tdr_config_compact(0) forces `rec`).
+   * The WIDE form (tdr_k_compact_map_wide: rec_floats == 8, cwords == 4, dict_n > TDR_CMAP_MAX_DICT) holds 16-bit
+   * indices, two per dword (class k in dword k/2 at bit 2 + 16*(k%2)), into a dictionary of up to
+   * TDR_CMAP_WIDE_MAX_DICT values. */
   int32_t cwords, dict_n;
   const uint32_t* crec;
-  const float* dict;    /* [TDR_CMAP_MAX_DICT], entry 0 = +0.0f */
+  const float* dict;    /* [TDR_CMAP_WIDE_MAX_DICT], entry 0 = +0.0f */
   /* Optional SCRATCH of tdr_map_rec16_bytes(ncls, rows, cols) bytes of device memory (NULL: none).  The 40-rotation
    * search of tdr_k_score_polar(init_search != 0) writes the map's records there as pre-split f16 pairs with the
    * filter's class weights folded in and gathers those (twice as fast as splitting the f32 records per sample; same
@@ -97,15 +100,21 @@ int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls,
                    void* stream);
 
 /* Compact form of the cell records (csrc/tdr_cmap.hip).  Fills map->crec / dict / dict_n / cwords from map->rec;
- * crec_out: tdr_cmap_words_total(ncls, rows, cols) dwords, dict_out: TDR_CMAP_MAX_DICT floats, workspace:
+ * crec_out: tdr_cmap_words_total(ncls, rows, cols) dwords, dict_out: TDR_CMAP_WIDE_MAX_DICT floats, workspace:
  * TDR_CMAP_WORKSPACE_BYTES, all device memory.  Load-time work: synchronises with `stream`.  Maps with more than
- * TDR_CMAP_MAX_DICT distinct distance values or more than 11 classes have no compact form: cwords stays 0, TDR_OK.
- * tdr_k_unpack_compact_map decodes it back into dense records (rec_out like tdr_k_pack_map's output). */
-#define TDR_CMAP_MAX_DICT 1024
-#define TDR_CMAP_WORKSPACE_BYTES (8192 * 4 + 8192 * 2 + 256)
+ * TDR_CMAP_MAX_DICT distinct distance values or more than 11 classes have no (narrow) compact form: cwords stays 0,
+ * TDR_OK — and dict_n = -(distinct values) when the WIDE form exists for the map (4-7 classes, up to
+ * TDR_CMAP_WIDE_MAX_DICT values: 16 bytes per cell instead of 8): tdr_k_compact_map_wide then builds it into
+ * tdr_cmap_wide_words_total(ncls, rows, cols) dwords.
+ * tdr_k_unpack_compact_map decodes either form back into dense records (rec_out like tdr_k_pack_map's output). */
+#define TDR_CMAP_MAX_DICT 1024        /* dictionary entries of the narrow form (10-bit fields) */
+#define TDR_CMAP_WIDE_MAX_DICT 4096   /* ... of the wide form (16-bit fields; tdr_k_compact_map_wide) */
+#define TDR_CMAP_WORKSPACE_BYTES (16384 * 4 + 16384 * 2 + 256)
 int tdr_cmap_words(int ncls);
 size_t tdr_cmap_words_total(int ncls, int rows, int cols);
 int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream);
+size_t tdr_cmap_wide_words_total(int ncls, int rows, int cols);   /* 0: no wide form for this class count */
+int tdr_k_compact_map_wide(tdr_map_desc* map, uint32_t* wrec_out, float* dict_out, void* workspace, void* stream);
 int tdr_k_unpack_compact_map(const tdr_map_desc* map, float* rec_out, void* stream);
 
 /* Map ingest on the device: TopDownMap::loadCompressedRasterMap (src/top_down_map.cpp:116-144) +

@@ -435,7 +435,7 @@ def test_compact_map_round_trip(tdr, ncls, rows, cols):
 
 
 def test_map_without_compact_form_falls_back_to_dense(tdr, oracle):
-    """More than 1024 distinct distance values (here: random floats) or more than 11 classes: no compact records, every
+    """More than 4096 distinct distance values (here: random floats) or more than 11 classes: no compact records, every
     wave reads the dense ones; scoring is unaffected."""
     from top_down_renderer_amd import synth
     pkg, k = tdr
@@ -453,6 +453,64 @@ def test_map_without_compact_form_falls_back_to_dense(tdr, oracle):
     f.update(scan, None, cfg.res)
     _assert_weights(f.raw_weights(), ref)
     assert k.lib.tdr_cmap_words(12) == 0 and k.lib.tdr_cmap_words(11) == 4 and k.lib.tdr_cmap_words(6) == 2
+
+
+@pytest.mark.parametrize("ncls", [4, 6, 7])
+def test_wide_compact_records_for_maps_with_many_distinct_values(tdr, oracle, ncls):
+    """More than 1024 distinct distance values (a fine map resolution: min(50, resolution * sqrt(d2)) takes more values)
+    but at most 4096, 4-7 classes: the WIDE compact form (16-bit fields, csrc/tdr_cmap.hip) instead of the dense
+    fallback.  It decodes to the dense records bit for bit, and the scoring kernel that reads it gives the bits of the
+    dense-record kernel — and the oracle's weights to 1e-5."""
+    import ctypes as C
+    import torch
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("wide", 4000, ncls, 48, 24, 220, 1200, seed=1700 + ncls)
+    sc = synth.make_scene(cfg)
+    # the scene's class geometry (zero inside a class) with ~3000 distinct distance values outside it
+    rng = np.random.default_rng(ncls)
+    maps = (rng.integers(1, 3000, sc.class_maps.shape) / 64.0).astype(np.float32)
+    maps[sc.class_maps == 0] = 0.0
+    assert 1024 < len(np.unique(maps)) <= 4096
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), maps, sc.class_mask, kernels=k)
+    d = m.dev.desc
+    assert d.cwords == 4 and d.rec_floats == 8 and 1024 < d.dict_n <= 4096
+    assert m.dev.crec.numel() == k.lib.tdr_cmap_wide_words_total(ncls, d.rows, d.cols)
+    back = k.zeros((m.dev.rec.numel(),))
+    assert k.lib.tdr_k_unpack_compact_map(C.byref(d), C.c_void_p(back.data_ptr()), k.stream()) == 0
+    assert torch.equal(back, m.dev.rec)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    st = sc.states.copy()
+    far = rng.random(len(st)) < 0.1
+    st["init_x_px"][far] = rng.uniform(-300, 500, int(far.sum())).astype(np.float32)   # partly outside the map
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref = oracle.compute_weights(oracle.OracleMap(maps, sc.class_mask, 1.0), oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res),
+                                 cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls), st.copy())
+    before = k.lib.tdr_config_compact(-1)
+    out = []
+    try:
+        for on in (0, 1):
+            k.lib.tdr_config_compact(on)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
+                                   locality_every=on)
+            f.set_states(st)
+            f.update(scan, None, cfg.res)
+            out.append(f.raw_weights())
+    finally:
+        k.lib.tdr_config_compact(before)
+    _assert_weights(out[0], ref)
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+    # the Cartesian score of such a map reads the dense records (its kernel knows the narrow form only): still right
+    mc = pkg.TopDownMap(pkg.Params(resolution=1.0), maps, sc.class_mask, kernels=k)
+    assert mc.dev.desc.cwords == 4
+    mc.setWindow(20, 28)
+    scan_c = oracle.raster_cart(sc.pts, cfg.res, sc.lut, cfg.ncls, 20, 28)
+    fc = pkg.ParticleFilter(len(st), mc, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False)
+    fc.set_states(st)
+    fc.update(scan_c, None, cfg.res)
+    ref_c = oracle.compute_weights_cart(oracle.OracleMap(maps, sc.class_mask, 1.0), 20, 28, scan_c, cfg.res,
+                                        oracle.make_params(cfg.ncls), st.copy())
+    _assert_weights(fc.raw_weights(), ref_c)
 
 
 @pytest.mark.parametrize("ncls,nb,scale_fixed", [(3, 36, True), (6, 64, True), (6, 50, False), (7, 33, True), (9, 40, False)])

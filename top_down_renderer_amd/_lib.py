@@ -44,6 +44,8 @@ SIGNATURES = {
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
+    "tdr_cmap_wide_words_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_k_compact_map_wide": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
     "tdr_k_unpack_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp]),
     "tdr_k_selftest_atan2": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tdr_libm_variant": (_i, []),

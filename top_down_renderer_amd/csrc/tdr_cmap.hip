@@ -14,14 +14,16 @@
 //   cmap_collect_kernel  every distance value -> a hash set in device memory (distinct count capped at 1024)
 //   host                 the <= 1024 values, sorted, become the dictionary; slot -> index table for the hash set
 //   cmap_pack_kernel     one thread per compact record: look the cell's values up, pack, store tile-major (coalesced)
-// A map with more than 1024 distinct values (fine resolutions) or more than 11 classes has no compact form: the
-// scoring kernels then read the dense records for every wave, as before.
+// A map with more than 1024 distinct values (fine resolutions) takes the WIDE form further down (4-7 classes, up to 4096
+// values); beyond that, or with more than 11 classes, there is no compact form and the scoring kernels read the dense
+// records.
 #include <algorithm>
 
 #include "tdr_common.h"
 
-#define CMAP_HASH_BITS 13
+#define CMAP_HASH_BITS 14
 #define CMAP_HASH_SLOTS (1 << CMAP_HASH_BITS)
+static_assert(TDR_CMAP_WORKSPACE_BYTES >= CMAP_HASH_SLOTS * 6 + 64, "compact-map workspace");
 #define CMAP_EMPTY 0xFFFFFFFFu
 
 __device__ __forceinline__ unsigned cmap_hash(unsigned v) { return (v * 2654435761u) >> (32 - CMAP_HASH_BITS); }
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void cmap_collect_kernel(const float* __restri
         if (count[1]) return;                                     // already overflowed: stop filling the table
         const unsigned old = atomicCAS(&hash[h], CMAP_EMPTY, v);
         if (old == CMAP_EMPTY) {
-          if (atomicAdd(&count[0], 1) >= TDR_CMAP_MAX_DICT) atomicExch(&count[1], 1);
+          if (atomicAdd(&count[0], 1) >= TDR_CMAP_WIDE_MAX_DICT) atomicExch(&count[1], 1);
           break;
         }
         if (old == v) break;
@@ -83,9 +85,10 @@ extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
   return (size_t)g.tiles_r * g.tiles_c * 32;   // 128 bytes per tile
 }
 
+// wide: 16-bit fields, two per dword (the wide form, below) instead of 10-bit fields, three per dword
 __global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
                                                         int ncls, const unsigned* __restrict__ hash,
-                                                        const uint16_t* __restrict__ hidx, CmapGeom g,
+                                                        const uint16_t* __restrict__ hidx, CmapGeom g, int wide,
                                                         uint32_t* __restrict__ crec) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_tile = 4 << g.lc;
@@ -102,26 +105,29 @@ __global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict_
       const unsigned v = __float_as_uint(src[k]);
       unsigned h = cmap_hash(v);
       while (hash[h] != v) h = (h + 1) & (CMAP_HASH_SLOTS - 1);   // every map value is in the set
-      w[k / 3] |= (uint32_t)hidx[h] << (2 + 10 * (k % 3));
+      if (wide) w[k / 2] |= ((uint32_t)hidx[h] << 2) << (16 * (k & 1));
+      else w[k / 3] |= (uint32_t)hidx[h] << (2 + 10 * (k % 3));
     }
     if (src[rf - 1] != 0.f) w[g.cw - 1] |= 1u;                     // known
   }
   for (int d = 0; d < g.cw; d++) crec[t * g.cw + d] = w[d];
 }
 
-// Builds the compact form of map->rec into crec_out (tdr_cmap_words_total dwords) / dict_out (TDR_CMAP_MAX_DICT
-// floats), workspace = TDR_CMAP_WORKSPACE_BYTES of device scratch, and fills map->crec / dict / dict_n / cwords.
-// Load-time work: synchronises with `stream` in the middle (the dictionary is sorted on the host).  A map that has no
-// compact form leaves map->cwords = 0 and returns TDR_OK.
-extern "C" int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream) {
-  if (!map || !map->rec || !crec_out || !dict_out || !workspace) return fail(TDR_ERR_ARG, "compact_map: null pointer");
-  map->crec = nullptr; map->dict = nullptr; map->dict_n = 0; map->cwords = 0;
+// The WIDE form: maps with more than 1024 distinct distance values (a `resolution` below ~0.8: min(50, resolution *
+// sqrt(d2)) then takes more values) keep 16-bit fields, two per dword — 16 bytes per cell for 4-7 classes, tiles of 4 rows
+// x 2 columns, a dictionary of up to TDR_CMAP_WIDE_MAX_DICT values (16 KB of LDS in the scoring kernel).  Half the bytes
+// of the dense records instead of a quarter, still bit-identical operands.
+extern "C" size_t tdr_cmap_wide_words_total(int ncls, int rows, int cols) {
+  if (tdr_rec_floats(ncls) != 8) return 0;   // 4-7 classes
+  const CmapGeom g = cmap_geom(4, rows, cols);
+  return (size_t)g.tiles_r * g.tiles_c * 32;
+}
+
+// Shared by both forms: the map's distinct values -> dictionary (dict_out, TDR_CMAP_WIDE_MAX_DICT floats) and the hash
+// slot -> index table; returns the number of dictionary entries in *nvals (0: not compactable at all).
+static int cmap_dictionary(const tdr_map_desc* map, float* dict_out, void* workspace, hipStream_t s, int* nvals) {
+  *nvals = 0;
   const int ncls = map->ncls, rf = map->rec_floats, rows = map->rows, cols = map->cols;
-  const int cw = tdr_cmap_words(ncls);
-  if (!cw) return TDR_OK;
-  const CmapGeom g = cmap_geom(cw, rows, cols);
-  if ((uint64_t)g.tiles_r * g.tiles_c * 128 > 0xFFFFFFF0ull || g.tiles_c >= (1 << 22)) return TDR_OK;   // 32-bit offsets
-  hipStream_t s = (hipStream_t)stream;
   unsigned* hash = reinterpret_cast<unsigned*>(workspace);
   uint16_t* hidx = reinterpret_cast<uint16_t*>(hash + CMAP_HASH_SLOTS);
   int* count = reinterpret_cast<int*>(hidx + CMAP_HASH_SLOTS);
@@ -136,38 +142,82 @@ extern "C" int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* d
   HIP_TRY(hipMemcpyAsync(hcount, count, sizeof(hcount), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(hh.data(), hash, sizeof(unsigned) * CMAP_HASH_SLOTS, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (hcount[1] || hcount[0] > TDR_CMAP_MAX_DICT) return TDR_OK;   // too many distinct values: dense records only
+  if (hcount[1] || hcount[0] > TDR_CMAP_WIDE_MAX_DICT) return TDR_OK;   // too many distinct values: dense records only
   // dictionary: +0.0f first (the guard record and unused fields are index 0), the rest ascending by bit pattern
   std::vector<unsigned> vals;
   vals.push_back(0u);
   for (unsigned v : hh)
     if (v != CMAP_EMPTY && v != 0u) vals.push_back(v);
   std::sort(vals.begin() + 1, vals.end());
-  if ((int)vals.size() > TDR_CMAP_MAX_DICT) return TDR_OK;
-  std::vector<float> dict(TDR_CMAP_MAX_DICT, 0.f);
+  if ((int)vals.size() > TDR_CMAP_WIDE_MAX_DICT) return TDR_OK;
+  std::vector<float> dict(TDR_CMAP_WIDE_MAX_DICT, 0.f);
   std::memcpy(dict.data(), vals.data(), vals.size() * sizeof(unsigned));
   std::vector<uint16_t> hx(CMAP_HASH_SLOTS, 0);
   for (int h = 0; h < CMAP_HASH_SLOTS; h++)
     if (hh[h] != CMAP_EMPTY && hh[h] != 0u)
       hx[h] = (uint16_t)(std::lower_bound(vals.begin() + 1, vals.end(), hh[h]) - vals.begin());
-  HIP_TRY(hipMemcpyAsync(dict_out, dict.data(), sizeof(float) * TDR_CMAP_MAX_DICT, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dict_out, dict.data(), sizeof(float) * TDR_CMAP_WIDE_MAX_DICT, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(hidx, hx.data(), sizeof(uint16_t) * CMAP_HASH_SLOTS, hipMemcpyHostToDevice, s));
-  const int64_t nrec = (int64_t)g.tiles_r * g.tiles_c * (4 << g.lc);
-  hipLaunchKernelGGL(cmap_pack_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, map->rec, rows, cols, rf, ncls,
-                     (const unsigned*)hash, (const uint16_t*)hidx, g, crec_out);
-  LAUNCH_CHECK("cmap_pack");
   HIP_TRY(hipStreamSynchronize(s));   // dict / hx live on this stack frame until the copies are done
+  *nvals = (int)vals.size();
+  return TDR_OK;
+}
+static int cmap_pack(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, hipStream_t s, int cw,
+                     int wide, int nvals) {
+  const CmapGeom g = cmap_geom(cw, map->rows, map->cols);
+  if ((uint64_t)g.tiles_r * g.tiles_c * 128 > 0xFFFFFFF0ull || g.tiles_c >= (1 << 22)) return TDR_OK;   // 32-bit offsets
+  unsigned* hash = reinterpret_cast<unsigned*>(workspace);
+  uint16_t* hidx = reinterpret_cast<uint16_t*>(hash + CMAP_HASH_SLOTS);
+  const int64_t nrec = (int64_t)g.tiles_r * g.tiles_c * (4 << g.lc);
+  hipLaunchKernelGGL(cmap_pack_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, map->rec, map->rows, map->cols,
+                     map->rec_floats, map->ncls, (const unsigned*)hash, (const uint16_t*)hidx, g, wide, crec_out);
+  LAUNCH_CHECK("cmap_pack");
+  HIP_TRY(hipStreamSynchronize(s));
   map->crec = crec_out;
   map->dict = dict_out;
-  map->dict_n = (int)vals.size();
+  map->dict_n = nvals;
   map->cwords = cw;
   return TDR_OK;
+}
+
+// Builds the compact form of map->rec into crec_out (tdr_cmap_words_total dwords) / dict_out (TDR_CMAP_WIDE_MAX_DICT
+// floats), workspace = TDR_CMAP_WORKSPACE_BYTES of device scratch, and fills map->crec / dict / dict_n / cwords.
+// Load-time work: synchronises with `stream` (the dictionary is sorted on the host).  A map that has no compact form
+// leaves map->cwords = 0 and returns TDR_OK; if it has too many distinct values for this (narrow) form but a wide form
+// exists, map->dict_n = -(number of distinct values): the caller then provides tdr_cmap_wide_words_total dwords to
+// tdr_k_compact_map_wide.
+extern "C" int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream) {
+  if (!map || !map->rec || !crec_out || !dict_out || !workspace) return fail(TDR_ERR_ARG, "compact_map: null pointer");
+  map->crec = nullptr; map->dict = nullptr; map->dict_n = 0; map->cwords = 0;
+  const int cw = tdr_cmap_words(map->ncls);
+  if (!cw) return TDR_OK;
+  int nvals = 0;
+  if (int rc = cmap_dictionary(map, dict_out, workspace, (hipStream_t)stream, &nvals)) return rc;
+  if (nvals == 0) return TDR_OK;
+  if (nvals > TDR_CMAP_MAX_DICT) {
+    if (tdr_cmap_wide_words_total(map->ncls, map->rows, map->cols)) map->dict_n = -nvals;
+    return TDR_OK;
+  }
+  return cmap_pack(map, crec_out, dict_out, workspace, (hipStream_t)stream, cw, 0, nvals);
+}
+// The wide form (see above) into wrec_out (tdr_cmap_wide_words_total dwords); everything else as tdr_k_compact_map.
+// For maps tdr_k_compact_map answered with a negative dict_n (more than TDR_CMAP_MAX_DICT distinct values); others are
+// left without (cwords = 0).  A wide record is told from a narrow one by map->dict_n > TDR_CMAP_MAX_DICT.
+extern "C" int tdr_k_compact_map_wide(tdr_map_desc* map, uint32_t* wrec_out, float* dict_out, void* workspace,
+                                      void* stream) {
+  if (!map || !map->rec || !wrec_out || !dict_out || !workspace) return fail(TDR_ERR_ARG, "compact_map_wide: null pointer");
+  map->crec = nullptr; map->dict = nullptr; map->dict_n = 0; map->cwords = 0;
+  if (!tdr_cmap_wide_words_total(map->ncls, map->rows, map->cols)) return TDR_OK;
+  int nvals = 0;
+  if (int rc = cmap_dictionary(map, dict_out, workspace, (hipStream_t)stream, &nvals)) return rc;
+  if (nvals <= TDR_CMAP_MAX_DICT) return TDR_OK;   // the narrow form's case: a wide record is told by dict_n > 1024
+  return cmap_pack(map, wrec_out, dict_out, workspace, (hipStream_t)stream, 4, 1, nvals);
 }
 
 // Compact records back to dense ones: rec_out [(rows+2)*(cols+2)][rf] exactly as tdr_k_pack_map writes them — the
 // round-trip check of the encoding (tests/test_gpu_parity.py::test_compact_map_round_trip).
 __global__ __launch_bounds__(256) void cmap_unpack_kernel(const uint32_t* __restrict__ crec, const float* __restrict__ dict,
-                                                          int rows, int cols, int rf, int ncls, CmapGeom g,
+                                                          int rows, int cols, int rf, int ncls, CmapGeom g, int wide,
                                                           float* __restrict__ rec) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t gcols = cols + 2, gcell = (int64_t)(rows + 2) * gcols;
@@ -178,7 +228,8 @@ __global__ __launch_bounds__(256) void cmap_unpack_kernel(const uint32_t* __rest
   const uint32_t* w = crec + (tile * (4 << g.lc) + within) * g.cw;
   float* o = rec + idx * rf;
   for (int k = 0; k < rf; k++) o[k] = 0.f;
-  for (int k = 0; k < ncls; k++) o[k] = dict[(w[k / 3] >> (2 + 10 * (k % 3))) & 1023u];
+  for (int k = 0; k < ncls; k++)
+    o[k] = wide ? dict[(w[k / 2] >> (2 + 16 * (k & 1))) & 0x3FFFu] : dict[(w[k / 3] >> (2 + 10 * (k % 3))) & 1023u];
   const float known = (w[g.cw - 1] & 1u) ? 1.f : 0.f;
   o[rf - 1] = known;
   if (tdr_has_kslot(ncls, rf)) o[rf - 2] = known;
@@ -187,8 +238,9 @@ extern "C" int tdr_k_unpack_compact_map(const tdr_map_desc* map, float* rec_out,
   if (!map || !map->crec || !map->dict || !rec_out || !map->cwords) return fail(TDR_ERR_ARG, "unpack_compact_map: no compact map");
   const CmapGeom g = cmap_geom(map->cwords, map->rows, map->cols);
   const int64_t gcell = (int64_t)(map->rows + 2) * (map->cols + 2);
+  const int wide = (map->cwords == 4 && map->rec_floats == 8 && map->dict_n > TDR_CMAP_MAX_DICT) ? 1 : 0;
   hipLaunchKernelGGL(cmap_unpack_kernel, dim3((unsigned)cdiv(gcell, 256)), dim3(256), 0, (hipStream_t)stream, map->crec,
-                     map->dict, map->rows, map->cols, map->rec_floats, map->ncls, g, rec_out);
+                     map->dict, map->rows, map->cols, map->rec_floats, map->ncls, g, wide, rec_out);
   LAUNCH_CHECK("cmap_unpack");
   return TDR_OK;
 }

@@ -183,9 +183,16 @@ static int map_compact(tdr_map* m) {
   const size_t nw = tdr_cmap_words_total(m->desc.ncls, m->desc.rows, m->desc.cols);
   if (nw == 0) return TDR_OK;
   TTRY(m->crec.resize(nw));
-  TTRY(m->cdict.resize(TDR_CMAP_MAX_DICT));
+  TTRY(m->cdict.resize(TDR_CMAP_WIDE_MAX_DICT));
   TTRY(m->cws.resize(TDR_CMAP_WORKSPACE_BYTES));
-  return tdr_k_compact_map(&m->desc, m->crec.p, m->cdict.p, m->cws.p, nullptr);
+  TTRY(tdr_k_compact_map(&m->desc, m->crec.p, m->cdict.p, m->cws.p, nullptr));
+  if (m->desc.cwords == 0 && m->desc.dict_n < 0) {   // too many distinct values for 10-bit fields: the wide form
+    const size_t nww = tdr_cmap_wide_words_total(m->desc.ncls, m->desc.rows, m->desc.cols);
+    TTRY(m->crec.resize(nww));
+    TTRY(tdr_k_compact_map_wide(&m->desc, m->crec.p, m->cdict.p, m->cws.p, nullptr));
+  }
+  if (m->desc.cwords == 0) m->desc.dict_n = 0;
+  return TDR_OK;
 }
 
 extern "C" {

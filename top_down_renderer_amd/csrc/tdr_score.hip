@@ -31,6 +31,7 @@ struct ScoreArgs {
   // compact form of the records (tdr_cmap.hip), read by the COMPACT instantiations
   const uint32_t* crec;
   const float* dict;
+  int dict_n;           // dictionary entries in use
   int ctiles_c;         // tiles per tile row
 };
 
@@ -104,6 +105,21 @@ __device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KS
   m[RF - 1] = kf;
 }
 
+// the WIDE compact record (tdr_cmap.hip): 16-bit fields, two per dword, a dictionary of up to 4096 values
+template <int RF, bool KSLOT>
+__device__ __forceinline__ void cmap_decode_wide(const uint32_t (&w)[4], const float* ldict, float (&m)[RF]) {
+  constexpr int ND = CmapShape<RF, KSLOT>::ND;
+  static_assert(ND <= 7, "wide records hold up to seven distances");
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const uint32_t boff = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xFFFCu);   // index * 4
+    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+  }
+  const float kf = (float)(w[3] & 1u);
+  if (KSLOT) m[RF - 2] = kf;
+  m[RF - 1] = kf;
+}
+
 #ifdef TDR_SCORE_TIMELINE   // diagnostic build: start / end time stamp (100 MHz) of every workgroup
 #define TDR_TL_MAX (1 << 17)
 __device__ unsigned long long g_timeline[2 * TDR_TL_MAX];
@@ -124,16 +140,19 @@ extern "C" int tdr_debug_read_timeline(unsigned long long* out, int n) {
 // records are tiled 4 x 4 cells per 128-byte line, so a ray stays in a tile for ~3 steps: a lane whose neighbours are far
 // away (scattered particles) fetches ~0.5 lines per sample instead of one.  The scan rows of the whole group sit in LDS
 // ([ring][plane][row], not doubled: the row (i + shift) mod nb is computed once per direction).
-template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT>
-__global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(ScoreArgs a) {
+// WIDE: the compact records are the wide form (maps of more than 1024 distinct values, tdr_cmap.hip)
+template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT, bool WIDE = false>
+__global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
-  constexpr int CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
+  static_assert(!WIDE || (COMPACT && NV4 == 2), "wide compact records: 8-float dense records only");
+  constexpr int CW = WIDE ? 4 : CmapShape<RF, KSLOT>::CW, LC = WIDE ? 1 : CmapShape<RF, KSLOT>::LC;
+  constexpr int NDICT = WIDE ? TDR_CMAP_WIDE_MAX_DICT : TDR_CMAP_MAX_DICT;
 #ifdef TDR_SCORE_TIMELINE
   const unsigned tl_id = blockIdx.y * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0 && tl_id < TDR_TL_MAX) g_timeline[2 * tl_id] = wall_clock64();
 #endif
   extern __shared__ float4 ring[];  // [nb rows][rs]: a row's (ring, plane) records side by side, rs = group * NV4 | 1
-  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
+  __shared__ float ldict[COMPACT ? NDICT : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if TDR_XCD_SWIZZLE
   // Workgroups are dealt round-robin over the 8 XCDs; remap so that each XCD (its own L2) gets a contiguous run of
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
 
   // stage the group's scan rows and (compact) the dictionary
   if constexpr (COMPACT)
-    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
+    for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
   // One row of the LDS image = the scan records (ring, plane) of one direction, 16 bytes each, side by side: a step
   // reads them with ONE address per lane and immediate offsets.  The row stride is an ODD number of 16-byte slots, so
   // lanes on different rows (different headings) fall on different banks.
@@ -229,7 +248,8 @@ __global__ __launch_bounds__(256, COMPACT ? 5 : 1) void score_polar_kernel(Score
     }
   };
   auto operands = [&](const Raw& r, float (&m)[RF]) {
-    if constexpr (COMPACT) cmap_decode<RF, KSLOT>(r.w, ldict, m);
+    if constexpr (WIDE) cmap_decode_wide<RF, KSLOT>(r.w, ldict, m);
+    else if constexpr (COMPACT) cmap_decode<RF, KSLOT>(r.w, ldict, m);
     else {
 #pragma unroll
       for (int v = 0; v < NV4; v++) { m[4 * v] = r.q[v].x; m[4 * v + 1] = r.q[v].y; m[4 * v + 2] = r.q[v].z; m[4 * v + 3] = r.q[v].w; }
@@ -1567,20 +1587,37 @@ static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s
   LAUNCH_CHECK("score_polar");
   return TDR_OK;
 }
+static bool map_is_wide(const tdr_map_desc* map, int rf) {   // tdr_cmap.hip: 16-bit fields
+  return rf == 8 && map->cwords == 4 && map->dict_n > TDR_CMAP_MAX_DICT;
+}
 static bool map_has_compact(const tdr_map_desc* map, int rf) {
-  if (!(g_use_compact && map->cwords > 0 && map->crec && map->dict && map->cwords == tdr_cmap_words(map->ncls) && rf <= 12))
+  if (!(g_use_compact && map->cwords > 0 && map->crec && map->dict && map->dict_n > 0 && rf <= 12 &&
+        (map->cwords == tdr_cmap_words(map->ncls) || map_is_wide(map, rf))))
     return false;
+  if (map->dict_n > (map_is_wide(map, rf) ? TDR_CMAP_WIDE_MAX_DICT : TDR_CMAP_MAX_DICT)) return false;
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   return (int64_t)((map->cols >> lc) + 2) * 128 < (1 << 23);   // cmap_offset multiplies with 24-bit operands
 }
 static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s) {
-  a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
+  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_c = 0;
   ScoreProfScope prof(s);
   if (!map_has_compact(map, rf)) return launch_score_form<false>(a, rf, ncls, s);
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   a.crec = map->crec;
   a.dict = map->dict;
+  a.dict_n = map->dict_n;
   a.ctiles_c = (map->cols >> lc) + 2;
+  if (map_is_wide(map, rf)) {   // more than 1024 distinct values: 16-bit fields, a 16 KB dictionary in LDS
+    dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
+    const size_t lds = (size_t)a.nb * ((a.group * 2) | 1) * 16;
+    const bool ks = tdr_has_kslot(ncls, rf), us = a.utab != nullptr;
+    if (ks && us) hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U, true, true, true, true>), grid, block, lds, s, a);
+    else if (ks) hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U, true, false, true, true>), grid, block, lds, s, a);
+    else if (us) hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U, false, true, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((score_polar_kernel<2, TDR_SCORE_U, false, false, true, true>), grid, block, lds, s, a);
+    LAUNCH_CHECK("score_polar(wide)");
+    return TDR_OK;
+  }
   return launch_score_form<true>(a, rf, ncls, s);
 }
 
@@ -1873,7 +1910,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   a.libm_fma = tdr_libm_fma();
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
-  const bool cm = map_has_compact(map, rf);
+  const bool cm = map_has_compact(map, rf) && !map_is_wide(map, rf);   // (the Cartesian kernel reads the narrow form only)
   a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
   if (cm) {
     const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);

@@ -70,11 +70,17 @@ class DeviceMap:
         if nw == 0:
             return False
         crec = kernels.empty((nw,), torch.int32)
-        dic = kernels.empty((1024,))                    # TDR_CMAP_MAX_DICT
-        ws = kernels.empty((8192 * 4 + 8192 * 2 + 256,), torch.uint8)   # TDR_CMAP_WORKSPACE_BYTES
+        dic = kernels.empty((4096,))                    # TDR_CMAP_WIDE_MAX_DICT
+        ws = kernels.empty((16384 * 4 + 16384 * 2 + 256,), torch.uint8)   # TDR_CMAP_WORKSPACE_BYTES
         check(lib.tdr_k_compact_map(C.byref(self.desc), _ptr(crec), _ptr(dic), _ptr(ws), kernels.stream()))
+        if not self.desc.cwords and self.desc.dict_n < 0:
+            # more than 1024 distinct distance values (a fine map resolution): the wide form, 16-bit fields
+            crec = kernels.empty((int(lib.tdr_cmap_wide_words_total(self.ncls, self.rows, self.cols)),), torch.int32)
+            check(lib.tdr_k_compact_map_wide(C.byref(self.desc), _ptr(crec), _ptr(dic), _ptr(ws), kernels.stream()))
         if self.desc.cwords:
             self.crec, self.dict = crec, dic            # keep the device memory alive with the descriptor
+        else:
+            self.desc.dict_n = 0
         return bool(self.desc.cwords)
 
 
