@@ -500,7 +500,7 @@ def test_wide_compact_records_for_maps_with_many_distinct_values(tdr, oracle, nc
         k.lib.tdr_config_compact(before)
     _assert_weights(out[0], ref)
     assert np.array_equal(out[0], out[1], equal_nan=True)
-    # the Cartesian score of such a map reads the dense records (its kernel knows the narrow form only): still right
+    # the Cartesian score reads the wide form too
     mc = pkg.TopDownMap(pkg.Params(resolution=1.0), maps, sc.class_mask, kernels=k)
     assert mc.dev.desc.cwords == 4
     mc.setWindow(20, 28)

@@ -379,6 +379,7 @@ struct CartArgs {
   int libm_fma;          // which build of sinf / cosf the host's libm runs (tdr_sincosf.h)
   const uint32_t* crec;  // compact form of the records (COMPACT instantiations)
   const float* dict;
+  int dict_n;
   int ctiles_c;
 };
 
@@ -387,13 +388,14 @@ __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, floa
   return (i == size1) ? high : (low + (float)i * step);
 }
 
-template <int NV4, int U, bool KSLOT, bool COMPACT>
+template <int NV4, int U, bool KSLOT, bool COMPACT, bool WIDE = false>
 __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   constexpr int RF = 4 * NV4;
-  constexpr int CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
-  __shared__ float ldict[COMPACT ? TDR_CMAP_MAX_DICT : 1];
+  static_assert(!WIDE || (COMPACT && NV4 == 2), "wide compact records: 8-float dense records only");
+  constexpr int CW = WIDE ? 4 : CmapShape<RF, KSLOT>::CW, LC = WIDE ? 1 : CmapShape<RF, KSLOT>::LC;
+  __shared__ float ldict[COMPACT ? (WIDE ? TDR_CMAP_WIDE_MAX_DICT : TDR_CMAP_MAX_DICT) : 1];
   if constexpr (COMPACT) {
-    for (int t = threadIdx.x; t < TDR_CMAP_MAX_DICT; t += 256) ldict[t] = a.dict[t];
+    for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -440,7 +442,8 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
     if constexpr (COMPACT) {
       uint32_t w[CW];
       cmap_load<CW>(crecb, off, w);
-      cmap_decode<RF, KSLOT>(w, ldict, m);
+      if constexpr (WIDE) cmap_decode_wide<RF, KSLOT>(w, ldict, m);
+      else cmap_decode<RF, KSLOT>(w, ldict, m);
     } else {
 #pragma unroll
       for (int v = 0; v < NV4; v++) {
@@ -1910,11 +1913,11 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   a.libm_fma = tdr_libm_fma();
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
-  const bool cm = map_has_compact(map, rf) && !map_is_wide(map, rf);   // (the Cartesian kernel reads the narrow form only)
-  a.crec = nullptr; a.dict = nullptr; a.ctiles_c = 0;
+  const bool cm = map_has_compact(map, rf), wide = cm && map_is_wide(map, rf);
+  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_c = 0;
   if (cm) {
     const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-    a.crec = map->crec; a.dict = map->dict; a.ctiles_c = (map->cols >> lc) + 2;
+    a.crec = map->crec; a.dict = map->dict; a.dict_n = map->dict_n; a.ctiles_c = (map->cols >> lc) + 2;
   }
   {
     ScoreProfScope prof(s);
@@ -1924,6 +1927,10 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
 #define TDR_LAUNCH_CART(NV4)               \
   if (cm) { TDR_LAUNCH_CART2(NV4, true) }  \
   else { TDR_LAUNCH_CART2(NV4, false) }
+    if (wide) {   // more than 1024 distinct values: 16-bit fields (tdr_cmap.hip)
+      if (ks) hipLaunchKernelGGL((score_cart_kernel<2, TDR_SCORE_U, true, true, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((score_cart_kernel<2, TDR_SCORE_U, false, true, true>), grid, block, 0, s, a);
+    } else
     switch (rf / 4) {
       case 1: TDR_LAUNCH_CART(1) break;
       case 2: TDR_LAUNCH_CART(2) break;
