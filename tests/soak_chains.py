@@ -1,12 +1,12 @@
 """Soak test of the weight statistics: random raw-weight vectors (dynamic range, dyadic values that force rounding ties,
 zero runs, NaNs, tiny sums) of random length on both sides of the one-workgroup / multi-workgroup switch; `sum`, `mean`
 and `bottom_stddev` must equal the oracle's serial float chains bit for bit, the weights to 3e-6.
-usage: PYTHONPATH=. python tools/soak_chains.py [cases=300] (GPU box)"""
+usage: PYTHONPATH=. python tests/soak_chains.py [cases=300] (GPU box)"""
 import sys
 
 import numpy as np
 
-sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 from oracle import c_oracle as oracle  # noqa: E402
 from top_down_renderer_amd.kernels import HipKernels  # noqa: E402
 
