@@ -92,7 +92,7 @@ def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tdr_score.hip", "tdr_common.h", "tdr_sincosf.h"):
+    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
         h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -232,7 +232,9 @@ def main():
     if rank == 0:
         P = cfg.nb * cfg.nr
         b_pu = P * (4 * cfg.ncls + 1) + 64
-        kname = "score_polar_kernel" if cfg.polar else "score_cart_kernel"
+        kname = "score_cart_kernel"
+        if cfg.polar:
+            kname = "score_polar_su_kernel" if int(k.lib.tdr_shift_uniform_launches()) > 0 else "score_polar_kernel"
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -311,6 +311,15 @@ int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void
  * forces the dense records (A/B measurements, tests), 1 restores the default, < 0 only queries.  Results never depend on
  * it: both forms decode to the same operands.  Returns the value in force.  (Environment: TDR_COMPACT=0.) */
 int tdr_config_compact(int on);
+/* The polar scoring kernel has a second form that processes the particles in (heading bin, Morton) order with every
+ * bin padded to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes
+ * are skipped wave-wide (csrc/tdr_score_su.hip); same partial sums, bit for bit.  mode 0 = never, 1 = when the filter
+ * holds enough particles per heading bin for the padding to pay (default), 2 = whenever the shapes allow (ring groups
+ * and ring count multiples of 4, a map with narrow compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM
+ * sets the initial mode. */
+int tdr_config_shift_uniform(int mode);
+/* diagnostics: scoring launches of this process that took the shift-uniform kernel */
+int64_t tdr_shift_uniform_launches(void);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* While enabled, every launch of the scoring kernel is bracketed by HIP events on its launch stream;

@@ -1,0 +1,230 @@
+"""The shift-uniform scoring kernel (csrc/tdr_score_su.hip) against the lane-shift kernel (array equality: both produce
+the same partial sums) and against the CPU oracle (1e-5, BASELINE.json north_star).  Run with `pytest -m gpu`.
+
+Small launches are scored as SHARDS of a large filter (n_total = 10^6): the ring groups then have the size a large
+filter gets, which is what the kernel needs (groups of a multiple of 4 rings), and tdr_config_shift_uniform(2) takes the
+path whatever the padding costs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_TOTAL = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def tdr():
+    import torch
+    import top_down_renderer_amd as pkg
+    from top_down_renderer_amd.kernels import HipKernels
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return pkg, HipKernels()
+
+
+def _assert_weights(w, ref, rtol=1e-5):
+    assert np.array_equal(np.isnan(w), np.isnan(ref)), (np.isnan(w).sum(), np.isnan(ref).sum())
+    ok = ~np.isnan(ref)
+    err = np.abs(w[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)
+    assert err.max(initial=0.0) <= rtol, f"max rel err {err.max():.3e}"
+
+
+def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False):
+    """Raw weights (and the states after scoring) of the lane-shift kernel (mode 0) and the shift-uniform one (mode 2)."""
+    before = k.lib.tdr_config_shift_uniform(-1)
+    out = []
+    try:
+        for mode in (0, 2):
+            k.lib.tdr_config_shift_uniform(mode)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False,
+                                   locality_every=locality)
+            f.set_states(st)
+            n = len(st)
+            perm = None
+            if locality:
+                perm = k.zeros((f.cap_local,), __import__("torch").int32)
+                k.locality_order(f.st, n, m.rows, m.cols, perm)
+            launches = int(k.lib.tdr_shift_uniform_launches())
+            k.score(m.dev, m.scan_handle(scan), float(res), f.fp_c, f.st, n, f.raw_w, perm=perm, init_search=init_search,
+                    uniform_scale=f._uniform_scale, n_total=N_TOTAL)
+            k.synchronize()
+            took = int(k.lib.tdr_shift_uniform_launches()) - launches
+            assert took == (1 if mode == 2 else 0), f"mode {mode}: {took} shift-uniform launches"
+            out.append((f.raw_w[:n].cpu().numpy(), k.states_to_host(f.st, n, pkg.STATE_DTYPE)))
+    finally:
+        k.lib.tdr_config_shift_uniform(before)
+    return out
+
+
+CASES = [  # ncls, nb, nr, n, fixed scale, locality
+    (1, 32, 16, 700, True, 1),
+    (2, 64, 32, 1500, True, 0),
+    (3, 36, 24, 1500, True, 1),
+    (5, 48, 20, 2000, False, 1),
+    (6, 64, 24, 3000, True, 1),
+    (6, 50, 28, 1500, False, 0),
+    (7, 32, 16, 1000, True, 1),
+    (9, 40, 24, 1200, False, 1),
+    (11, 24, 12, 600, True, 1),
+]
+
+
+@pytest.mark.parametrize("ncls,nb,nr,n,scale_fixed,locality", CASES)
+def test_shift_uniform_equals_lane_shift_kernel_and_oracle(tdr, oracle, ncls, nb, nr, n, scale_fixed, locality):
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("su", 5000, ncls, nb, nr, 260, n, seed=4100 + 17 * ncls + nb)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    rng = np.random.default_rng(ncls * 100 + nb)
+    if not scale_fixed:
+        st["scale"] = rng.uniform(0.6, 1.7, n).astype(np.float32)
+    far = rng.random(n) < 0.1
+    st["init_x_px"][far] = rng.uniform(-300, 600, int(far.sum())).astype(np.float32)   # partly outside the map
+    wild = rng.random(n) < 0.05
+    st["theta"][wild] = rng.uniform(-40, 40, int(wild.sum())).astype(np.float32)       # many turns, negative headings
+    params = dict(fixed_scale=1.0 if scale_fixed else -1.0)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    assert m.dev.desc.cwords > 0
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0),
+                                 oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
+                                 oracle.make_params(cfg.ncls, **params), st.copy())
+    (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality)
+    assert np.array_equal(raw0, raw2, equal_nan=True)
+    _assert_weights(raw2, ref)
+
+
+@pytest.mark.parametrize("kind", ["empty", "dense", "fractional", "one bin"])
+def test_shift_uniform_scan_contents(tdr, oracle, kind):
+    """Descriptor classes: every bin empty; most bins holding several classes; counts that are not integers and negative
+    ones (ParticleFilter::update is handed images, not counts); a single occupied bin."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("suc", 3000, 6, 40, 16, 200, 900, seed=4300)
+    sc = synth.make_scene(cfg)
+    rng = np.random.default_rng(5)
+    P = cfg.nb * cfg.nr
+    if kind == "empty":
+        scan = np.zeros((cfg.ncls, P), np.float32)
+    elif kind == "dense":
+        scan = rng.integers(0, 4, (cfg.ncls, P)).astype(np.float32)
+    elif kind == "fractional":
+        scan = np.where(rng.random((cfg.ncls, P)) < 0.2, rng.normal(0, 2, (cfg.ncls, P)), 0).astype(np.float32)
+        scan[0, ::7] = -0.0
+    else:
+        scan = np.zeros((cfg.ncls, P), np.float32)
+        scan[3, 5 + cfg.nb * 7] = 9
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    st = sc.states.copy()
+    with np.errstate(all="ignore"):
+        ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0),
+                                     oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
+                                     oracle.make_params(cfg.ncls), st.copy())
+    (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0))
+    assert np.array_equal(raw0, raw2, equal_nan=True)
+    if kind != "fractional":   # sums of mixed signs cancel: the 1e-5 bound is for counts
+        fin = np.isfinite(ref)
+        _assert_weights(raw2[fin], ref[fin])
+        assert np.array_equal(np.isfinite(raw2), fin)
+
+
+def test_shift_uniform_keeps_zero_times_infinity(tdr, oracle):
+    """A map value of +inf makes 0 * inf = NaN in the reference's products (state_particle.cpp:136-139): with such a value
+    in the dictionary nothing is skipped, and both kernels agree on every NaN."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("sui", 3000, 6, 32, 16, 160, 800, seed=4400)
+    sc = synth.make_scene(cfg)
+    maps = sc.class_maps.copy()
+    maps[2, 40:90, 30:100] = np.inf
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), maps, sc.class_mask, kernels=k)
+    assert m.dev.desc.cwords > 0
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    st = sc.states.copy()
+    (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0))
+    assert np.isnan(raw0).any() and not np.isnan(raw0).all()
+    assert np.array_equal(raw0, raw2, equal_nan=True)
+    with np.errstate(all="ignore"):
+        ref = oracle.compute_weights(oracle.OracleMap(maps, sc.class_mask, 1.0),
+                                     oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
+                                     oracle.make_params(cfg.ncls), st.copy())
+    assert np.array_equal(np.isnan(raw2), np.isnan(ref))
+
+
+def test_shift_uniform_after_the_init_search(tdr, oracle):
+    """Un-initialised particles get their heading from the 40-rotation search first; the order is built from the headings
+    the search wrote."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("sus", 4000, 6, 40, 24, 220, 1200, seed=4500)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    st["have_init"][::3] = 0
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    (raw0, st0), (raw2, st2) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0), init_search=True)
+    assert np.array_equal(st0["theta"], st2["theta"]) and st2["have_init"].all()
+    assert np.array_equal(raw0, raw2, equal_nan=True)
+
+
+def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
+    """BASELINE configs[1] at full size: one step (propagate, render, update) with the default kernel choice — the
+    shift-uniform kernel at this size — against the lane-shift kernel (equality) and against the oracle over ALL 100 000
+    particles: raw weights to 1e-5, the NaN pattern, the normalised weights, the arg-max and the resample indices."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    sc = synth.make_scene("c2")
+    cfg = sc.cfg
+    n = len(sc.states)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    r.renderSemanticTopDown(sc.pts, cfg.res, cfg.ang_res)
+    res = []
+    before = k.lib.tdr_config_shift_uniform(-1)
+    try:
+        for mode in (0, 1):
+            k.lib.tdr_config_shift_uniform(mode)
+            launches = int(k.lib.tdr_shift_uniform_launches())
+            f = pkg.ParticleFilter(n, m, pkg.FilterParams(fixed_scale=1.0), seed=5, kernels=k, init_particles=False,
+                                   locality_every=1)   # parity RNG: the reference's mt19937 stream
+            f.set_states(sc.states)
+            f.propagate((1.0, 0.0), 0.01)
+            f.update(r.last_scan(), None, cfg.res, shift=0.37)
+            assert int(k.lib.tdr_shift_uniform_launches()) - launches == mode
+            res.append((f.raw_weights(), f.weights(), f.resample_indices(), f._argmax()))
+    finally:
+        k.lib.tdr_config_shift_uniform(before)
+    raw, w, idx, _ = res[1]
+    assert np.array_equal(res[0][0], raw, equal_nan=True)
+    assert np.array_equal(res[0][1], w) and np.array_equal(res[0][2], idx)
+    # the oracle's step on the same inputs
+    fpo = oracle.make_params(cfg.ncls)
+    st = sc.states.copy()
+    last = oracle.propagate(st, 1.0, 0.0, 0.01, True, fpo, oracle.Rng(5))
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref_raw = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0),
+                                     oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, 1.0), cfg.nb, cfg.nr, scan, cfg.res,
+                                     fpo, st)
+    _assert_weights(raw, ref_raw)
+    ref_w, ref_argmax, _ = oracle.update_weights(ref_raw, last)
+    assert np.allclose(w, ref_w, rtol=2e-5, atol=0)
+    assert res[1][3] == ref_argmax or abs(w[ref_argmax] - w.max()) <= 2e-5 * w.max()
+    # resampling the ORACLE's weights on the device reproduces the oracle's indices bit for bit (same weight inputs);
+    # the device's own weights differ in the last bits, which may move a handful of boundaries by one particle
+    ref_idx = oracle.resample_prefix(ref_w, n, 0.37)
+    import torch
+    wd = k.to_device(ref_w)
+    runmax = k.empty((n,))
+    k.prefix(wd, n, runmax)
+    out = k.zeros((n,), torch.int32)
+    k.resample(runmax, n, n, 0.37, 0, n, out)
+    assert np.array_equal(out.cpu().numpy(), ref_idx)
+    mism = int((idx != ref_idx).sum())
+    assert mism <= 2 + n // 200, f"{mism} resample indices differ"

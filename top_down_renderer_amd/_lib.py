@@ -41,6 +41,8 @@ SIGNATURES = {
     "tdr_map_rec16_bytes": (C.c_size_t, [_i, _i, _i]),
     "tdr_config_rec16_min_particles": (_i64, [_i64]),
     "tdr_config_compact": (_i, [_i]),
+    "tdr_config_shift_uniform": (_i, [_i]),
+    "tdr_shift_uniform_launches": (_i64, []),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
@@ -72,7 +74,7 @@ SIGNATURES = {
     "tdr_score_geo_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar_geo": (_i, [C.POINTER(MapDescC), C.POINTER(MapDescC), _vp, _vp, _vp, _f, _f, _i, _i, _f,
                                    C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),
-    "tdr_score_cart_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64]),
+    "tdr_score_cart_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_cart": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64,
                               _vp, _vp, _vp, _vp]),
     "tdr_k_propagate": (_i, [_vp, _i64, _i64, _vp, _f, _f, _f, _i, _f, _f, _vp, _u64, _u64, _i64, _vp]),

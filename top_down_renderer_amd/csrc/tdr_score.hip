@@ -35,90 +35,9 @@ struct ScoreArgs {
   int ctiles_c;         // tiles per tile row
 };
 
-__device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
-  // state_particle.cpp:124-128
-  int s = (int)round((double)(rot * (float)nb / 2) / M_PI);
-  s %= nb;
-  if (s < 0) s += nb;
-  return s;
-}
+#include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
+#include "tdr_score_su.h"    // the shift-uniform kernel's host interface (tdr_score_su.hip)
 
-// roundf (half away from zero) of a coordinate already clamped to [-1, limit], as an int, in two VALU ops:
-//     roundf(x) == floor(fl(x + (0.5 - 2^-25)))   for every float x in [-1, 2^23]
-// (the float addition's own rounding lands exact .5 ties on the next integer and everything below them under it;
-// checked exhaustively on the CPU over [-1, 8] and on the GPU by tests/test_gpu_parity.py).  The generic expansion
-// of roundf costs seven.
-__device__ __forceinline__ int round_half_away_clamped(float x) {
-  const float y = x + 0.49999997f;
-  int r;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(y));
-  return r;
-}
-
-// ---- compact records (tdr_cmap.hip): geometry, load, decode — shared by the polar and the Cartesian kernel ------------
-template <int RF, bool KSLOT>
-struct CmapShape {
-  static constexpr int ND = KSLOT ? RF - 2 : RF - 1;                               // distance slots of a record
-  static constexpr int CW = (ND + 2) / 3 <= 1 ? 1 : ((ND + 2) / 3 == 2 ? 2 : 4);   // dwords of a compact record
-  static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = 4 rows x (1 << LC) columns
-};
-// Byte offset of cell (ri, ci), ri in [-1, rows], ci in [-1, cols] (the clamped sample coordinate): it lives in tile
-// ((ri >> 2) + 1, (ci >> LC) + 1) at (ri & 3, ci & (2^LC - 1)); ckconst = (tiles_c + 1) * 128.  Cells outside the map are
-// guard records (distance 0, unknown).  Written separably — 128 * tile + 32 * (ri & 3) + RB * (ci & ..) =
-// [32 ri + (ri >> 2)(128 tiles_c - 128)] + [RB ci + 96 (ci >> LC)] with RB = 4 CW record bytes — it is six integer ops.
-template <int CW, int LC>
-__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ctiles_c, int ckconst) {
-  // spelled out: the compiler would otherwise emit the two products and the two shifts as separate instructions (8)
-  int t1, t2, t3, off;
-  const int rq = ri >> 2, cq = ci >> LC, krow = ctiles_c * 128 - 128, kcol = 96;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(rq), "s"(krow), "v"(ckconst));   // one SGPR operand at most
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t2) : "v"(cq), "v"(kcol), "v"(t1));
-  asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(t3) : "v"(ri), "v"(t2));
-  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t3));
-  return (unsigned)off;
-}
-template <int CW>
-__device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsigned off, uint32_t (&w)[CW]) {
-  if constexpr (CW == 1) {
-    w[0] = *reinterpret_cast<const uint32_t*>(crecb + off);
-  } else if constexpr (CW == 2) {
-    const uint2 v = *reinterpret_cast<const uint2*>(crecb + off);
-    w[0] = v.x; w[1] = v.y;
-  } else {
-    const uint4 v = *reinterpret_cast<const uint4*>(crecb + off);
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-  }
-}
-// one compact record -> the RF operands the dense record would have delivered, bit for bit (ldict: the dictionary in LDS)
-template <int RF, bool KSLOT>
-__device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KSLOT>::CW], const float* ldict, float (&m)[RF]) {
-  constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
-#pragma unroll
-  for (int k = 0; k < ND; k++) {
-    const uint32_t ww = w[k / 3];
-    const int sh = 10 * (k % 3);                        // field at bits [2 + sh, 12 + sh): (ww >> sh) & 0xFFC = index * 4
-    const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
-  }
-  const float kf = (float)(w[CW - 1] & 1u);
-  if (KSLOT) m[RF - 2] = kf;
-  m[RF - 1] = kf;
-}
-
-// the WIDE compact record (tdr_cmap.hip): 16-bit fields, two per dword, a dictionary of up to 4096 values
-template <int RF, bool KSLOT>
-__device__ __forceinline__ void cmap_decode_wide(const uint32_t (&w)[4], const float* ldict, float (&m)[RF]) {
-  constexpr int ND = CmapShape<RF, KSLOT>::ND;
-  static_assert(ND <= 7, "wide records hold up to seven distances");
-#pragma unroll
-  for (int k = 0; k < ND; k++) {
-    const uint32_t boff = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xFFFCu);   // index * 4
-    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
-  }
-  const float kf = (float)(w[3] & 1u);
-  if (KSLOT) m[RF - 2] = kf;
-  m[RF - 1] = kf;
-}
 
 #ifdef TDR_SCORE_TIMELINE   // diagnostic build: start / end time stamp (100 MHz) of every workgroup
 #define TDR_TL_MAX (1 << 17)
@@ -644,6 +563,7 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if (slot >= nact) return;
   const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
+  if (p < 0) return;   // a padding slot of the shift-uniform order (tdr_score_su.h)
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
   const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
@@ -1479,21 +1399,44 @@ static int init_half_image_rows(int nb, int R) {
   }
   return 2 * nb + R + best_c;
 }
+// The scoring workspace (floats): [partial sums nchunks*(rf+1)*npad_part][res_flag | best_cost npad][res_theta |
+// best_theta npad][list npad + 64: rotation table of the init search][uniform-scale table 2*nb*nr][shift-uniform order,
+// tdr_score_su.h].  npad_part = the slot count of the shift-uniform order where the shapes allow it (its partial sums are
+// slot-indexed and the slots include the padding), else npad.
+extern "C" int tdr_cmap_words(int ncls);   // tdr_cmap.hip
+struct ScoreWs {
+  int group, nchunks;
+  int64_t npad, npad_part, off_aux, off_utab, off_su, total;
+  bool su;
+  SuWs suw;
+};
+static ScoreWs score_ws(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
+  ScoreWs w;
+  const int rf = tdr_rec_floats(ncls);
+  if (n_total <= 0) n_total = n;
+  w.group = score_group_rings(nb, nr, rf, n_total);
+  w.nchunks = (int)cdiv(nr, w.group);
+  w.npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  w.su = tdr_su_shape_ok(nb, nr, w.group, n_total) && tdr_cmap_words(ncls) != 0;
+  w.npad_part = w.su ? su_npad(std::max<int64_t>(n, 1), nb) : w.npad;
+  w.off_aux = (int64_t)w.nchunks * (rf + 1) * w.npad_part;
+  w.off_utab = w.off_aux + 3 * w.npad + 64;
+  w.off_su = (w.off_utab + 2 * (int64_t)nb * nr + 63) / 64 * 64;
+  w.total = w.off_su;
+  if (w.su) {
+    w.suw = tdr_su_ws(nb, nr, w.group, std::max<int64_t>(n, 1));
+    w.total += w.suw.total;
+  }
+  return w;
+}
 extern "C" size_t tdr_score_workspace_floats(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
-  const int group = score_group_rings(nb, nr, tdr_rec_floats(ncls), n_total > 0 ? n_total : n);
-  const int nchunks = (int)cdiv(nr, group);
-  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
-  int rf = tdr_rec_floats(ncls);
-  // partials + best_cost + best_theta + list + count(64) + uniform-scale table
-  return (size_t)((int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64 + 2 * (int64_t)nb * nr);
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || nb < 1 || nr < 1 || n < 0) return 0;
+  return (size_t)score_ws(ncls, nb, nr, n, n_total).total;
 }
-static float* ws_utab(float* workspace, int rf, int nchunks, int64_t npad) {
-  return workspace + (int64_t)nchunks * (rf + 1) * npad + 3 * npad + 64;
-}
-static int fill_utab(ScoreArgs& a, float* workspace, int rf, float uniform_scale, hipStream_t s) {
+static int fill_utab(ScoreArgs& a, float* workspace, const ScoreWs& W, float uniform_scale, hipStream_t s) {
   a.utab = nullptr;
   if (!(uniform_scale > 0.f)) return TDR_OK;
-  float* ut = ws_utab(workspace, rf, a.nchunks, a.npad);
+  float* ut = workspace + W.off_utab;
   const int64_t n2 = 2 * (int64_t)a.nb * a.nr;
   hipLaunchKernelGGL(utab_kernel, dim3((unsigned)cdiv(n2, 256)), dim3(256), 0, s, a.tab, n2, uniform_scale, a.res, ut);
   LAUNCH_CHECK("utab");
@@ -1648,13 +1591,14 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
-  a.group = score_group_rings(nb, nr, rf, n_total);
-  a.nchunks = (int)cdiv(nr, a.group);
-  a.npad = cdiv(n, 64) * 64;
+  const ScoreWs W = score_ws(map->ncls, nb, nr, n, n_total);
+  a.group = W.group;
+  a.nchunks = W.nchunks;
+  a.npad = W.npad;
   a.part = workspace;
-  int rc = fill_utab(a, workspace, rf, uniform_scale, s);
+  int rc = fill_utab(a, workspace, W, uniform_scale, s);
   if (rc) return rc;
-  float* res_flag = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;  // npad floats
+  float* res_flag = workspace + W.off_aux;                             // npad floats
   float* res_theta = res_flag + a.npad;                                // npad floats
   if (init_search) {
     // state_particle.cpp:195-206 first: it fixes theta / have_init of the un-initialised particles, the regular pass
@@ -1748,9 +1692,6 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
                        (const float*)res_flag, n, st, cap);
     LAUNCH_CHECK("init_apply");
   }
-  rc = launch_score(a, map, rf, map->ncls, s);
-  if (rc) return rc;
-
   FinalizeArgs f;
   f.part = a.part; f.rf = rf; f.nchunks = a.nchunks; f.npad = a.npad; f.n = n; f.cap = cap;
   f.order = perm; f.count = nullptr; f.st = st; f.fp = *fp;
@@ -1758,7 +1699,28 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
   f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
-  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  if (W.su && map_has_compact(map, rf) && !map_is_wide(map, rf)) {
+    // shift-uniform order (tdr_score_su.h): same partial sums, slot-indexed over the padded order
+    const int32_t* slots = nullptr;
+    const int32_t* nslots = nullptr;
+    SuLaunch L;
+    L.map = map; L.tab = a.utab ? a.utab : a.tab; L.uniform_scale = a.utab != nullptr; L.scan_pk = scan_pk;
+    L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
+    L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
+    L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
+    if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &nslots))) return rc;
+    {
+      ScoreProfScope prof(s);
+      rc = tdr_su_score(L, W.suw, s);
+    }
+    if (rc) return rc;
+    f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = nslots;
+    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(W.npad_part, 256)), dim3(256), 0, s, f);
+  } else {
+    rc = launch_score(a, map, rf, map->ncls, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  }
   LAUNCH_CHECK("score_finalize");
   if (init_search) {
     hipLaunchKernelGGL(init_fixup_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)res_flag, n,
@@ -1823,13 +1785,14 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
   a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
-  a.group = score_group_rings(nb, nr, rf, n_total);
-  a.nchunks = (int)cdiv(nr, a.group);
-  a.npad = cdiv(n, 64) * 64;
+  const ScoreWs W = score_ws(map->ncls, nb, nr, n, n_total);
+  a.group = W.group;
+  a.nchunks = W.nchunks;
+  a.npad = W.npad;
   a.part = workspace;
-  int rc = fill_utab(a, workspace, rf, uniform_scale, s);
+  int rc = fill_utab(a, workspace, W, uniform_scale, s);
   if (rc) return rc;
-  float* best_cost = workspace + (int64_t)a.nchunks * (rf + 1) * a.npad;   // npad floats (res_flag's place)
+  float* best_cost = workspace + W.off_aux;                               // npad floats (res_flag's place)
   float* best_theta = best_cost + a.npad;                                 // npad floats
   float* res_flag = best_theta + a.npad;                                  // npad floats ("list" region)
   ScoreArgs g = a;   // the geometric launch: same particles, same table, the 2-layer map and scan

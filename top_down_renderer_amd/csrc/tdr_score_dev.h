@@ -1,0 +1,90 @@
+// tdr_score_dev.h — device helpers shared by the scoring kernels (tdr_score.hip, tdr_score_su.hip).
+#ifndef TDR_SCORE_DEV_H_
+#define TDR_SCORE_DEV_H_
+#include "tdr_common.h"
+
+__device__ __forceinline__ int rot_shift_dev(float rot, int nb) {
+  // state_particle.cpp:124-128
+  int s = (int)round((double)(rot * (float)nb / 2) / M_PI);
+  s %= nb;
+  if (s < 0) s += nb;
+  return s;
+}
+
+// roundf (half away from zero) of a coordinate already clamped to [-1, limit], as an int, in two VALU ops:
+//     roundf(x) == floor(fl(x + (0.5 - 2^-25)))   for every float x in [-1, 2^23]
+// (the float addition's own rounding lands exact .5 ties on the next integer and everything below them under it;
+// checked exhaustively on the CPU over [-1, 8] and on the GPU by tests/test_gpu_parity.py).  The generic expansion
+// of roundf costs seven.
+__device__ __forceinline__ int round_half_away_clamped(float x) {
+  const float y = x + 0.49999997f;
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  return r;
+}
+
+// ---- compact records (tdr_cmap.hip): geometry, load, decode — shared by the polar and the Cartesian kernel ------------
+template <int RF, bool KSLOT>
+struct CmapShape {
+  static constexpr int ND = KSLOT ? RF - 2 : RF - 1;                               // distance slots of a record
+  static constexpr int CW = (ND + 2) / 3 <= 1 ? 1 : ((ND + 2) / 3 == 2 ? 2 : 4);   // dwords of a compact record
+  static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = 4 rows x (1 << LC) columns
+};
+// Byte offset of cell (ri, ci), ri in [-1, rows], ci in [-1, cols] (the clamped sample coordinate): it lives in tile
+// ((ri >> 2) + 1, (ci >> LC) + 1) at (ri & 3, ci & (2^LC - 1)); ckconst = (tiles_c + 1) * 128.  Cells outside the map are
+// guard records (distance 0, unknown).  Written separably — 128 * tile + 32 * (ri & 3) + RB * (ci & ..) =
+// [32 ri + (ri >> 2)(128 tiles_c - 128)] + [RB ci + 96 (ci >> LC)] with RB = 4 CW record bytes — it is six integer ops.
+template <int CW, int LC>
+__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ctiles_c, int ckconst) {
+  // spelled out: the compiler would otherwise emit the two products and the two shifts as separate instructions (8)
+  int t1, t2, t3, off;
+  const int rq = ri >> 2, cq = ci >> LC, krow = ctiles_c * 128 - 128, kcol = 96;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(rq), "s"(krow), "v"(ckconst));   // one SGPR operand at most
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t2) : "v"(cq), "v"(kcol), "v"(t1));
+  asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(t3) : "v"(ri), "v"(t2));
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t3));
+  return (unsigned)off;
+}
+template <int CW>
+__device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsigned off, uint32_t (&w)[CW]) {
+  if constexpr (CW == 1) {
+    w[0] = *reinterpret_cast<const uint32_t*>(crecb + off);
+  } else if constexpr (CW == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(crecb + off);
+    w[0] = v.x; w[1] = v.y;
+  } else {
+    const uint4 v = *reinterpret_cast<const uint4*>(crecb + off);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  }
+}
+// one compact record -> the RF operands the dense record would have delivered, bit for bit (ldict: the dictionary in LDS)
+template <int RF, bool KSLOT>
+__device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KSLOT>::CW], const float* ldict, float (&m)[RF]) {
+  constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const uint32_t ww = w[k / 3];
+    const int sh = 10 * (k % 3);                        // field at bits [2 + sh, 12 + sh): (ww >> sh) & 0xFFC = index * 4
+    const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
+    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+  }
+  const float kf = (float)(w[CW - 1] & 1u);
+  if (KSLOT) m[RF - 2] = kf;
+  m[RF - 1] = kf;
+}
+
+// the WIDE compact record (tdr_cmap.hip): 16-bit fields, two per dword, a dictionary of up to 4096 values
+template <int RF, bool KSLOT>
+__device__ __forceinline__ void cmap_decode_wide(const uint32_t (&w)[4], const float* ldict, float (&m)[RF]) {
+  constexpr int ND = CmapShape<RF, KSLOT>::ND;
+  static_assert(ND <= 7, "wide records hold up to seven distances");
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const uint32_t boff = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xFFFCu);   // index * 4
+    m[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+  }
+  const float kf = (float)(w[3] & 1u);
+  if (KSLOT) m[RF - 2] = kf;
+  m[RF - 1] = kf;
+}
+#endif  // TDR_SCORE_DEV_H_

@@ -1,0 +1,37 @@
+// tdr_score_su.h — host interface of the shift-uniform polar scoring path (tdr_score_su.hip), used by tdr_score.hip.
+#ifndef TDR_SCORE_SU_H_
+#define TDR_SCORE_SU_H_
+#include "tdr_common.h"
+
+// slots a launch of n particles can need: every non-empty heading bin rounded up to whole waves
+static inline int64_t su_npad(int64_t n, int nb) { return cdiv(n + 63 * std::min<int64_t>(nb, n), 64) * 64; }
+// whether the path applies to a launch shape (tdr_config_shift_uniform, padding economics, kernel constraints)
+bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
+// The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
+struct SuWs {
+  int64_t tab_su, desc, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, total;
+  // ints: [cnt nb][start nb][slot_start nb][nslots 1][flags 1]
+};
+SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
+
+struct SuLaunch {
+  const tdr_map_desc* map;   // with a narrow compact form
+  const float* tab;          // [P][2]: (tab*scale)*res when uniform_scale, else the table itself
+  bool uniform_scale;
+  const float* scan_pk;
+  int nb, nr, rf;
+  float res;
+  const float* st;
+  int64_t cap, n;
+  const int32_t* perm;       // caller's locality order (NULL = identity)
+  int group, nchunks;
+  int64_t npad;              // slot capacity = stride of part (su_npad)
+  float* part;
+  int32_t* ws;               // tdr_su_ws(...).total words
+};
+// ordering passes + descriptors (everything but the scoring kernel); slots_out / nslots_out: the padded order and the
+// device word holding the number of slots in use (finalize walks them)
+int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** nslots_out);
+// the scoring kernel over the prepared order
+int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
+#endif  // TDR_SCORE_SU_H_
