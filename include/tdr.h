@@ -63,8 +63,9 @@ typedef struct tdr_map_desc {
   int32_t ncls, rows, cols, rec_floats;   /* rec_floats = 4*ceil((ncls+1)/4) */
   float resolution;     /* TopDownMap::Params::resolution (top_down_map.h:61) */
   /* Optional compact form of the same records (tdr_k_compact_map; cwords == 0: absent).  A cell is cwords dwords of
-   * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 2 + 10*(k%3)), `known` in bit 0 of the last
-   * dword; records are tiled 4 rows x 32/(4*cwords) columns per 128-byte line.  Decoding reproduces `rec` bit for bit;
+   * 10-bit indices into `dict` (three per dword, class k in dword k/3 at bit 2 + 10*(k%3)), `known` in bit 0 of every
+   * dword; records are tiled 32/(4*cwords) rows x 4 columns per 128-byte line, row-major inside a tile, the tiles column
+   * by column over the map (csrc/tdr_cmap.hip); the map's known mask follows the tiles (tdr_cmap_words_total).  Decoding reproduces `rec` bit for bit;
    * the scoring kernels read it instead of `rec` whenever it is present (tdr_config_compact(0) forces `rec`).
    * The WIDE form (tdr_k_compact_map_wide: rec_floats == 8, cwords == 4, dict_n > TDR_CMAP_MAX_DICT) holds 16-bit
    * indices, two per dword (class k in dword k/2 at bit 2 + 16*(k%2)), into a dictionary of up to
@@ -111,7 +112,10 @@ int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls,
 #define TDR_CMAP_WIDE_MAX_DICT 4096   /* ... of the wide form (16-bit fields; tdr_k_compact_map_wide) */
 #define TDR_CMAP_WORKSPACE_BYTES (16384 * 4 + 16384 * 2 + 256)
 int tdr_cmap_words(int ncls);
+/* dwords behind crec: the tiles (tdr_cmap_tile_words) followed by the map's known mask, one bit per cell, rows -1..rows of
+ * (cols >> 5) + 2 words, cell (r, c) in word (r + 1) * wpr + (c >> 5) + 1 at bit c & 31 */
 size_t tdr_cmap_words_total(int ncls, int rows, int cols);
+size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
 int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream);
 size_t tdr_cmap_wide_words_total(int ncls, int rows, int cols);   /* 0: no wide form for this class count */
 int tdr_k_compact_map_wide(tdr_map_desc* map, uint32_t* wrec_out, float* dict_out, void* workspace, void* stream);

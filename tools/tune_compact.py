@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the record form tdr_k_score_polar reads, on one device, config-2 scene: ms per call for several particle
 distributions with the dense-record kernel and the compact-record kernel.
-    python3 tools/tune_compact.py [config] [distribution-name filter]"""
+    python3 tools/tune_compact.py [config] [distribution-name filter] [axis]
+axis "compact" (default): dense records vs compact records; axis "su": lane-shift kernel vs shift-uniform kernel (both on
+the compact records); axis "su-only" / "lane-only": one kernel (counter passes)."""
 import ctypes as C
 import os
 import sys
@@ -20,6 +22,7 @@ from top_down_renderer_amd.kernels import HipKernels  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c2"
     only = sys.argv[2] if len(sys.argv) > 2 else ""      # substring filter on the distribution name (profiling runs)
+    axis = sys.argv[3] if len(sys.argv) > 3 else "compact"
 
     k = HipKernels()
     cfg = synth.CONFIGS[name]
@@ -41,11 +44,16 @@ def main():
         "100% Gaussian 5 px": synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, uniform_frac=0.0, sigma_px=5.0),
         "100% uniform": synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, uniform_frac=1.0),
         "8 clusters 40 px": synth.make_cluster_particles(cfg, sc.lab, rng, per_cluster=n // 8),
+        "Gaussian 30 px, one heading": synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, uniform_frac=0.0, sigma_deg=0.0),
+        "Gaussian 30 px, headings uniform": synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, uniform_frac=0.0,
+                                                                 sigma_deg=1e4),
     }
     for pct in (1, 2, 3, 5):
         dists[f"Gaussian 30 px + {pct}% uniform"] = synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n,
                                                                          uniform_frac=pct / 100.0)
-    modes = [("dense", 0), ("compact", 1)]
+    modes = {"compact": [("dense", 0), ("compact", 1)], "su": [("lane-shift", 0), ("shift-uniform", 1)],
+             "su-only": [("shift-uniform", 1)], "lane-only": [("lane-shift", 0)]}[axis]
+    setter = k.lib.tdr_config_compact if axis == "compact" else k.lib.tdr_config_shift_uniform
     fp = pkg.FilterParams(fixed_scale=1.0).to_c(cfg.ncls)
     ref = {}
     for dname, states in dists.items():
@@ -60,7 +68,7 @@ def main():
         raw = k.zeros((n,))
         line = []
         for mname, on in modes:
-            k.lib.tdr_config_compact(on)
+            setter(on)
             for _ in range(2):
                 k.score(m.dev, scan, cfg.res, fp, st, n, raw, perm=perm, uniform_scale=1.0)
             k.synchronize()

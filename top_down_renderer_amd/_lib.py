@@ -45,6 +45,7 @@ SIGNATURES = {
     "tdr_shift_uniform_launches": (_i64, []),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
+    "tdr_cmap_tile_words": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
     "tdr_cmap_wide_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map_wide": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),

@@ -5,10 +5,14 @@
 // kernel then runs at the HBM rate and only fewer bytes make it faster.  Distance maps are
 // `min(50, resolution * sqrt(d2))` with integer d2 (src/top_down_map.cpp:312-317, cv::distanceTransform DIST_L2 /
 // MASK_PRECISE): a 4000 x 4000 six-class map holds < 800 DISTINCT float values.  So a cell is stored as 10-bit indices
-// into a dictionary of the map's own float values — three per dword, `known` in the top bit of the record's last dword —
+// into a dictionary of the map's own float values — three per dword at bits [2 + 10k, 12 + 10k), `known` in bit 0 of every
+// dword (the wide form: of the last dword only) —
 // and decoded through an LDS copy of the dictionary: bit-identical operands, 8 bytes instead of 32 for six classes.
-// Records are tiled 4 rows x (32 / record bytes) columns per 128-byte line, so a ray crosses (|sin| + |cos|) / 4 lines
-// per cell step instead of one (row direction) or a quarter (column direction) of a row-major layout.
+// Records are tiled (32 / record bytes) rows x 4 columns per 128-byte line, so a ray crosses about (|sin| + |cos|) / 4
+// lines per cell step instead of one (row direction) or a quarter (column direction) of a row-major layout.  Inside a
+// tile the records run row-major and the tiles themselves column by column over the map: the row's share of a byte
+// offset is then plainly linear — row * 4 * record bytes, tile and all — and an offset is four integer instructions
+// (cmap_offset, tdr_score_dev.h).
 //
 // Built from the dense records, whoever produced them (tdr_k_pack_map, tdr_k_map_from_labels), once per map:
 //   cmap_collect_kernel  every distance value -> a hash set in device memory (distinct count capped at 1024)
@@ -59,16 +63,16 @@ __global__ __launch_bounds__(256) void cmap_collect_kernel(const float* __restri
 
 struct CmapGeom {
   int cw;            // dwords per record: 1, 2 or 4
-  int lc;            // log2 of the tile's column count: tile = 4 rows x (1 << lc) columns = 128 bytes
+  int lc;            // log2 of the tile's row count: tile = (1 << lc) rows x 4 columns = 128 bytes
   int tiles_r, tiles_c;
 };
 static CmapGeom cmap_geom(int cw, int rows, int cols) {
   CmapGeom g;
   g.cw = cw;
   g.lc = cw == 1 ? 3 : (cw == 2 ? 2 : 1);
-  // cell (r, c), r in [-1, rows], lives in tile ((r >> 2) + 1, (c >> lc) + 1): tile row / column 0 hold the guard ring
-  g.tiles_r = (rows >> 2) + 2;
-  g.tiles_c = (cols >> g.lc) + 2;
+  // cell (r, c), r in [-1, rows], lives in tile ((r >> lc) + 1, (c >> 2) + 1): tile row / column 0 hold the guard ring
+  g.tiles_r = (rows >> g.lc) + 2;
+  g.tiles_c = (cols >> 2) + 2;
   return g;
 }
 extern "C" int tdr_cmap_words(int ncls) {
@@ -78,11 +82,32 @@ extern "C" int tdr_cmap_words(int ncls) {
   if (dw > 4) return 0;
   return dw <= 1 ? 1 : (dw == 2 ? 2 : 4);
 }
-extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
+// Behind the tiles of a narrow compact map sits its KNOWN MASK: one bit per cell, rows -1 .. rows, cell (r, c) in word
+// (r + 1) * wpr + (c >> 5) + 1 at bit c & 31 (c = -1: bit 31 of word 0), wpr = (cols >> 5) + 2 words per row; cells outside
+// the map are 0 = unknown, like their guard records.  2 MB for a 4000 x 4000 map: the shift-uniform scoring kernel stages
+// the part a workgroup's windows cover in LDS and reads the `known` bit of every sample there (tdr_score_su.hip).
+extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols) {
   const int cw = tdr_cmap_words(ncls);
   if (!cw) return 0;
   const CmapGeom g = cmap_geom(cw, rows, cols);
   return (size_t)g.tiles_r * g.tiles_c * 32;   // 128 bytes per tile
+}
+extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
+  const size_t tiles = tdr_cmap_tile_words(ncls, rows, cols);
+  return tiles ? tiles + (size_t)(rows + 2) * ((cols >> 5) + 2) : 0;
+}
+__global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf, int wpr,
+                                                         uint32_t* __restrict__ kmask) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)(rows + 2) * wpr) return;
+  const int r = (int)(t / wpr) - 1, w = (int)(t % wpr);
+  uint32_t bits = 0;
+  if (r >= 0 && r < rows)
+    for (int b = 0; b < 32; b++) {
+      const int c = ((w - 1) << 5) + b;
+      if (c >= 0 && c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) bits |= 1u << b;
+    }
+  kmask[t] = bits;
 }
 
 // wide: 16-bit fields, two per dword (the wide form, below) instead of 10-bit fields, three per dword
@@ -96,8 +121,8 @@ __global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict_
   if (t >= ntile * per_tile) return;
   const int64_t tile = t / per_tile;
   const int within = (int)(t - tile * per_tile);
-  const int tr = (int)(tile / g.tiles_c), tc = (int)(tile - (int64_t)tr * g.tiles_c);
-  const int r = ((tr - 1) << 2) + (within >> g.lc), c = ((tc - 1) << g.lc) + (within & ((1 << g.lc) - 1));
+  const int tc = (int)(tile / g.tiles_r), tr = (int)(tile - (int64_t)tc * g.tiles_r);   // tiles run column by column
+  const int r = ((tr - 1) << g.lc) + (within >> 2), c = ((tc - 1) << 2) + (within & 3);  // row-major inside the tile
   uint32_t w[4] = {0u, 0u, 0u, 0u};
   if (r >= 0 && r < rows && c >= 0 && c < cols) {
     const float* src = rec + ((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf;
@@ -108,7 +133,11 @@ __global__ __launch_bounds__(256) void cmap_pack_kernel(const float* __restrict_
       if (wide) w[k / 2] |= ((uint32_t)hidx[h] << 2) << (16 * (k & 1));
       else w[k / 3] |= (uint32_t)hidx[h] << (2 + 10 * (k % 3));
     }
-    if (src[rf - 1] != 0.f) w[g.cw - 1] |= 1u;                     // known
+    if (src[rf - 1] != 0.f) {                                      // known: bit 0 of the last dword — and of every
+      w[g.cw - 1] |= 1u;                                           // other dword of a narrow record (a reader that needs
+      if (!wide)                                                   // one class reads one dword, tdr_score_su.hip)
+        for (int d = 0; d < g.cw - 1; d++) w[d] |= 1u;
+    }
   }
   for (int d = 0; d < g.cw; d++) crec[t * g.cw + d] = w[d];
 }
@@ -165,13 +194,20 @@ static int cmap_dictionary(const tdr_map_desc* map, float* dict_out, void* works
 static int cmap_pack(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, hipStream_t s, int cw,
                      int wide, int nvals) {
   const CmapGeom g = cmap_geom(cw, map->rows, map->cols);
-  if ((uint64_t)g.tiles_r * g.tiles_c * 128 > 0xFFFFFFF0ull || g.tiles_c >= (1 << 22)) return TDR_OK;   // 32-bit offsets
+  if ((uint64_t)g.tiles_r * g.tiles_c * 128 > 0xFFFFFFF0ull || g.tiles_r >= (1 << 16)) return TDR_OK;   // 32-bit offsets
   unsigned* hash = reinterpret_cast<unsigned*>(workspace);
   uint16_t* hidx = reinterpret_cast<uint16_t*>(hash + CMAP_HASH_SLOTS);
   const int64_t nrec = (int64_t)g.tiles_r * g.tiles_c * (4 << g.lc);
   hipLaunchKernelGGL(cmap_pack_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, map->rec, map->rows, map->cols,
                      map->rec_floats, map->ncls, (const unsigned*)hash, (const uint16_t*)hidx, g, wide, crec_out);
   LAUNCH_CHECK("cmap_pack");
+  if (!wide) {   // the known mask behind the tiles
+    const int wpr = (map->cols >> 5) + 2;
+    const int64_t nwords = (int64_t)(map->rows + 2) * wpr;
+    hipLaunchKernelGGL(cmap_kmask_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, s, map->rec, map->rows, map->cols,
+                       map->rec_floats, wpr, crec_out + (size_t)g.tiles_r * g.tiles_c * 32);
+    LAUNCH_CHECK("cmap_kmask");
+  }
   HIP_TRY(hipStreamSynchronize(s));
   map->crec = crec_out;
   map->dict = dict_out;
@@ -223,8 +259,8 @@ __global__ __launch_bounds__(256) void cmap_unpack_kernel(const uint32_t* __rest
   const int64_t gcols = cols + 2, gcell = (int64_t)(rows + 2) * gcols;
   if (idx >= gcell) return;
   const int r = (int)(idx / gcols) - 1, c = (int)(idx % gcols) - 1;
-  const int64_t tile = (int64_t)((r >> 2) + 1) * g.tiles_c + ((c >> g.lc) + 1);
-  const int within = ((r & 3) << g.lc) | (c & ((1 << g.lc) - 1));
+  const int64_t tile = (int64_t)((c >> 2) + 1) * g.tiles_r + ((r >> g.lc) + 1);
+  const int within = ((r & ((1 << g.lc) - 1)) << 2) | (c & 3);
   const uint32_t* w = crec + (tile * (4 << g.lc) + within) * g.cw;
   float* o = rec + idx * rf;
   for (int k = 0; k < rf; k++) o[k] = 0.f;

@@ -32,7 +32,7 @@ struct ScoreArgs {
   const uint32_t* crec;
   const float* dict;
   int dict_n;           // dictionary entries in use
-  int ctiles_c;         // tiles per tile row
+  int ctiles_r;         // tiles per tile column
 };
 
 #include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
   const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
-  const int ckconst = (a.ctiles_c + 1) * 128;
+  const int ckcol = a.ctiles_r * 128 - 16 * CW, ckconst = a.ctiles_r * 128 + 128;   // cmap_offset
   // The sample table is read-only for the whole launch and every lane of a wave reads the same entry: it is addressed
   // through the CONSTANT address space so that these are scalar loads whatever else the kernel contains.  (Left to its
   // own no-clobber analysis the compiler gives up in the compact kernel — the dictionary staging is one store too many —
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
     if constexpr (COMPACT) {
       // cells of the guard ring are zero records in their own right (distance 0, unknown): no select needed
-      return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
+      return cmap_offset<CW, LC>(ri, ci, ckcol, ckconst);
     } else {
 #if TDR_OOB_ALIAS
       // every out-of-bounds sample reads the SAME guard record (always cache-resident) instead of a distinct one
@@ -299,7 +299,7 @@ struct CartArgs {
   const uint32_t* crec;  // compact form of the records (COMPACT instantiations)
   const float* dict;
   int dict_n;
-  int ctiles_c;
+  int ctiles_r;
 };
 
 __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
   const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
   const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
   const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
-  const int ckconst = (a.ctiles_c + 1) * 128;
+  const int ckcol = a.ctiles_r * 128 - 16 * CW, ckconst = a.ctiles_r * 128 + 128;   // cmap_offset
   // the scan record of sample (i, j) is the same for every lane: read through the CONSTANT address space = scalar loads
   // whatever else the kernel contains (see score_polar_kernel)
   typedef const float __attribute__((address_space(4))) * tdr_const_f;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void score_cart_kernel(CartArgs a) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
     const bool inb = (unsigned)ri < (unsigned)a.map_rows && (unsigned)ci < (unsigned)a.map_cols;
-    if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
+    if constexpr (COMPACT) return cmap_offset<CW, LC>(ri, ci, ckcol, ckconst);
     else return inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u;
   };
   auto column_terms = [&](int j) -> tdr_v2f {
@@ -1542,17 +1542,17 @@ static bool map_has_compact(const tdr_map_desc* map, int rf) {
     return false;
   if (map->dict_n > (map_is_wide(map, rf) ? TDR_CMAP_WIDE_MAX_DICT : TDR_CMAP_MAX_DICT)) return false;
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-  return (int64_t)((map->cols >> lc) + 2) * 128 < (1 << 23);   // cmap_offset multiplies with 24-bit operands
+  return (int64_t)((map->rows >> lc) + 2) * 128 < (1 << 23) && map->cols < (1 << 24);   // cmap_offset: 24-bit operands
 }
 static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s) {
-  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_c = 0;
+  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_r = 0;
   ScoreProfScope prof(s);
   if (!map_has_compact(map, rf)) return launch_score_form<false>(a, rf, ncls, s);
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   a.crec = map->crec;
   a.dict = map->dict;
   a.dict_n = map->dict_n;
-  a.ctiles_c = (map->cols >> lc) + 2;
+  a.ctiles_r = (map->rows >> lc) + 2;
   if (map_is_wide(map, rf)) {   // more than 1024 distinct values: 16-bit fields, a 16 KB dictionary in LDS
     dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
     const size_t lds = (size_t)a.nb * ((a.group * 2) | 1) * 16;
@@ -1877,10 +1877,10 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   dim3 grid((unsigned)cdiv(n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
   const bool cm = map_has_compact(map, rf), wide = cm && map_is_wide(map, rf);
-  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_c = 0;
+  a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_r = 0;
   if (cm) {
     const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-    a.crec = map->crec; a.dict = map->dict; a.dict_n = map->dict_n; a.ctiles_c = (map->cols >> lc) + 2;
+    a.crec = map->crec; a.dict = map->dict; a.dict_n = map->dict_n; a.ctiles_r = (map->rows >> lc) + 2;
   }
   {
     ScoreProfScope prof(s);

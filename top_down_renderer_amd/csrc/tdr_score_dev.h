@@ -28,21 +28,22 @@ template <int RF, bool KSLOT>
 struct CmapShape {
   static constexpr int ND = KSLOT ? RF - 2 : RF - 1;                               // distance slots of a record
   static constexpr int CW = (ND + 2) / 3 <= 1 ? 1 : ((ND + 2) / 3 == 2 ? 2 : 4);   // dwords of a compact record
-  static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = 4 rows x (1 << LC) columns
+  static constexpr int LC = CW == 1 ? 3 : (CW == 2 ? 2 : 1);                       // tile = (1 << LC) rows x 4 columns
 };
 // Byte offset of cell (ri, ci), ri in [-1, rows], ci in [-1, cols] (the clamped sample coordinate): it lives in tile
-// ((ri >> 2) + 1, (ci >> LC) + 1) at (ri & 3, ci & (2^LC - 1)); ckconst = (tiles_c + 1) * 128.  Cells outside the map are
-// guard records (distance 0, unknown).  Written separably — 128 * tile + 32 * (ri & 3) + RB * (ci & ..) =
-// [32 ri + (ri >> 2)(128 tiles_c - 128)] + [RB ci + 96 (ci >> LC)] with RB = 4 CW record bytes — it is six integer ops.
+// ((ri >> LC) + 1, (ci >> 2) + 1) — tiles ordered column by column, tiles_r per column — at record
+// (ri & (2^LC - 1)) * 4 + (ci & 3) (tdr_cmap.hip).  Cells outside the map are guard records (distance 0, unknown).
+// With RB = 4 CW record bytes, CS = 128 tiles_r bytes per tile column and 2^LC * 4 RB = 128 the offset is separable and
+// its row part linear:
+//     128 * tile + RB * ((ri & ..) * 4 + (ci & 3)) = (ci >> 2) * (CS - 4 RB) + ci * RB + ri * 4 RB + (CS + 128)
+// ckcol = CS - 4 RB, ckconst = CS + 128: four integer ops.
 template <int CW, int LC>
-__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ctiles_c, int ckconst) {
-  // spelled out: the compiler would otherwise emit the two products and the two shifts as separate instructions (8)
-  int t1, t2, t3, off;
-  const int rq = ri >> 2, cq = ci >> LC, krow = ctiles_c * 128 - 128, kcol = 96;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(rq), "s"(krow), "v"(ckconst));   // one SGPR operand at most
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t2) : "v"(cq), "v"(kcol), "v"(t1));
-  asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(t3) : "v"(ri), "v"(t2));
-  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t3));
+__device__ __forceinline__ unsigned cmap_offset(int ri, int ci, int ckcol, int ckconst) {
+  int t1, t2, off;
+  const int cq = ci >> 2;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "s"(ckcol), "v"(ckconst));   // one SGPR operand at most
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
   return (unsigned)off;
 }
 template <int CW>

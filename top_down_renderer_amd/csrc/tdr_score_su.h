@@ -9,8 +9,8 @@ static inline int64_t su_npad(int64_t n, int nb) { return cdiv(n + 63 * std::min
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
 // The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
 struct SuWs {
-  int64_t tab_su, desc, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, total;
-  // ints: [cnt nb][start nb][slot_start nb][nslots 1][flags 1]
+  int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, total;
+  // ints: [cnt nb][start nb][slot_start nb][nslots 1]
 };
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
 

@@ -6,16 +6,18 @@
 // empty in every class and a non-empty bin holds ~1.0 class (90 % of the class-bins are zero).
 //
 // Here the particles are processed in (shift, Morton) order with every shift bucket padded to whole waves, so the shift
-// is WAVE-uniform: the scan side of a sample becomes a scalar operand (a two-dword descriptor read through the scalar
-// cache — no LDS scan image) and "this bin is empty" / "this bin holds class c only" are wave-uniform branches:
-//   empty bin          coordinates + record load + the `known` bit                  (14 vector instructions)
-//   one class present  ... + one dictionary decode + 2 FMAs (class, normalisation)  (~19)
-//   several classes    the packed scan record through scalar loads, one decode + FMA per class present
-// against ~30 for every sample in score_polar_kernel.  Skipping an FMA whose scan operand is zero leaves the accumulator
+// is WAVE-uniform: the scan side of a sample is a scalar operand (a four-dword descriptor read through the scalar cache —
+// no LDS scan image) and "this bin is empty" / "this bin holds class c only" are wave-uniform branches:
+//   every sample        coordinates + the `known` bit from the KNOWN MASK (tdr_cmap.hip), which the workgroup stages in LDS
+//                       for the part of the map the windows of its 256 particles cover in the current sector of directions
+//   one class present   + ONE dword of the compact record (4-byte gather), one dictionary decode, 2 FMAs (class, norm)
+//   several classes     the packed scan record through scalar loads, one decode + FMA per class present
+// An empty bin — 44 % of the samples — touches no map record at all; a 64-lane gather is what the L1 address path prices
+// highest (>= 16 cycles per CU, tools/ta_cost.hip).  Skipping an FMA whose scan operand is zero leaves the accumulator
 // unchanged bit for bit (fma(0, m, acc) == acc for finite m, acc never -0), and the samples of a particle are visited in
 // the same order — direction ascending, ring ascending within the group — with the same partition into per-group partial
-// sums, so both kernels produce IDENTICAL partial sums (tests/test_gpu_parity.py::test_shift_uniform_*).  A dictionary
-// holding a non-finite value (0 * inf = NaN must not be skipped) turns the skipping off (flags[0], set by su_prep_kernel).
+// sums, so both kernels produce IDENTICAL partial sums (tests/test_shift_uniform.py).  Non-finite dictionary or scan
+// values (0 * inf = NaN must not be skipped) turn the skipping off bin by bin (descriptor code SU_CODE_FULL_ALL).
 //
 // Per launch (all on the caller's stream, nothing synchronises):
 //   su_key_kernel      heading bin of every particle (in the caller's locality order) + histogram of the bins
@@ -23,28 +25,36 @@
 //   su_offsets_kernel  bucket starts in the sorted list and in the padded slot list, number of slots in use
 //   su_scatter_kernel  slot -> particle (-1 = padding)
 //   su_prep_kernel     per (direction, ring): sample offset and scan descriptor, group-major (a wave streams them in order)
+//   su_bbox_kernel     bounding box of the sample offsets of every (ring group, sector of directions)
 //   score_polar_su_kernel, then score_finalize_kernel over the slots
 //
 // Compiled with -mllvm -structurizecfg-skip-uniform-regions (build.py): the per-sample dispatch on the descriptor is a
 // tree of wave-uniform branches; left to the structuriser each leaf is followed by copies of all accumulators (phi
 // merges of its flow blocks: 128 v_mov_b64 in the loop), with uniform regions skipped the leaves are 3-4 instructions.
+// Memory operations of the loop are inline assembly with ONE explicit wait per step: the compiler's own placement
+// serialises the four record loads of a step as soon as one of them is conditional.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "tdr_score_dev.h"
 #include "tdr_score_su.h"
 
-#define SU_CODE_FULL 0xFFFFFFFFu
+#define SU_CODE_FULL 0xFFu       // several classes present: packed scan record, classes with a zero count skipped
+#define SU_CODE_FULL_ALL 0xFEu   // a non-finite value is in play: every class multiplied like score_polar_kernel does
+#define SU_NSECT 8               // sectors of directions per known-mask staging
+#define SU_BOX_WORDS 3072        // LDS words of the staged known mask (12 KB: occupancy stays at 8 waves per SIMD)
 
 struct SuArgs {
   const uint32_t* crec;    // compact records (narrow form)
+  const uint32_t* kmask;   // the map's known mask (behind the tiles of crec)
+  int kwpr;                // its words per row
   const float* dict;
-  int dict_n, ctiles_c;
+  int dict_n, ctiles_r;
   int rows, cols;          // map
   float resolution;
   const float* tab_su;     // [nchunks][nb][group][2]: (tab*scale)*res (USCALE) or tab
-  const uint32_t* desc;    // [nchunks][nb][group][2]: {code, value bits} of scan bin (row, ring)
+  const uint32_t* desc;    // [nchunks][nb][group][4]: scan descriptor of bin (row, ring), see su_prep_kernel
+  const float* bbox;       // [nchunks][SU_NSECT][4]: min / max of tab_su's two coordinates over the sector
   const float* scan_pk;    // [nr][nb][rf]: read for bins holding several classes
-  const int* flags;        // [0] != 0: never skip (non-finite dictionary value)
   int nb, nr;
   float res;
   const float* st;
@@ -56,18 +66,20 @@ struct SuArgs {
   float* part;             // [nchunks][rf+1][npad]
 };
 
-// descriptor code: 0 = every class zero; c + 1 = class c alone is non-zero (value = its count = the bin's sum);
-// SU_CODE_FULL = several classes (value = the bin's sum, slot rf-1 of the packed record)
+// Scan descriptor of a bin, four dwords:
+//   [0] code: 0 = every class zero; c + 1 = class c alone is non-zero; SU_CODE_FULL = several classes;
+//       SU_CODE_FULL_ALL = a non-finite dictionary / scan value: no skipping in this bin
+//   [1] the bin's sum over the classes (float bits; slot rf-1 of the packed record) — for a single class: its value
+//   [2] the constant of the record offset (cmap_offset) advanced to the dword the class lives in: ckconst + 4 * (c / 3)
+//   [3] 0
 __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk,
-                                                      int nb, int nr, int rf, int ncls, int group, int nchunks,
+                                                      int nb, int nr, int rf, int ncls, int ckconst, int group, int nchunks,
                                                       const float* __restrict__ dict, int dict_n, float* __restrict__ tab_su,
-                                                      uint32_t* __restrict__ desc, int* __restrict__ flags) {
+                                                      uint32_t* __restrict__ desc) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0) {
-    bool bad = false;
-    for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
-    if (bad) atomicOr(flags, 1);
-  }
+  bool bad = false;   // the dictionary is small: every workgroup checks it for itself
+  for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
+  const bool dict_bad = __syncthreads_or(bad);
   const int64_t total = (int64_t)nchunks * nb * group;
   if (t >= total) return;
   const int jj = (int)(t % group);
@@ -75,25 +87,60 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
   const int i = (int)(q % nb), chunk = (int)(q / nb);
   const int j = chunk * group + jj;
   float tx = 0.f, ty = 0.f, val = 0.f;
-  uint32_t code = 0;
+  uint32_t code = 0, ckc = (uint32_t)ckconst;
   if (j < nr) {
     const int64_t k = (int64_t)j * nb + i;
     tx = tab[2 * k];
     ty = tab[2 * k + 1];
     const float* r = scan_pk + k * rf;
     int nz = 0, first = 0;
-    for (int c = 0; c < ncls; c++)
+    bool finite = true;
+    for (int c = 0; c < ncls; c++) {
+      finite &= fabsf(r[c]) <= 3.402823466e+38f;
       if (r[c] != 0.f) {
         if (!nz) first = c;
         nz++;
       }
-    if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; }
+    }
+    if (dict_bad || !finite) { code = SU_CODE_FULL_ALL; val = r[rf - 1]; }
+    else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc += 4u * (uint32_t)(first / 3); }
     else if (nz > 1) { code = SU_CODE_FULL; val = r[rf - 1]; }
   }
   tab_su[2 * t] = tx;
   tab_su[2 * t + 1] = ty;
-  desc[2 * t] = code;
-  desc[2 * t + 1] = __float_as_uint(val);
+  desc[4 * t] = code;
+  desc[4 * t + 1] = __float_as_uint(val);
+  desc[4 * t + 2] = ckc;
+  desc[4 * t + 3] = 0u;
+}
+
+// bounding box of the sample offsets of ring group blockIdx.x, sector blockIdx.y (directions [sect nb / NSECT, ...))
+__global__ __launch_bounds__(256) void su_bbox_kernel(const float* __restrict__ tab_su, int nb, int nr, int group,
+                                                      float* __restrict__ bbox) {
+  const int chunk = blockIdx.x, sect = blockIdx.y;
+  const int i0 = (int)((int64_t)sect * nb / SU_NSECT), i1 = (int)((int64_t)(sect + 1) * nb / SU_NSECT);
+  const int gn = min(nr - chunk * group, group);
+  float lo0 = 3.402823466e+38f, hi0 = -3.402823466e+38f, lo1 = lo0, hi1 = hi0;
+  const int cnt = (i1 - i0) * gn;
+  for (int t = threadIdx.x; t < cnt; t += 256) {
+    const int i = i0 + t / gn, jj = t % gn;
+    const float* e = tab_su + (((int64_t)chunk * nb + i) * group + jj) * 2;
+    lo0 = fminf(lo0, e[0]); hi0 = fmaxf(hi0, e[0]);
+    lo1 = fminf(lo1, e[1]); hi1 = fmaxf(hi1, e[1]);
+  }
+  __shared__ float red[4][256];
+  red[0][threadIdx.x] = lo0; red[1][threadIdx.x] = hi0; red[2][threadIdx.x] = lo1; red[3][threadIdx.x] = hi1;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) {
+      red[0][threadIdx.x] = fminf(red[0][threadIdx.x], red[0][threadIdx.x + d]);
+      red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + d]);
+      red[2][threadIdx.x] = fminf(red[2][threadIdx.x], red[2][threadIdx.x + d]);
+      red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + d]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) bbox[((int64_t)chunk * SU_NSECT + sect) * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 __global__ __launch_bounds__(256) void su_key_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
@@ -152,19 +199,23 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
 
 // lane = particle; every wave holds particles of ONE heading bin (see the file comment).  grid.y = group of a.group
 // consecutive range rings (score_group_rings: a multiple of 4, nr a multiple of 4), samples visited ray-major like
-// score_polar_kernel: direction i ascending, the group's rings in steps of 4 consecutive cells along the ray.
+// score_polar_kernel: direction i ascending, the group's rings in steps of 4 consecutive cells along the ray.  The
+// directions are walked in SU_NSECT sectors; for each the workgroup stages the known mask of the cells its windows can reach.
 template <int NV4, bool KSLOT, bool USCALE>
 __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   constexpr int RF = 4 * NV4;
   constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
   __shared__ float ldict[TDR_CMAP_MAX_DICT];
+  __shared__ uint32_t lbits[SU_BOX_WORDS];
+  __shared__ int sbox[4];
   for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nsl = (int64_t)*a.nslots;
+  if ((int64_t)blockIdx.x * 256 >= nsl) return;   // the whole workgroup is beyond the slots in use (uniform)
   const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
-  if (base >= (int64_t)*a.nslots) return;   // wave-uniform; no barrier follows
-  const int32_t sp = a.slots[base + lane];
-  const int32_t p0 = __builtin_amdgcn_readfirstlane(sp);   // a batch's first slot is never padding
+  const bool active = base < nsl;                 // wave-uniform; an idle wave still keeps the barriers below
+  const int32_t sp = active ? a.slots[base + lane] : -1;
+  const int32_t p0 = a.slots[active ? base : (int64_t)blockIdx.x * 256];   // a batch's first slot is never padding
   const int64_t p = sp >= 0 ? sp : p0;
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
@@ -175,31 +226,28 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   const int nb = a.nb, G = a.group;
   const int j0 = blockIdx.y * G, gn = min(a.nr - j0, G);
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
-  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
-  const int ckconst = (a.ctiles_c + 1) * 128;
+  const int ckcol = a.ctiles_r * 128 - 16 * CW;   // cmap_offset; its constant comes with the descriptor
   typedef const float __attribute__((address_space(4))) * tdr_const_f;
   typedef const uint32_t __attribute__((address_space(4))) * tdr_const_u;
   const tdr_const_f tbase = (tdr_const_f)a.tab_su + (int64_t)blockIdx.y * nb * G * 2;
-  const tdr_const_u dbase = (tdr_const_u)a.desc + (int64_t)blockIdx.y * nb * G * 2;
+  const tdr_const_u dbase = (tdr_const_u)a.desc + (int64_t)blockIdx.y * nb * G * 4;
+  const tdr_const_f bbase = (tdr_const_f)a.bbox + (int64_t)blockIdx.y * SU_NSECT * 4;
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
-  const bool noskip = *(const int __attribute__((address_space(4)))*)a.flags != 0;
+  const uint32_t* __restrict__ crec = a.crec;
+  const uint32_t* __restrict__ kmask = a.kmask;
+  const unsigned lbits_lds = (unsigned)(uintptr_t)lbits;   // LDS byte address of the staged mask
 
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));
   const tdr_v2f offv = {off0, off1};
-  auto cell_offset = [&](float tx, float ty) -> unsigned {
-    tdr_v2f pv = {tx, ty};
-    if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
-    pv = pv + offv;                                     // :29-30
-    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
-    qv = qv + 0.49999997f;                              // round_half_away_clamped
-    int ri, ci;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
-    return cmap_offset<CW, LC>(ri, ci, a.ctiles_c, ckconst);
-  };
-  // distance k of a compact record (cmap_decode, one field)
-  auto field = [&](const uint32_t (&w)[CW], int k) -> float {
+  // what scale * res does to a sample offset of this lane, for the sector boxes (USCALE: tab_su carries it already)
+  const bool weird = !(fabsf(off0) <= 1e9f) || !(fabsf(off1) <= 1e9f) || (!USCALE && !(fabsf(scale * a.res) <= 1e9f));
+  auto field = [&](const uint32_t (&w)[CW], int k) -> float {   // distance k of a compact record (cmap_decode, one field)
     const uint32_t ww = w[k / 3];
+    const int sh = 10 * (k % 3);
+    const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+  };
+  auto field1 = [&](uint32_t ww, int k) -> float {   // ... when the sample loaded only the dword class k lives in
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
@@ -211,61 +259,152 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   float norm = 0.f;
   uint32_t known = 0;
 
-  for (int i = 0; i < nb; i++) {
-    int r = i + shift;
-    r -= r >= nb ? nb : 0;
-    const tdr_const_f T = tbase + (int64_t)i * G * 2;
-    const tdr_const_u D = dbase + (int64_t)r * G * 2;
-    for (int jj = 0; jj < gn; jj += 4) {
-      float tx[4], ty[4], val[4];
-      uint32_t code[4];
+  // One sector of directions [i0, i1).  Known bits come from word  ri * krow4 + (ci >> 5) * 4 + kconst  of the staged
+  // mask in LDS (LDSMASK) or of the map's own mask in global memory (a workgroup whose windows are too far apart).
+  auto run_sector = [&](auto ldsmask, int i0, int i1, int krow4, int kconst) {
+    constexpr bool LDSMASK = decltype(ldsmask)::value;
+    for (int i = i0; i < i1; i++) {
+      int r = i + shift;
+      r -= r >= nb ? nb : 0;
+      const tdr_const_f T = tbase + (int64_t)i * G * 2;
+      const tdr_const_u D = dbase + (int64_t)r * G * 4;
+      for (int jj = 0; jj < gn; jj += 4) {
+        float tx[4], ty[4], val[4];
+        uint32_t code[4], ckc[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        tx[u] = T[2 * (jj + u)];
-        ty[u] = T[2 * (jj + u) + 1];
-        code[u] = D[2 * (jj + u)];
-        val[u] = __uint_as_float(D[2 * (jj + u) + 1]);
-      }
-      uint32_t w[4][CW];
+        for (int u = 0; u < 4; u++) {
+          tx[u] = T[2 * (jj + u)];
+          ty[u] = T[2 * (jj + u) + 1];
+          code[u] = D[4 * (jj + u)];
+          val[u] = __uint_as_float(D[4 * (jj + u) + 1]);
+          ckc[u] = D[4 * (jj + u) + 2];
+        }
+        uint32_t w[4], bits[4];
+        int cis[4];
+        unsigned offs[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) cmap_load<CW>(crecb, cell_offset(tx[u], ty[u]), w[u]);
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t kb = w[u][CW - 1] & 1u;
-        known += kb;
-        const uint32_t cd = noskip ? SU_CODE_FULL : code[u];
-        if (cd != 0) {   // wave-uniform
-          norm = __builtin_fmaf(val[u], (float)kb, norm);   // the bin's sum x known (state_particle.cpp:141-142)
-          if (cd != SU_CODE_FULL) {
-            switch (cd) {   // wave-uniform
-#define SU_CASE(K)                                                            \
-  case K + 1:                                                                 \
-    if constexpr (K < ND) acc[K < ND ? K : 0] = __builtin_fmaf(val[u], field(w[u], K < ND ? K : 0), acc[K < ND ? K : 0]); \
-    break;
-              SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
-              SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
-#undef SU_CASE
-              default: break;
-            }
+        for (int u = 0; u < 4; u++) {
+          tdr_v2f pv = {tx[u], ty[u]};
+          if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
+          pv = pv + offv;                                     // :29-30
+          tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+          qv = qv + 0.49999997f;                              // round_half_away_clamped
+          int ri, ci;
+          asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+          asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+          cis[u] = ci;
+          int wa;
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(wa) : "v"(ri), "v"(krow4), "s"(kconst));
+          const int cw5 = ci >> 5;
+          unsigned la;
+          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
+          if constexpr (LDSMASK) asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
+          else asm volatile("global_load_dword %0, %1, %2" : "=v"(bits[u]) : "v"(la), "s"(kmask));
+          if (code[u] != 0) {   // wave-uniform: only a non-empty bin needs its record — one dword of it
+            int t1, t2;
+            const int cq = ci >> 2;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc[u]));
+            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
+            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
           } else {
-            const tdr_const_f S = scanc + ((int64_t)(j0 + jj + u) * nb + r) * RF;
+            asm volatile("" : "=v"(w[u]), "=v"(offs[u]));   // not read
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
 #pragma unroll
-            for (int k = 0; k < ND; k++) {
-              const float sk = S[k];
-              if (noskip || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(w[u], k), acc[k]);
+        for (int u = 0; u < 4; u++) {
+          int kmsk;   // 0 / -1: the cell's known bit
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(bits[u]), "v"(cis[u]));
+          known -= (uint32_t)kmsk;
+          const uint32_t cd = code[u];
+          if (cd != 0) {   // wave-uniform
+            if (cd < SU_CODE_FULL_ALL) {
+              // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
+              norm = norm + __uint_as_float((uint32_t)kmsk & __float_as_uint(val[u]));
+              switch (cd) {   // wave-uniform
+#define SU_CASE(K)                                                                                          \
+  case K + 1:                                                                                               \
+    if constexpr (K < ND) {                                                                                 \
+      const float m = field1(w[u], K < ND ? K : 0);                                                         \
+      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(val[u]), "v"(m));              \
+    }                                                                                                       \
+    break;
+                SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
+                SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
+#undef SU_CASE
+                default: break;
+              }
+            } else {   // several classes (or a non-finite value in play): the whole record, the packed scan record
+              uint32_t wr[CW];
+              wr[0] = w[u];
+#pragma unroll
+              for (int d = 1; d < CW; d++)
+                wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
+              const tdr_const_f S = scanc + ((int64_t)(j0 + jj + u) * nb + r) * RF;
+              norm = __builtin_fmaf(val[u], (float)(kmsk & 1), norm);
+#pragma unroll
+              for (int k = 0; k < ND; k++) {
+                const float sk = S[k];
+                if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
+              }
             }
           }
         }
       }
     }
-  }
-  const int64_t slot = base + lane;
-  float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+  };
+
+  for (int sect = 0; sect < SU_NSECT; sect++) {
+    const int i0 = (int)((int64_t)sect * nb / SU_NSECT), i1 = (int)((int64_t)(sect + 1) * nb / SU_NSECT);
+    // cells this lane's samples of the sector can fall on: rounding is monotone, so the box of the offsets carries over
+    float a0 = bbase[4 * sect], b0 = bbase[4 * sect + 1], a1 = bbase[4 * sect + 2], b1 = bbase[4 * sect + 3];
+    if constexpr (!USCALE) {
+      const float x0 = (a0 * scale) * a.res, y0 = (b0 * scale) * a.res, x1 = (a1 * scale) * a.res, y1 = (b1 * scale) * a.res;
+      a0 = fminf(x0, y0); b0 = fmaxf(x0, y0); a1 = fminf(x1, y1); b1 = fmaxf(x1, y1);
+    }
+    int rl = (int)fminf(fmaxf(floorf(a0 + off0) - 1.f, -1.f), rmaxf), rh = (int)fminf(fmaxf(ceilf(b0 + off0) + 1.f, -1.f), rmaxf);
+    int cl = (int)fminf(fmaxf(floorf(a1 + off1) - 1.f, -1.f), cmaxf), ch = (int)fminf(fmaxf(ceilf(b1 + off1) + 1.f, -1.f), cmaxf);
+    if (weird) { rl = -1; rh = a.rows; cl = -1; ch = a.cols; }
+    if (!active) { rl = 0x7FFFFFFF; rh = -0x7FFFFFFF; cl = 0x7FFFFFFF; ch = -0x7FFFFFFF; }
 #pragma unroll
-  for (int k = 0; k < ND; k++)
-    if (k < a.ncls) o[(int64_t)k * a.npad] = acc[k];
-  o[(int64_t)(RF - 1) * a.npad] = norm;
-  o[(int64_t)RF * a.npad] = (float)known;
+    for (int d = 32; d > 0; d >>= 1) {
+      rl = min(rl, __shfl_xor(rl, d)); rh = max(rh, __shfl_xor(rh, d));
+      cl = min(cl, __shfl_xor(cl, d)); ch = max(ch, __shfl_xor(ch, d));
+    }
+    __syncthreads();   // the previous sector's lookups are done (and, the first time, the dictionary is staged)
+    if (threadIdx.x == 0) { sbox[0] = 0x7FFFFFFF; sbox[1] = -0x7FFFFFFF; sbox[2] = 0x7FFFFFFF; sbox[3] = -0x7FFFFFFF; }
+    __syncthreads();
+    if (lane == 0 && active) {
+      atomicMin(&sbox[0], rl); atomicMax(&sbox[1], rh); atomicMin(&sbox[2], cl); atomicMax(&sbox[3], ch);
+    }
+    __syncthreads();
+    const int rlo = sbox[0], rhi = sbox[1], wlo = (sbox[2] >> 5) + 1, whi = (sbox[3] >> 5) + 1;   // mask rows / words
+    const int H = rhi - rlo + 1, Wb = whi - wlo + 1;
+    const bool fits = (int64_t)H * Wb <= SU_BOX_WORDS;   // uniform over the workgroup
+    if (fits) {
+      const int total = H * Wb;
+      for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int row = idx / Wb, wc = idx - row * Wb;
+        lbits[idx] = kmask[(int64_t)(rlo + 1 + row) * a.kwpr + (wlo + wc)];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      if (fits) run_sector(std::true_type{}, i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4);
+      else run_sector(std::false_type{}, i0, i1, a.kwpr * 4, (a.kwpr + 1) * 4);
+    }
+  }
+  if (active) {
+    const int64_t slot = base + lane;
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      if (k < a.ncls) o[(int64_t)k * a.npad] = acc[k];
+    o[(int64_t)(RF - 1) * a.npad] = norm;
+    o[(int64_t)RF * a.npad] = (float)known;
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -278,6 +417,7 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
   if (mode >= 0) g_su_mode = mode > 2 ? 2 : mode;
   return g_su_mode;
 }
+extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
 static int64_t g_su_launches = 0;
 extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches; }
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
@@ -298,11 +438,12 @@ static size_t su_sort_tmp_bytes(int64_t n) {
 }
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   SuWs w;
-  const int64_t nchunks = cdiv(nr, group), desc_words = nchunks * nb * group * 2;
+  const int64_t nchunks = cdiv(nr, group), nbins = nchunks * nb * group;
   int64_t o = 0;
   auto take = [&](int64_t words) { const int64_t at = o; o += (words + 63) / 64 * 64; return at; };   // 256-byte aligned
-  w.tab_su = take(desc_words);
-  w.desc = take(desc_words);
+  w.tab_su = take(2 * nbins);
+  w.desc = take(4 * nbins);
+  w.bbox = take(nchunks * SU_NSECT * 4);
   w.keys_in = take(n);
   w.keys_out = take(n);
   w.vals_in = take(n);
@@ -326,10 +467,9 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   int* start = cnt + L.nb;
   int* slot_start = start + L.nb;
   int* nslots = slot_start + L.nb;
-  int* flags = nslots + 1;
   int32_t* slots = base + W.slots;
   const int64_t n = L.n;
-  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * L.nb + 2), s));
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * L.nb + 1), s));
   HIP_TRY(hipMemsetAsync(slots, 0xFF, sizeof(int32_t) * (size_t)L.npad, s));
   hipLaunchKernelGGL(su_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, L.st, L.cap, n, L.perm, L.nb, keys_in,
                      vals_in, cnt);
@@ -345,9 +485,14 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
                      (const int32_t*)vals_out, n, (const int*)start, (const int*)slot_start, slots);
   LAUNCH_CHECK("su_scatter");
   const int64_t ndesc = (int64_t)L.nchunks * L.nb * L.group;
+  const int lc = L.map->cwords == 1 ? 3 : (L.map->cwords == 2 ? 2 : 1);
+  const int ckconst = ((L.map->rows >> lc) + 2) * 128 + 128;   // cmap_offset (tdr_score_dev.h)
   hipLaunchKernelGGL(su_prep_kernel, dim3((unsigned)cdiv(ndesc, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
-                     L.map->ncls, L.group, L.nchunks, L.map->dict, L.map->dict_n, tab_su, desc, flags);
+                     L.map->ncls, ckconst, L.group, L.nchunks, L.map->dict, L.map->dict_n, tab_su, desc);
   LAUNCH_CHECK("su_prep");
+  hipLaunchKernelGGL(su_bbox_kernel, dim3((unsigned)L.nchunks, SU_NSECT), dim3(256), 0, s, (const float*)tab_su, L.nb, L.nr,
+                     L.group, reinterpret_cast<float*>(base + W.bbox));
+  LAUNCH_CHECK("su_bbox");
   *slots_out = slots;
   *nslots_out = nslots;
   return TDR_OK;
@@ -359,11 +504,14 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   int* nslots = base + W.ints + 3 * L.nb;
   SuArgs u;
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-  u.crec = map->crec; u.dict = map->dict; u.dict_n = map->dict_n; u.ctiles_c = (map->cols >> lc) + 2;
+  u.crec = map->crec; u.dict = map->dict; u.dict_n = map->dict_n; u.ctiles_r = (map->rows >> lc) + 2;
   u.rows = map->rows; u.cols = map->cols; u.resolution = map->resolution;
   u.tab_su = reinterpret_cast<const float*>(base + W.tab_su);
   u.desc = reinterpret_cast<const uint32_t*>(base + W.desc);
-  u.scan_pk = L.scan_pk; u.flags = nslots + 1;
+  u.bbox = reinterpret_cast<const float*>(base + W.bbox);
+  u.kmask = map->crec + tdr_cmap_tile_words(map->ncls, map->rows, map->cols);
+  u.kwpr = (map->cols >> 5) + 2;
+  u.scan_pk = L.scan_pk;
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
   u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = L.part;
