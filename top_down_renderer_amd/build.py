@@ -14,7 +14,7 @@ SRC = [os.path.join(PKG, "csrc", f) for f in
        ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_score_su.hip", "tdr_filter.hip", "tdr_prefix.hip",
         "tdr_geo.hip", "tdr_cmap.hip", "tdr_host.cpp", "tdr_comm.cpp", "tdr_gmm.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h")] + \
-      [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h")]
+      [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h", "tdr_score_su_asm.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 OBJ_DIR = os.path.join(PKG, "_obj")
 

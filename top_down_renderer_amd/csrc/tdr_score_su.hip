@@ -37,6 +37,7 @@
 
 #include "tdr_score_dev.h"
 #include "tdr_score_su.h"
+#include "tdr_score_su_asm.h"
 
 #define SU_CODE_FULL 0xFFu       // several classes present: packed scan record, classes with a zero count skipped
 #define SU_CODE_FULL_ALL 0xFEu   // a non-finite value is in play: every class multiplied like score_polar_kernel does
@@ -64,6 +65,8 @@ struct SuArgs {
   int group, nchunks, ncls;
   int64_t npad;            // stride of `part`
   float* part;             // [nchunks][rf+1][npad]
+  int use_asm;             // 0: the C++ loop everywhere (TDR_SU_ASM=0; A/B and debugging)
+  const uint32_t* dbg;     // SU_ASM_DEBUG builds: offset limits in, largest offsets out
 };
 
 // Scan descriptor of a bin, four dwords:
@@ -71,7 +74,8 @@ struct SuArgs {
 //       SU_CODE_FULL_ALL = a non-finite dictionary / scan value: no skipping in this bin
 //   [1] the bin's sum over the classes (float bits; slot rf-1 of the packed record) — for a single class: its value
 //   [2] the constant of the record offset (cmap_offset) advanced to the dword the class lives in: ckconst + 4 * (c / 3)
-//   [3] 0
+//   [3] bits 0-4: the bit offset of the class's field in that dword minus 2 (10 * (c % 3)); bit 31, on the first bin of a
+//       step (4 consecutive rings) only: one of the step's bins is SU_CODE_FULL / SU_CODE_FULL_ALL
 __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk,
                                                       int nb, int nr, int rf, int ncls, int ckconst, int group, int nchunks,
                                                       const float* __restrict__ dict, int dict_n, float* __restrict__ tab_su,
@@ -81,14 +85,15 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
   for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
   const bool dict_bad = __syncthreads_or(bad);
   const int64_t total = (int64_t)nchunks * nb * group;
-  if (t >= total) return;
-  const int jj = (int)(t % group);
-  const int64_t q = t / group;
+  const bool live = t < total;
+  const int64_t tt = live ? t : 0;
+  const int jj = (int)(tt % group);
+  const int64_t q = tt / group;
   const int i = (int)(q % nb), chunk = (int)(q / nb);
   const int j = chunk * group + jj;
   float tx = 0.f, ty = 0.f, val = 0.f;
-  uint32_t code = 0, ckc = (uint32_t)ckconst;
-  if (j < nr) {
+  uint32_t code = 0, ckc = (uint32_t)ckconst, sh = 0;
+  if (live && j < nr) {
     const int64_t k = (int64_t)j * nb + i;
     tx = tab[2 * k];
     ty = tab[2 * k + 1];
@@ -103,15 +108,20 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
       }
     }
     if (dict_bad || !finite) { code = SU_CODE_FULL_ALL; val = r[rf - 1]; }
-    else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc += 4u * (uint32_t)(first / 3); }
+    else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc += 4u * (uint32_t)(first / 3); sh = 10u * (uint32_t)(first % 3); }
     else if (nz > 1) { code = SU_CODE_FULL; val = r[rf - 1]; }
   }
+  // steps are 4 consecutive bins (group is a multiple of 4, so they are 4 consecutive threads of a wave)
+  uint32_t anyfull = code >= SU_CODE_FULL_ALL ? 1u : 0u;
+  anyfull |= __shfl_xor(anyfull, 1);
+  anyfull |= __shfl_xor(anyfull, 2);
+  if (!live) return;
   tab_su[2 * t] = tx;
   tab_su[2 * t + 1] = ty;
   desc[4 * t] = code;
   desc[4 * t + 1] = __float_as_uint(val);
   desc[4 * t + 2] = ckc;
-  desc[4 * t + 3] = 0u;
+  desc[4 * t + 3] = sh | (((jj & 3) == 0 && anyfull) ? 0x80000000u : 0u);
 }
 
 // bounding box of the sample offsets of ring group blockIdx.x, sector blockIdx.y (directions [sect nb / NSECT, ...))
@@ -197,6 +207,13 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
   slots[slot_start[s] + ((int)t - start[s])] = vals[t];
 }
 
+// LDS of the scoring kernel, ONE object so that the dictionary sits at LDS address 0 (the assembly loop reads it there)
+struct SuLds {
+  float dict[TDR_CMAP_MAX_DICT];
+  uint32_t bits[SU_BOX_WORDS];   // the staged known mask: rows rlo..rhi of words wlo..whi of the map's mask
+  int box[4];
+};
+
 // lane = particle; every wave holds particles of ONE heading bin (see the file comment).  grid.y = group of a.group
 // consecutive range rings (score_group_rings: a multiple of 4, nr a multiple of 4), samples visited ray-major like
 // score_polar_kernel: direction i ascending, the group's rings in steps of 4 consecutive cells along the ray.  The
@@ -204,13 +221,12 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
 template <int NV4, bool KSLOT, bool USCALE>
 __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   constexpr int RF = 4 * NV4;
-  constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
-  __shared__ float ldict[TDR_CMAP_MAX_DICT];
-  __shared__ uint32_t lbits[SU_BOX_WORDS];
-  __shared__ int sbox[4];
-  for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t nsl = (int64_t)*a.nslots;
+  constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
+  constexpr bool ASM_LOOP = CW == 2 && ND == 6;   // tdr_score_su_asm.h: two-dword records
+  __shared__ SuLds lds;
+  for (int t = threadIdx.x; t < a.dict_n; t += 256) lds.dict[t] = a.dict[t];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+  const int64_t nsl = (int64_t)__builtin_amdgcn_readfirstlane(*a.nslots);
   if ((int64_t)blockIdx.x * 256 >= nsl) return;   // the whole workgroup is beyond the slots in use (uniform)
   const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
   const bool active = base < nsl;                 // wave-uniform; an idle wave still keeps the barriers below
@@ -235,22 +251,22 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
   const uint32_t* __restrict__ crec = a.crec;
   const uint32_t* __restrict__ kmask = a.kmask;
-  const unsigned lbits_lds = (unsigned)(uintptr_t)lbits;   // LDS byte address of the staged mask
+  const unsigned lds_base = (unsigned)(uintptr_t)&lds;                // LDS byte address of the dictionary ...
+  const unsigned lbits_lds = (unsigned)(uintptr_t)&lds.bits[0];      // ... and of the staged mask
 
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));
   const tdr_v2f offv = {off0, off1};
-  // what scale * res does to a sample offset of this lane, for the sector boxes (USCALE: tab_su carries it already)
   const bool weird = !(fabsf(off0) <= 1e9f) || !(fabsf(off1) <= 1e9f) || (!USCALE && !(fabsf(scale * a.res) <= 1e9f));
   auto field = [&](const uint32_t (&w)[CW], int k) -> float {   // distance k of a compact record (cmap_decode, one field)
     const uint32_t ww = w[k / 3];
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.dict) + boff);
   };
   auto field1 = [&](uint32_t ww, int k) -> float {   // ... when the sample loaded only the dword class k lives in
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.dict) + boff);
   };
 
   float acc[ND];
@@ -259,71 +275,68 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   float norm = 0.f;
   uint32_t known = 0;
 
-  // One sector of directions [i0, i1).  Known bits come from word  ri * krow4 + (ci >> 5) * 4 + kconst  of the staged
-  // mask in LDS (LDSMASK) or of the map's own mask in global memory (a workgroup whose windows are too far apart).
-  auto run_sector = [&](auto ldsmask, int i0, int i1, int krow4, int kconst) {
+  // One step: the 4 samples (i, j0 + jj .. jj + 3), paired with scan row r.  Known bits come from word
+  // ri * krow4 + (ci >> 5) * 4 + kconst of the staged mask in LDS (LDSMASK) or of the map's own mask in global memory (a
+  // workgroup whose windows are too far apart to stage).
+  auto cpp_step = [&](auto ldsmask, int i, int r, int jj, int krow4, int kconst) {
     constexpr bool LDSMASK = decltype(ldsmask)::value;
-    for (int i = i0; i < i1; i++) {
-      int r = i + shift;
-      r -= r >= nb ? nb : 0;
-      const tdr_const_f T = tbase + (int64_t)i * G * 2;
-      const tdr_const_u D = dbase + (int64_t)r * G * 4;
-      for (int jj = 0; jj < gn; jj += 4) {
-        float tx[4], ty[4], val[4];
-        uint32_t code[4], ckc[4];
+    const tdr_const_f T = tbase + ((int64_t)i * G + jj) * 2;
+    const tdr_const_u D = dbase + ((int64_t)r * G + jj) * 4;
+    float tx[4], ty[4], val[4];
+    uint32_t code[4], ckc[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          tx[u] = T[2 * (jj + u)];
-          ty[u] = T[2 * (jj + u) + 1];
-          code[u] = D[4 * (jj + u)];
-          val[u] = __uint_as_float(D[4 * (jj + u) + 1]);
-          ckc[u] = D[4 * (jj + u) + 2];
-        }
-        uint32_t w[4], bits[4];
-        int cis[4];
-        unsigned offs[4];
+    for (int u = 0; u < 4; u++) {
+      tx[u] = T[2 * u];
+      ty[u] = T[2 * u + 1];
+      code[u] = D[4 * u];
+      val[u] = __uint_as_float(D[4 * u + 1]);
+      ckc[u] = D[4 * u + 2];
+    }
+    uint32_t w[4], bits[4];
+    int cis[4];
+    unsigned offs[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          tdr_v2f pv = {tx[u], ty[u]};
-          if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
-          pv = pv + offv;                                     // :29-30
-          tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
-          qv = qv + 0.49999997f;                              // round_half_away_clamped
-          int ri, ci;
-          asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
-          asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
-          cis[u] = ci;
-          int wa;
-          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(wa) : "v"(ri), "v"(krow4), "s"(kconst));
-          const int cw5 = ci >> 5;
-          unsigned la;
-          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
-          if constexpr (LDSMASK) asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
-          else asm volatile("global_load_dword %0, %1, %2" : "=v"(bits[u]) : "v"(la), "s"(kmask));
-          if (code[u] != 0) {   // wave-uniform: only a non-empty bin needs its record — one dword of it
-            int t1, t2;
-            const int cq = ci >> 2;
-            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc[u]));
-            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
-            asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
-          } else {
-            asm volatile("" : "=v"(w[u]), "=v"(offs[u]));   // not read
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
+    for (int u = 0; u < 4; u++) {
+      tdr_v2f pv = {tx[u], ty[u]};
+      if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
+      pv = pv + offv;                                     // :29-30
+      tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+      qv = qv + 0.49999997f;                              // round_half_away_clamped
+      int ri, ci;
+      asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+      asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+      cis[u] = ci;
+      int wa;
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(wa) : "v"(ri), "v"(krow4), "s"(kconst));
+      const int cw5 = ci >> 5;
+      unsigned la;
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
+      if constexpr (LDSMASK) asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
+      else asm volatile("global_load_dword %0, %1, %2" : "=v"(bits[u]) : "v"(la), "s"(kmask));
+      if (code[u] != 0) {   // wave-uniform: only a non-empty bin needs its record — one dword of it
+        int t1, t2;
+        const int cq = ci >> 2;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc[u]));
+        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
+        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
+      } else {
+        asm volatile("" : "=v"(w[u]), "=v"(offs[u]));   // not read
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int kmsk;   // 0 / -1: the cell's known bit
-          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(bits[u]), "v"(cis[u]));
-          known -= (uint32_t)kmsk;
-          const uint32_t cd = code[u];
-          if (cd != 0) {   // wave-uniform
-            if (cd < SU_CODE_FULL_ALL) {
-              // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
-              norm = norm + __uint_as_float((uint32_t)kmsk & __float_as_uint(val[u]));
-              switch (cd) {   // wave-uniform
+    for (int u = 0; u < 4; u++) {
+      int kmsk;   // 0 / -1: the cell's known bit
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(bits[u]), "v"(cis[u]));
+      known -= (uint32_t)kmsk;
+      const uint32_t cd = code[u];
+      if (cd != 0) {   // wave-uniform
+        if (cd < SU_CODE_FULL_ALL) {
+          // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
+          norm = norm + __uint_as_float((uint32_t)kmsk & __float_as_uint(val[u]));
+          switch (cd) {   // wave-uniform
 #define SU_CASE(K)                                                                                          \
   case K + 1:                                                                                               \
     if constexpr (K < ND) {                                                                                 \
@@ -331,28 +344,91 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
       asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(val[u]), "v"(m));              \
     }                                                                                                       \
     break;
-                SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
-                SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
+            SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
+            SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
 #undef SU_CASE
-                default: break;
-              }
-            } else {   // several classes (or a non-finite value in play): the whole record, the packed scan record
-              uint32_t wr[CW];
-              wr[0] = w[u];
+            default: break;
+          }
+        } else {   // several classes (or a non-finite value in play): the whole record, the packed scan record
+          uint32_t wr[CW];
+          wr[0] = w[u];
 #pragma unroll
-              for (int d = 1; d < CW; d++)
-                wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
-              const tdr_const_f S = scanc + ((int64_t)(j0 + jj + u) * nb + r) * RF;
-              norm = __builtin_fmaf(val[u], (float)(kmsk & 1), norm);
+          for (int d = 1; d < CW; d++)
+            wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
+          const tdr_const_f S = scanc + ((int64_t)(j0 + jj + u) * nb + r) * RF;
+          norm = __builtin_fmaf(val[u], (float)(kmsk & 1), norm);
 #pragma unroll
-              for (int k = 0; k < ND; k++) {
-                const float sk = S[k];
-                if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
-              }
-            }
+          for (int k = 0; k < ND; k++) {
+            const float sk = S[k];
+            if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
           }
         }
       }
+    }
+  };
+  // One sector of directions [i0, i1)
+  auto run_sector = [&](auto ldsmask, int i0, int i1, int krow4, int kconst) {
+    constexpr bool LDSMASK = decltype(ldsmask)::value;
+    if constexpr (ASM_LOOP) {
+      if (a.use_asm && gn == G && lds_base == 0 && (G == 4 || G == 8 || G == 16)) {
+        // the steps of the sector as one stream: step k reads T at byte k * 32 from its start and D at byte k * 64 from the
+        // start of scan row (i0 + shift) mod nb, wrapping to row 0; the loop hands a step that holds a bin with several
+        // classes back (nleft >= 0 on exit), cpp_step does that one, and the loop goes on behind it
+        const int spd = G / 4;                                // steps per direction
+        int r0 = i0 + shift;
+        r0 -= r0 >= nb ? nb : 0;
+        // (readfirstlane: values the compiler cannot prove wave-uniform must not reach an "s" operand)
+        uint32_t toff = __builtin_amdgcn_readfirstlane((uint32_t)i0 * (uint32_t)G * 8u);
+        uint32_t doff = __builtin_amdgcn_readfirstlane((uint32_t)r0 * (uint32_t)G * 16u);
+        uint32_t nleft = __builtin_amdgcn_readfirstlane((uint32_t)((i1 - i0) * spd - 1));
+        uint32_t wleft = __builtin_amdgcn_readfirstlane((uint32_t)((nb - r0) * spd - 1));
+        const uint32_t wrapm1 = __builtin_amdgcn_readfirstlane((uint32_t)(nb * spd - 1));
+        const int kconst_s = __builtin_amdgcn_readfirstlane(kconst);
+        const uint64_t half2 = 0x3EFFFFFF3EFFFFFFull;         // {0.49999997f, 0.49999997f}
+        // int -> float is a vector instruction: bring the map's limits back to scalar registers
+        const float rmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rmaxf)));
+        const float cmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cmaxf)));
+        const tdr_v2f scale2 = {scale, scale};
+        const uint64_t res2 = (uint64_t)__float_as_uint(a.res) * 0x100000001ull;   // {res, res} in an SGPR pair
+        while (nleft != 0xFFFFFFFFu) {
+#define SU_ASM_OPERANDS                                                                                               \
+          : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),             \
+            [a5] "+v"(acc[ND > 5 ? 5 : 0]), [norm] "+v"(norm), [known] "+v"(known), [toff] "+v"(toff), [doff] "+v"(doff), \
+            [nleft] "+v"(nleft), [wleft] "+v"(wleft)                                                                   \
+          : [offv] "v"(offv), [krow4] "v"(krow4), [ckcol] "v"(ckcol), [tb] "s"(tbase), [db] "s"(dbase),              \
+            [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
+            [kmask] "s"(kmask), [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2), [dbgp] "s"(a.dbg)        \
+          : SU_ASM_CLOBBERS
+          if constexpr (USCALE && LDSMASK) asm volatile(SU_ASM_US_LDS SU_ASM_OPERANDS);
+          else if constexpr (USCALE) asm volatile(SU_ASM_US_GLB SU_ASM_OPERANDS);
+          else if constexpr (LDSMASK) asm volatile(SU_ASM_PS_LDS SU_ASM_OPERANDS);
+          else asm volatile(SU_ASM_PS_GLB SU_ASM_OPERANDS);
+#undef SU_ASM_OPERANDS
+          // (the compiler takes the outputs of an asm statement for divergent)
+          toff = __builtin_amdgcn_readfirstlane(toff); doff = __builtin_amdgcn_readfirstlane(doff);
+          nleft = __builtin_amdgcn_readfirstlane(nleft); wleft = __builtin_amdgcn_readfirstlane(wleft);
+          if (nleft == 0xFFFFFFFFu) break;
+          // the step the loop stopped in front of
+          // (no division here: it would run on the vector unit and drag the loop's scalar state there with it)
+          const int k = (i1 - i0) * spd - 1 - (int)nleft, lsp = G == 4 ? 0 : (G == 8 ? 1 : 2);
+          const int i = i0 + (k >> lsp), jj = (k & (spd - 1)) * 4;
+          int r = i + shift;
+          r -= r >= nb ? nb : 0;
+          cpp_step(ldsmask, i, r, jj, krow4, kconst);
+          toff += 32u;
+          doff += 64u;
+          if (wleft == 0) { doff = 0; wleft = wrapm1; } else wleft--;
+          nleft--;   // 0 -> 0xFFFFFFFF: the sector is done
+          toff = __builtin_amdgcn_readfirstlane(toff); doff = __builtin_amdgcn_readfirstlane(doff);
+          nleft = __builtin_amdgcn_readfirstlane(nleft); wleft = __builtin_amdgcn_readfirstlane(wleft);
+        }
+        return;
+      }
+    }
+    for (int i = i0; i < i1; i++) {
+      int r = i + shift;
+      r -= r >= nb ? nb : 0;
+      for (int jj = 0; jj < gn; jj += 4) cpp_step(ldsmask, i, r, jj, krow4, kconst);
     }
   };
 
@@ -374,20 +450,22 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
       cl = min(cl, __shfl_xor(cl, d)); ch = max(ch, __shfl_xor(ch, d));
     }
     __syncthreads();   // the previous sector's lookups are done (and, the first time, the dictionary is staged)
-    if (threadIdx.x == 0) { sbox[0] = 0x7FFFFFFF; sbox[1] = -0x7FFFFFFF; sbox[2] = 0x7FFFFFFF; sbox[3] = -0x7FFFFFFF; }
+    if (threadIdx.x == 0) { lds.box[0] = 0x7FFFFFFF; lds.box[1] = -0x7FFFFFFF; lds.box[2] = 0x7FFFFFFF; lds.box[3] = -0x7FFFFFFF; }
     __syncthreads();
     if (lane == 0 && active) {
-      atomicMin(&sbox[0], rl); atomicMax(&sbox[1], rh); atomicMin(&sbox[2], cl); atomicMax(&sbox[3], ch);
+      atomicMin(&lds.box[0], rl); atomicMax(&lds.box[1], rh); atomicMin(&lds.box[2], cl); atomicMax(&lds.box[3], ch);
     }
     __syncthreads();
-    const int rlo = sbox[0], rhi = sbox[1], wlo = (sbox[2] >> 5) + 1, whi = (sbox[3] >> 5) + 1;   // mask rows / words
+    const int rlo = __builtin_amdgcn_readfirstlane(lds.box[0]), rhi = __builtin_amdgcn_readfirstlane(lds.box[1]);   // mask rows
+    const int wlo = (__builtin_amdgcn_readfirstlane(lds.box[2]) >> 5) + 1;                                            // mask words
+    const int whi = (__builtin_amdgcn_readfirstlane(lds.box[3]) >> 5) + 1;
     const int H = rhi - rlo + 1, Wb = whi - wlo + 1;
     const bool fits = (int64_t)H * Wb <= SU_BOX_WORDS;   // uniform over the workgroup
     if (fits) {
       const int total = H * Wb;
       for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int row = idx / Wb, wc = idx - row * Wb;
-        lbits[idx] = kmask[(int64_t)(rlo + 1 + row) * a.kwpr + (wlo + wc)];
+        lds.bits[idx] = kmask[(int64_t)(rlo + 1 + row) * a.kwpr + (wlo + wc)];
       }
     }
     __syncthreads();
@@ -515,6 +593,20 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
   u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = L.part;
+  static const int use_asm = [] {
+    const char* e = getenv("TDR_SU_ASM");
+    return e ? atoi(e) : 1;
+  }();
+  u.use_asm = use_asm;
+  uint32_t* dbg = reinterpret_cast<uint32_t*>(base + W.ints + 3 * L.nb + 8);
+  u.dbg = dbg;
+  if (getenv("TDR_SU_DEBUG")) {
+    const uint32_t lim[16] = {(uint32_t)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4 - 4),
+                             (uint32_t)((size_t)(map->rows + 2) * u.kwpr * 4 - 4), (uint32_t)(L.nb * L.group * 8 - 32),
+                             (uint32_t)(L.nb * L.group * 16 - 64), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(dbg, lim, sizeof(lim), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   const dim3 grid((unsigned)cdiv(L.npad, 256), (unsigned)L.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, L.rf), us = L.uniform_scale;
 #define TDR_LAUNCH_SU(NV4)                                                                         \
@@ -531,5 +623,17 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
 #undef TDR_LAUNCH_SU
   LAUNCH_CHECK("score_polar_su");
   g_su_launches++;
+  if (getenv("TDR_SU_DEBUG")) {
+    uint32_t out[16];
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(out, dbg, sizeof(out), hipMemcpyDeviceToHost));
+    fprintf(stderr, "su debug: limits rec %u mask %u T %u D %u | max seen rec %u mask %u T/D %u\n", out[0], out[1], out[2],
+            out[3], out[4], out[5], out[6]);
+    float tx, ty;
+    memcpy(&tx, &out[14], 4);
+    memcpy(&ty, &out[15], 4);
+    fprintf(stderr, "su debug: offending offset %u ri %d ci %d krow4 %u kconst %u ci>>5 %d tx %g ty %g\n", out[8], (int)out[9],
+            (int)out[10], out[11], out[12], (int)out[13], tx, ty);
+  }
   return TDR_OK;
 }
