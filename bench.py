@@ -17,13 +17,17 @@ BASELINE.json configs[1] ("c2": 100k-pt scan, 6 classes, 256x256 polar render, 4
 for N > 1 every GPU holds the same number of particles (weak scaling; N = 8 with --particles-per-gpu 125000 is
 configs[2]).
 
-One JSON line on stdout (rank 0).  `roofline` prices the scoring kernel (its average launch duration measured live
-with HIP events on its launch stream) against the 8 TB/s HBM peak:
-  * `traffic` = HBM bytes per launch MEASURED with rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum in a pass
-    of its own over this same command (tools/traffic_from_pmc.py -> profiles/score_traffic.json).  The record carries a
-    hash of the kernel sources and the launch shape: when either differs from what runs now, `traffic` is null.
-  * `achieved` / `frac` = traffic / launch duration (/ peak) when traffic is known — the fraction of the HBM roofline the
-    kernel actually runs at;
+One JSON line on stdout (rank 0).  `roofline` prices the scoring launch (its average duration measured live with HIP
+events on its launch stream; a polar launch may run two kernels side by side, the events span both) against the 8 TB/s
+HBM peak:
+  * `traffic` = read bytes per launch the L2s request from the fabric, MEASURED with rocprofv3 --pmc
+    TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum in a pass of its own over this same command (tools/traffic_from_pmc.py ->
+    profiles/score_traffic.json).  Hits in the Infinity Cache are among them: an upper bound on what HBM delivers.  The
+    record carries a hash of the kernel sources and the launch shape: when either differs from what runs now, `traffic`
+    and `issue` are null.
+  * `achieved` / `frac` = traffic / launch duration (/ peak) when traffic is known;
+  * `issue` = {valu_busy, lds_busy, insts_per_sample} from a second counter pass; `bound` = the busiest of
+    {hbm: `frac`, valu, lds};
   * `algorithmic` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the same
     duration.  Particles share map cells, so L1/L2 serve much of it and this figure can exceed the peak: it is a
     work-rate, kept under its own key; it becomes `achieved` (flagged by `basis`) only when no measured traffic exists.
@@ -92,24 +96,24 @@ def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
+    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_su_asm.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
         h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def measured_traffic(cfg_name, kernel, n_local):
-    """(HBM bytes per launch from profiles/score_traffic.json, note) — None unless the record was made from the kernel
-    sources in this tree, for this kernel and this launch shape."""
+    """(bytes per launch from profiles/score_traffic.json, issue figures, note) — None unless the record was made from
+    the kernel sources in this tree, for this kernel and this launch shape."""
     tpath = os.path.join(ROOT, "profiles", "score_traffic.json")
     try:
         rec = json.load(open(tpath))["entries"][cfg_name]
     except Exception:
-        return None, "no record"
+        return None, None, "no record"
     if rec.get("kernel_source_hash") != kernel_source_hash():
-        return None, "record is from other kernel sources"
+        return None, None, "record is from other kernel sources"
     if rec.get("particles_per_launch") != n_local or kernel not in rec.get("kernel", ""):
-        return None, "record is for another launch shape"
-    return float(rec["hbm_bytes_per_launch"]), rec.get("source", "")
+        return None, None, "record is for another launch shape"
+    return float(rec["hbm_bytes_per_launch"]), rec.get("issue"), rec.get("source", "")
 
 
 def main():
@@ -234,16 +238,27 @@ def main():
         b_pu = P * (4 * cfg.ncls + 1) + 64
         kname = "score_cart_kernel"
         if cfg.polar:
-            kname = "score_polar_su_kernel" if int(k.lib.tdr_shift_uniform_launches()) > 0 else "score_polar_kernel"
+            kname = "score_polar"   # score_polar_kernel, or score_polar_su_kernel + score_polar_kernel side by side
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         alg_gbps = achieved
-        traffic, traffic_note = measured_traffic(cfg.name, kname, n_local)
+        traffic, issue, traffic_note = measured_traffic(cfg.name, kname, n_local)
         if traffic is not None and avg_ms > 0:
             achieved, basis = traffic / (avg_ms * 1e-3) / 1e9, "pmc_traffic"
         else:
             basis = "algorithmic (no measured traffic for this build / shape: " + traffic_note + ")"
+        # the unit the launch keeps busiest: memory system (fraction of the HBM peak), vector issue or the LDS arrays
+        util = {"hbm": achieved / 8000.0 if traffic is not None else 0.0}
+        if issue:
+            issue = {"valu_busy": issue.get("valu_busy"), "lds_busy": issue.get("lds_busy"),
+                     "insts_per_sample": issue.get("insts_per_sample"),
+                     "how": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE over this "
+                            "command (tools/traffic_from_pmc.py): issue cycles of the vector units / cycles of the LDS arrays "
+                            "over the kernels' cycles, vector instructions per wave per window sample"}
+            util["valu"] = issue["valu_busy"] or 0.0
+            util["lds"] = issue["lds_busy"] or 0.0
+        bound = max(util, key=util.get)
         out = {
             "metric": "particle-updates/sec (render+score+resample)",
             "value": n_global * a.steps / dt,
@@ -258,13 +273,17 @@ def main():
                        "particle_distribution": ("90% Gaussian (30 px, 10 deg) about the true pose + 10% uniform"
                                                  if cfg.have_init else "8 Gaussian clusters (40 px) on road cells"),
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0,
+            "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
-                         "note": "with the compact map records the kernel moves a quarter of the bytes and is bound by "
-                                 "vector-instruction issue for clustered particles (SQ_ACTIVE_INST_VALU = 85 % of the SIMD "
-                                 "cycles, profiles/r02_pmc_score_compact_gaussian5_v1.txt; 68 % for this bench's 90/10 mix, "
-                                 "..._mix_v1.txt; memory-bound at 0.73 of the peak only when all particles are scattered, "
-                                 "..._uniform_v1.txt); `frac` is what it still takes of the HBM roofline (DESIGN.md 5.1)",
+                         "traffic_is": "read requests the L2s send to the fabric (TCC_EA0_RDREQ), Infinity-Cache hits "
+                                       "included: an upper bound on the bytes HBM itself delivers",
+                         "issue": issue,
+                         "note": "`achieved`, `peak`, `frac` price the launch against the HBM roofline whatever `bound` says; "
+                                 "`bound` names the unit the launch keeps busiest (hbm = `frac`, valu / lds = `issue`).  "
+                                 "Clustered particles are bound by vector-instruction issue, scattered ones by the memory "
+                                 "system (DESIGN.md 5.1); a polar launch may run two kernels side by side — "
+                                 "score_polar_su_kernel for the dense particles, score_polar_kernel for the scattered ones — "
+                                 "and `avg_launch_ms` spans both",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
                                          "frac": alg_gbps / 8000.0}},

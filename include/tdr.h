@@ -315,13 +315,16 @@ int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void
  * forces the dense records (A/B measurements, tests), 1 restores the default, < 0 only queries.  Results never depend on
  * it: both forms decode to the same operands.  Returns the value in force.  (Environment: TDR_COMPACT=0.) */
 int tdr_config_compact(int on);
-/* The polar scoring kernel has a second form that processes the particles in (heading bin, Morton) order with every
- * bin padded to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes
- * are skipped wave-wide (csrc/tdr_score_su.hip); same partial sums, bit for bit.  mode 0 = never, 1 = when the filter
- * holds enough particles per heading bin for the padding to pay (default), 2 = whenever the shapes allow (ring groups
- * and ring count multiples of 4, a map with narrow compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM
- * sets the initial mode. */
+/* The polar scoring kernel has a second form that processes particles in (heading bin, Morton) order, every bin padded
+ * to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes are skipped
+ * wave-wide (csrc/tdr_score_su.hip).  Per launch the DENSE particles take it — those whose 64 neighbours in the locality
+ * order lie within tdr_config_shift_uniform_span map cells (default 16; 0 = every particle counts as dense) — and the
+ * others the lane-shift kernel, side by side: same partial sums, bit for bit, whichever kernel scores a particle.
+ * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
+ * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow
+ * compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM / TDR_SU_SPAN set the initial values. */
 int tdr_config_shift_uniform(int mode);
+float tdr_config_shift_uniform_span(float cells);   /* < 0 only returns it */
 /* diagnostics: scoring launches of this process that took the shift-uniform kernel */
 int64_t tdr_shift_uniform_launches(void);
 

@@ -29,11 +29,14 @@ def _assert_weights(w, ref, rtol=1e-5):
     assert err.max(initial=0.0) <= rtol, f"max rel err {err.max():.3e}"
 
 
-def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False):
-    """Raw weights (and the states after scoring) of the lane-shift kernel (mode 0) and the shift-uniform one (mode 2)."""
-    before = k.lib.tdr_config_shift_uniform(-1)
+def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False, span=0.0):
+    """Raw weights (and the states after scoring) of the lane-shift kernel (mode 0) and the shift-uniform one (mode 2).
+    span 0: every particle through the shift-uniform kernel; > 0: particles farther than that from their neighbours in
+    the locality order stay with the lane-shift kernel (the mixed launch)."""
+    before, before_span = k.lib.tdr_config_shift_uniform(-1), k.lib.tdr_config_shift_uniform_span(-1.0)
     out = []
     try:
+        k.lib.tdr_config_shift_uniform_span(span)
         for mode in (0, 2):
             k.lib.tdr_config_shift_uniform(mode)
             f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False,
@@ -53,6 +56,7 @@ def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False)
             out.append((f.raw_w[:n].cpu().numpy(), k.states_to_host(f.st, n, pkg.STATE_DTYPE)))
     finally:
         k.lib.tdr_config_shift_uniform(before)
+        k.lib.tdr_config_shift_uniform_span(before_span)
     return out
 
 
@@ -94,6 +98,9 @@ def test_shift_uniform_equals_lane_shift_kernel_and_oracle(tdr, oracle, ncls, nb
     (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality)
     assert np.array_equal(raw0, raw2, equal_nan=True)
     _assert_weights(raw2, ref)
+    # mixed launch: the particles with neighbours within 3 cells through the shift-uniform kernel, the others not
+    (_, _), (raw3, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality, span=3.0)
+    assert np.array_equal(raw0, raw3, equal_nan=True)
 
 
 @pytest.mark.parametrize("kind", ["empty", "dense", "fractional", "one bin"])

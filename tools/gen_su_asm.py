@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes top_down_renderer_amd/csrc/tdr_score_su_asm.h: the hand-scheduled gfx950 inner loop of score_polar_su_kernel
-(records of two dwords: 4-6 classes) as inline-assembly text, in four variants — uniform / per-lane scale, known mask in
-LDS / in global memory.  The text is generated so that the four samples of a step and the four variants cannot drift apart.
+(records of two dwords: 4-6 classes) as inline-assembly text, in two variants — uniform / per-lane scale.  The text is
+generated so that the four samples of a step and the variants cannot drift apart.
 
     python3 tools/gen_su_asm.py        (re-run after editing; the header is committed)
 
@@ -26,23 +26,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su_asm.h")
 
 
-def loop_text(uscale, ldsmask, debug=False):
+def loop_text(uscale):
     L = []
     a = L.append
     # hipcc waits for one of its own loads where the VALUE is used; a load whose value the taken path never reads is still
     # in flight here, and hipcc does not wait for it on behalf of the registers this statement clobbers: it would land in
     # the middle of the loop (found as garbage mask offsets / memory faults at full size only)
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    if int(os.environ.get("SU_ASM_BISECT", "0")) == 5:
-        a("v_mov_b32 v38, 0")
-        a("v_mov_b32 v39, 0")
-        a("v_mov_b32 v40, 0")
-    if debug or int(os.environ.get("SU_ASM_BISECT", "0")) == 5:
-        a("s_load_dwordx4 s[72:75], %[dbgp], 0x0")        # limits: record bytes, mask bytes, T bytes, D bytes
-        a("v_mov_b32 v38, 0")
-        a("v_mov_b32 v39, 0")
-        a("v_mov_b32 v40, 0")
-        a("s_waitcnt lgkmcnt(0)")
     # the loop's scalar state travels through vector operands: the compiler keeps loop-carried values that meet vector
     # code in VGPRs, whatever the constraint says
     a("v_readfirstlane_b32 s65, %[toff]")
@@ -52,19 +42,11 @@ def loop_text(uscale, ldsmask, debug=False):
     for k in range(6):
         a(f"v_mov_b32 v{32 + k}, %[a{k}]")
     a(".Lsu_step%=:")
-    if debug:
-        a("v_max_u32 v40, s65, v40")
-        a("v_max_u32 v40, s66, v40")
-        a("s_min_u32 s65, s65, s74")
-        a("s_min_u32 s66, s66, s75")
     a("s_load_dwordx8 s[40:47], %[tb], s65")
     a("s_load_dwordx16 s[48:63], %[db], s66")
     a("s_waitcnt lgkmcnt(0)")
     a("s_bitcmp1_b32 s51, 31")                      # a bin with several classes in this step: hand it to the C++ step
     a("s_cbranch_scc1 .Lsu_out%=")
-    bis = int(os.environ.get("SU_ASM_BISECT", "0"))
-    if bis == 2:
-        a("s_branch .Lsu_next%=")
     # ---- phase A: cells of the four samples (top_down_map_polar.cpp:28-31)
     for u in range(4):
         p, t = 8 + 2 * u, 40 + 2 * u
@@ -91,7 +73,7 @@ def loop_text(uscale, ldsmask, debug=False):
         p = 8 + 2 * u
         a(f"v_cvt_flr_i32_f32 v{p}, v{p}")
         a(f"v_cvt_flr_i32_f32 v{p + 1}, v{p + 1}")
-    # known-mask word of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
+    # word of the staged known mask (LDS) of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
     for u in range(4):
         a(f"v_mad_i32_i24 v{16 + u}, v{8 + 2 * u}, %[krow4], %[kconst]")
     for u in range(4):
@@ -99,44 +81,8 @@ def loop_text(uscale, ldsmask, debug=False):
     for u in range(4):
         a(f"v_lshl_add_u32 v{16 + u}, v{20 + u}, 2, v{16 + u}")
     a("s_nop 0")
-    if debug and not ldsmask:
-        for u in range(4):
-            a(f"v_max_u32 v39, v39, v{16 + u}")
-        for u in range(4):
-            a(f"v_min_u32 v{16 + u}, s73, v{16 + u}")
-        a("s_nop 0")
     for u in range(4):
-        if ldsmask:
-            if bis != 4:
-                a(f"ds_read_b32 v{28 + u}, v{16 + u}")
-        elif bis == 5:
-            a(f"v_max_u32 v39, v39, v{16 + u}")          # diagnostic: the largest mask offset, no load
-            # a mask offset beyond the mask: snapshot (ONE lane's values) of everything it was made of
-            a(f"v_cmp_lt_u32 vcc, s73, v{16 + u}")
-            a("s_and_saveexec_b64 s[70:71], vcc")
-            a(f"s_cbranch_execz .Lsu_dg{u}%=")
-            a("v_mov_b32 v27, 0")
-            for k, reg in enumerate((f"v{16 + u}", f"v{8 + 2 * u}", f"v{9 + 2 * u}", "%[krow4]", "v41", f"v{20 + u}")):
-                a(f"v_readfirstlane_b32 s76, {reg}")
-                a("s_nop 1")
-                a("v_mov_b32 v26, s76")
-                a("s_nop 1")
-                a(f"global_store_dword v27, v26, %[dbgp] offset:{32 + 4 * k}")
-            a(f"v_mov_b32 v26, s{40 + 2 * u}")
-            a("s_nop 1")
-            a("global_store_dword v27, v26, %[dbgp] offset:56")
-            a(f"v_mov_b32 v26, s{41 + 2 * u}")
-            a("s_nop 1")
-            a("global_store_dword v27, v26, %[dbgp] offset:60")
-            a("s_waitcnt vmcnt(0)")
-            a(f".Lsu_dg{u}%=:")
-            a("s_mov_b64 exec, s[70:71]")
-        elif bis != 3:
-            # never into its own address register: a load that is replayed (XNACK) reads its address again
-            a(f"global_load_dword v{28 + u}, v{16 + u}, %[kmask]")
-    if bis in (1, 3, 4, 5):    # mask lookups only (3: only the LDS ones, 4: only the global ones)
-        a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        a("s_branch .Lsu_next%=")
+        a(f"ds_read_b32 v{28 + u}, v{16 + u}")
     # the record dword of every non-empty bin (cmap_offset with the dword folded into its constant)
     for u in range(4):
         code, ckc = 48 + 4 * u, 50 + 4 * u
@@ -150,10 +96,7 @@ def loop_text(uscale, ldsmask, debug=False):
         a("s_nop 0")
         a(f"v_lshl_add_u32 v{20 + u}, v{8 + 2 * u}, 5, v{20 + u}")
         a("s_nop 0")
-        if debug:
-            a(f"v_max_u32 v38, v38, v{20 + u}")
-            a(f"v_min_u32 v{20 + u}, s72, v{20 + u}")
-            a("s_nop 0")
+        # (never into its own address register: a load that is replayed reads its address again)
         a(f"global_load_dword v{24 + u}, v{20 + u}, %[crec]")
         a(f".Lsu_a{u}%=:")
     # ---- phase B
@@ -206,7 +149,6 @@ def loop_text(uscale, ldsmask, debug=False):
         a(f"v_fmac_f32 v32, s{val}, v21")
         a(f".Lsu_b{u}%=:")
     # ---- next step
-    a(".Lsu_next%=:")
     a("s_add_u32 s65, s65, 32")
     a("s_add_u32 s66, s66, 64")
     a("s_sub_u32 s68, s68, 1")
@@ -223,18 +165,6 @@ def loop_text(uscale, ldsmask, debug=False):
     a("v_mov_b32 %[doff], s66")
     a("v_mov_b32 %[nleft], s67")
     a("v_mov_b32 %[wleft], s68")
-    if int(os.environ.get("SU_ASM_BISECT", "0")) == 5:
-        a("v_mov_b32 v27, 0")
-        a("global_atomic_umax v27, v38, %[dbgp] offset:16")
-        a("global_atomic_umax v27, v39, %[dbgp] offset:20")
-        a("global_atomic_umax v27, v40, %[dbgp] offset:24")
-        a("s_waitcnt vmcnt(0)")
-    if debug:
-        a("v_mov_b32 v27, 0")
-        a("global_atomic_umax v27, v38, %[dbgp] offset:16")
-        a("global_atomic_umax v27, v39, %[dbgp] offset:20")
-        a("global_atomic_umax v27, v40, %[dbgp] offset:24")
-        a("s_waitcnt vmcnt(0)")
     return L
 
 
@@ -244,16 +174,14 @@ def main():
            "// register plan and the schedule's cost model.",
            "#ifndef TDR_SCORE_SU_ASM_H_", "#define TDR_SCORE_SU_ASM_H_", ""]
     for uscale in (True, False):
-        for ldsmask in (True, False):
-            name = f"SU_ASM_{'US' if uscale else 'PS'}_{'LDS' if ldsmask else 'GLB'}"
-            out.append(f"#define {name} \\")
-            lines = loop_text(uscale, ldsmask, debug=bool(os.environ.get("SU_ASM_DEBUG")))
-            for i, ln in enumerate(lines):
-                out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
-            out.append("")
+        out.append(f"#define SU_ASM_{'US' if uscale else 'PS'} \\")
+        lines = loop_text(uscale)
+        for i, ln in enumerate(lines):
+            out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+        out.append("")
     out.append('#define SU_ASM_CLOBBERS                                                                                      \\')
-    vregs = ", ".join(f'"v{i}"' for i in range(8, 42))
-    sregs = ", ".join(f'"s{i}"' for i in range(40, 78))
+    vregs = ", ".join(f'"v{i}"' for i in range(8, 38))
+    sregs = ", ".join(f'"s{i}"' for i in range(40, 69))
     out.append(f"  {vregs}, \\")
     out.append(f'  {sregs}, "vcc", "memory"')
     out.append("#endif  // TDR_SCORE_SU_ASM_H_")

@@ -13,10 +13,12 @@ if [ "$MODE" = tests ]; then
 fi
 for C in $CONFIGS; do
   N=$(python3 -c "from top_down_renderer_amd import synth; c=synth.CONFIGS['$C']; print(c.n_particles//8 if c.name in ('c3','c5') else c.n_particles)")
-  K=score_polar_kernel; [ "$C" = c4 ] && K=score_cart_kernel
+  K=score_polar; [ "$C" = c4 ] && K=score_cart_kernel
   STEPS=20; [ "$C" = c4 ] && STEPS=5
   # PMC pass first (its own run, counters only), then the record, then the bench proper so that it reports the traffic
-  rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc_$C -o pmc --output-format csv -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu > $OUT/pmc_$C.log 2>&1 || { echo "pmc $C failed"; tail -5 $OUT/pmc_$C.log; }
+  rm -rf $OUT/pmc_$C
+  rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc_$C/traffic -o pmc --output-format csv -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu > $OUT/pmc_$C.log 2>&1 || { echo "pmc $C failed"; tail -5 $OUT/pmc_$C.log; }
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_$C/issue -o pmc --output-format csv -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu > $OUT/pmc_issue_$C.log 2>&1 || { echo "pmc issue $C failed"; tail -5 $OUT/pmc_issue_$C.log; }
   python3 tools/traffic_from_pmc.py $C $K $N $OUT/pmc_$C $OUT/pmc_${C}_summary.txt || echo "no traffic record for $C"
   cp profiles/score_traffic.json $OUT/score_traffic.json
   CPU=""; [ "$C" != c2 ] && CPU="--no-cpu"

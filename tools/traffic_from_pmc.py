@@ -6,10 +6,12 @@
         python3 bench.py --config c2 --steps 5 --warmup 1 --no-cpu
     python3 tools/traffic_from_pmc.py c2 score_polar_kernel 100000 gpurun_out/pmc_c2 profiles/r02_pmc_c2.txt
 
-HBM read bytes per launch = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64 (MI355X_MICROARCH.md, HBM section: the L2's
-memory-side request counters; FETCH_SIZE tallies the 128-byte requests at 64 bytes on gfx950, so it is not used).
-Counters are summed over the XCDs per dispatch and averaged over the dispatches of the kernel.  The record stores a hash
-of the kernel sources: bench.py ignores it once they change.
+Read bytes per launch = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64 (MI355X_MICROARCH.md, HBM section: the L2's
+memory-side request counters; FETCH_SIZE tallies the 128-byte requests at 64 bytes on gfx950, so it is not used).  These
+are the requests the L2s send to the fabric: what the Infinity Cache serves is among them.  A second pass
+(SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE) gives the issue figures bench.py reports beside
+the traffic.  Counters are summed over the XCDs per dispatch, averaged over the dispatches of each kernel, and the
+kernels of one scoring launch added up.  The record stores a hash of the kernel sources: bench.py ignores it once they change.
 """
 import csv
 import glob
@@ -27,40 +29,68 @@ def main():
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {d}")
+    # (pass, kernel, dispatch) -> counter -> value summed over the XCDs / shader engines
     per = defaultdict(lambda: defaultdict(float))
-    names = set()
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if pat in row["Kernel_Name"]:
-                    per[(f, row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
-                    names.add(row["Kernel_Name"])
+                    per[(f, row["Kernel_Name"].split("(")[0], row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
     if not per:
         raise SystemExit(f"no dispatch of {pat} in {files}")
-    rd128 = [v.get("TCC_EA0_RDREQ_128B_sum", 0.0) for v in per.values()]
-    rd = [v.get("TCC_EA0_RDREQ_sum", 0.0) for v in per.values()]
-    m128, mrd = sum(rd128) / len(rd128), sum(rd) / len(rd)
+    # mean per dispatch of every kernel, then the kernels of one scoring launch added up (a mixed launch runs two)
+    by_kernel = defaultdict(lambda: defaultdict(list))
+    for (_, kern, _), ctr in per.items():
+        for c, v in ctr.items():
+            by_kernel[kern][c].append(v)
+    names = sorted(by_kernel)
+    launch = defaultdict(float)
+    for kern in names:
+        for c, v in by_kernel[kern].items():
+            launch[c] += sum(v) / len(v)
+    m128, mrd = launch.get("TCC_EA0_RDREQ_128B_sum", 0.0), launch.get("TCC_EA0_RDREQ_sum", 0.0)
     bytes_per_launch = m128 * 128 + max(0.0, mrd - m128) * 64
     from bench import kernel_source_hash
+    from top_down_renderer_amd import synth
+    c = synth.CONFIGS[cfg]
+    wave_samples = -(-n_launch // 64) * c.nb * c.nr
+    issue = None
+    if "SQ_ACTIVE_INST_VALU" in launch and "GRBM_GUI_ACTIVE" in launch:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_ACTIVE_INST_VALU counts 4-cycle issue slots summed over the 1024 SIMDs;
+        # SQ_LDS_IDX_ACTIVE counts cycles summed over the 256 LDS arrays.  The counter pass runs the kernels of a launch
+        # one after the other, so the cycles are the sum of theirs.
+        cycles = launch["GRBM_GUI_ACTIVE"] / 8.0
+        issue = {"valu_busy": launch["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
+                 "lds_busy": (launch["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles)) if "SQ_LDS_IDX_ACTIVE" in launch else None,
+                 "insts_per_sample": (launch["SQ_INSTS_VALU"] / wave_samples) if "SQ_INSTS_VALU" in launch else None,
+                 "cycles": cycles, "wave_samples": wave_samples}
     path = os.path.join(ROOT, "profiles", "score_traffic.json")
     try:
         rec = json.load(open(path))
         assert "entries" in rec
     except Exception:
         rec = {"entries": {}}
-    kname = sorted(names)[0].split("(")[0]
     rec["entries"][cfg] = {
-        "kernel": kname, "particles_per_launch": n_launch, "hbm_bytes_per_launch": bytes_per_launch,
-        "dispatches": len(per), "TCC_EA0_RDREQ_128B_sum": m128, "TCC_EA0_RDREQ_sum": mrd,
+        "kernel": " + ".join(names), "particles_per_launch": n_launch, "hbm_bytes_per_launch": bytes_per_launch,
+        "dispatches": len(per), "TCC_EA0_RDREQ_128B_sum": m128, "TCC_EA0_RDREQ_sum": mrd, "issue": issue,
         "kernel_source_hash": kernel_source_hash(), "source": os.path.relpath(summary, ROOT),
-        "how": "rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum, own pass over bench.py; "
-               "bytes = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64, mean over the kernel's dispatches",
+        "how": "rocprofv3 --pmc, passes of their own over bench.py (counters only); mean over the dispatches of each scoring "
+               "kernel, the kernels of one launch added up; bytes = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64: requests "
+               "the L2s send to the fabric — hits in the 256 MB Infinity Cache are among them, so this is an upper bound on "
+               "what HBM itself delivers",
     }
     json.dump(rec, open(path, "w"), indent=1)
     with open(summary, "w") as fh:
-        fh.write(f"{cfg}: kernel {kname}, {len(per)} dispatches, {n_launch} particles per launch\n"
-                 f"TCC_EA0_RDREQ_128B_sum mean {m128:.6g}\nTCC_EA0_RDREQ_sum      mean {mrd:.6g}\n"
-                 f"HBM read bytes per launch {bytes_per_launch:.6g}  ({bytes_per_launch / n_launch:.6g} per particle)\n")
+        fh.write(f"{cfg}: kernels {' + '.join(names)}, {len(per)} dispatches, {n_launch} particles per launch\n")
+        for kern in names:
+            fh.write(f"  {kern}\n")
+            for cn, v in sorted(by_kernel[kern].items()):
+                fh.write(f"     {cn:32s} n={len(v)} mean={sum(v) / len(v):.6g}\n")
+        fh.write(f"L2 -> fabric read bytes per launch {bytes_per_launch:.6g}  ({bytes_per_launch / n_launch:.6g} per particle; "
+                 f"Infinity-Cache hits included)\n")
+        if issue:
+            fh.write(f"issue: vector units busy {issue['valu_busy']:.3f}, LDS busy {issue['lds_busy']}, vector instructions per "
+                     f"wave-sample {issue['insts_per_sample']}\n")
     print(open(summary).read())
 
 

@@ -94,7 +94,8 @@ extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols) {
 }
 extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
   const size_t tiles = tdr_cmap_tile_words(ncls, rows, cols);
-  return tiles ? tiles + (size_t)(rows + 2) * ((cols >> 5) + 2) : 0;
+  // (+ 4 words: a lane of score_polar_kernel<SKIP> reads a whole record's worth of dwords at a mask word)
+  return tiles ? tiles + (size_t)(rows + 2) * ((cols >> 5) + 2) + 4 : 0;
 }
 __global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf, int wpr,
                                                          uint32_t* __restrict__ kmask) {

@@ -21,7 +21,8 @@ struct ScoreArgs {
   const float* st;      // [7][cap]
   int64_t cap, n;
   const int32_t* order; // slot -> particle (NULL = identity)
-  const int32_t* count; // optional device count limiting the active slots (init search)
+  const int32_t* count; // optional device count limiting the active slots (init search; the sparse share of a mixed launch)
+  const int32_t* slot_base;  // optional device word: this launch's slot 0 is slot *slot_base of `order` and of `part`
   int use_theta_override;
   float theta_override;
   int only_uninit;      // score only workgroups that hold a particle without a heading (the geometric init search)
@@ -33,6 +34,10 @@ struct ScoreArgs {
   const float* dict;
   int dict_n;           // dictionary entries in use
   int ctiles_r;         // tiles per tile column
+  // the map's known mask (tdr_cmap.hip), read by the SKIP instantiations: byte offset of its word (0, 0) from crec,
+  // bytes per mask row
+  unsigned kmask_off;
+  int kmask_row;
 };
 
 #include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
@@ -60,10 +65,16 @@ extern "C" int tdr_debug_read_timeline(unsigned long long* out, int n) {
 // away (scattered particles) fetches ~0.5 lines per sample instead of one.  The scan rows of the whole group sit in LDS
 // ([ring][plane][row], not doubled: the row (i + shift) mod nb is computed once per direction).
 // WIDE: the compact records are the wide form (maps of more than 1024 distinct values, tdr_cmap.hip)
-template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT, bool WIDE = false>
+// SKIP (the scattered particles of a mixed launch, tdr_k_score_polar): a sample whose scan bin is empty in every class
+// reads the cell's bit of the known mask instead of its record.  Scattered particles share no cache lines and are bound
+// by the lines they pull through the fabric; the empty bins of a LiDAR scan are mostly its outer rings, where a window
+// touches the most lines: half of a scattered particle's lines are never requested.  The FMAs of such a
+// sample are still executed, with a zero scan operand against the dictionary's entry 0: the sums are bit-identical.
+template <int NV4, int U, bool KSLOT, bool USCALE, bool COMPACT, bool WIDE = false, bool SKIP = false>
 __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar_kernel(ScoreArgs a) {
   constexpr int RF = 4 * NV4;
   static_assert(!WIDE || (COMPACT && NV4 == 2), "wide compact records: 8-float dense records only");
+  static_assert(!SKIP || (COMPACT && !WIDE), "SKIP: narrow compact records only");
   constexpr int CW = WIDE ? 4 : CmapShape<RF, KSLOT>::CW, LC = WIDE ? 1 : CmapShape<RF, KSLOT>::LC;
   constexpr int NDICT = WIDE ? TDR_CMAP_WIDE_MAX_DICT : TDR_CMAP_MAX_DICT;
 #ifdef TDR_SCORE_TIMELINE
@@ -86,7 +97,8 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if ((int64_t)bx * 256 >= nact) return;  // whole workgroup idle (uniform)
   const bool valid = slot < nact;
-  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const int64_t sbase = a.slot_base ? (int64_t)*a.slot_base : 0;
+  const int64_t p = a.order ? (int64_t)a.order[sbase + (valid ? slot : 0)] : (valid ? slot : 0);
   if (a.only_uninit && !__syncthreads_or(valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f)) return;
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
@@ -114,8 +126,13 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const int nb = a.nb;
 
   // stage the group's scan rows and (compact) the dictionary
+  bool dict_bad = false;   // a non-finite dictionary value: 0 x inf must stay NaN, nothing may be skipped
   if constexpr (COMPACT)
-    for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
+    for (int t = threadIdx.x; t < a.dict_n; t += 256) {
+      const float v = a.dict[t];
+      ldict[t] = v;
+      if constexpr (SKIP) dict_bad |= !(fabsf(v) <= 3.402823466e+38f);
+    }
   // One row of the LDS image = the scan records (ring, plane) of one direction, 16 bytes each, side by side: a step
   // reads them with ONE address per lane and immediate offsets.  The row stride is an ODD number of 16-byte slots, so
   // lanes on different rows (different headings) fall on different banks.
@@ -126,14 +143,19 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
       const int row = t / NV4, pl = t - row * NV4;
       ring[row * rs + jj * NV4 + pl] = v;
     }
-  __syncthreads();
+  bool skip_ok = false;
+  if constexpr (SKIP) skip_ok = !__syncthreads_or(dict_bad);
+  else __syncthreads();
 
   // USCALE: every particle has the same scale, so (tab*scale)*res was evaluated once per step into a.utab and is
   // wave-uniform here; otherwise it is evaluated per lane.  Identical float operations either way.
   // Returns the byte offset of the sample's record (dense: guarded row-major grid; compact: tiled).
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));   // both coordinates in one v_pk_add_f32 / v_pk_mul_f32
   const tdr_v2f offv = {off0, off1};
-  auto cell_offset = [&](float2 t) -> unsigned {
+  unsigned moff[SKIP ? U : 1];   // SKIP: byte offset (from crec) of the known-mask word of sample u's cell ...
+  int mbit[SKIP ? U : 1];        // ... and the cell's column (its low 5 bits: the bit in that word)
+  const int mconst = (int)a.kmask_off + a.kmask_row + 4;   // word (row + 1, (col >> 5) + 1)
+  auto cell_offset = [&](float2 t, int u) -> unsigned {
     tdr_v2f pv = {t.x, t.y};
     if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
     pv = pv + offv;                                     // :29-30
@@ -144,6 +166,10 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
     int ri, ci;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+    if constexpr (SKIP) {
+      moff[u] = (unsigned)(__mul24(ri, a.kmask_row) + ((ci >> 5) * 4 + mconst));
+      mbit[u] = ci;
+    }
     if constexpr (COMPACT) {
       // cells of the guard ring are zero records in their own right (distance 0, unknown): no select needed
       return cmap_offset<CW, LC>(ri, ci, ckcol, ckconst);
@@ -186,15 +212,47 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
     constexpr bool FULL = decltype(full_step)::value;   // all U samples are real: no per-sample predicate
     Raw raw[U];
     float4 s[U][NV4];
+    if constexpr (SKIP) {
+      // the scan records first: a lane whose bin is empty in every class asks for the mask word instead of the record
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (FULL || u < cnt) load_raw(boff[u], raw[u]);
+      for (int u = 0; u < U; u++)
+        if (FULL || u < cnt) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (FULL || u < cnt) {
+          for (int v = 0; v < NV4; v++) s[u][v] = sp[u][v];
+        }
+      bool empty[U];
 #pragma unroll
-        for (int v = 0; v < NV4; v++) s[u][v] = sp[u][v];
-      }
+      for (int u = 0; u < U; u++)
+        if (FULL || u < cnt) {
+          constexpr int ND = CmapShape<RF, KSLOT>::ND;
+          uint32_t any = 0;
+#pragma unroll
+          for (int k = 0; k < ND; k++) {
+            const float4 q = s[u][k / 4];
+            any |= __float_as_uint(k % 4 == 0 ? q.x : (k % 4 == 1 ? q.y : (k % 4 == 2 ? q.z : q.w)));
+          }
+          empty[u] = skip_ok && any == 0;
+          load_raw(empty[u] ? moff[u] : boff[u], raw[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (FULL || u < cnt) {
+          // an empty bin's "record": dictionary entry 0 for every distance, the known bit from the mask
+          const uint32_t kb = (raw[u].w[0] >> (mbit[u] & 31)) & 1u;
+#pragma unroll
+          for (int d = 0; d < CW; d++) raw[u].w[d] = empty[u] ? kb : raw[u].w[d];
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (FULL || u < cnt) load_raw(boff[u], raw[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (FULL || u < cnt) {
+#pragma unroll
+          for (int v = 0; v < NV4; v++) s[u][v] = sp[u][v];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++)
       if (FULL || u < cnt) {
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
         const float4* const rj = rl + jj * NV4;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj + u) * nb + i));
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj + u) * nb + i), u);
           sp[u] = rj + u * NV4;
         }
         step(std::true_type{}, boff, sp, U);
@@ -239,7 +297,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int jc = min(gfull + u, gn - 1);
-          boff[u] = cell_offset(tab_at((int64_t)(j0 + jc) * nb + i));
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jc) * nb + i), u);
           sp[u] = rl + jc * NV4;
         }
         step(std::false_type{}, boff, sp, gn - gfull);
@@ -257,15 +315,15 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
           const int ic = min(i + u, nb - 1);
           int row = ic + shift;
           row -= row >= nb ? nb : 0;
-          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj) * nb + ic));
+          boff[u] = cell_offset(tab_at((int64_t)(j0 + jj) * nb + ic), u);
           sp[u] = rj + __mul24(row, rs);
         }
         step(std::false_type{}, boff, sp, min(U, nb - i));
       }
     }
   }
-  if (slot < a.npad) {
-    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+  if (sbase + slot < a.npad) {
+    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + sbase + slot;
 #pragma unroll
     for (int k = 0; k < RF; k++) o[(int64_t)k * a.npad] = acc[k];
     o[(int64_t)RF * a.npad] = KSLOT ? acc[RF - 2] : known;
@@ -1508,6 +1566,7 @@ extern "C" int tdr_config_compact(int on) {   // < 0: query only
   return g_use_compact;
 }
 extern "C" int tdr_cmap_words(int ncls);
+extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
 
 template <bool CM>
 static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
@@ -1515,11 +1574,16 @@ static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s
   size_t lds = (size_t)a.nb * ((a.group * (rf / 4)) | 1) * 16;   // [row][group * planes | 1] float4 (+ 4 KB dictionary)
   const bool ks = tdr_has_kslot(ncls, rf);
   const bool us = a.utab != nullptr;
-#define TDR_LAUNCH_SCORE(NV4)                                                                                       \
-  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true, CM>), grid, block, lds, s, a);   \
-  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false, CM>), grid, block, lds, s, a);   \
-  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true, CM>), grid, block, lds, s, a);   \
-  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false, CM>), grid, block, lds, s, a);
+#define TDR_LAUNCH_SCORE_F(NV4, SK)                                                                                             \
+  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true, CM, false, SK>), grid, block, lds, s, a);   \
+  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false, CM, false, SK>), grid, block, lds, s, a);   \
+  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true, CM, false, SK>), grid, block, lds, s, a);   \
+  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false, CM, false, SK>), grid, block, lds, s, a);
+#define TDR_LAUNCH_SCORE(NV4)                                  \
+  if constexpr (CM) {                                          \
+    if (a.kmask_row) { TDR_LAUNCH_SCORE_F(NV4, true) }         \
+    else { TDR_LAUNCH_SCORE_F(NV4, false) }                    \
+  } else { TDR_LAUNCH_SCORE_F(NV4, false) }
   switch (rf / 4) {
     case 1: TDR_LAUNCH_SCORE(1) break;
     case 2: TDR_LAUNCH_SCORE(2) break;
@@ -1530,6 +1594,7 @@ static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s
     default: return fail(TDR_ERR_ARG, "score: unsupported record size %d", rf);
   }
 #undef TDR_LAUNCH_SCORE
+#undef TDR_LAUNCH_SCORE_F
   LAUNCH_CHECK("score_polar");
   return TDR_OK;
 }
@@ -1567,6 +1632,29 @@ static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, 
   return launch_score_form<true>(a, rf, ncls, s);
 }
 
+// A stream of the library's own (one per device) for work that runs beside the caller's stream inside one call; joined
+// again through events before the call's last kernel, so the caller sees plain stream order.
+struct SideStream {
+  hipStream_t s;
+  hipEvent_t fork, join;
+};
+static SideStream* side_stream() {
+  static SideStream* tab[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!tab[dev]) {
+    SideStream* x = new SideStream;
+    const hipError_t rc = hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking);
+    if (rc != hipSuccess || hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->join, hipEventDisableTiming) != hipSuccess) {
+      delete x;
+      return nullptr;
+    }
+    tab[dev] = x;
+  }
+  return tab[dev];
+}
+
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                  float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
                                  int64_t n_total, const int32_t* perm, float uniform_scale, int init_search,
@@ -1589,7 +1677,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   ScoreArgs a;
   a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
-  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr; a.slot_base = nullptr; a.kmask_off = 0; a.kmask_row = 0;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
   const ScoreWs W = score_ws(map->ncls, nb, nr, n, n_total);
   a.group = W.group;
@@ -1702,19 +1790,35 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   if (W.su && map_has_compact(map, rf) && !map_is_wide(map, rf)) {
     // shift-uniform order (tdr_score_su.h): same partial sums, slot-indexed over the padded order
     const int32_t* slots = nullptr;
-    const int32_t* nslots = nullptr;
+    const int32_t* counts = nullptr;   // device words {slots of the shift-uniform share, lane-shift share, both}
     SuLaunch L;
     L.map = map; L.tab = a.utab ? a.utab : a.tab; L.uniform_scale = a.utab != nullptr; L.scan_pk = scan_pk;
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
     L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
-    if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &nslots))) return rc;
+    if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &counts))) return rc;
     {
+      // dense particles by heading bin through the shift-uniform kernel, sparse ones — in their locality order, behind the
+      // bins in the same slot list — through the lane-shift kernel: identical partial sums either way.  The two launches
+      // run side by side (a stream of the library's own): one is bound by vector issue, the other by the memory system.
       ScoreProfScope prof(s);
-      rc = tdr_su_score(L, W.suw, s);
+      SideStream* side = side_stream();
+      if (!side) return fail(TDR_ERR_HIP, "score: cannot create the side stream");
+      HIP_TRY(hipEventRecord(side->fork, s));
+      HIP_TRY(hipStreamWaitEvent(side->s, side->fork, 0));
+      ScoreArgs r = a;
+      r.order = slots; r.slot_base = counts; r.count = counts + 1; r.npad = W.npad_part;
+      r.crec = map->crec; r.dict = map->dict; r.dict_n = map->dict_n;
+      const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
+      r.ctiles_r = (map->rows >> lc) + 2;
+      r.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
+      r.kmask_row = ((map->cols >> 5) + 2) * 4;
+      if ((rc = launch_score_form<true>(r, rf, map->ncls, side->s))) return rc;
+      HIP_TRY(hipEventRecord(side->join, side->s));
+      if ((rc = tdr_su_score(L, W.suw, s))) return rc;
+      HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
     }
-    if (rc) return rc;
-    f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = nslots;
+    f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = counts + 2;
     hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(W.npad_part, 256)), dim3(256), 0, s, f);
   } else {
     rc = launch_score(a, map, rf, map->ncls, s);
@@ -1783,7 +1887,7 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   ScoreArgs a;
   a.rec = map->rec; a.rows = map->rows; a.cols = map->cols; a.resolution = map->resolution;
   a.tab = tab; a.scan_pk = scan_pk; a.nb = nb; a.nr = nr; a.res = res;
-  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr;
+  a.st = st; a.cap = cap; a.n = n; a.order = perm; a.count = nullptr; a.slot_base = nullptr; a.kmask_off = 0; a.kmask_row = 0;
   a.use_theta_override = 0; a.theta_override = 0.f; a.only_uninit = 0;
   const ScoreWs W = score_ws(map->ncls, nb, nr, n, n_total);
   a.group = W.group;

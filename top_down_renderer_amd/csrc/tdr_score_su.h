@@ -10,7 +10,7 @@ bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
 // The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
 struct SuWs {
   int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, total;
-  // ints: [cnt nb][start nb][slot_start nb][nslots 1]
+  // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3]
 };
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
 
@@ -29,9 +29,10 @@ struct SuLaunch {
   float* part;
   int32_t* ws;               // tdr_su_ws(...).total words
 };
-// ordering passes + descriptors (everything but the scoring kernel); slots_out / nslots_out: the padded order and the
-// device word holding the number of slots in use (finalize walks them)
-int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** nslots_out);
-// the scoring kernel over the prepared order
+// ordering passes + descriptors (everything but the scoring kernels).  slots_out: the slot list — the dense particles
+// by heading bin, every bin padded to whole waves (-1), then the sparse particles in the caller's order (su_key_kernel);
+// counts_out: device words {slots of the heading bins, sparse particles behind them, both together (what finalize walks)}
+int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out);
+// the shift-uniform kernel over the heading bins' slots
 int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 #endif  // TDR_SCORE_SU_H_

@@ -65,8 +65,6 @@ struct SuArgs {
   int group, nchunks, ncls;
   int64_t npad;            // stride of `part`
   float* part;             // [nchunks][rf+1][npad]
-  int use_asm;             // 0: the C++ loop everywhere (TDR_SU_ASM=0; A/B and debugging)
-  const uint32_t* dbg;     // SU_ASM_DEBUG builds: offset limits in, largest offsets out
 };
 
 // Scan descriptor of a bin, four dwords:
@@ -153,29 +151,56 @@ __global__ __launch_bounds__(256) void su_bbox_kernel(const float* __restrict__ 
   if (threadIdx.x < 4) bbox[((int64_t)chunk * SU_NSECT + sect) * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// Sort key of every particle (in the caller's locality order): its heading bin when its neighbourhood is DENSE, nb when
+// it is SPARSE — the 64 particles around it in the locality (Morton) order are more than `span` map cells apart.  A
+// workgroup of the shift-uniform kernel stages the known mask of everything its 256 particles' windows cover: dense
+// particles sorted together keep that box small and share the cache lines of their record gathers.  Sparse ones share
+// nothing whatever the order and are bound by the memory system, not by instruction issue: they keep their locality order
+// and go through score_polar_kernel (tdr_score.hip), behind the dense ones in the same slot list.
+// Histogram of the nb + 1 keys: per workgroup in LDS first (a converged filter fills a few bins).
 __global__ __launch_bounds__(256) void su_key_kernel(const float* __restrict__ st, int64_t cap, int64_t n,
-                                                     const int32_t* __restrict__ perm, int nb,
+                                                     const int32_t* __restrict__ perm, int nb, float span,
                                                      uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
                                                      int* __restrict__ cnt) {
+  extern __shared__ int hist[];
+  for (int k = threadIdx.x; k <= nb; k += 256) hist[k] = 0;
+  __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int32_t p = perm ? perm[t] : (int32_t)t;
-  const int s = rot_shift_dev(st[TDR_ST_THETA * cap + p], nb);
-  keys[t] = (uint32_t)s;
-  vals[t] = p;
-  atomicAdd(&cnt[s], 1);
+  if (t < n) {
+    const int32_t p = perm ? perm[t] : (int32_t)t;
+    uint32_t key = (uint32_t)rot_shift_dev(st[TDR_ST_THETA * cap + p], nb);
+    if (span > 0.f) {
+      auto centre = [&](int64_t q, float& x, float& y) {
+        const float sc = st[TDR_ST_SCALE * cap + q];
+        x = st[TDR_ST_DX * cap + q] * sc + st[TDR_ST_INIT_X * cap + q];
+        y = st[TDR_ST_DY * cap + q] * sc + st[TDR_ST_INIT_Y * cap + q];
+      };
+      const int64_t ta = t >= 32 ? t - 32 : 0, tb = t + 32 < n ? t + 32 : n - 1;
+      float x0, y0, x1, y1;
+      centre(perm ? perm[ta] : ta, x0, y0);
+      centre(perm ? perm[tb] : tb, x1, y1);
+      if (!(fabsf(x1 - x0) <= span && fabsf(y1 - y0) <= span)) key = (uint32_t)nb;   // (NaN positions: sparse)
+    }
+    keys[t] = key;
+    vals[t] = p;
+    atomicAdd(&hist[key], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= nb; k += 256)
+    if (hist[k]) atomicAdd(&cnt[k], hist[k]);
 }
 
-// one workgroup: exclusive sums of the bucket sizes (start in the sorted list) and of the sizes rounded up to whole waves
-// (start in the slot list); nslots = slots in use
-__global__ __launch_bounds__(256) void su_offsets_kernel(const int* __restrict__ cnt, int nb, int* __restrict__ start,
-                                                         int* __restrict__ slot_start, int* __restrict__ nslots) {
+// One workgroup.  The particles of key k start at start[k] in the sorted list and take slots [slot_start[k], + count) of
+// the slot list, the count of a heading bin (k < nkeys - 1) rounded up to whole waves.
+// counts = {slots of the heading bins (a multiple of 64), sparse particles behind them, both together}
+__global__ __launch_bounds__(256) void su_offsets_kernel(const int* __restrict__ cnt, int nkeys, int* __restrict__ start,
+                                                         int* __restrict__ slot_start, int* __restrict__ counts) {
   __shared__ int sa[256], sb[256];
   int carry_a = 0, carry_b = 0;
-  for (int base = 0; base < nb; base += 256) {
+  for (int base = 0; base < nkeys; base += 256) {
     const int k = base + threadIdx.x;
-    const int c = k < nb ? cnt[k] : 0;
-    const int cp = (c + 63) & ~63;
+    const int c = k < nkeys ? cnt[k] : 0;
+    const int cp = k < nkeys - 1 ? (c + 63) & ~63 : c;
     sa[threadIdx.x] = c;
     sb[threadIdx.x] = cp;
     __syncthreads();
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(256) void su_offsets_kernel(const int* __restrict__
       sb[threadIdx.x] += vb;
       __syncthreads();
     }
-    if (k < nb) {
+    if (k < nkeys) {
       start[k] = carry_a + sa[threadIdx.x] - c;
       slot_start[k] = carry_b + sb[threadIdx.x] - cp;
     }
@@ -195,7 +220,12 @@ __global__ __launch_bounds__(256) void su_offsets_kernel(const int* __restrict__
     carry_b += sb[255];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *nslots = carry_b;
+  if (threadIdx.x == 0) {
+    const int sparse = cnt[nkeys - 1];
+    counts[0] = carry_b - sparse;
+    counts[1] = sparse;
+    counts[2] = carry_b;
+  }
 }
 
 __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
@@ -203,8 +233,8 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
                                                          const int* __restrict__ slot_start, int32_t* __restrict__ slots) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const uint32_t s = keys[t];
-  slots[slot_start[s] + ((int)t - start[s])] = vals[t];
+  const uint32_t k = keys[t];
+  slots[slot_start[k] + ((int)t - start[k])] = vals[t];
 }
 
 // LDS of the scoring kernel, ONE object so that the dictionary sits at LDS address 0 (the assembly loop reads it there)
@@ -219,7 +249,7 @@ struct SuLds {
 // score_polar_kernel: direction i ascending, the group's rings in steps of 4 consecutive cells along the ray.  The
 // directions are walked in SU_NSECT sectors; for each the workgroup stages the known mask of the cells its windows can reach.
 template <int NV4, bool KSLOT, bool USCALE>
-__global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void score_polar_su_kernel(SuArgs a) {
   constexpr int RF = 4 * NV4;
   constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
   constexpr bool ASM_LOOP = CW == 2 && ND == 6;   // tdr_score_su_asm.h: two-dword records
@@ -275,48 +305,71 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
   float norm = 0.f;
   uint32_t known = 0;
 
-  // One step: the 4 samples (i, j0 + jj .. jj + 3), paired with scan row r.  Known bits come from word
-  // ri * krow4 + (ci >> 5) * 4 + kconst of the staged mask in LDS (LDSMASK) or of the map's own mask in global memory (a
-  // workgroup whose windows are too far apart to stage).
-  auto cpp_step = [&](auto ldsmask, int i, int r, int jj, int krow4, int kconst) {
-    constexpr bool LDSMASK = decltype(ldsmask)::value;
+  // per-class accumulate of a bin that holds class cd - 1 only: a switch over a wave-uniform value
+  auto single_class = [&](uint32_t cd, float v, uint32_t ww) {
+    switch (cd) {
+#define SU_CASE(K)                                                                                 \
+  case K + 1:                                                                                      \
+    if constexpr (K < ND) {                                                                        \
+      const float m = field1(ww, K < ND ? K : 0);                                                  \
+      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m));          \
+    }                                                                                              \
+    break;
+      SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
+      SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
+#undef SU_CASE
+      default: break;
+    }
+  };
+  // a bin with several classes (or a non-finite value in play): the whole record against the packed scan record
+  auto full_bin = [&](uint32_t cd, float v, const uint32_t (&wr)[CW], int kbit, int64_t bin) {
+    const tdr_const_f S = scanc + bin * RF;
+    norm = __builtin_fmaf(v, (float)kbit, norm);
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const float sk = S[k];
+      if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
+    }
+  };
+  // cell of one sample (top_down_map_polar.cpp:28-31)
+  auto cell = [&](float tx, float ty, int& ri, int& ci) {
+    tdr_v2f pv = {tx, ty};
+    if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
+    pv = pv + offv;                                     // :29-30
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;                              // round_half_away_clamped
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+  };
+
+  // One step with the known mask staged in LDS: the 4 samples (i, j0 + jj .. jj + 3), paired with scan row r.  Known bits
+  // come from word ri * krow4 + (ci >> 5) * 4 + kconst of the staged mask.
+  auto cpp_step = [&](int i, int r, int jj, int krow4, int kconst) {
     const tdr_const_f T = tbase + ((int64_t)i * G + jj) * 2;
     const tdr_const_u D = dbase + ((int64_t)r * G + jj) * 4;
-    float tx[4], ty[4], val[4];
-    uint32_t code[4], ckc[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      tx[u] = T[2 * u];
-      ty[u] = T[2 * u + 1];
-      code[u] = D[4 * u];
-      val[u] = __uint_as_float(D[4 * u + 1]);
-      ckc[u] = D[4 * u + 2];
-    }
+    float val[4];
+    uint32_t code[4];
     uint32_t w[4], bits[4];
     int cis[4];
     unsigned offs[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      tdr_v2f pv = {tx[u], ty[u]};
-      if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
-      pv = pv + offv;                                     // :29-30
-      tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
-      qv = qv + 0.49999997f;                              // round_half_away_clamped
+      code[u] = D[4 * u];
+      val[u] = __uint_as_float(D[4 * u + 1]);
+      const uint32_t ckc = D[4 * u + 2];
       int ri, ci;
-      asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
-      asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+      cell(T[2 * u], T[2 * u + 1], ri, ci);
       cis[u] = ci;
       int wa;
       asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(wa) : "v"(ri), "v"(krow4), "s"(kconst));
       const int cw5 = ci >> 5;
       unsigned la;
       asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
-      if constexpr (LDSMASK) asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
-      else asm volatile("global_load_dword %0, %1, %2" : "=v"(bits[u]) : "v"(la), "s"(kmask));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
       if (code[u] != 0) {   // wave-uniform: only a non-empty bin needs its record — one dword of it
         int t1, t2;
         const int cq = ci >> 2;
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc[u]));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
         asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
@@ -336,41 +389,113 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
         if (cd < SU_CODE_FULL_ALL) {
           // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
           norm = norm + __uint_as_float((uint32_t)kmsk & __float_as_uint(val[u]));
-          switch (cd) {   // wave-uniform
-#define SU_CASE(K)                                                                                          \
-  case K + 1:                                                                                               \
-    if constexpr (K < ND) {                                                                                 \
-      const float m = field1(w[u], K < ND ? K : 0);                                                         \
-      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(val[u]), "v"(m));              \
-    }                                                                                                       \
-    break;
-            SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
-            SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
-#undef SU_CASE
-            default: break;
-          }
-        } else {   // several classes (or a non-finite value in play): the whole record, the packed scan record
+          single_class(cd, val[u], w[u]);
+        } else {
           uint32_t wr[CW];
           wr[0] = w[u];
 #pragma unroll
           for (int d = 1; d < CW; d++)
             wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
-          const tdr_const_f S = scanc + ((int64_t)(j0 + jj + u) * nb + r) * RF;
-          norm = __builtin_fmaf(val[u], (float)(kmsk & 1), norm);
-#pragma unroll
-          for (int k = 0; k < ND; k++) {
-            const float sk = S[k];
-            if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
-          }
+          full_bin(cd, val[u], wr, kmsk & 1, (int64_t)(j0 + jj + u) * nb + r);
         }
       }
     }
   };
-  // One sector of directions [i0, i1)
-  auto run_sector = [&](auto ldsmask, int i0, int i1, int krow4, int kconst) {
-    constexpr bool LDSMASK = decltype(ldsmask)::value;
+  // NS consecutive steps of a sector (step k = direction i0 + k / spd, rings (k % spd) * 4 ..) WITHOUT the staged mask:
+  // the windows of the workgroup's particles are too far apart to stage (scattered particles: su_key_kernel gives them
+  // waves of their own).  Every gather of such a wave misses the caches, so the wave is bound by how many it keeps in
+  // flight: the records of all 4 NS samples are requested before the first is used, and the known bit comes with the
+  // record (bit 0 of every dword of a compact record, tdr_cmap.hip) instead of a second gather from the mask.
+  auto far_steps = [&](auto nsteps_c, int i, int jj) {
+    constexpr int NS = decltype(nsteps_c)::value;
+    uint32_t w[4 * NS];
+    int ii = i, jx = jj;
+#pragma unroll
+    for (int d = 0; d < NS; d++) {
+      int r = ii + shift;
+      r -= r >= nb ? nb : 0;
+      const tdr_const_f T = tbase + ((int64_t)ii * G + jx) * 2;
+      const tdr_const_u D = dbase + ((int64_t)r * G + jx) * 4;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int ri, ci;
+        cell(T[2 * u], T[2 * u + 1], ri, ci);
+        // a single class: the dword it lives in; an empty bin (for its known bit) or several classes: dword 0
+        const uint32_t ckc = D[4 * u + 2];
+        int t1, t2;
+        unsigned off;
+        const int cq = ci >> 2;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
+        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
+        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(w[4 * d + u]) : "v"(off), "s"(crec));
+      }
+      jx += 4;
+      if (jx >= gn) { jx = 0; ii++; }
+    }
+    ii = i; jx = jj;
+#pragma unroll
+    for (int d = 0; d < NS; d++) {
+      int r = ii + shift;
+      r -= r >= nb ? nb : 0;
+      const tdr_const_u D = dbase + ((int64_t)r * G + jx) * 4;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        // (the requests return in order: sample 4 d + u is there once all but the 4 NS - 1 - (4 d + u) behind it are)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[4 * d + u]) : "n"(4 * NS - 1 - (4 * d + u)));
+        const uint32_t ww = w[4 * d + u];
+        const uint32_t kb = ww & 1u;
+        known += kb;
+        const uint32_t cd = D[4 * u];
+        if (cd != 0) {   // wave-uniform
+          const float v = __uint_as_float(D[4 * u + 1]);
+          if (cd < SU_CODE_FULL_ALL) {
+            norm = norm + __uint_as_float((0u - kb) & __float_as_uint(v));
+            single_class(cd, v, ww);
+          } else {
+            // the other dwords of the record: its offset again (rare: ~1 % of the bins hold several classes)
+            // (behind a barrier the optimiser cannot see through: it would keep the coordinates of all 4 NS samples
+            // alive from the request pass for the sake of this branch — 8 NS registers, a wave per SIMD less)
+            int iq = ii;
+            asm volatile("" : "+s"(iq));
+            const tdr_const_f T = tbase + ((int64_t)iq * G + jx) * 2;
+            int ri, ci;
+            cell(T[2 * u], T[2 * u + 1], ri, ci);
+            const unsigned off = cmap_offset<CW, (CW == 1 ? 3 : (CW == 2 ? 2 : 1))>(ri, ci, ckcol, a.ctiles_r * 128 + 128);
+            uint32_t wr[CW];
+            wr[0] = ww;
+#pragma unroll
+            for (int q = 1; q < CW; q++)
+              wr[q] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * q + off);
+            full_bin(cd, v, wr, (int)kb, (int64_t)(j0 + jx + u) * nb + r);
+          }
+        }
+      }
+      jx += 4;
+      if (jx >= gn) { jx = 0; ii++; }
+    }
+  };
+  constexpr int FAR_DEPTH = 4;   // steps (of 4 samples) a wave of the memory-bound path keeps in flight
+  auto far_sector = [&](int i0, int i1) {
+    const int spd = gn >> 2, total = (i1 - i0) * spd;
+    int i = i0, jj = 0, k = 0;
+    auto advance = [&](int steps) {
+      jj += 4 * steps;
+      while (jj >= gn) { jj -= gn; i++; }
+    };
+    for (; k + FAR_DEPTH <= total; k += FAR_DEPTH) {
+      far_steps(std::integral_constant<int, FAR_DEPTH>{}, i, jj);
+      advance(FAR_DEPTH);
+    }
+    for (; k < total; k++) {
+      far_steps(std::integral_constant<int, 1>{}, i, jj);
+      advance(1);
+    }
+  };
+  // One sector of directions [i0, i1) with the known mask staged in LDS
+  auto run_sector = [&](int i0, int i1, int krow4, int kconst) {
     if constexpr (ASM_LOOP) {
-      if (a.use_asm && gn == G && lds_base == 0 && (G == 4 || G == 8 || G == 16)) {
+      if (gn == G && lds_base == 0 && (G == 4 || G == 8 || G == 16)) {
         // the steps of the sector as one stream: step k reads T at byte k * 32 from its start and D at byte k * 64 from the
         // start of scan row (i0 + shift) mod nb, wrapping to row 0; the loop hands a step that holds a bin with several
         // classes back (nleft >= 0 on exit), cpp_step does that one, and the loop goes on behind it
@@ -397,12 +522,10 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
             [nleft] "+v"(nleft), [wleft] "+v"(wleft)                                                                   \
           : [offv] "v"(offv), [krow4] "v"(krow4), [ckcol] "v"(ckcol), [tb] "s"(tbase), [db] "s"(dbase),              \
             [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
-            [kmask] "s"(kmask), [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2), [dbgp] "s"(a.dbg)        \
+            [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2)                                               \
           : SU_ASM_CLOBBERS
-          if constexpr (USCALE && LDSMASK) asm volatile(SU_ASM_US_LDS SU_ASM_OPERANDS);
-          else if constexpr (USCALE) asm volatile(SU_ASM_US_GLB SU_ASM_OPERANDS);
-          else if constexpr (LDSMASK) asm volatile(SU_ASM_PS_LDS SU_ASM_OPERANDS);
-          else asm volatile(SU_ASM_PS_GLB SU_ASM_OPERANDS);
+          if constexpr (USCALE) asm volatile(SU_ASM_US SU_ASM_OPERANDS);
+          else asm volatile(SU_ASM_PS SU_ASM_OPERANDS);
 #undef SU_ASM_OPERANDS
           // (the compiler takes the outputs of an asm statement for divergent)
           toff = __builtin_amdgcn_readfirstlane(toff); doff = __builtin_amdgcn_readfirstlane(doff);
@@ -414,7 +537,7 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
           const int i = i0 + (k >> lsp), jj = (k & (spd - 1)) * 4;
           int r = i + shift;
           r -= r >= nb ? nb : 0;
-          cpp_step(ldsmask, i, r, jj, krow4, kconst);
+          cpp_step(i, r, jj, krow4, kconst);
           toff += 32u;
           doff += 64u;
           if (wleft == 0) { doff = 0; wleft = wrapm1; } else wleft--;
@@ -428,7 +551,7 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
     for (int i = i0; i < i1; i++) {
       int r = i + shift;
       r -= r >= nb ? nb : 0;
-      for (int jj = 0; jj < gn; jj += 4) cpp_step(ldsmask, i, r, jj, krow4, kconst);
+      for (int jj = 0; jj < gn; jj += 4) cpp_step(i, r, jj, krow4, kconst);
     }
   };
 
@@ -470,8 +593,8 @@ __global__ __launch_bounds__(256) void score_polar_su_kernel(SuArgs a) {
     }
     __syncthreads();
     if (active) {
-      if (fits) run_sector(std::true_type{}, i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4);
-      else run_sector(std::false_type{}, i0, i1, a.kwpr * 4, (a.kwpr + 1) * 4);
+      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4);
+      else far_sector(i0, i1);
     }
   }
   if (active) {
@@ -496,14 +619,22 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
   return g_su_mode;
 }
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
+static float g_su_span = [] {   // map cells the 64 locality neighbours of a "dense" particle may span
+  const char* e = getenv("TDR_SU_SPAN");
+  return e ? (float)atof(e) : 16.f;
+}();
+extern "C" float tdr_config_shift_uniform_span(float cells) {   // < 0: query only; 0: every particle counts as dense
+  if (cells >= 0.f) g_su_span = cells;
+  return g_su_span;
+}
 static int64_t g_su_launches = 0;
 extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches; }
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total) {
   if (g_su_mode == 0) return false;
-  if (group % 4 != 0 || nr % 4 != 0 || nb > 4096) return false;
-  if (g_su_mode == 2) return true;
-  return n_total >= (int64_t)192 * nb;
+  if (group % 4 != 0 || nr % 4 != 0 || nb > 4095) return false;
+  if (g_su_mode == 2) return true;   // tests: small filters too
+  return n_total >= (int64_t)64 * nb;
 }
 static size_t su_sort_tmp_bytes(int64_t n) {
   size_t bytes = 0;
@@ -526,14 +657,14 @@ SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   w.keys_out = take(n);
   w.vals_in = take(n);
   w.vals_out = take(n);
-  w.ints = take(3 * (int64_t)nb + 64);
+  w.ints = take(3 * ((int64_t)nb + 1) + 4);   // [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3]
   w.slots = take(su_npad(n, nb));
   w.sort_tmp = take((int64_t)((su_sort_tmp_bytes(n) + 3) / 4));
   w.total = o;
   return w;
 }
 
-int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** nslots_out) {
+int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out) {
   int32_t* base = L.ws;
   float* tab_su = reinterpret_cast<float*>(base + W.tab_su);
   uint32_t* desc = reinterpret_cast<uint32_t*>(base + W.desc);
@@ -542,23 +673,24 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   int32_t* vals_in = base + W.vals_in;
   int32_t* vals_out = base + W.vals_out;
   int* cnt = base + W.ints;
-  int* start = cnt + L.nb;
-  int* slot_start = start + L.nb;
-  int* nslots = slot_start + L.nb;
+  const int nkeys = L.nb + 1;
+  int* start = cnt + nkeys;
+  int* slot_start = start + nkeys;
+  int* counts = slot_start + nkeys;
   int32_t* slots = base + W.slots;
   const int64_t n = L.n;
-  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * L.nb + 1), s));
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * nkeys + 3), s));
   HIP_TRY(hipMemsetAsync(slots, 0xFF, sizeof(int32_t) * (size_t)L.npad, s));
-  hipLaunchKernelGGL(su_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, L.st, L.cap, n, L.perm, L.nb, keys_in,
-                     vals_in, cnt);
+  hipLaunchKernelGGL(su_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), sizeof(int) * (size_t)nkeys, s, L.st, L.cap, n,
+                     L.perm, L.nb, g_su_span, keys_in, vals_in, cnt);
   LAUNCH_CHECK("su_key");
+  hipLaunchKernelGGL(su_offsets_kernel, dim3(1), dim3(256), 0, s, (const int*)cnt, nkeys, start, slot_start, counts);
+  LAUNCH_CHECK("su_offsets");
   unsigned bits = 1;
-  while ((1u << bits) < (unsigned)L.nb) bits++;
+  while ((1u << bits) < (unsigned)nkeys) bits++;
   size_t tmp_bytes = su_sort_tmp_bytes(n);
   HIP_TRY(rocprim::radix_sort_pairs(base + W.sort_tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, bits,
                                     s, false));
-  hipLaunchKernelGGL(su_offsets_kernel, dim3(1), dim3(256), 0, s, (const int*)cnt, L.nb, start, slot_start, nslots);
-  LAUNCH_CHECK("su_offsets");
   hipLaunchKernelGGL(su_scatter_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const uint32_t*)keys_out,
                      (const int32_t*)vals_out, n, (const int*)start, (const int*)slot_start, slots);
   LAUNCH_CHECK("su_scatter");
@@ -572,14 +704,14 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
                      L.group, reinterpret_cast<float*>(base + W.bbox));
   LAUNCH_CHECK("su_bbox");
   *slots_out = slots;
-  *nslots_out = nslots;
+  *counts_out = counts;
   return TDR_OK;
 }
 
 int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   const tdr_map_desc* map = L.map;
   int32_t* base = L.ws;
-  int* nslots = base + W.ints + 3 * L.nb;
+  int* nslots = base + W.ints + 3 * (L.nb + 1);   // counts[0]
   SuArgs u;
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   u.crec = map->crec; u.dict = map->dict; u.dict_n = map->dict_n; u.ctiles_r = (map->rows >> lc) + 2;
@@ -593,20 +725,6 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
   u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = L.part;
-  static const int use_asm = [] {
-    const char* e = getenv("TDR_SU_ASM");
-    return e ? atoi(e) : 1;
-  }();
-  u.use_asm = use_asm;
-  uint32_t* dbg = reinterpret_cast<uint32_t*>(base + W.ints + 3 * L.nb + 8);
-  u.dbg = dbg;
-  if (getenv("TDR_SU_DEBUG")) {
-    const uint32_t lim[16] = {(uint32_t)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4 - 4),
-                             (uint32_t)((size_t)(map->rows + 2) * u.kwpr * 4 - 4), (uint32_t)(L.nb * L.group * 8 - 32),
-                             (uint32_t)(L.nb * L.group * 16 - 64), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(dbg, lim, sizeof(lim), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
   const dim3 grid((unsigned)cdiv(L.npad, 256), (unsigned)L.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, L.rf), us = L.uniform_scale;
 #define TDR_LAUNCH_SU(NV4)                                                                         \
@@ -623,17 +741,5 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
 #undef TDR_LAUNCH_SU
   LAUNCH_CHECK("score_polar_su");
   g_su_launches++;
-  if (getenv("TDR_SU_DEBUG")) {
-    uint32_t out[16];
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(out, dbg, sizeof(out), hipMemcpyDeviceToHost));
-    fprintf(stderr, "su debug: limits rec %u mask %u T %u D %u | max seen rec %u mask %u T/D %u\n", out[0], out[1], out[2],
-            out[3], out[4], out[5], out[6]);
-    float tx, ty;
-    memcpy(&tx, &out[14], 4);
-    memcpy(&ty, &out[15], 4);
-    fprintf(stderr, "su debug: offending offset %u ri %d ci %d krow4 %u kconst %u ci>>5 %d tx %g ty %g\n", out[8], (int)out[9],
-            (int)out[10], out[11], out[12], (int)out[13], tx, ty);
-  }
   return TDR_OK;
 }
