@@ -265,8 +265,7 @@ def test_geometric_cost_term_matches_oracle(tdr, oracle, seed, uninit):
     got = f.raw_weights()
     pre = k.states_to_host(f.st_new, len(st), pkg.STATE_DTYPE)
     assert np.array_equal(np.isnan(got), np.isnan(ref))
-    same = pre["theta"] == st_o["theta"]
-    assert same.mean() > 0.9
+    same = pre["theta"] == st_o["theta"]   # (no floor on how many agree: every mismatch must be a tie, below)
     err = np.abs(got[ok & same] - ref[ok & same]) / np.abs(ref[ok & same])
     assert err.max(initial=0.0) <= 1e-5, err.max()
     if not same.all():   # another candidate of the search: the weight is the oracle's at that rotation, which is a near-tie

@@ -145,8 +145,7 @@ def test_random_init_search_against_oracle(env, oracle, seed, ncls, pile):
         raw_g = f.raw_w[: len(st)].cpu().numpy()
         got = k.states_to_host(f.st, len(st), st.dtype)
         assert np.array_equal(got["have_init"], st_o["have_init"])
-        same = got["theta"] == st_o["theta"]
-        assert same.mean() > 0.9
+        same = got["theta"] == st_o["theta"]   # (no floor on how many agree: every mismatch must be a tie, below)
         _assert_weights(raw_g[same], raw_o[same], 1e-5)
         # Where another candidate was chosen: the weight is the oracle's AT THAT rotation (1e-5), and that rotation ties
         # with the oracle's minimum to within the rounding of the candidates' float sums (the reference's own Eigen sums

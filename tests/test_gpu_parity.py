@@ -894,10 +894,15 @@ def test_init_search_c1(tdr, oracle):
     f.update(scan, None, cfg.res)
     _assert_weights(f.raw_weights(), ref)
     pre = k.states_to_host(f.st_new, len(st), pkg.STATE_DTYPE)
-    # near-ties between rotations may resolve differently within the 1e-5 weight tolerance; thetas must agree
-    # wherever the best cost is unique at that tolerance
-    agree = np.isclose(pre["theta"], st_o["theta"], rtol=0, atol=1e-6)
-    assert agree.mean() > 0.97
+    # Rotations may tie to within the rounding of the candidates' float sums: wherever another candidate was chosen, it
+    # is a tie of the oracle's minimum (<= 2e-5 on the weight) — no floor on how many agree, every mismatch is checked.
+    differ = pre["theta"] != st_o["theta"]
+    if differ.any():
+        st2 = st_o.copy()
+        st2["theta"], st2["have_init"] = pre["theta"], 1
+        ref2 = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls), st2)
+        tie = np.abs(ref2[differ] - ref[differ]) / np.maximum(np.abs(ref[differ]), 1e-30)
+        assert np.nanmax(tie, initial=0.0) <= 2e-5, f"chosen rotation is not a near-tie: {np.nanmax(tie):.2e}"
     assert pre["have_init"].all()
 
 
@@ -995,6 +1000,14 @@ def _full_size_polar(tdr, oracle, big_polar, states, n_sel=64):
     f.set_states(states)
     f.update(scan, None, cfg.res)
     sel = np.arange(0, n, n // n_sel)[:n_sel]
+    # ... plus the special cases wherever the set has them: particles whose window leaves the map (centre within a window
+    # radius of the border) and particles scored NaN (more than half of the window unknown, state_particle.cpp:117-120)
+    raw_all = f.raw_weights()
+    cx = states["dx_m"] * states["scale"] + states["init_x_px"]
+    cy = states["dy_m"] * states["scale"] + states["init_y_px"]
+    edge = np.nonzero((cx < cfg.nr) | (cy < cfg.nr) | (cx > m.cols - cfg.nr) | (cy > m.rows - cfg.nr))[0][:256]
+    nan = np.nonzero(np.isnan(raw_all))[0][:256]
+    sel = np.unique(np.concatenate([sel, edge, nan]))
     st_sel = np.ascontiguousarray(states[sel])
     ref = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls), st_sel)
     return f, sel, st_sel, ref
@@ -1003,7 +1016,8 @@ def _full_size_polar(tdr, oracle, big_polar, states, n_sel=64):
 def test_c2_full_size_properties(tdr, oracle, big_polar):
     """BASELINE configs[1]: 100k particles (90 % Gaussian about the true pose + 10 % uniform)."""
     sc = big_polar[0]
-    f, sel, _, ref = _full_size_polar(tdr, oracle, big_polar, sc.states)
+    f, sel, _, ref = _full_size_polar(tdr, oracle, big_polar, sc.states, n_sel=4096)
+    assert len(sel) >= 4096      # (all 100 000 against the oracle: tests/test_shift_uniform.py, the c2 full step)
     _assert_weights(f.raw_weights()[sel], ref)
 
 
@@ -1015,7 +1029,8 @@ def test_c3_shard_full_size_properties(tdr, oracle, big_polar):
     rng = np.random.default_rng(cfg3.seed)
     st = synth.make_particles(cfg3, sc.lab, sc.pose, rng, n=cfg3.n_particles)[: cfg3.n_particles // 8].copy()
     assert len(st) == 125_000
-    f, sel, _, ref = _full_size_polar(tdr, oracle, big_polar, st)
+    f, sel, _, ref = _full_size_polar(tdr, oracle, big_polar, st, n_sel=4096)
+    assert len(sel) >= 4096
     _assert_weights(f.raw_weights()[sel], ref)
 
 
@@ -1045,13 +1060,12 @@ def test_c5_shard_full_size_init_search(tdr, oracle, big_polar):
         cand.append(t)
         t = np.float32(np.float64(t) + 2 * np.pi / 40)
     assert np.isin(pre["theta"], np.asarray(cand, np.float32)).all()
-    sel = np.arange(0, n, n // 64)[:64]
+    sel = np.arange(0, n, n // 2048)[:2048]
     st_o = np.ascontiguousarray(st[sel])
     fpo = oracle.make_params(cfg.ncls)
     ref = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, fpo, st_o)     # runs the search too
     same = pre["theta"][sel] == st_o["theta"]
-    assert same.mean() > 0.9
-    _assert_weights(raw[sel][same], ref[same])
+    _assert_weights(raw[sel][same], ref[same])   # (no floor on how many agree: every mismatch must be a tie, below)
     if not same.all():
         st2 = st_o.copy()
         st2["theta"] = pre["theta"][sel]
@@ -1110,7 +1124,12 @@ def test_c4_full_size_cartesian(tdr, oracle):
     raw, w, idx = res[1]
     assert np.array_equal(raw, res[0][0], equal_nan=True) and np.array_equal(idx, res[0][2])  # order invariance
     _resample_properties(w, idx, n)
-    sel = np.arange(0, n, n // 48)[:48]
+    sel = np.arange(0, n, n // 1024)[:1024]
+    stt = sc.states
+    cx, cy = stt["dx_m"] * stt["scale"] + stt["init_x_px"], stt["dy_m"] * stt["scale"] + stt["init_y_px"]
+    half = 0.75 * max(rows, cols) * cfg.res                 # a rotated window reaches half a diagonal from its centre
+    edge = np.nonzero((cx < half) | (cy < half) | (cx > 8000 - half) | (cy > 8000 - half))[0][:128]
+    sel = np.unique(np.concatenate([sel, edge, np.nonzero(np.isnan(raw))[0][:128]]))   # + windows off the map, NaN scores
     om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
     ref = oracle.compute_weights_cart(om, rows, cols, scan, cfg.res, oracle.make_params(cfg.ncls),
                                       np.ascontiguousarray(sc.states[sel]))

@@ -1568,17 +1568,23 @@ extern "C" int tdr_config_compact(int on) {   // < 0: query only
 extern "C" int tdr_cmap_words(int ncls);
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
 
+template <int NV4, bool KS, bool US, bool CM, bool SK>
+static void launch_polar_kernel(dim3 grid, dim3 block, size_t lds, hipStream_t s, const ScoreArgs& a) {
+  auto kfn = score_polar_kernel<NV4, TDR_SCORE_U, KS, US, CM, false, SK>;
+  if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, grid, block, lds, s, a);
+}
 template <bool CM>
 static int launch_score_form(const ScoreArgs& a, int rf, int ncls, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
   size_t lds = (size_t)a.nb * ((a.group * (rf / 4)) | 1) * 16;   // [row][group * planes | 1] float4 (+ 4 KB dictionary)
   const bool ks = tdr_has_kslot(ncls, rf);
   const bool us = a.utab != nullptr;
-#define TDR_LAUNCH_SCORE_F(NV4, SK)                                                                                             \
-  if (ks && us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, true, CM, false, SK>), grid, block, lds, s, a);   \
-  else if (ks) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, true, false, CM, false, SK>), grid, block, lds, s, a);   \
-  else if (us) hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, true, CM, false, SK>), grid, block, lds, s, a);   \
-  else hipLaunchKernelGGL((score_polar_kernel<NV4, TDR_SCORE_U, false, false, CM, false, SK>), grid, block, lds, s, a);
+#define TDR_LAUNCH_SCORE_F(NV4, SK)                                                                 \
+  if (ks && us) launch_polar_kernel<NV4, true, true, CM, SK>(grid, block, lds, s, a);                \
+  else if (ks) launch_polar_kernel<NV4, true, false, CM, SK>(grid, block, lds, s, a);                \
+  else if (us) launch_polar_kernel<NV4, false, true, CM, SK>(grid, block, lds, s, a);                \
+  else launch_polar_kernel<NV4, false, false, CM, SK>(grid, block, lds, s, a);
 #define TDR_LAUNCH_SCORE(NV4)                                  \
   if constexpr (CM) {                                          \
     if (a.kmask_row) { TDR_LAUNCH_SCORE_F(NV4, true) }         \
