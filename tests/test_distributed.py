@@ -43,7 +43,7 @@ def _scene():
     return sc, cfg, st
 
 
-def _run_filter(group, out_path):
+def _run_filter(group, out_path, n_targets=(None, 64, None)):
     from oracle import c_oracle as oracle
     from oracle_backend import OracleKernels, OracleMapStub
     from top_down_renderer_amd.particle_filter import FilterParams, ParticleFilter
@@ -58,7 +58,7 @@ def _run_filter(group, out_path):
     rank = f.comm.rank
     scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
     log = {}
-    n_targets = [None, 64, None]       # shrink once: exercises N' != N and re-partitioning
+    # n_targets: shrink once — exercises N' != N and re-partitioning
     for step in range(STEPS):
         f.propagate((1.0, 0.2), 0.02)
         # only rank 0 holds the real scan; the other rank must receive it through the broadcast in update()
@@ -79,13 +79,14 @@ def _run_filter(group, out_path):
     np.savez(out_path, **log)
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, n_targets=(None, 64, None)):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run_filter(dist.group.WORLD, os.path.join(tmp, f"rank{rank}.npz"))
+        _run_filter(dist.group.WORLD, os.path.join(tmp, f"rank{rank}.npz"), n_targets)
     finally:
         dist.destroy_process_group()
 
@@ -158,6 +159,31 @@ def test_sharded_run_matches_plain_oracle_sequence(runs, oracle):
     assert np.allclose(raw, single["raw0"], rtol=1e-5, atol=0, equal_nan=True)
     assert np.allclose(w, single["w0"], rtol=1e-5, atol=0)
     assert (idx != single["idx0"]).sum() <= 2
+
+
+def test_eight_ranks_equal_one_rank_with_a_count_that_does_not_divide(oracle):
+    """world_size 8 (the node the scaling run uses): 12 particles per rank, among them particles without a heading on
+    several shards, one of those with an all-unknown window, and a NaN weight on a later shard (_scene).  The second update
+    asks for 70 particles: a sharded filter rounds the count DOWN to a multiple of the world size (64: 8 per rank —
+    ParticleFilter.update), so the one-rank run it must reproduce bit for bit is the one asked for 64."""
+    import torch.multiprocessing as mp
+    tmp = tempfile.mkdtemp(prefix="tdr_dist8_")
+    _run_filter(None, os.path.join(tmp, "single.npz"), (None, 64, None))
+    mp.spawn(_worker, args=(8, _free_port(), tmp, (None, 70, None)), nprocs=8, join=True)
+    load = lambda n: np.load(os.path.join(tmp, n), allow_pickle=False)
+    single, ranks = load("single.npz"), [load(f"rank{r}.npz") for r in range(8)]
+    assert [int(single[f"n{s}"]) for s in range(STEPS)] == [96, 64, 64]
+    assert np.isnan(single["raw0"]).any()
+    for step in range(STEPS):
+        for r in ranks:
+            assert int(r[f"n{step}"]) == int(single[f"n{step}"])
+            assert np.array_equal(r[f"w{step}"], single[f"w{step}"], equal_nan=True)
+            assert np.array_equal(r[f"ml{step}"], single[f"ml{step}"])
+            assert np.array_equal(r[f"mean{step}"], ranks[0][f"mean{step}"])
+        for key in ("raw", "idx", "st"):
+            allr = np.concatenate([r[f"{key}{step}"] for r in ranks])
+            assert np.array_equal(allr, single[f"{key}{step}"], equal_nan=True), (key, step)
+    assert all(list(r["calls"]) == [12, 12, 8] for r in ranks)
 
 
 def test_particle_count_must_divide_evenly():

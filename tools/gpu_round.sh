@@ -21,7 +21,7 @@ for C in $CONFIGS; do
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_$C/issue -o pmc --output-format csv -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu > $OUT/pmc_issue_$C.log 2>&1 || { echo "pmc issue $C failed"; tail -5 $OUT/pmc_issue_$C.log; }
   python3 tools/traffic_from_pmc.py $C $K $N $OUT/pmc_$C $OUT/pmc_${C}_summary.txt || echo "no traffic record for $C"
   cp profiles/score_traffic.json $OUT/score_traffic.json
-  CPU=""; [ "$C" != c2 ] && CPU="--no-cpu"
+  CPU=""
   python3 bench.py --config $C --steps $STEPS --warmup 3 $CPU > $OUT/bench_$C.json 2> $OUT/bench_$C.err || { echo "bench $C failed"; tail -5 $OUT/bench_$C.err; }
   cat $OUT/bench_$C.json
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$C -o trace --output-format csv -- python3 bench.py --config $C --steps 5 --warmup 1 --no-cpu > $OUT/trace_$C.log 2>&1 || echo "trace $C failed"

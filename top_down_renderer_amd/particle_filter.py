@@ -233,7 +233,10 @@ class ParticleFilter:
     def update(self, top_down_scan, top_down_geo=None, res=1.0, n_target=None, covs=None, shift=None):
         """top_down_scan: list of per-class (nb x nr) column-major images (the reference's std::vector<ArrayXXf>),
         an (ncls, nb*nr) array, or a device scan handle from ScanRendererPolar (.last_scan()).
-        n_target / covs: explicit input of the adaptive particle count (:151-157); default keeps the count.
+        n_target / covs: explicit input of the adaptive particle count (:151-157); default keeps the count.  A filter
+        sharded over W ranks keeps the same number of particles on every rank: the new count is rounded DOWN to a
+        multiple of W (at least W) — a W-rank run asked for 70 particles resamples 64 at W = 8 and equals, bit for bit,
+        the one-rank run asked for 64 (tests/test_distributed.py).
         shift: override of the systematic-resampling offset (default: one draw from the shared generator, :172-173)."""
         if self.num_particles_ == 0:
             return  # :96-99
