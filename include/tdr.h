@@ -325,6 +325,11 @@ int tdr_config_compact(int on);
  * compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM / TDR_SU_SPAN set the initial values. */
 int tdr_config_shift_uniform(int mode);
 float tdr_config_shift_uniform_span(float cells);   /* < 0 only returns it */
+/* The Cartesian scoring has a second kernel that reads the scan side of a sample as a scalar descriptor and gives an empty
+ * scan bin one 4-byte gather from the map's known mask instead of the record gather, decode and FMAs
+ * (csrc/tdr_score_cart.hip); same partial sums, bit for bit.  It is used whenever the map has narrow compact records;
+ * 0 forces the general kernel (A/B measurements, tests), 1 restores the default, < 0 only queries.  Env TDR_CART_SKIP. */
+int tdr_config_cart_skip(int on);
 /* diagnostics: scoring launches of this process that took the shift-uniform kernel */
 int64_t tdr_shift_uniform_launches(void);
 

@@ -379,6 +379,52 @@ def test_score_cartesian_vs_oracle(tdr, oracle):
         _assert_weights(f.raw_weights(), ref)   # cos/sin of theta are the host libm's bit for bit (test_libm.py)
 
 
+@pytest.mark.parametrize("ncls,rows,cols,kind", [(6, 50, 64, "scan"), (3, 33, 21, "scan"), (9, 18, 40, "scan"),
+                                                 (6, 37, 29, "dense"), (6, 24, 24, "empty"), (6, 20, 36, "inf")])
+def test_cart_skip_kernel_equals_general_kernel(tdr, oracle, ncls, rows, cols, kind):
+    """score_cart_skip_kernel (csrc/tdr_score_cart.hip: scalar scan descriptors, an empty bin costs one known-mask gather)
+    against score_cart_kernel on the same inputs: raw weights array-equal, and within 1e-5 of the oracle.  Window shapes
+    with rows % 4 != 0 (the tail rows), a scan with several classes in every bin, an empty scan, and a non-finite scan
+    value (0 x inf must stay NaN: nothing may be skipped in that bin)."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("cartskip", 6000, ncls, rows, cols, 500, 700, polar=False, seed=77 + ncls + rows, res=0.75)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    rng = np.random.default_rng(5)
+    st["scale"] = rng.uniform(0.8, 1.25, len(st)).astype(np.float32)
+    st["init_x_px"][:6] = np.asarray([-50, 5, 500, 495, 250, 0.5], np.float32)          # off / at the border
+    st["init_y_px"][:6] = np.asarray([250, 250, 250, 250, -40, 0.5], np.float32)
+    scan = oracle.raster_cart(sc.pts, cfg.res, sc.lut, ncls, rows, cols)
+    if kind == "dense":
+        scan = rng.integers(0, 3, scan.shape).astype(np.float32)
+    elif kind == "empty":
+        scan = np.zeros_like(scan)
+    elif kind == "inf":
+        scan = scan.copy()
+        scan[1, 7] = np.inf
+        scan[0, 11] = np.nan
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
+    with np.errstate(all="ignore"):
+        ref = oracle.compute_weights_cart(om, rows, cols, scan, cfg.res, oracle.make_params(ncls), st.copy())
+    m = pkg.TopDownMap(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.setWindow(rows, cols)
+    before = k.lib.tdr_config_cart_skip(-1)
+    got = []
+    try:
+        for on in (0, 1):
+            k.lib.tdr_config_cart_skip(on)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
+                                   locality_every=1)
+            f.set_states(st)
+            f.update(np.ascontiguousarray(scan, np.float32), None, cfg.res)
+            got.append(f.raw_weights())
+    finally:
+        k.lib.tdr_config_cart_skip(before)
+    assert np.array_equal(got[0], got[1], equal_nan=True)
+    _assert_weights(got[1], ref)
+
+
 def test_local_map_polar_and_cartesian_bit_exact(tdr, oracle):
     """getLocalMap materialised (top_down_map_polar.cpp:21-53, top_down_map.cpp:429-459): the window addressing of the
     scoring kernels as a function of its own — every gathered value and mask bit against the oracle, for poses inside,

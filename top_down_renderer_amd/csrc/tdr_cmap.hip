@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "tdr_common.h"
+#include "tdr_score_dev.h"   // the known mask's geometry
 
 #define CMAP_HASH_BITS 14
 #define CMAP_HASH_SLOTS (1 << CMAP_HASH_BITS)
@@ -82,10 +83,11 @@ extern "C" int tdr_cmap_words(int ncls) {
   if (dw > 4) return 0;
   return dw <= 1 ? 1 : (dw == 2 ? 2 : 4);
 }
-// Behind the tiles of a narrow compact map sits its KNOWN MASK: one bit per cell, rows -1 .. rows, cell (r, c) in word
-// (r + 1) * wpr + (c >> 5) + 1 at bit c & 31 (c = -1: bit 31 of word 0), wpr = (cols >> 5) + 2 words per row; cells outside
-// the map are 0 = unknown, like their guard records.  2 MB for a 4000 x 4000 map: the shift-uniform scoring kernel stages
-// the part a workgroup's windows cover in LDS and reads the `known` bit of every sample there (tdr_score_su.hip).
+// Behind the tiles of a narrow compact map sits its KNOWN MASK: one bit per cell in 32 x 32-cell tiles of 32 words (layout:
+// tdr_score_dev.h, kmask_offset); cells outside the map are 0 = unknown, like their guard records.  2 MB for a 4000 x 4000
+// map.  The shift-uniform scoring kernel stages the part a workgroup's windows cover in LDS and reads the `known` bit of
+// every sample there (tdr_score_su.hip); the kernels that skip empty scan bins gather it (tdr_score_cart.hip,
+// score_polar_kernel<SKIP>).
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols) {
   const int cw = tdr_cmap_words(ncls);
   if (!cw) return 0;
@@ -95,17 +97,19 @@ extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols) {
 extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
   const size_t tiles = tdr_cmap_tile_words(ncls, rows, cols);
   // (+ 4 words: a lane of score_polar_kernel<SKIP> reads a whole record's worth of dwords at a mask word)
-  return tiles ? tiles + (size_t)(rows + 2) * ((cols >> 5) + 2) + 4 : 0;
+  return tiles ? tiles + (size_t)kmask_trows(rows) * kmask_tcols(cols) * 32 + 4 : 0;
 }
-__global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf, int wpr,
+__global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
                                                          uint32_t* __restrict__ kmask) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)(rows + 2) * wpr) return;
-  const int r = (int)(t / wpr) - 1, w = (int)(t % wpr);
+  const int tcols = kmask_tcols(cols);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // word t = tile t / 32, row t % 32 of the tile
+  if (t >= (int64_t)kmask_trows(rows) * tcols * 32) return;
+  const int64_t tile = t >> 5;
+  const int r = (int)(tile / tcols) * 32 + (int)(t & 31) - 32, c0 = (int)(tile % tcols) * 32 - 32;
   uint32_t bits = 0;
   if (r >= 0 && r < rows)
     for (int b = 0; b < 32; b++) {
-      const int c = ((w - 1) << 5) + b;
+      const int c = c0 + b;
       if (c >= 0 && c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) bits |= 1u << b;
     }
   kmask[t] = bits;
@@ -203,10 +207,9 @@ static int cmap_pack(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, voi
                      map->rec_floats, map->ncls, (const unsigned*)hash, (const uint16_t*)hidx, g, wide, crec_out);
   LAUNCH_CHECK("cmap_pack");
   if (!wide) {   // the known mask behind the tiles
-    const int wpr = (map->cols >> 5) + 2;
-    const int64_t nwords = (int64_t)(map->rows + 2) * wpr;
+    const int64_t nwords = (int64_t)kmask_trows(map->rows) * kmask_tcols(map->cols) * 32;
     hipLaunchKernelGGL(cmap_kmask_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, s, map->rec, map->rows, map->cols,
-                       map->rec_floats, wpr, crec_out + (size_t)g.tiles_r * g.tiles_c * 32);
+                       map->rec_floats, crec_out + (size_t)g.tiles_r * g.tiles_c * 32);
     LAUNCH_CHECK("cmap_kmask");
   }
   HIP_TRY(hipStreamSynchronize(s));

@@ -34,14 +34,15 @@ struct ScoreArgs {
   const float* dict;
   int dict_n;           // dictionary entries in use
   int ctiles_r;         // tiles per tile column
-  // the map's known mask (tdr_cmap.hip), read by the SKIP instantiations: byte offset of its word (0, 0) from crec,
-  // bytes per mask row
+  // the map's known mask (tdr_cmap.hip, layout: kmask_offset), read by the SKIP instantiations: its byte offset from
+  // crec, bytes per row of its tiles
   unsigned kmask_off;
   int kmask_row;
 };
 
 #include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
 #include "tdr_score_su.h"    // the shift-uniform kernel's host interface (tdr_score_su.hip)
+#include "tdr_score_cart.h"  // CartArgs, the Cartesian kernel that skips empty scan bins (tdr_score_cart.hip)
 
 
 #ifdef TDR_SCORE_TIMELINE   // diagnostic build: start / end time stamp (100 MHz) of every workgroup
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const tdr_v2f offv = {off0, off1};
   unsigned moff[SKIP ? U : 1];   // SKIP: byte offset (from crec) of the known-mask word of sample u's cell ...
   int mbit[SKIP ? U : 1];        // ... and the cell's column (its low 5 bits: the bit in that word)
-  const int mconst = (int)a.kmask_off + a.kmask_row + 4;   // word (row + 1, (col >> 5) + 1)
+  const int mconst = (int)a.kmask_off + 128;               // kmask_offset
   auto cell_offset = [&](float2 t, int u) -> unsigned {
     tdr_v2f pv = {t.x, t.y};
     if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
     if constexpr (SKIP) {
-      moff[u] = (unsigned)(__mul24(ri, a.kmask_row) + ((ci >> 5) * 4 + mconst));
+      moff[u] = kmask_offset(ri, ci, a.kmask_row, mconst);
       mbit[u] = ci;
     }
     if constexpr (COMPACT) {
@@ -340,26 +341,6 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
 // with shift 0 (src/state_particle.cpp:132-143) (definition recorded in include/tdr.h:tdr_k_score_cart and DESIGN.md).
 // Same mapping as the polar kernel (lane = particle); the rotation now lives in the sampling, so the scan record of
 // sample (i,j) is the same for every lane and comes through the scalar cache instead of LDS.
-struct CartArgs {
-  const float* rec;
-  int map_rows, map_cols;
-  float resolution;
-  const float* scan_pk;  // [cols][rows][rf]
-  int rows, cols;        // window (image) shape
-  float res;
-  const float* st;
-  int64_t cap, n;
-  const int32_t* order;
-  int cpc, nchunks;      // window columns per chunk
-  int64_t npad;
-  float* part;
-  int libm_fma;          // which build of sinf / cosf the host's libm runs (tdr_sincosf.h)
-  const uint32_t* crec;  // compact form of the records (COMPACT instantiations)
-  const float* dict;
-  int dict_n;
-  int ctiles_r;
-};
-
 __device__ __forceinline__ float linspaced_dev(int i, int size1, float low, float high, float step) {
   // Eigen LinSpaced<float>, |high| == |low| here, so never the flipped branch of linspaced_op_impl
   return (i == size1) ? high : (low + (float)i * step);
@@ -1818,7 +1799,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
       const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
       r.ctiles_r = (map->rows >> lc) + 2;
       r.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
-      r.kmask_row = ((map->cols >> 5) + 2) * 4;
+      r.kmask_row = kmask_tcols(map->cols) * 128;
       if ((rc = launch_score_form<true>(r, rf, map->ncls, side->s))) return rc;
       HIP_TRY(hipEventRecord(side->join, side->s));
       if ((rc = tdr_su_score(L, W.suw, s))) return rc;
@@ -1952,12 +1933,14 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   return TDR_OK;
 }
 
-extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n, int64_t n_total) {
-  (void)rows;
+static int64_t cart_part_floats(int ncls, int cols, int64_t n, int64_t n_total) {   // partial sums, 256-byte aligned
   int cpc, nchunks;
   choose_chunks(n_total > 0 ? n_total : n, cols, cpc, nchunks, TDR_CART_WAVE_MUL);
-  int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
-  return (size_t)((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64);
+  const int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
+  return cdiv((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64, 64) * 64;
+}
+extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n, int64_t n_total) {
+  return (size_t)(cart_part_floats(ncls, cols, n, n_total) + tdr_cart_desc_words(rows, cols));   // + scan descriptors
 }
 
 extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
@@ -1992,7 +1975,11 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
     const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
     a.crec = map->crec; a.dict = map->dict; a.dict_n = map->dict_n; a.ctiles_r = (map->rows >> lc) + 2;
   }
-  {
+  if (cm && !wide && tdr_cart_skip_ok(map, rf)) {
+    ScoreProfScope prof(s);
+    uint32_t* desc_ws = reinterpret_cast<uint32_t*>(workspace + cart_part_floats(map->ncls, cols, n, n_total));
+    if (int rc = tdr_cart_skip_launch(a, map, rf, desc_ws, s)) return rc;
+  } else {
     ScoreProfScope prof(s);
 #define TDR_LAUNCH_CART2(NV4, CM)                                                                       \
   if (ks) hipLaunchKernelGGL((score_cart_kernel<NV4, TDR_SCORE_U, true, CM>), grid, block, 0, s, a);    \

@@ -1,0 +1,37 @@
+// tdr_score_cart.h — argument block of the Cartesian scoring kernels (tdr_score.hip: the general kernel; tdr_score_cart.hip:
+// the kernel that skips empty scan bins) and the host interface of the latter.
+#ifndef TDR_SCORE_CART_H_
+#define TDR_SCORE_CART_H_
+#include "tdr_common.h"
+
+struct CartArgs {
+  const float* rec;
+  int map_rows, map_cols;
+  float resolution;
+  const float* scan_pk;  // [cols][rows][rf]
+  int rows, cols;        // window (image) shape
+  float res;
+  const float* st;
+  int64_t cap, n;
+  const int32_t* order;
+  int cpc, nchunks;      // window columns per chunk
+  int64_t npad;
+  float* part;
+  int libm_fma;          // which build of sinf / cosf the host's libm runs (tdr_sincosf.h)
+  const uint32_t* crec;  // compact form of the records (COMPACT instantiations)
+  const float* dict;
+  int dict_n;
+  int ctiles_r;
+  // tdr_score_cart.hip only
+  const uint32_t* desc;  // [cols][rows][4]: scan descriptor of every bin (cart_prep_kernel)
+  unsigned kmask_off;    // byte offset of the known mask from crec
+  int kmask_row;         // bytes per row of its tiles (kmask_offset, tdr_score_dev.h)
+};
+
+// dwords of workspace the descriptors take (behind the partial sums of tdr_score_cart_workspace_floats)
+static inline int64_t tdr_cart_desc_words(int rows, int cols) { return (int64_t)rows * cols * 4 + 64; }
+// whether the skipping kernel applies (tdr_config_cart_skip, a map with narrow compact records of at most 11 classes)
+bool tdr_cart_skip_ok(const tdr_map_desc* map, int rf);
+// descriptors + the scoring kernel; `a` complete but for desc / kmask_*; desc_ws: tdr_cart_desc_words dwords
+int tdr_cart_skip_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* desc_ws, hipStream_t s);
+#endif  // TDR_SCORE_CART_H_

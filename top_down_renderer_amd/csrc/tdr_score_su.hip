@@ -47,7 +47,7 @@
 struct SuArgs {
   const uint32_t* crec;    // compact records (narrow form)
   const uint32_t* kmask;   // the map's known mask (behind the tiles of crec)
-  int kwpr;                // its words per row
+  int ktcols;              // its tiles per tile row (kmask_tcols)
   const float* dict;
   int dict_n, ctiles_r;
   int rows, cols;          // map
@@ -586,9 +586,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const bool fits = (int64_t)H * Wb <= SU_BOX_WORDS;   // uniform over the workgroup
     if (fits) {
       const int total = H * Wb;
+      // (row fastest: consecutive threads read consecutive words of one 32 x 32-cell tile of the mask, kmask_offset)
       for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int row = idx / Wb, wc = idx - row * Wb;
-        lds.bits[idx] = kmask[(int64_t)(rlo + 1 + row) * a.kwpr + (wlo + wc)];
+        const int wc = idx / H, row = idx - wc * H;
+        const int rp = rlo + row + 32;
+        lds.bits[row * Wb + wc] = kmask[((int64_t)(rp >> 5) * a.ktcols + (wlo + wc)) * 32 + (rp & 31)];
       }
     }
     __syncthreads();
@@ -720,7 +722,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.desc = reinterpret_cast<const uint32_t*>(base + W.desc);
   u.bbox = reinterpret_cast<const float*>(base + W.bbox);
   u.kmask = map->crec + tdr_cmap_tile_words(map->ncls, map->rows, map->cols);
-  u.kwpr = (map->cols >> 5) + 2;
+  u.ktcols = kmask_tcols(map->cols);
   u.scan_pk = L.scan_pk;
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
