@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes top_down_renderer_amd/csrc/tdr_score_su_asm.h: the hand-scheduled gfx950 inner loop of score_polar_su_kernel
-(records of two dwords: 4-6 classes) as inline-assembly text, in two variants — uniform / per-lane scale.  The text is
-generated so that the four samples of a step and the variants cannot drift apart.
+(records of two dwords: 4-6 classes) as inline-assembly text, in four variants — uniform / per-lane scale, with / without
+the clamp of the coordinates into the map's guard ring.  The text is generated so that the four samples of a step and the
+variants cannot drift apart.
 
     python3 tools/gen_su_asm.py        (re-run after editing; the header is committed)
 
@@ -26,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su_asm.h")
 
 
-def loop_text(uscale):
+def loop_text(uscale, clamp):
     L = []
     a = L.append
     # hipcc waits for one of its own loads where the VALUE is used; a load whose value the taken path never reads is still
@@ -62,10 +63,11 @@ def loop_text(uscale):
         for u in range(4):
             p = 8 + 2 * u
             a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[offv]")          # + centre / resolution
-    for u in range(4):
-        p = 8 + 2 * u
-        a(f"v_med3_f32 v{p}, v{p}, %[rmax], -1.0")                               # clamp into the guard ring
-        a(f"v_med3_f32 v{p + 1}, v{p + 1}, %[cmax], -1.0")
+    if clamp:   # (the variant without: every cell the workgroup's windows can reach in this sector lies inside the map)
+        for u in range(4):
+            p = 8 + 2 * u
+            a(f"v_med3_f32 v{p}, v{p}, %[rmax], -1.0")                           # clamp into the guard ring
+            a(f"v_med3_f32 v{p + 1}, v{p + 1}, %[cmax], -1.0")
     for u in range(4):
         p = 8 + 2 * u
         a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[half]")              # round_half_away_clamped
@@ -174,11 +176,12 @@ def main():
            "// register plan and the schedule's cost model.",
            "#ifndef TDR_SCORE_SU_ASM_H_", "#define TDR_SCORE_SU_ASM_H_", ""]
     for uscale in (True, False):
-        out.append(f"#define SU_ASM_{'US' if uscale else 'PS'} \\")
-        lines = loop_text(uscale)
-        for i, ln in enumerate(lines):
-            out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
-        out.append("")
+        for clamp in (True, False):
+            out.append(f"#define SU_ASM_{'US' if uscale else 'PS'}{'' if clamp else '_NOCLAMP'} \\")
+            lines = loop_text(uscale, clamp)
+            for i, ln in enumerate(lines):
+                out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+            out.append("")
     out.append('#define SU_ASM_CLOBBERS                                                                                      \\')
     vregs = ", ".join(f'"v{i}"' for i in range(8, 38))
     sregs = ", ".join(f'"s{i}"' for i in range(40, 69))

@@ -493,7 +493,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
   };
   // One sector of directions [i0, i1) with the known mask staged in LDS
-  auto run_sector = [&](int i0, int i1, int krow4, int kconst) {
+  // (inside: every cell the workgroup's windows can reach in this sector lies inside the map — the clamp into the guard
+  // ring is the identity and the loop without it runs)
+  auto run_sector = [&](int i0, int i1, int krow4, int kconst, bool inside) {
     if constexpr (ASM_LOOP) {
       if (gn == G && lds_base == 0 && (G == 4 || G == 8 || G == 16)) {
         // the steps of the sector as one stream: step k reads T at byte k * 32 from its start and D at byte k * 64 from the
@@ -524,8 +526,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
             [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2)                                               \
           : SU_ASM_CLOBBERS
-          if constexpr (USCALE) asm volatile(SU_ASM_US SU_ASM_OPERANDS);
-          else asm volatile(SU_ASM_PS SU_ASM_OPERANDS);
+          if (inside) {   // wave-uniform
+            if constexpr (USCALE) asm volatile(SU_ASM_US_NOCLAMP SU_ASM_OPERANDS);
+            else asm volatile(SU_ASM_PS_NOCLAMP SU_ASM_OPERANDS);
+          } else {
+            if constexpr (USCALE) asm volatile(SU_ASM_US SU_ASM_OPERANDS);
+            else asm volatile(SU_ASM_PS SU_ASM_OPERANDS);
+          }
 #undef SU_ASM_OPERANDS
           // (the compiler takes the outputs of an asm statement for divergent)
           toff = __builtin_amdgcn_readfirstlane(toff); doff = __builtin_amdgcn_readfirstlane(doff);
@@ -595,7 +602,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     __syncthreads();
     if (active) {
-      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4);
+      const bool inside = rlo >= 0 && rhi < a.rows && __builtin_amdgcn_readfirstlane(lds.box[2]) >= 0 &&
+                          __builtin_amdgcn_readfirstlane(lds.box[3]) < a.cols;
+      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4, inside);
       else far_sector(i0, i1);
     }
   }
