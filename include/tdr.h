@@ -476,7 +476,9 @@ int tdr_filter_get_states(tdr_filter* f, tdr_state* out, int64_t n);
 int tdr_filter_propagate(tdr_filter* f, float tx, float ty, float omega);                /* particle_filter.cpp:86-92 */
 /* particle_filter.cpp:94-189.  scan_imgs: HOST [ncls][nb*nr] images or NULL (= renderer's last render, no host round
  * trip), (nb, nr) = tdr_map_polar_shape — the caller checks its images against it, ncls*nb*nr floats are read;
- * n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157). */
+ * n_target < 0 keeps the particle count (explicit input of the adaptive count :151-157).  A filter sharded over W ranks
+ * keeps the same number of particles on every rank: n_target is rounded DOWN to a multiple of W (at least W), so a W-rank
+ * filter asked for 70 particles at W = 8 resamples 64 and equals, bit for bit, the one-rank filter asked for 64. */
 int tdr_filter_update(tdr_filter* f, const float* scan_imgs, const tdr_renderer* renderer, float res, int64_t n_target);
 /* The same with the geometric images top_down_geo (HOST [2][nb*nr]) entering the score (tdr_k_score_polar_geo); the
  * reference passes them to update() too but its score ignores them.  Not available on a sharded filter. */

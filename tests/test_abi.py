@@ -68,6 +68,31 @@ def test_argument_validation_happens_before_any_launch(lib):
                                  C.c_float(0.0), 0, dummy, dummy, None) == -1
     assert b"4 GiB" in lib.tdr_last_error()
     assert lib.tdr_prefix_workspace_bytes(0) == 0 and lib.tdr_prefix_workspace_bytes(4097) == 64
+    # the init search addresses its 32-byte half records with 32-bit offsets and a 24-bit row multiply: no half records
+    # for a map beyond that (the search then splits the dense records on the fly), instead of offsets that wrap
+    assert lib.tdr_map_rec16_bytes(3, 4000, 4000) == 4002 * 4002 * 32 + 32
+    assert lib.tdr_map_rec16_bytes(3, 11600, 11600) == 0           # > 4 GiB of half records
+    assert lib.tdr_map_rec16_bytes(3, 100, 600000) == 0            # a row of more than 2^24 bytes
+    assert lib.tdr_map_rec16_bytes(8, 100, 100) == 0               # more than 7 classes: no half-record form
+
+
+def test_ctypes_signatures_have_the_arity_of_the_header(lib):
+    """Every prototype of include/tdr.h has as many parameters as its ctypes declaration lists argument types."""
+    from top_down_renderer_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "tdr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    protos = re.findall(r"\b(tdr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 25
+    seen = set()
+    for name, params in protos:
+        if name not in _lib.SIGNATURES or "(*" in params:   # (function-pointer members of structs are not prototypes)
+            continue
+        params = params.strip()
+        n = 0 if params in ("", "void") else len([x for x in params.split(",") if x.strip()])
+        assert n == len(_lib.SIGNATURES[name][1]), f"{name}: tdr.h takes {n} parameters, _lib.py lists {len(_lib.SIGNATURES[name][1])}"
+        seen.add(name)
+    assert len(seen) >= 0.9 * len(_lib.SIGNATURES)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -7,6 +7,8 @@
 // One caller thread per handle (the reference calls everything from the ROS spinner thread).  A filter lives on one GPU
 // or is sharded over the ranks of a tdr_comm (one process per GPU, tdr_comm.cpp: RCCL or caller-supplied transport).
 // No CPU fallback: every entry point fails with TDR_ERR_HIP when no device is present.
+#include <sys/stat.h>
+#include <cerrno>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -138,6 +140,13 @@ static int read_eig(const std::string& path, std::vector<T>& out, int64_t& rows,
   if (!fh) return failh(TDR_ERR_ARG, "map cache: cannot open %s", path.c_str());
   int64_t hdr[2] = {0, 0};
   bool ok = fread(hdr, sizeof(int64_t), 2, fh) == 2 && hdr[0] > 0 && hdr[1] > 0 && hdr[0] < (1 << 24) && hdr[1] < (1 << 24);
+  if (ok) {   // the payload the header promises must be what the file holds (a damaged header must not size the buffer)
+    const long at = ftell(fh);
+    ok = at >= 0 && fseek(fh, 0, SEEK_END) == 0;
+    const long end = ok ? ftell(fh) : -1;
+    ok = ok && end >= at && (uint64_t)(end - at) == (uint64_t)hdr[0] * (uint64_t)hdr[1] * sizeof(T) &&
+         fseek(fh, at, SEEK_SET) == 0;
+  }
   if (ok) {
     out.resize((size_t)hdr[0] * hdr[1]);
     ok = fread(out.data(), sizeof(T), out.size(), fh) == out.size() && fgetc(fh) == EOF;
@@ -430,8 +439,11 @@ int tdr_map_save_cache(tdr_map* m, const char* cache_dir, const char* map_path) 
   const std::string dir = cache_dir_or_default(cache_dir);
   const int ncls = m->desc.ncls, rows = m->desc.rows, cols = m->desc.cols;
   const size_t ncell = (size_t)rows * cols;
+  // the reference creates the directory (boost::filesystem::create_directory, src/top_down_map.cpp:228-232): one level
+  if (mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST)
+    return failh(TDR_ERR_ARG, "map_save_cache: cannot create %s (its parent must exist)", dir.c_str());
   FILE* fh = fopen((dir + "/cached_data.txt").c_str(), "w");
-  if (!fh) return failh(TDR_ERR_ARG, "map_save_cache: cannot write into %s (the directory must exist)", dir.c_str());
+  if (!fh) return failh(TDR_ERR_ARG, "map_save_cache: cannot write into %s", dir.c_str());
   fprintf(fh, "%s\n%d\n%g\n", map_path, ncls, (double)m->desc.resolution);
   fclose(fh);
   for (int c = 0; c < ncls; c++)

@@ -1241,12 +1241,14 @@ __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __r
 int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st) {
   if (n < 1 || n > 32768) return fail(TDR_ERR_ARG, "uw_small: n out of range");
   const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+  static bool attr_set[64] = {false};   // per device: the attribute lives with the device's copy of the code object
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  if (dev >= 64 || !attr_set[dev]) {   // more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(uw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024) != hipSuccess)
       return fail(TDR_ERR_HIP, "uw_small: cannot raise the dynamic LDS limit");
-    attr_set = true;
+    if (dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(uw_small_kernel, dim3(1), dim3(PFXW_THREADS), lds, st, raw, last_dist, (int)n, w, info);
   return TDR_OK;

@@ -1378,7 +1378,11 @@ static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
 // bytes of the scratch behind tdr_map_desc.rec16 (0: this record size has no matrix-core search)
 extern "C" size_t tdr_map_rec16_bytes(int ncls, int rows, int cols) {
   if (ncls < 1 || ncls > 7 || rows < 1 || cols < 1) return 0;
-  return (size_t)(rows + 2) * (size_t)(cols + 2) * 32 + 32;   // + the all-zero record behind the grid
+  // the search addresses this grid with 32-bit byte offsets and a 24-bit row multiply: a map beyond that has no half
+  // records (0: the caller passes none and the search splits the dense records on the fly)
+  const uint64_t bytes = (uint64_t)(rows + 2) * (uint64_t)(cols + 2) * 32 + 32;   // + the all-zero record behind the grid
+  if (bytes > 0xFFFFFFFFull || (uint64_t)(cols + 2) * 32 >= (1u << 24)) return 0;
+  return (size_t)bytes;
 }
 // Rebuilding the half records is one pass over the whole map: it pays from a few thousand particles on (4000^2 cells:
 // 0.35 ms, the price of searching ~2000 particles with 256 x 256 windows on the fly).  Filters below the threshold
@@ -1700,7 +1704,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     unitw &= fp->class_weights[0] > 0.f;
     int* d_inexact = d_nrot + 1;
     const bool half_path = (rf == 4 || rf == 8) && map->ncls <= 7 && init_use_mfma() && map->rec16 &&
-                           n_total >= g_rec16_min &&
+                           tdr_map_rec16_bytes(map->ncls, map->rows, map->cols) != 0 && n_total >= g_rec16_min &&
                            (size_t)4 * (2 * nb + 20) * 16 + (size_t)4 * (nb + 8) * 8 <= 64 * 1024;
     if (half_path) {
       // matrix-core pass on pre-split half records (weights folded in), built into the map owner's scratch first; the
