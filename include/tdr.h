@@ -129,6 +129,12 @@ int tdr_k_unpack_compact_map(const tdr_map_desc* map, float* rec_out, void* stre
  * (tdr_map_rec_floats_total floats).  The Euclidean distance transform is exact. */
 size_t tdr_map_ingest_workspace_bytes(int ncls, int rows, int cols);
 int tdr_map_ingest_shape(int img_h, int img_w, float resolution, int* rows, int* cols);
+/* The same from the per-class rasters of the raster cache: planes [ncls][rows][cols] device bytes = the class<i>.png
+ * images as stored (8-bit grey, row 0 = top; src/top_down_map.cpp:213-224 flips and scales them, computeDists :289-326
+ * binarises: p <= 127 = inside the class, a cell is unknown where every class holds 255).  Classes may overlap.  The map
+ * has the images' shape; rec_out / workspace as for tdr_k_map_from_labels (tdr_map_ingest_workspace_bytes). */
+int tdr_k_map_from_rasters(const uint8_t* planes, int ncls, int rows, int cols, float resolution, float* rec_out,
+                           void* workspace, void* stream);
 int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int img_w, const int32_t* flatten_lut, int lut_size,
                           int ncls, float resolution, float* rec_out, void* workspace, void* stream);
 /* geo_maps_ (top_down_map.h:79) as a 2-class record map {d_without, d_with, 1, 1}, derived from the class records
@@ -413,6 +419,16 @@ int tdr_map_local_geo_map(tdr_map* m, int polar, float cx, float cy, float scale
 int tdr_map_load_cache(tdr_map* m, const char* cache_dir, const char* map_path, int num_classes, float resolution,
                        int center_x, int center_y, int* loaded);
 int tdr_map_save_cache(tdr_map* m, const char* cache_dir, const char* map_path);
+/* The raster cache (TopDownMap::saveRasterizedMaps / loadRasterizedMaps, src/top_down_map.cpp:197-224): a directory of
+ * class<i>.png — 8-bit greyscale, 0 inside class i and 255 elsewhere, stored flipped like the reference stores them — read
+ * and written over zlib (no OpenCV).  load = the constructor's path for such a directory (:44-58): rasters -> geometric
+ * layers -> distance transforms, on the device; the map takes the images' shape. */
+int tdr_map_save_rasters(tdr_map* m, const char* dir);
+/* the codec on its own (host only): 8-bit greyscale, non-interlaced PNG; px row-major, row 0 = top.  read: px_out holds
+ * `capacity` bytes, *w / *h are set even when the image does not fit (then TDR_ERR_ARG). */
+int tdr_png_read_gray8_host(const char* path, uint8_t* px_out, int64_t capacity, int* w, int* h);
+int tdr_png_write_gray8_host(const char* path, const uint8_t* px, int w, int h);
+int tdr_map_load_rasters(tdr_map* m, const char* dir, int num_classes, float resolution, int center_x, int center_y);
 
 int tdr_renderer_create(const int32_t* flatten_lut256, tdr_renderer** out);              /* scan_renderer.cpp:3-5 */
 void tdr_renderer_destroy(tdr_renderer* r);

@@ -146,6 +146,25 @@ def test_raster_polar_vs_oracle(tdr, oracle, name):
     assert np.array_equal(got, ref)
 
 
+def test_raster_image_column_larger_than_64kb_of_lds(tdr, oracle):
+    """6 classes x 4096 direction bins: one image column is 96 KB of LDS counters — more than the default dynamic-LDS
+    limit, within the 160 KB of a CU."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    ncls, nb, nr = 6, 4096, 24
+    rng = np.random.default_rng(21)
+    pts = np.zeros((60_000, 4), np.float32)
+    pts[:, :2] = rng.normal(0, 9, (len(pts), 2))
+    pts[:, 3] = rng.integers(0, ncls, len(pts))
+    lut = synth.make_lut(ncls)
+    ang = np.float32(2 * np.pi / nb)
+    ref = oracle.raster_polar(pts, 1.0, ang, lut, ncls, nb, nr)
+    r = pkg.ScanRendererPolar(lut, kernels=k)
+    r.set_output_shape(ncls, nb, nr)
+    r.renderSemanticTopDown(pts, 1.0, ang)
+    assert np.array_equal(r.last_images().cpu().numpy(), ref) and ref.sum() > 10_000
+
+
 def test_raster_with_and_without_workspace(tdr, oracle):
     """tdr_k_raster_polar / _cart: the two-phase raster (bins once, tiles stream keys) and the single-phase one (no
     workspace) write the same images."""

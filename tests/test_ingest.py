@@ -100,3 +100,170 @@ def test_ingested_map_scores_like_an_uploaded_one(oracle):
         f.update(scan, None, cfg.res)
         out.append(f.raw_weights())
     assert np.array_equal(out[0], out[1], equal_nan=True)
+
+
+# ---- the raster cache: class<i>.png (src/top_down_map.cpp:197-224) ---------------------------------------------------------
+def _png_bytes(img, filters, colour_type=0, bit_depth=8, interlace=0, break_crc=False):
+    """A PNG file made by hand (zlib + struct): one filter type per scanline, cycling through `filters`."""
+    import struct
+    import zlib
+    h, w = img.shape
+    raw = bytearray()
+    prev = np.zeros(w, np.int64)
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        cur = img[y].astype(np.int64)
+        left = np.concatenate([[0], cur[:-1]])
+        upleft = np.concatenate([[0], prev[:-1]])
+        if ft == 0:
+            pred = np.zeros(w, np.int64)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(ft)
+        raw += bytes(((cur - pred) % 256).astype(np.uint8))
+        prev = cur
+
+    def chunk(t, d):
+        crc = zlib.crc32(t + d) ^ (1 if break_crc and t == b"IDAT" else 0)
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", crc)
+    z = zlib.compress(bytes(raw), 9)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, colour_type, 0, 0, interlace)) +
+            chunk(b"tEXt", b"Comment\x00by hand") + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) +
+            chunk(b"IEND", b""))
+
+
+def _png_decode(data):
+    """A PNG reader of the test's own (filter 0 only: what the library writes)."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, w, h = 8, b"", 0, 0
+    while at < len(data):
+        n, t = struct.unpack(">I", data[at:at + 4])[0], data[at + 4:at + 8]
+        d = data[at + 8:at + 8 + n]
+        assert zlib.crc32(t + d) == struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0]
+        if t == b"IHDR":
+            w, h, bd, ct, cm, fm, il = struct.unpack(">IIBBBBB", d)
+            assert (bd, ct, cm, fm, il) == (8, 0, 0, 0, 0)
+        elif t == b"IDAT":
+            idat += d
+        at += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].copy()
+
+
+def test_png_codec_of_the_raster_cache(tmp_path):
+    """8-bit greyscale PNG over zlib (csrc/tdr_png.cpp), no GPU: files written by hand with every filter type, split IDAT
+    and an ancillary chunk are read exactly; what the library writes is a PNG an independent reader decodes; other kinds of
+    PNG and damaged files are refused."""
+    import ctypes as C
+    from top_down_renderer_amd import _lib, build
+    build.build()
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+    vp = C.c_void_p
+
+    def read(path, cap=None):
+        w, h = C.c_int(0), C.c_int(0)
+        out = np.zeros(1 << 16 if cap is None else cap, np.uint8)
+        rc = L.tdr_png_read_gray8_host(str(path).encode(), out.ctypes.data_as(vp), len(out), C.byref(w), C.byref(h))
+        return rc, w.value, h.value, out
+    for shape, filters in (((13, 29), [0, 1, 2, 3, 4]), ((1, 1), [4]), ((40, 7), [3, 3, 4]), ((5, 64), [2, 1])):
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        img[rng.random(shape) < 0.5] = 255
+        p = tmp_path / "hand.png"
+        p.write_bytes(_png_bytes(img, filters))
+        rc, w, h, out = read(p)
+        assert rc == 0 and (h, w) == shape and np.array_equal(out[: w * h].reshape(h, w), img)
+        q = tmp_path / "lib.png"
+        assert L.tdr_png_write_gray8_host(str(q).encode(), img.ctypes.data_as(vp), shape[1], shape[0]) == 0
+        assert np.array_equal(_png_decode(q.read_bytes()), img)
+        rc, w, h, out = read(q)
+        assert rc == 0 and np.array_equal(out[: w * h].reshape(h, w), img)
+    img = rng.integers(0, 256, (6, 6)).astype(np.uint8)
+    bad = {"rgb": dict(colour_type=2), "16 bit": dict(bit_depth=16), "interlaced": dict(interlace=1), "crc": dict(break_crc=True)}
+    for name, kw in bad.items():
+        p = tmp_path / "bad.png"
+        p.write_bytes(_png_bytes(img, [0], **kw))
+        assert read(p)[0] == -1, name
+        assert b"png" in L.tdr_last_error()
+    p.write_bytes(_png_bytes(img, [0])[:-30])
+    assert read(p)[0] == -1                                   # truncated
+    p.write_bytes(_png_bytes(img, [1]))
+    rc, w, h, _ = read(p, cap=10)
+    assert rc == -1 and (w, h) == (6, 6)                      # buffer too small: the size is still reported
+    assert read(tmp_path / "missing.png")[0] == -1
+
+
+@pytest.mark.gpu
+def test_raster_cache_round_trip_and_overlapping_classes(tmp_path):
+    """saveRasterizedMaps / loadRasterizedMaps through the C ABI: a map ingested from a label image, saved as class<i>.png
+    and loaded back is the same map (records array-equal); rasters whose classes OVERLAP (an SVG map's polygons may) give the
+    distance maps and mask of computeDists — checked against scipy's exact Euclidean distance transform."""
+    import ctypes as C
+    from scipy.ndimage import distance_transform_edt
+    import torch
+    from top_down_renderer_amd import synth
+    from top_down_renderer_amd._lib import check
+    from top_down_renderer_amd.kernels import HipKernels
+    k = HipKernels()
+    L, vp = k.lib, C.c_void_p
+    rng = np.random.default_rng(12)
+    h, w, ncls = 150, 210, 4
+    lab = synth.make_label_image(max(h, w), ncls, rng)[:h, :w]
+    img = np.where(lab < 0, 255, lab).astype(np.uint8)[::-1].copy()       # label image, row 0 = top
+    lut = np.full(256, -1, np.int32)
+    lut[:ncls] = np.arange(ncls)
+
+    def records(m):
+        d = np.zeros((ncls, 30 * 40), np.float32)
+        mk = np.zeros(30 * 40, np.uint8)
+        out = []
+        for cx, cy in ((60.0, 50.0), (5.0, 140.0), (200.0, 10.0)):
+            check(L.tdr_map_local_map(m, 0, C.c_float(cx), C.c_float(cy), C.c_float(1.7), C.c_float(1.0), 30, 40,
+                                      d.ctypes.data_as(vp), mk.ctypes.data_as(vp)))
+            out.append((d.copy(), mk.copy()))
+        return out
+    m = vp()
+    check(L.tdr_map_create(C.byref(m)))
+    check(L.tdr_map_set_labels(m, img.ctypes.data_as(vp), h, w, lut.ctypes.data_as(vp), 256, ncls, C.c_float(1.0), 0, 0))
+    d = str(tmp_path / "site_raster_cache").encode()
+    check(L.tdr_map_save_rasters(m, d))
+    m2 = vp()
+    check(L.tdr_map_create(C.byref(m2)))
+    check(L.tdr_map_load_rasters(m2, d, ncls, C.c_float(1.0), 0, 0))
+    for (a, am), (b, bm) in zip(records(m), records(m2)):
+        assert np.array_equal(a, b) and np.array_equal(am, bm)
+    # overlapping classes, grey values off 0 / 255, a hole no class covers
+    planes = np.full((3, 90, 120), 255, np.uint8)                 # as stored: row 0 = top
+    planes[0, 10:50, 10:70] = 0
+    planes[1, 30:80, 40:100] = 0                                  # overlaps class 0
+    planes[2, 60:85, 5:30] = 100                                  # <= 127: inside
+    planes[2, 0:5, :] = 200                                       # > 127: outside, yet not 255: the cell counts as known
+    dp = k.to_device(planes.reshape(-1)).view(torch.uint8) if False else torch.from_numpy(planes.reshape(-1)).to(k.device)
+    rows, cols = 90, 120
+    rec = k.zeros((int(L.tdr_map_rec_floats_total(3, rows, cols)),))
+    ws = torch.zeros(int(L.tdr_map_ingest_workspace_bytes(3, rows, cols)), dtype=torch.uint8, device=k.device)
+    check(L.tdr_k_map_from_rasters(vp(dp.data_ptr()), 3, rows, cols, C.c_float(0.5), vp(rec.data_ptr()), vp(ws.data_ptr()), None))
+    k.synchronize()
+    rf = int(L.tdr_rec_floats(3))
+    got = rec.cpu().numpy().reshape(rows + 2, cols + 2, rf)[1:-1, 1:-1]
+    flipped = planes[:, ::-1, :]                                  # map row 0 = bottom image row (:217)
+    unknown = (flipped == 255).all(axis=0)
+    for c in range(3):
+        inside = flipped[c] <= 127
+        dist = distance_transform_edt(~inside).astype(np.float32) * np.float32(0.5)
+        want = np.where(unknown, 0.0, np.minimum(dist, 50.0)).astype(np.float32)
+        assert np.array_equal(got[:, :, c], want), c
+    assert np.array_equal(got[:, :, rf - 1] == 0, unknown)
+    L.tdr_map_destroy(m)
+    L.tdr_map_destroy(m2)

@@ -62,6 +62,11 @@ SIGNATURES = {
     "tdr_map_ingest_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "tdr_map_ingest_shape": (_i, [_i, _i, _f, C.POINTER(_i), C.POINTER(_i)]),
     "tdr_k_map_from_labels": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "tdr_k_map_from_rasters": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "tdr_map_save_rasters": (_i, [_vp, C.c_char_p]),
+    "tdr_png_read_gray8_host": (_i, [C.c_char_p, _vp, _i64, _vp, _vp]),
+    "tdr_png_write_gray8_host": (_i, [C.c_char_p, _vp, _i, _i]),
+    "tdr_map_load_rasters": (_i, [_vp, C.c_char_p, _i, _f, _i, _i]),
     "tdr_k_unpack_map": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tdr_polar_table_host": (_i, [_i, _i, _f, _f, _vp]),
     "tdr_raster_workspace_bytes": (_i64, [_i64]),

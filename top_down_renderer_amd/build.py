@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", f) for f in
        ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_score_su.hip", "tdr_score_cart.hip", "tdr_filter.hip", "tdr_prefix.hip",
-        "tdr_geo.hip", "tdr_cmap.hip", "tdr_host.cpp", "tdr_comm.cpp", "tdr_gmm.cpp")]
+        "tdr_geo.hip", "tdr_cmap.hip", "tdr_host.cpp", "tdr_comm.cpp", "tdr_gmm.cpp", "tdr_png.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h")] + \
       [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h", "tdr_score_su_asm.h", "tdr_score_cart.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
@@ -20,7 +20,7 @@ OBJ_DIR = os.path.join(PKG, "_obj")
 
 # -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include")]
-LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl", "-lz"]   # zlib: the PNG files of the raster cache
 # per-file flags.  tdr_score.hip: matrix-core accumulators in VGPRs — with AGPR accumulators the register allocator rotates
 # the six accumulator tiles of the init-search loop through ~36 v_accvgpr moves per step (there is no register pressure:
 # 112 VGPRs at 4 waves per SIMD)

@@ -62,9 +62,12 @@ struct DevBuf {
     n = count;
     return TDR_OK;
   }
-  ~DevBuf() {
+  void release() {
     if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
   }
+  ~DevBuf() { release(); }
 };
 
 }  // namespace
@@ -79,12 +82,18 @@ struct tdr_map {
   std::vector<float> maps_host;  // class_maps_ (column-major), kept for getClassesAtPoint / particle initialisation
   std::vector<uint8_t> mask_host;  // class_mask_ (column-major), kept for the map cache
   tdr_map_desc desc{};
-  DevBuf<float> geo_rec;         // geo_maps_[0..1] as a 2-class record map (tdr_k_geo_map_from_map)
+  DevBuf<float> geo_rec;         // geo_maps_[0..1] as a 2-class record map (tdr_k_geo_map_from_map), built on first use
+  int geo_pending = 0;           // 0: geo_rec is current (or there is no map); 1: derive from the classes; 2: constant 1
   tdr_map_desc geo_desc{};
   int nb = 0, nr = 0;
   float ang_res = 0;
   int center_x = 0, center_y = 0;
   bool have_map = false;
+  // staging of the run-time map replacement (tdr_map_set_labels: aerial maps keep arriving, top_down_render.cpp:574-600),
+  // kept between calls: allocating and freeing ~1 GB per map costs more than the ingest itself
+  DevBuf<uint8_t> ing_img, ing_ws, ing_mask;
+  DevBuf<int32_t> ing_lut;
+  DevBuf<float> ing_maps;
 };
 
 struct tdr_renderer {
@@ -134,6 +143,9 @@ static std::string cache_dir_or_default(const char* cache_dir) {
   const char* home = getenv("HOME");
   return std::string(home ? home : ".") + "/.ros/xview_cache";
 }
+int tdr_png_read_gray8(const char* path, std::vector<uint8_t>& px, int& w, int& h);   // tdr_png.cpp
+int tdr_png_write_gray8(const char* path, const uint8_t* px, int w, int h);
+
 template <class T>
 static int read_eig(const std::string& path, std::vector<T>& out, int64_t& rows, int64_t& cols) {
   FILE* fh = fopen(path.c_str(), "rb");
@@ -168,7 +180,17 @@ static int write_eig(const std::string& path, const T* data, int64_t rows, int64
 }
 // geo_maps_ for a freshly packed map: computed from the class maps like the static-map constructor does
 // (src/top_down_map.cpp:48-58), or the constant 1 the dynamic-map path leaves them at (:126-133)
+// Nothing on the hot path reads them (the reference's score ignores top_down_geo, state_particle.cpp:145-152): they are
+// built — two more distance transforms over the whole map — when something first asks for them (map_ensure_geo).
 static int map_make_geo(tdr_map* m, bool constant_one) {
+  m->geo_pending = constant_one ? 2 : 1;
+  m->geo_rec.release();
+  m->geo_desc = tdr_map_desc{};
+  return TDR_OK;
+}
+static int map_ensure_geo(tdr_map* m) {
+  if (!m->geo_pending) return TDR_OK;
+  const bool constant_one = m->geo_pending == 2;
   const int rows = m->desc.rows, cols = m->desc.cols;
   TTRY(m->geo_rec.resize(tdr_map_rec_floats_total(2, rows, cols)));
   DevBuf<uint8_t> ws;
@@ -182,6 +204,7 @@ static int map_make_geo(tdr_map* m, bool constant_one) {
   m->geo_desc.cols = cols;
   m->geo_desc.rec_floats = tdr_rec_floats(2);
   m->geo_desc.resolution = m->desc.resolution;
+  m->geo_pending = 0;
   return TDR_OK;
 }
 
@@ -257,9 +280,9 @@ int tdr_map_set_labels(tdr_map* m, const uint8_t* label_img, int img_h, int img_
   int rows = 0, cols = 0;
   TTRY(tdr_map_ingest_shape(img_h, img_w, resolution, &rows, &cols));
   if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1) return failh(TDR_ERR_ARG, "map_set_labels: bad shape");
-  DevBuf<uint8_t> d_img, d_ws, d_mask;
-  DevBuf<int32_t> d_lut;
-  DevBuf<float> d_maps;
+  DevBuf<uint8_t>&d_img = m->ing_img, &d_ws = m->ing_ws, &d_mask = m->ing_mask;
+  DevBuf<int32_t>& d_lut = m->ing_lut;
+  DevBuf<float>& d_maps = m->ing_maps;
   const size_t ncell = (size_t)rows * cols;
   TTRY(d_img.resize((size_t)img_h * img_w));
   TTRY(d_lut.resize((size_t)lut_size));
@@ -362,7 +385,8 @@ int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_
 // geometric layers; dists_out HOST [2][rows*cols]
 int tdr_map_local_geo_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
                           float* dists_out) {
-  if (!m || !m->have_map || !dists_out || !m->geo_rec.p) return failh(TDR_ERR_ARG, "map_local_geo_map: no map / null output");
+  if (!m || !m->have_map || !dists_out) return failh(TDR_ERR_ARG, "map_local_geo_map: no map / null output");
+  TTRY(map_ensure_geo(m));
   if (polar) {
     if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "map_local_geo_map: samplePtsPolar was never called");
     rows = m->nb;
@@ -420,6 +444,8 @@ int tdr_map_load_cache(tdr_map* m, const char* cache_dir, const char* map_path, 
   if (read_eig(dir + "/geo_map0.eig", g0, r2, c2) == TDR_OK && r2 == rows && c2 == cols &&
       read_eig(dir + "/geo_map1.eig", g1, r2, c2) == TDR_OK && r2 == rows && c2 == cols) {
     g0.insert(g0.end(), g1.begin(), g1.end());
+    m->geo_pending = 2;        // (cheapest fill: sizes geo_rec and sets geo_desc; the records are overwritten below)
+    TTRY(map_ensure_geo(m));
     std::vector<uint8_t> zero((size_t)rows * cols, 0);
     DevBuf<float> d_maps;
     DevBuf<uint8_t> d_mask;
@@ -453,11 +479,78 @@ int tdr_map_save_cache(tdr_map* m, const char* cache_dir, const char* map_path) 
   DevBuf<uint8_t> d_mask;
   TTRY(d_maps.resize(ncell * 2));
   TTRY(d_mask.resize(ncell));
+  TTRY(map_ensure_geo(m));
   TTRY(tdr_k_unpack_map(m->geo_rec.p, 2, rows, cols, d_maps.p, d_mask.p, nullptr));
   std::vector<float> g(ncell * 2);
   HTRY(hipMemcpy(g.data(), d_maps.p, g.size() * sizeof(float), hipMemcpyDeviceToHost));
   TTRY(write_eig(dir + "/geo_map0.eig", g.data(), rows, cols));
   TTRY(write_eig(dir + "/geo_map1.eig", g.data() + ncell, rows, cols));
+  return TDR_OK;
+}
+
+// TopDownMap::saveRasterizedMaps (top_down_map.cpp:197-211): class<i>.png, 8-bit grey, 0 inside the class and 255
+// elsewhere, flipped to look like the input map (:208).  The reference writes its binary rasters before computeDists turns
+// them into distances; from the distance maps held here the raster of a class is "known cell at distance 0".
+int tdr_map_save_rasters(tdr_map* m, const char* dir) {
+  if (!m || !m->have_map || !dir) return failh(TDR_ERR_ARG, "map_save_rasters: no map");
+  const int ncls = m->desc.ncls, rows = m->desc.rows, cols = m->desc.cols;
+  const size_t ncell = (size_t)rows * cols;
+  if (mkdir(dir, 0700) != 0 && errno != EEXIST) return failh(TDR_ERR_ARG, "map_save_rasters: cannot create %s", dir);   // :198
+  std::vector<uint8_t> img(ncell);
+  for (int c = 0; c < ncls; c++) {
+    const float* d = m->maps_host.data() + ncell * c;   // column-major like class_maps_
+    for (int r = 0; r < rows; r++)
+      for (int x = 0; x < cols; x++) {
+        const size_t k = (size_t)x * rows + r;
+        img[(size_t)(rows - 1 - r) * cols + x] = (m->mask_host[k] == 0 && d[k] == 0.f) ? 0 : 255;
+      }
+    TTRY(tdr_png_write_gray8((std::string(dir) + "/class" + std::to_string(c) + ".png").c_str(), img.data(), cols, rows));
+  }
+  return TDR_OK;
+}
+// TopDownMap::loadRasterizedMaps (:213-224) followed by what the constructor does with the rasters (:48-58): the geometric
+// layers derived from them and computeDists on both — on the device (tdr_k_map_from_rasters).
+int tdr_map_load_rasters(tdr_map* m, const char* dir, int num_classes, float resolution, int center_x, int center_y) {
+  if (!m || !dir) return failh(TDR_ERR_ARG, "map_load_rasters: null pointer");
+  if (num_classes < 1 || num_classes > TDR_MAX_CLASSES || !(resolution > 0.f))
+    return failh(TDR_ERR_ARG, "map_load_rasters: bad class count / resolution");
+  std::vector<uint8_t> planes, one;
+  int w = 0, h = 0;
+  for (int c = 0; c < num_classes; c++) {
+    int w2 = 0, h2 = 0;
+    TTRY(tdr_png_read_gray8((std::string(dir) + "/class" + std::to_string(c) + ".png").c_str(), one, w2, h2));
+    if (c == 0) { w = w2; h = h2; }
+    if (w2 != w || h2 != h) return failh(TDR_ERR_ARG, "map_load_rasters: class%d.png differs in size from class0.png", c);
+    planes.insert(planes.end(), one.begin(), one.end());
+  }
+  const int rows = h, cols = w;
+  const size_t ncell = (size_t)rows * cols;
+  DevBuf<uint8_t> d_planes, d_ws, d_mask;
+  DevBuf<float> d_maps;
+  TTRY(d_planes.resize(planes.size()));
+  TTRY(d_ws.resize(tdr_map_ingest_workspace_bytes(num_classes, rows, cols)));
+  HTRY(hipMemcpy(d_planes.p, planes.data(), planes.size(), hipMemcpyHostToDevice));
+  TTRY(m->rec.resize(tdr_map_rec_floats_total(num_classes, rows, cols)));
+  TTRY(tdr_k_map_from_rasters(d_planes.p, num_classes, rows, cols, resolution, m->rec.p, d_ws.p, nullptr));
+  TTRY(d_maps.resize(ncell * num_classes));
+  TTRY(d_mask.resize(ncell));
+  TTRY(tdr_k_unpack_map(m->rec.p, num_classes, rows, cols, d_maps.p, d_mask.p, nullptr));
+  m->maps_host.resize(ncell * num_classes);
+  m->mask_host.resize(ncell);
+  HTRY(hipMemcpy(m->maps_host.data(), d_maps.p, ncell * num_classes * sizeof(float), hipMemcpyDeviceToHost));
+  HTRY(hipMemcpy(m->mask_host.data(), d_mask.p, ncell, hipMemcpyDeviceToHost));
+  m->desc.rec = m->rec.p;
+  m->desc.ncls = num_classes;
+  m->desc.rows = rows;
+  m->desc.cols = cols;
+  m->desc.rec_floats = tdr_rec_floats(num_classes);
+  m->desc.resolution = resolution;
+  m->center_x = center_x;
+  m->center_y = center_y;
+  TTRY(map_compact(m));
+  TTRY(map_make_geo(m, false));   // getGeoRasterMap + computeDists (:48-58)
+  m->have_map = true;             // :63
+  if (m->nb > 0) return tdr_map_sample_pts_polar(m, m->nb, m->nr, m->ang_res);
   return TDR_OK;
 }
 
@@ -761,7 +854,8 @@ int tdr_filter_update_geo(tdr_filter* f, const float* scan_imgs, const float* ge
   if (f->comm) return failh(TDR_ERR_ARG, "filter_update_geo: not available on a sharded filter");
   if (f->n == 0) return TDR_OK;
   tdr_map* m = f->map;
-  if (m->nb < 1 || !m->tab.p || !m->geo_rec.p) return failh(TDR_ERR_ARG, "filter_update_geo: samplePtsPolar was never called");
+  if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "filter_update_geo: samplePtsPolar was never called");
+  TTRY(map_ensure_geo(m));
   f->fp.num_classes = m->desc.ncls;
   const int ncls = m->desc.ncls, nb = m->nb, nr = m->nr;
   const size_t P = (size_t)nb * nr;

@@ -50,10 +50,13 @@ extern "C" int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask
 // DIST_MASK_PRECISE): squared Euclidean distances are integers, minimised exactly; because distances are truncated at
 // 50 (:315) only cells within R = ceil(50/resolution) matter, so both separable passes are windowed brute force —
 // every cell independent, integer arithmetic, one correctly rounded sqrtf at the end.
+// Per cell the ingest keeps a word of class bits: bit c = the cell lies inside class c; bit 31 = no known class (mask = 1).
+// A label image gives one bit per cell; the per-class rasters of the raster cache may overlap.
 #define INGEST_MAXC 16
+#define INGEST_UNKNOWN 0x80000000u
 __global__ void ingest_labels_kernel(const uint8_t* __restrict__ img, int img_h, int img_w,
                                      const int32_t* __restrict__ lut, int lut_size, int ncls, int rows, int cols,
-                                     float resolution, int8_t* __restrict__ cls_map) {
+                                     float resolution, uint32_t* __restrict__ cls_map) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
   const int yi = (int)(idx / cols), xi = (int)(idx % cols);
@@ -65,11 +68,30 @@ __global__ void ingest_labels_kernel(const uint8_t* __restrict__ img, int img_h,
   const int label = img[(int64_t)iy * img_w + ix];
   int c = label < lut_size ? lut[label] : -1;
   if (c < 0 || c >= ncls) c = -1;  // :139
-  cls_map[idx] = (int8_t)c;
+  cls_map[idx] = c < 0 ? INGEST_UNKNOWN : (1u << c);
+}
+// TopDownMap::loadRasterizedMaps (src/top_down_map.cpp:213-224) + the first lines of computeDists (:293-305): planes
+// [ncls][h][w] are the class<i>.png images as stored (8-bit grey, row 0 = top); the loader flips them back (:217), scales by
+// 1/255 (:218); computeDists binarises with convertTo(CV_8UC1) — round to nearest: p <= 127 -> 0 = inside the class — and
+// marks a cell unknown where every class casts to 1 (:294-299: float -> uint8 truncation, so only p == 255 counts).
+__global__ void ingest_rasters_kernel(const uint8_t* __restrict__ planes, int ncls, int rows, int cols,
+                                      uint32_t* __restrict__ cls_map) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ncell = (int64_t)rows * cols;
+  if (idx >= ncell) return;
+  const int r = (int)(idx / cols), c = (int)(idx % cols);
+  uint32_t bits = 0;
+  int ones = 0;
+  for (int k = 0; k < ncls; k++) {
+    const int p = planes[(int64_t)k * ncell + (int64_t)(rows - 1 - r) * cols + c];
+    if (p <= 127) bits |= 1u << k;
+    ones += p == 255 ? 1 : 0;
+  }
+  cls_map[idx] = bits | (ones > ncls - 1 ? INGEST_UNKNOWN : 0u);
 }
 
 // pass 1: per cell and class, distance (in cells, along the column) to the nearest cell of that class, capped at 255
-__global__ void ingest_coldist_kernel(const int8_t* __restrict__ cls_map, int ncls, int rows, int cols, int R,
+__global__ void ingest_coldist_kernel(const uint32_t* __restrict__ cls_map, int ncls, int rows, int cols, int R,
                                       uint8_t* __restrict__ g /* [rows*cols][INGEST_MAXC] */) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
@@ -79,11 +101,12 @@ __global__ void ingest_coldist_kernel(const int8_t* __restrict__ cls_map, int nc
   for (int c = 0; c < INGEST_MAXC; c++) gd[c] = 255;
   for (int d = 0; d <= R; d++) {
     const int ya = y - d, yb = y + d;
-    const int ca = ya >= 0 ? (int)cls_map[(int64_t)ya * cols + x] : -1;
-    const int cb = yb < rows ? (int)cls_map[(int64_t)yb * cols + x] : -1;
+    const uint32_t ca = ya >= 0 ? cls_map[(int64_t)ya * cols + x] : 0u;
+    const uint32_t cb = yb < rows ? cls_map[(int64_t)yb * cols + x] : 0u;
+    const uint32_t either = ca | cb;
 #pragma unroll
     for (int c = 0; c < INGEST_MAXC; c++)
-      if ((ca == c || cb == c) && gd[c] == 255) gd[c] = d;
+      if (((either >> c) & 1u) && gd[c] == 255) gd[c] = d;
   }
   uint8_t* o = g + idx * INGEST_MAXC;
 #pragma unroll
@@ -92,7 +115,7 @@ __global__ void ingest_coldist_kernel(const int8_t* __restrict__ cls_map, int nc
 }
 
 // pass 2: exact squared distance = min over the row window of dx^2 + g^2; then the reference's post-processing
-__global__ void ingest_rowmin_kernel(const int8_t* __restrict__ cls_map, const uint8_t* __restrict__ g, int ncls,
+__global__ void ingest_rowmin_kernel(const uint32_t* __restrict__ cls_map, const uint8_t* __restrict__ g, int ncls,
                                      int rows, int cols, int R, float resolution, int rf, float* __restrict__ rec) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
@@ -112,7 +135,7 @@ __global__ void ingest_rowmin_kernel(const int8_t* __restrict__ cls_map, const u
       best[c] = cand < best[c] ? cand : best[c];
     }
   }
-  const bool unknown = cls_map[idx] < 0;  // no class at this cell (:294-299): mask = 1, distances zeroed (:317)
+  const bool unknown = (cls_map[idx] & INGEST_UNKNOWN) != 0;  // no class at this cell (:294-299): mask = 1, distances zeroed (:317)
   float* o = rec + ((int64_t)(y + 1) * (cols + 2) + (x + 1)) * rf;
 #pragma unroll
   for (int c = 0; c < INGEST_MAXC; c++) {
@@ -135,7 +158,7 @@ __global__ void zero_floats_kernel(float* __restrict__ p, int64_t n) {
 
 extern "C" size_t tdr_map_ingest_workspace_bytes(int ncls, int rows, int cols) {
   (void)ncls;
-  return (size_t)rows * cols * (1 + INGEST_MAXC) + 256;
+  return (size_t)rows * cols * (4 + INGEST_MAXC) + 256;
 }
 extern "C" int tdr_map_ingest_shape(int img_h, int img_w, float resolution, int* rows, int* cols) {
   if (!rows || !cols || !(resolution > 0) || img_h < 1 || img_w < 1) return fail(TDR_ERR_ARG, "ingest_shape: bad arguments");
@@ -158,18 +181,44 @@ extern "C" int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int im
   if (R > 250) return fail(TDR_ERR_ARG, "map_from_labels: resolution %g needs a %d-cell window (max 250)", resolution, R);
   const int rf = tdr_rec_floats(ncls);
   hipStream_t s = (hipStream_t)stream;
-  int8_t* cls_map = reinterpret_cast<int8_t*>(workspace);
-  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)rows * cols + 255) & ~(size_t)255);
+  uint32_t* cls_map = reinterpret_cast<uint32_t*>(workspace);
+  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)rows * cols * 4 + 255) & ~(size_t)255);
   const int64_t ncell = (int64_t)rows * cols;
   const int64_t nrec = (int64_t)tdr_map_rec_floats_total(ncls, rows, cols);
   hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, rec_out, nrec);  // guard ring
   hipLaunchKernelGGL(ingest_labels_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, label_img, img_h, img_w,
                      flatten_lut, lut_size, ncls, rows, cols, resolution, cls_map);
-  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map,
+  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map,
                      ncls, rows, cols, R, g);
-  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map,
+  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map,
                      (const uint8_t*)g, ncls, rows, cols, R, resolution, rf, rec_out);
   LAUNCH_CHECK("map_from_labels");
+  return TDR_OK;
+}
+
+// The same from the per-class rasters of the raster cache (ingest_rasters_kernel): planes [ncls][rows][cols] device bytes,
+// the PNG images as stored.  The map has the images' shape; rec_out / workspace as for tdr_k_map_from_labels.
+extern "C" int tdr_k_map_from_rasters(const uint8_t* planes, int ncls, int rows, int cols, float resolution, float* rec_out,
+                                      void* workspace, void* stream) {
+  if (!planes || !rec_out || !workspace) return fail(TDR_ERR_ARG, "map_from_rasters: null pointer");
+  if (ncls < 1 || ncls > TDR_MAX_CLASSES || rows < 1 || cols < 1 || !(resolution > 0.f))
+    return fail(TDR_ERR_ARG, "map_from_rasters: bad class count / shape / resolution");
+  const int R = (int)std::ceil(50.0 / (double)resolution);
+  if (R > 250) return fail(TDR_ERR_ARG, "map_from_rasters: resolution %g needs a %d-cell window (max 250)", resolution, R);
+  const int rf = tdr_rec_floats(ncls);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* cls_map = reinterpret_cast<uint32_t*>(workspace);
+  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)rows * cols * 4 + 255) & ~(size_t)255);
+  const int64_t ncell = (int64_t)rows * cols;
+  const int64_t nrec = (int64_t)tdr_map_rec_floats_total(ncls, rows, cols);
+  hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, rec_out, nrec);  // guard ring
+  hipLaunchKernelGGL(ingest_rasters_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, planes, ncls, rows, cols,
+                     cls_map);
+  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map,
+                     ncls, rows, cols, R, g);
+  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map,
+                     (const uint8_t*)g, ncls, rows, cols, R, resolution, rf, rec_out);
+  LAUNCH_CHECK("map_from_rasters");
   return TDR_OK;
 }
 
@@ -182,7 +231,7 @@ extern "C" int tdr_k_map_from_labels(const uint8_t* label_img, int img_h, int im
 // records (distance 0 on a known cell) and the two layers go through the same exact distance transform as the class
 // maps, into records of their own: a 2-class map {d_without, d_with, 1, 1}.
 __global__ void geo_labels_kernel(const float* __restrict__ rec, int ncls, int rows, int cols, int rf,
-                                  int8_t* __restrict__ cls_map) {
+                                  uint32_t* __restrict__ cls_map) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
   const int r = (int)(idx / cols), c = (int)(idx % cols);
@@ -190,7 +239,7 @@ __global__ void geo_labels_kernel(const float* __restrict__ rec, int ncls, int r
   bool geo = false;
   if (o[rf - 1] != 0.f)
     for (int k = 3; k < ncls; k++) geo |= o[k] == 0.f;                          // :417-419
-  cls_map[idx] = geo ? 1 : 0;
+  cls_map[idx] = geo ? 2u : 1u;   // class 1 = with a geometric class, class 0 = without; never unknown
 }
 // the dynamic-map path leaves both layers at their initial constant 1 (loadCompressedRasterMap :126-133, "Not actually
 // used at the moment"; updateMap never recomputes them): records {1, 1, 1, 1} inside the map, the zero guard ring outside
@@ -218,14 +267,14 @@ extern "C" int tdr_k_geo_map_from_map(const tdr_map_desc* map, int constant_one,
   if (!workspace) return fail(TDR_ERR_ARG, "geo_map_from_map: workspace required");
   const int R = (int)std::ceil(50.0 / (double)map->resolution);
   if (R > 250) return fail(TDR_ERR_ARG, "geo_map_from_map: resolution %g needs a %d-cell window (max 250)", map->resolution, R);
-  int8_t* cls_map = reinterpret_cast<int8_t*>(workspace);
-  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)ncell + 255) & ~(size_t)255);
+  uint32_t* cls_map = reinterpret_cast<uint32_t*>(workspace);
+  uint8_t* g = reinterpret_cast<uint8_t*>(workspace) + (((size_t)ncell * 4 + 255) & ~(size_t)255);
   hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, geo_rec_out, nrec);
   hipLaunchKernelGGL(geo_labels_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, map->rec, map->ncls, rows, cols,
                      map->rec_floats, cls_map);
-  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map, 2,
+  hipLaunchKernelGGL(ingest_coldist_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map, 2,
                      rows, cols, R, g);
-  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const int8_t*)cls_map,
+  hipLaunchKernelGGL(ingest_rowmin_kernel, dim3((unsigned)cdiv(ncell, 256)), dim3(256), 0, s, (const uint32_t*)cls_map,
                      (const uint8_t*)g, 2, rows, cols, R, map->resolution, 4, geo_rec_out);
   LAUNCH_CHECK("geo_map_from_map");
   return TDR_OK;

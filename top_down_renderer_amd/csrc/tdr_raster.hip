@@ -137,7 +137,7 @@ static int launch_raster(const float* pts, int stride, int ioff, int64_t n, floa
   if (stride < 3 || ioff < 0 || ioff >= stride) return fail(TDR_ERR_ARG, "raster: bad point stride / offset");
   if (!(res > 0.f) || (polar && !(ang_res > 0.f))) return fail(TDR_ERR_ARG, "raster: resolution must be > 0");
   int64_t per_col = (int64_t)ncls * rows * 4;
-  if (per_col > 64 * 1024) return fail(TDR_ERR_ARG, "raster: ncls*rows too large for one LDS tile");
+  if (per_col > 152 * 1024) return fail(TDR_ERR_ARG, "raster: ncls*rows too large for one LDS tile (152 KB)");
   RasterArgs a;
   a.pts = pts; a.stride = stride; a.ioff = ioff; a.n = n; a.res = res; a.ang_res = ang_res; a.lut = lut;
   a.ncls = ncls; a.rows = rows; a.cols = cols; a.rf = tdr_rec_floats(ncls); a.polar = polar; a.img = img; a.pk = pk;
@@ -146,6 +146,16 @@ static int launch_raster(const float* pts, int stride, int ioff, int64_t n, floa
   // enough workgroups to spread over the chip when the image is small
   while (a.cpt > 1 && cdiv(cols, a.cpt) < 32) a.cpt = (a.cpt + 1) / 2;
   size_t lds = (size_t)a.cpt * per_col;
+  if (lds > 64 * 1024) {   // one image column of more than 64 KB (cpt = 1): most of a CU's 160 KB, allowed per device
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev >= 64 || !attr_set[dev]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(raster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  152 * 1024));
+      if (dev < 64) attr_set[dev] = true;
+    }
+  }
   a.keys = nullptr;
   if (workspace && n > 0 && cols <= RASTER_KEY_MAX_COLS && rows <= RASTER_KEY_MAX_ROWS) {
     a.keys = reinterpret_cast<uint32_t*>(workspace);
