@@ -256,7 +256,7 @@ def main():
     if rank == 0:
         P = cfg.nb * cfg.nr
         b_pu = P * (4 * cfg.ncls + 1) + 64
-        kname = "score_cart_kernel"
+        kname = "score_cart"   # score_cart_skip_kernel (tdr_score_cart.hip) or the general score_cart_kernel
         if cfg.polar:
             kname = "score_polar"   # score_polar_kernel, or score_polar_su_kernel + score_polar_kernel side by side
         n_local = per_gpu

@@ -13,7 +13,7 @@ if [ "$MODE" = tests ]; then
 fi
 for C in $CONFIGS; do
   N=$(python3 -c "from top_down_renderer_amd import synth; c=synth.CONFIGS['$C']; print(c.n_particles//8 if c.name in ('c3','c5') else c.n_particles)")
-  K=score_polar; [ "$C" = c4 ] && K=score_cart_kernel
+  K=score_polar; [ "$C" = c4 ] && K=score_cart
   STEPS=20; [ "$C" = c4 ] && STEPS=5
   # PMC pass first (its own run, counters only), then the record, then the bench proper so that it reports the traffic
   rm -rf $OUT/pmc_$C

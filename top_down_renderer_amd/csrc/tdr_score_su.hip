@@ -41,13 +41,14 @@
 
 #define SU_CODE_FULL 0xFFu       // several classes present: packed scan record, classes with a zero count skipped
 #define SU_CODE_FULL_ALL 0xFEu   // a non-finite value is in play: every class multiplied like score_polar_kernel does
-#define SU_NSECT 8               // sectors of directions per known-mask staging
-#define SU_BOX_WORDS 3072        // LDS words of the staged known mask (12 KB: occupancy stays at 8 waves per SIMD)
+#define SU_NSECT 8               // sectors of directions per known-mask staging (16: 2 % slower on config 2)
+#define SU_BOX_WORDS 3072        // LDS words of the staged known mask (12 KB; 18 KB measured 4 % slower on config 2)
 
 struct SuArgs {
   const uint32_t* crec;    // compact records (narrow form)
   const uint32_t* kmask;   // the map's known mask (behind the tiles of crec)
   int ktcols;              // its tiles per tile row (kmask_tcols)
+  unsigned kmask_off;      // its byte offset from crec
   const float* dict;
   int dict_n, ctiles_r;
   int rows, cols;          // map
@@ -404,11 +405,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   // NS consecutive steps of a sector (step k = direction i0 + k / spd, rings (k % spd) * 4 ..) WITHOUT the staged mask:
   // the windows of the workgroup's particles are too far apart to stage (scattered particles: su_key_kernel gives them
   // waves of their own).  Every gather of such a wave misses the caches, so the wave is bound by how many it keeps in
-  // flight: the records of all 4 NS samples are requested before the first is used, and the known bit comes with the
-  // record (bit 0 of every dword of a compact record, tdr_cmap.hip) instead of a second gather from the mask.
+  // flight: the gathers of all 4 NS samples are requested before the first is used — ONE per sample: the mask word of an
+  // empty bin (the global mask: 32 x 32-cell tiles, a cache line each), the record dword of a bin with a class (its bit 0 is
+  // the known bit: every dword of a compact record carries it, tdr_cmap.hip).
   auto far_steps = [&](auto nsteps_c, int i, int jj) {
     constexpr int NS = decltype(nsteps_c)::value;
     uint32_t w[4 * NS];
+    uint32_t cbits[(4 * NS + 5) / 6];   // the column's low 5 bits of every sample (the bit of its mask word), six per word
+#pragma unroll
+    for (int q = 0; q < (4 * NS + 5) / 6; q++) cbits[q] = 0;
+    const int mtrb = a.ktcols * 128, mconst = (int)a.kmask_off + 128;   // kmask_offset
     int ii = i, jx = jj;
 #pragma unroll
     for (int d = 0; d < NS; d++) {
@@ -420,14 +426,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       for (int u = 0; u < 4; u++) {
         int ri, ci;
         cell(T[2 * u], T[2 * u + 1], ri, ci);
-        // a single class: the dword it lives in; an empty bin (for its known bit) or several classes: dword 0
-        const uint32_t ckc = D[4 * u + 2];
-        int t1, t2;
         unsigned off;
-        const int cq = ci >> 2;
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
-        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
-        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
+        const int sidx = 4 * d + u;   // (d, u are unrolled: constants after unrolling)
+        if (D[4 * u] == 0) {   // wave-uniform: an empty bin reads the cell's mask word
+          off = kmask_offset(ri, ci, mtrb, mconst);
+          cbits[sidx / 6] |= (uint32_t)(ci & 31) << (5 * (sidx % 6));
+        } else {               // a single class: the dword it lives in; several classes: dword 0
+          const uint32_t ckc = D[4 * u + 2];
+          int t1, t2;
+          const int cq = ci >> 2;
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
+          asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
+          asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
+        }
         asm volatile("global_load_dword %0, %1, %2" : "=v"(w[4 * d + u]) : "v"(off), "s"(crec));
       }
       jx += 4;
@@ -444,9 +455,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // (the requests return in order: sample 4 d + u is there once all but the 4 NS - 1 - (4 d + u) behind it are)
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[4 * d + u]) : "n"(4 * NS - 1 - (4 * d + u)));
         const uint32_t ww = w[4 * d + u];
-        const uint32_t kb = ww & 1u;
-        known += kb;
         const uint32_t cd = D[4 * u];
+        const int sidx = 4 * d + u;
+        const uint32_t kb = cd == 0 ? (ww >> ((cbits[sidx / 6] >> (5 * (sidx % 6))) & 31u)) & 1u : (ww & 1u);
+        known += kb;
         if (cd != 0) {   // wave-uniform
           const float v = __uint_as_float(D[4 * u + 1]);
           if (cd < SU_CODE_FULL_ALL) {
@@ -732,6 +744,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.bbox = reinterpret_cast<const float*>(base + W.bbox);
   u.kmask = map->crec + tdr_cmap_tile_words(map->ncls, map->rows, map->cols);
   u.ktcols = kmask_tcols(map->cols);
+  u.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
   u.scan_pk = L.scan_pk;
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
