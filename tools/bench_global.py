@@ -1,12 +1,14 @@
 """Times the global-N stages every rank runs after the all-gather (statistics, exact prefix, resample slice, gather)
 for particle counts up to the 8-GPU configurations.  GPU only; prints one line per n."""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-from top_down_renderer_amd.kernels import HipKernels
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from top_down_renderer_amd.kernels import HipKernels  # noqa: E402
 
 
 def timeit(fn, k, reps=10):
