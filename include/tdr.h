@@ -336,6 +336,11 @@ float tdr_config_shift_uniform_span(float cells);   /* < 0 only returns it */
  * (csrc/tdr_score_cart.hip); same partial sums, bit for bit.  It is used whenever the map has narrow compact records;
  * 0 forces the general kernel (A/B measurements, tests), 1 restores the default, < 0 only queries.  Env TDR_CART_SKIP. */
 int tdr_config_cart_skip(int on);
+/* The 40-rotation search of a particle without a heading (src/state_particle.cpp:195-206) runs on the matrix cores
+ * (v_mfma_f32_16x16x32_f16; every record size: 4 / 8 floats through pre-split half records or split on the fly, 12 / 16
+ * floats in two groups of 8 slots); 0 forces the vector-unit search (A/B measurements, tests), 1 restores the default,
+ * < 0 only queries.  Only the choice among rotations whose costs tie to rounding can differ.  Env TDR_INIT_MFMA. */
+int tdr_config_init_mfma(int on);
 /* diagnostics: scoring launches of this process that took the shift-uniform kernel */
 int64_t tdr_shift_uniform_launches(void);
 

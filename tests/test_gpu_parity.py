@@ -971,6 +971,56 @@ def test_init_search_c1(tdr, oracle):
     assert pre["have_init"].all()
 
 
+@pytest.mark.parametrize("ncls", [8, 11, 12, 15])
+def test_init_search_on_the_matrix_cores_for_wide_records(tdr, oracle, ncls):
+    """8-15 classes (records of 12 / 16 floats): the 40-rotation search through score_init_mfma_wide_kernel against the
+    vector-unit search and the oracle — the same rotation, or a tie of the two costs within 2e-5; weights within 1e-5 at
+    the chosen rotation."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("initwide", 9000, ncls, 48, 20, 400, 600, seed=300 + ncls)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    st["have_init"] = 0
+    st["theta"] = 0
+    st["init_x_px"][:4] = np.asarray([-300, 3, 399, 200], np.float32)     # all unknown / at the border
+    cw = [float(0.5 + (c % 4) * 0.5) for c in range(ncls)]
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, 1.0)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, ncls, cfg.nb, cfg.nr)
+    fpo = oracle.make_params(ncls, class_weights=cw)
+    st_o = st.copy()
+    ref = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, fpo, st_o)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    before = k.lib.tdr_config_init_mfma(-1)
+    got = {}
+    try:
+        for on in (0, 1):
+            k.lib.tdr_config_init_mfma(on)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0, class_weights=cw), kernels=k,
+                                   init_particles=False)
+            f.set_states(st)
+            k.score(m.dev, m.scan_handle(scan), cfg.res, f.fp_c, f.st, len(st), f.raw_w, init_search=True,
+                    uniform_scale=f._uniform_scale)
+            got[on] = (f.raw_w[: len(st)].cpu().numpy(), k.states_to_host(f.st, len(st), pkg.STATE_DTYPE))
+    finally:
+        k.lib.tdr_config_init_mfma(before)
+    for on in (0, 1):
+        raw, sts = got[on]
+        assert sts["have_init"].all()
+        same = sts["theta"] == st_o["theta"]
+        _assert_weights(raw[same], ref[same])
+        if not same.all():
+            st2 = st_o.copy()
+            st2["theta"], st2["have_init"] = sts["theta"], 1
+            ref2 = oracle.compute_weights(om, tab, cfg.nb, cfg.nr, scan, cfg.res, fpo, st2)
+            _assert_weights(raw[~same], ref2[~same])
+            tie = np.abs(ref2[~same] - ref[~same]) / np.maximum(np.abs(ref[~same]), 1e-30)
+            assert np.nanmax(tie, initial=0.0) <= 2e-5, f"mfma={on}: chosen rotation is not a near-tie: {np.nanmax(tie):.2e}"
+    assert (got[0][1]["theta"] != got[1][1]["theta"]).mean() < 0.02
+
+
 def test_freeze_scale_and_shift_init(tdr, oracle, g):
     pkg, k = tdr
     ncls, nb, nr, _ = [int(v) for v in g["shape"]]

@@ -1052,6 +1052,176 @@ __global__ __launch_bounds__(256) void score_init_mfma_kernel(InitArgs a, int* _
   }
 }
 
+// The same for records of 12 and 16 floats (8-15 classes): a sample's record is two groups of 8 slots, each group its own
+// pair of fragments — B from the gathered record, A from a second LDS image of the scan row — so a step of 4 samples is
+// 2 x (hi + lo) products per tile instead of one, plus the normalisation product on the group that holds slot RF - 1.
+// Class weights are always folded in (no unit-weight form); slots past the class count meet a zero weight.
+template <int NV4, bool USCALE>
+__global__ __launch_bounds__(256) void score_init_mfma_wide_kernel(InitArgs a, int* __restrict__ inexact) {
+  constexpr int RF = 4 * NV4, NH = 2;
+  static_assert(NV4 == 3 || NV4 == 4, "records of 12 or 16 floats");
+  constexpr int HN = (RF - 1) / 8, KN = (RF - 1) % 8;   // group and slot of `known` / the scan's sum
+  extern __shared__ uint4 ring16[];   // [2*nb + 1 rows][NH groups]: 8 x f16 each; rows r and r+nb hold scan row r, the last is zero
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + wave * 16 + col;
+  const bool valid = slot < a.n;
+  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const bool want = valid && a.st[TDR_ST_HAVE_INIT * a.cap + p] == 0.f && !particle_gated(a.gate, cx, cy, scale);
+  if (!__syncthreads_or(want)) return;   // nothing to initialise in this batch of 64 particles
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const int rowstride = (a.cols + 2) * (RF * 4);
+  const int kbase = (a.cols + 3) * (RF * 4);
+  const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
+  const char* __restrict__ recb = reinterpret_cast<const char*>(a.rec);
+  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(USCALE ? a.utab : a.tab);
+  const float4* __restrict__ scan4 = reinterpret_cast<const float4*>(a.scan_pk);
+  const int nrot = *a.nrot;
+  const int zero_row = 2 * a.nb;
+  int sh[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) {
+    const int m = 16 * T + col;
+    sh[T] = m < nrot ? a.shift[m] : -1;
+  }
+  if (threadIdx.x < NH) ring16[zero_row * NH + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+  float wc[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) wc[c] = (c < a.ncls && c < TDR_MAX_CLASSES) ? (float)(0.01 * (double)a.fp.class_weights[c < TDR_MAX_CLASSES ? c : 0]) : 0.f;
+  tdr_f4 accC[INITM_TILES], accN[INITM_TILES];
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++) { accC[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; accN[T] = (tdr_f4){0.f, 0.f, 0.f, 0.f}; }
+  float known = 0.f;
+  const int steps = (a.nb + 3) / 4;
+  const tdr_h2 zero2 = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+
+  for (int j = 0; j < a.nr; j++) {
+    const float2* trow = tab2 + (int64_t)j * a.nb;
+    const float4* srow = scan4 + (int64_t)j * a.nb * NV4;
+    __syncthreads();
+    bool big = false;
+    for (int t = threadIdx.x; t < a.nb; t += 256) {
+      float f[16];
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float4 x = v < NV4 ? srow[NV4 * t + (v < NV4 ? v : 0)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) big |= f[k] > 2048.f;
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        union { tdr_h2 h2[4]; uint4 u; } pk;
+#pragma unroll
+        for (int c = 0; c < 4; c++) pk.h2[c] = __builtin_amdgcn_cvt_pkrtz(f[8 * h + 2 * c], f[8 * h + 2 * c + 1]);
+        ring16[t * NH + h] = pk.u;
+        ring16[(t + a.nb) * NH + h] = pk.u;
+      }
+    }
+    if (big) atomicOr(inexact, 1);
+    __syncthreads();
+    auto tab_at = [&](int t) -> float2 { return trow[min(4 * t + q, a.nb - 1)]; };
+    auto rec_addr = [&](float2 tv) -> const char* {
+      float p0, p1;
+      if constexpr (USCALE) { p0 = tv.x; p1 = tv.y; }
+      else { p0 = (tv.x * scale) * a.res; p1 = (tv.y * scale) * a.res; }   // top_down_map_polar.cpp:28
+      p0 = __builtin_amdgcn_fmed3f(p0 + off0, -1.f, rmaxf);
+      p1 = __builtin_amdgcn_fmed3f(p1 + off1, -1.f, cmaxf);
+      const int ri = round_half_away_clamped(p0), ci = round_half_away_clamped(p1);   // :31
+      const bool inb = (unsigned)ri < (unsigned)a.rows && (unsigned)ci < (unsigned)a.cols;
+      return recb + (inb ? (unsigned)(__mul24(ri, rowstride) + (ci * (RF * 4) + kbase)) : 0u);
+    };
+    float2 tv_next = tab_at(1);
+    float4 nx[NV4];
+    {
+      const char* r0 = rec_addr(tab_at(0));
+#pragma unroll
+      for (int v = 0; v < NV4; v++) nx[v] = *reinterpret_cast<const float4*>(r0 + 16 * v);
+    }
+    for (int t = 0; t < steps; t++) {
+      const int i = 4 * t + q;
+      const bool in = i < a.nb;
+      const int ic = in ? i : a.nb - 1;
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NV4; g++) { v[4 * g] = nx[g].x; v[4 * g + 1] = nx[g].y; v[4 * g + 2] = nx[g].z; v[4 * g + 3] = nx[g].w; }
+      {
+        const char* r1 = rec_addr(tv_next);        // step t+1 (clamped to the ring: an in-range address)
+        tv_next = tab_at(t + 2);
+#pragma unroll
+        for (int g = 0; g < NV4; g++) nx[g] = *reinterpret_cast<const float4*>(r1 + 16 * g);
+      }
+      if (!in) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = 0.f;
+      }
+      const float kn = v[RF - 1];
+      known += kn;
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] *= wc[k];   // (slots past the classes: weight 0)
+      union { tdr_h2 h[4]; tdr_h8 v8; } bh[NH], bl[NH], bn;
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const tdr_h2 hi = __builtin_amdgcn_cvt_pkrtz(v[8 * h + 2 * c], v[8 * h + 2 * c + 1]);
+          bh[h].h[c] = hi;
+          bl[h].h[c] = __builtin_amdgcn_cvt_pkrtz(v[8 * h + 2 * c] - (float)hi[0], v[8 * h + 2 * c + 1] - (float)hi[1]);
+        }
+#pragma unroll
+      for (int c = 0; c < 4; c++) bn.h[c] = zero2;
+      bn.h[KN / 2] = (KN & 1) ? __builtin_amdgcn_cvt_pkrtz(0.f, kn) : __builtin_amdgcn_cvt_pkrtz(kn, 0.f);
+      union { uint4 u; tdr_h8 v8; } av[INITM_TILES][NH];
+#pragma unroll
+      for (int T = 0; T < INITM_TILES; T++)
+#pragma unroll
+        for (int h = 0; h < NH; h++) av[T][h].u = ring16[(sh[T] < 0 ? zero_row : ic + sh[T]) * NH + h];
+      // dependent MFMAs (same accumulator) are kept three instructions apart
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+#pragma unroll
+        for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T][h].v8, bh[h].v8, accC[T], 0, 0, 0);
+        if (h == HN) {
+#pragma unroll
+          for (int T = 0; T < INITM_TILES; T++) accN[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T][h].v8, bn.v8, accN[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int T = 0; T < INITM_TILES; T++) accC[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[T][h].v8, bl[h].v8, accC[T], 0, 0, 0);
+      }
+    }
+  }
+  known += __shfl_xor(known, 16, 64);
+  known += __shfl_xor(known, 32, 64);
+  const bool unknown = (known / (float)a.P) < 0.5;   // state_particle.cpp:117-120
+  float best = 3.402823466e+38f;
+  int bm = -1;
+#pragma unroll
+  for (int T = 0; T < INITM_TILES; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * T + 4 * q + r;
+      float cost = accC[T][r] / accN[T][r];             // :154
+      if (unknown) cost = __builtin_nanf("");
+      if (m < nrot && cost < best) { best = cost; bm = m; }   // :200-203 (NaN never wins)
+    }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {   // first minimum in rotation order over the particle's four lanes
+    const float oc = __shfl_xor(best, o, 64);
+    const int om = __shfl_xor(bm, o, 64);
+    const bool take = om >= 0 && (bm < 0 || oc < best || (oc == best && om < bm));
+    if (take) { best = oc; bm = om; }
+  }
+  if (q == 0 && want) {
+    a.res_theta[p] = bm >= 0 ? a.theta[bm] : 0.f;  // :205 (best_theta stays 0 if nothing won)
+    a.res_flag[p] = bm < 0 ? 2.f : 1.f;
+  }
+}
+
 // ---- the matrix-core search on pre-split half records ------------------------------------------------------------------
 // score_init_mfma_kernel spends most of its vector instructions turning a gathered f32 record into the f16 hi / lo
 // operands (weights, two conversions and a subtraction per pair, the zeroing of ragged lanes), per sample per particle.
@@ -1321,12 +1491,14 @@ __global__ void init_fixup_kernel(const float* __restrict__ res_flag, int64_t n,
   if (p < n && res_flag[p] == 2.f) raw_w[p] = (float)(1. / (double)(3.402823466e+38f + regularization));
 }
 
-static bool init_use_mfma() {
-  static bool v = [] {
-    const char* e = getenv("TDR_INIT_MFMA");   // 0 = vector-unit search only (A/B and debugging)
-    return !(e && atoi(e) == 0);
-  }();
-  return v;
+static int g_init_mfma = [] {
+  const char* e = getenv("TDR_INIT_MFMA");   // 0 = vector-unit search only (A/B and debugging)
+  return (e && atoi(e) == 0) ? 0 : 1;
+}();
+static bool init_use_mfma() { return g_init_mfma != 0; }
+extern "C" int tdr_config_init_mfma(int on) {   // < 0: query only
+  if (on >= 0) g_init_mfma = on ? 1 : 0;
+  return g_init_mfma;
 }
 // the Cartesian kernel likes twice as many, shorter waves (A/B on MI355X, config 4: x1 183 ms, x2 179 ms, x4 177 ms)
 #define TDR_CART_WAVE_MUL 2
@@ -1751,6 +1923,18 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
 #undef TDR_LAUNCH_MFMA
       }
       LAUNCH_CHECK("score_init_mfma");
+      ia.only_if = d_inexact;
+    } else if ((rf == 12 || rf == 16) && init_use_mfma()) {
+      // 8-15 classes: two groups of 8 slots per sample (score_init_mfma_wide_kernel)
+      const size_t lds16 = ((size_t)2 * nb + 1) * 2 * 16;
+      if (rf == 12) {
+        if (us) hipLaunchKernelGGL((score_init_mfma_wide_kernel<3, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+        else hipLaunchKernelGGL((score_init_mfma_wide_kernel<3, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      } else {
+        if (us) hipLaunchKernelGGL((score_init_mfma_wide_kernel<4, true>), grid, dim3(256), lds16, s, ia, d_inexact);
+        else hipLaunchKernelGGL((score_init_mfma_wide_kernel<4, false>), grid, dim3(256), lds16, s, ia, d_inexact);
+      }
+      LAUNCH_CHECK("score_init_mfma_wide");
       ia.only_if = d_inexact;
     }
 #define TDR_LAUNCH_INIT(NV4)                                                                                \
