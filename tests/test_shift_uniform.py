@@ -103,6 +103,38 @@ def test_shift_uniform_equals_lane_shift_kernel_and_oracle(tdr, oracle, ncls, nb
     assert np.array_equal(raw0, raw3, equal_nan=True)
 
 
+@pytest.mark.parametrize("holes", ["none", "one far corner"])
+def test_shift_uniform_on_a_fully_known_map(tdr, oracle, holes):
+    """A map without unknown cells: every sector of every workgroup whose windows stay inside it takes the loop without
+    clamp and without known-mask lookups (`allknown`); windows that reach the border, or the one unknown corner, do not."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("suk", 6000, 6, 64, 24, 420, 4096, seed=4700)
+    sc = synth.make_scene(cfg)
+    mask = np.zeros_like(sc.class_mask)
+    maps = sc.class_maps.copy()
+    if holes != "none":
+        mask[:40, :40] = 1
+        maps[:, :40, :40] = 0
+    st = sc.states.copy()
+    rng = np.random.default_rng(9)
+    st["init_x_px"] = rng.normal(210, 12, len(st)).astype(np.float32)      # one tight cluster in the middle
+    st["init_y_px"] = rng.normal(210, 12, len(st)).astype(np.float32)
+    st["dx_m"] = 0
+    st["dy_m"] = 0
+    st["theta"] = rng.normal(0.3, 0.05, len(st)).astype(np.float32)
+    st["init_x_px"][:64] = rng.uniform(0, 420, 64).astype(np.float32)       # and a few anywhere, borders included
+    params = dict(fixed_scale=1.0)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), maps, mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+    ref = oracle.compute_weights(oracle.OracleMap(maps, mask, 1.0), oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res),
+                                 cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls, **params), st.copy())
+    (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, params)
+    assert np.array_equal(raw0, raw2, equal_nan=True)
+    _assert_weights(raw2, ref)
+
+
 @pytest.mark.parametrize("kind", ["empty", "dense", "fractional", "one bin"])
 def test_shift_uniform_scan_contents(tdr, oracle, kind):
     """Descriptor classes: every bin empty; most bins holding several classes; counts that are not integers and negative

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes top_down_renderer_amd/csrc/tdr_score_su_asm.h: the hand-scheduled gfx950 inner loop of score_polar_su_kernel
-(records of two dwords: 4-6 classes) as inline-assembly text, in four variants — uniform / per-lane scale, with / without
-the clamp of the coordinates into the map's guard ring.  The text is generated so that the four samples of a step and the
+(records of two dwords: 4-6 classes) as inline-assembly text, in six variants — uniform / per-lane scale x {general, without
+the clamp of the coordinates into the map's guard ring, without clamp and known-mask lookups (every reachable cell known)}.  The text is generated so that the four samples of a step and the
 variants cannot drift apart.
 
     python3 tools/gen_su_asm.py        (re-run after editing; the header is committed)
@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su_asm.h")
 
 
-def loop_text(uscale, clamp):
+def loop_text(uscale, clamp, mask=True):
     L = []
     a = L.append
     # hipcc waits for one of its own loads where the VALUE is used; a load whose value the taken path never reads is still
@@ -75,16 +75,17 @@ def loop_text(uscale, clamp):
         p = 8 + 2 * u
         a(f"v_cvt_flr_i32_f32 v{p}, v{p}")
         a(f"v_cvt_flr_i32_f32 v{p + 1}, v{p + 1}")
-    # word of the staged known mask (LDS) of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
-    for u in range(4):
-        a(f"v_mad_i32_i24 v{16 + u}, v{8 + 2 * u}, %[krow4], %[kconst]")
-    for u in range(4):
-        a(f"v_ashrrev_i32 v{20 + u}, 5, v{9 + 2 * u}")
-    for u in range(4):
-        a(f"v_lshl_add_u32 v{16 + u}, v{20 + u}, 2, v{16 + u}")
-    a("s_nop 0")
-    for u in range(4):
-        a(f"ds_read_b32 v{28 + u}, v{16 + u}")
+    if mask:
+        # word of the staged known mask (LDS) of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
+        for u in range(4):
+            a(f"v_mad_i32_i24 v{16 + u}, v{8 + 2 * u}, %[krow4], %[kconst]")
+        for u in range(4):
+            a(f"v_ashrrev_i32 v{20 + u}, 5, v{9 + 2 * u}")
+        for u in range(4):
+            a(f"v_lshl_add_u32 v{16 + u}, v{20 + u}, 2, v{16 + u}")
+        a("s_nop 0")
+        for u in range(4):
+            a(f"ds_read_b32 v{28 + u}, v{16 + u}")
     # the record dword of every non-empty bin (cmap_offset with the dword folded into its constant)
     for u in range(4):
         code, ckc = 48 + 4 * u, 50 + 4 * u
@@ -103,21 +104,28 @@ def loop_text(uscale, clamp):
         a(f".Lsu_a{u}%=:")
     # ---- phase B
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    for u in range(4):
-        a(f"v_bfe_i32 v{16 + u}, v{28 + u}, v{9 + 2 * u}, 1")                   # 0 / -1: the cell's known bit
-    a("v_add_u32 v20, v16, v17")
-    a("v_add_u32 v21, v18, v19")
-    a("s_nop 0")
-    a("v_add_u32 v20, v20, v21")
-    a("s_nop 0")
-    a("v_sub_u32 %[known], %[known], v20")
+    if mask:
+        for u in range(4):
+            a(f"v_bfe_i32 v{16 + u}, v{28 + u}, v{9 + 2 * u}, 1")               # 0 / -1: the cell's known bit
+        a("v_add_u32 v20, v16, v17")
+        a("v_add_u32 v21, v18, v19")
+        a("s_nop 0")
+        a("v_add_u32 v20, v20, v21")
+        a("s_nop 0")
+        a("v_sub_u32 %[known], %[known], v20")
+    else:   # every cell the sector can reach is known: four more known samples, nothing to look up
+        a("v_add_u32 %[known], 4, %[known]")
     for u in range(4):
         code, val, sh = 48 + 4 * u, 49 + 4 * u, 51 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
         a(f"s_cbranch_scc1 .Lsu_b{u}%=")
-        a(f"v_and_b32 v20, s{val}, v{16 + u}")                                   # the bin's sum x known (:141-142)
+        if mask:
+            a(f"v_and_b32 v20, s{val}, v{16 + u}")                               # the bin's sum x known (:141-142)
         a(f"v_lshrrev_b32 v21, s{sh}, v{24 + u}")                                # the class's dictionary index * 4
-        a("v_add_f32 %[norm], %[norm], v20")
+        if mask:
+            a("v_add_f32 %[norm], %[norm], v20")
+        else:
+            a(f"v_add_f32 %[norm], s{val}, %[norm]")
         a("v_and_b32 v21, 0xffc, v21")
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                # the dictionary sits at LDS address 0
@@ -176,9 +184,9 @@ def main():
            "// register plan and the schedule's cost model.",
            "#ifndef TDR_SCORE_SU_ASM_H_", "#define TDR_SCORE_SU_ASM_H_", ""]
     for uscale in (True, False):
-        for clamp in (True, False):
-            out.append(f"#define SU_ASM_{'US' if uscale else 'PS'}{'' if clamp else '_NOCLAMP'} \\")
-            lines = loop_text(uscale, clamp)
+        for clamp, mask, tag in ((True, True, ""), (False, True, "_NOCLAMP"), (False, False, "_ALLKNOWN")):
+            out.append(f"#define SU_ASM_{'US' if uscale else 'PS'}{tag} \\")
+            lines = loop_text(uscale, clamp, mask)
             for i, ln in enumerate(lines):
                 out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
             out.append("")

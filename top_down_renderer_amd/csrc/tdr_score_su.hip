@@ -506,8 +506,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   };
   // One sector of directions [i0, i1) with the known mask staged in LDS
   // (inside: every cell the workgroup's windows can reach in this sector lies inside the map — the clamp into the guard
-  // ring is the identity and the loop without it runs)
-  auto run_sector = [&](int i0, int i1, int krow4, int kconst, bool inside) {
+  // ring is the identity and the loop without it runs; allknown: every staged mask word is all ones — every sample is a
+  // known cell and the loop without clamp and without mask lookups runs)
+  auto run_sector = [&](int i0, int i1, int krow4, int kconst, bool inside, bool allknown) {
     if constexpr (ASM_LOOP) {
       if (gn == G && lds_base == 0 && (G == 4 || G == 8 || G == 16)) {
         // the steps of the sector as one stream: step k reads T at byte k * 32 from its start and D at byte k * 64 from the
@@ -538,7 +539,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
             [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2)                                               \
           : SU_ASM_CLOBBERS
-          if (inside) {   // wave-uniform
+          if (allknown) {   // wave-uniform
+            if constexpr (USCALE) asm volatile(SU_ASM_US_ALLKNOWN SU_ASM_OPERANDS);
+            else asm volatile(SU_ASM_PS_ALLKNOWN SU_ASM_OPERANDS);
+          } else if (inside) {
             if constexpr (USCALE) asm volatile(SU_ASM_US_NOCLAMP SU_ASM_OPERANDS);
             else asm volatile(SU_ASM_PS_NOCLAMP SU_ASM_OPERANDS);
           } else {
@@ -603,20 +607,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int whi = (__builtin_amdgcn_readfirstlane(lds.box[3]) >> 5) + 1;
     const int H = rhi - rlo + 1, Wb = whi - wlo + 1;
     const bool fits = (int64_t)H * Wb <= SU_BOX_WORDS;   // uniform over the workgroup
+    uint32_t every = 0xFFFFFFFFu;   // AND of the words this thread staged
     if (fits) {
       const int total = H * Wb;
       // (row fastest: consecutive threads read consecutive words of one 32 x 32-cell tile of the mask, kmask_offset)
       for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int wc = idx / H, row = idx - wc * H;
         const int rp = rlo + row + 32;
-        lds.bits[row * Wb + wc] = kmask[((int64_t)(rp >> 5) * a.ktcols + (wlo + wc)) * 32 + (rp & 31)];
+        const uint32_t wv = kmask[((int64_t)(rp >> 5) * a.ktcols + (wlo + wc)) * 32 + (rp & 31)];
+        lds.bits[row * Wb + wc] = wv;
+        every &= wv;
       }
     }
-    __syncthreads();
+    const bool allknown = __syncthreads_and(fits && every == 0xFFFFFFFFu);   // (cells outside the map are unknown)
     if (active) {
       const bool inside = rlo >= 0 && rhi < a.rows && __builtin_amdgcn_readfirstlane(lds.box[2]) >= 0 &&
                           __builtin_amdgcn_readfirstlane(lds.box[3]) < a.cols;
-      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4, inside);
+      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4, inside, allknown);
       else far_sector(i0, i1);
     }
   }
