@@ -49,32 +49,40 @@ def loop_text(uscale, clamp, mask=True):
     a("s_bitcmp1_b32 s51, 31")                      # a bin with several classes in this step: hand it to the C++ step
     a("s_cbranch_scc1 .Lsu_out%=")
     # ---- phase A: cells of the four samples (top_down_map_polar.cpp:28-31)
-    for u in range(4):
-        p, t = 8 + 2 * u, 40 + 2 * u
-        if uscale:
-            a(f"v_pk_add_f32 v[{p}:{p + 1}], %[offv], s[{t}:{t + 1}]")
-    if not uscale:
-        for u in range(4):
+    def coords(us):
+        for u in us:
             p, t = 8 + 2 * u, 40 + 2 * u
-            a(f"v_pk_mul_f32 v[{p}:{p + 1}], %[scale2], s[{t}:{t + 1}]")       # (tab * scale)
-        for u in range(4):
+            if uscale:
+                a(f"v_pk_add_f32 v[{p}:{p + 1}], %[offv], s[{t}:{t + 1}]")
+        if not uscale:
+            for u in us:
+                p, t = 8 + 2 * u, 40 + 2 * u
+                a(f"v_pk_mul_f32 v[{p}:{p + 1}], %[scale2], s[{t}:{t + 1}]")   # (tab * scale)
+            for u in us:
+                p = 8 + 2 * u
+                a(f"v_pk_mul_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[res2]")      # * res
+            for u in us:
+                p = 8 + 2 * u
+                a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[offv]")      # + centre / resolution
+        if len(us) == 1:
+            a("s_nop 0")
+        if clamp:   # (the variants without: every cell the workgroup's windows can reach in this sector lies inside the map)
+            for u in us:
+                p = 8 + 2 * u
+                a(f"v_med3_f32 v{p}, v{p}, %[rmax], -1.0")                       # clamp into the guard ring
+                a(f"v_med3_f32 v{p + 1}, v{p + 1}, %[cmax], -1.0")
+        for u in us:
             p = 8 + 2 * u
-            a(f"v_pk_mul_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[res2]")          # * res
-        for u in range(4):
+            a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[half]")          # round_half_away_clamped
+        if len(us) == 1:
+            a("s_nop 0")
+        for u in us:
             p = 8 + 2 * u
-            a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[offv]")          # + centre / resolution
-    if clamp:   # (the variant without: every cell the workgroup's windows can reach in this sector lies inside the map)
-        for u in range(4):
-            p = 8 + 2 * u
-            a(f"v_med3_f32 v{p}, v{p}, %[rmax], -1.0")                           # clamp into the guard ring
-            a(f"v_med3_f32 v{p + 1}, v{p + 1}, %[cmax], -1.0")
-    for u in range(4):
-        p = 8 + 2 * u
-        a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[half]")              # round_half_away_clamped
-    for u in range(4):
-        p = 8 + 2 * u
-        a(f"v_cvt_flr_i32_f32 v{p}, v{p}")
-        a(f"v_cvt_flr_i32_f32 v{p + 1}, v{p + 1}")
+            a(f"v_cvt_flr_i32_f32 v{p}, v{p}")
+            a(f"v_cvt_flr_i32_f32 v{p + 1}, v{p + 1}")
+    if mask:
+        coords(range(4))
+    # (without the mask an empty bin needs no cell at all: the coordinates are computed with the record offset below)
     if mask:
         # word of the staged known mask (LDS) of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
         for u in range(4):
@@ -91,6 +99,8 @@ def loop_text(uscale, clamp, mask=True):
         code, ckc = 48 + 4 * u, 50 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
         a(f"s_cbranch_scc1 .Lsu_a{u}%=")
+        if not mask:
+            coords([u])
         a(f"v_ashrrev_i32 v{20 + u}, 2, v{9 + 2 * u}")
         a("s_nop 0")
         a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[ckcol], s{ckc}")
