@@ -324,7 +324,7 @@ int tdr_config_compact(int on);
 /* The polar scoring kernel has a second form that processes particles in (heading bin, Morton) order, every bin padded
  * to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes are skipped
  * wave-wide (csrc/tdr_score_su.hip).  Per launch the DENSE particles take it — those whose 64 neighbours in the locality
- * order lie within tdr_config_shift_uniform_span map cells (default 16; 0 = every particle counts as dense) — and the
+ * order lie within tdr_config_shift_uniform_span map cells (default 24; 0 = every particle counts as dense) — and the
  * others the lane-shift kernel, side by side: same partial sums, bit for bit, whichever kernel scores a particle.
  * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
  * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow

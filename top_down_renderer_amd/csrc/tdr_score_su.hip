@@ -651,7 +651,7 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
 static float g_su_span = [] {   // map cells the 64 locality neighbours of a "dense" particle may span
   const char* e = getenv("TDR_SU_SPAN");
-  return e ? (float)atof(e) : 16.f;
+  return e ? (float)atof(e) : 24.f;
 }();
 extern "C" float tdr_config_shift_uniform_span(float cells) {   // < 0: query only; 0: every particle counts as dense
   if (cells >= 0.f) g_su_span = cells;
