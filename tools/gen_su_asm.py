@@ -42,21 +42,47 @@ def loop_text(uscale, clamp, mask=True):
     a("v_readfirstlane_b32 s68, %[wleft]")
     for k in range(6):
         a(f"v_mov_b32 v{32 + k}, %[a{k}]")
-    a(".Lsu_step%=:")
     a("s_load_dwordx8 s[40:47], %[tb], s65")
     a("s_load_dwordx16 s[48:63], %[db], s66")
     a("s_waitcnt lgkmcnt(0)")
-    a("s_bitcmp1_b32 s51, 31")                      # a bin with several classes in this step: hand it to the C++ step
+    # The loop body exists twice: the offsets / descriptors of step k + 1 are requested (into the other register set) before
+    # step k is worked on, so their scalar-cache latency hides behind it
+    step(a, uscale, clamp, mask, T=40, D=48, TN=72, DN=80, tag="e", nxt="o")
+    step(a, uscale, clamp, mask, T=72, D=80, TN=40, DN=48, tag="o", nxt="e")
+    a(".Lsu_out%=:")
+    a("s_waitcnt lgkmcnt(0)")                        # (a request for the step behind the last one may still be in flight)
+    for k in range(6):
+        a(f"v_mov_b32 %[a{k}], v{32 + k}")
+    a("v_mov_b32 %[toff], s65")
+    a("v_mov_b32 %[doff], s66")
+    a("v_mov_b32 %[nleft], s67")
+    a("v_mov_b32 %[wleft], s68")
+    return L
+
+
+def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
+    a(f".Lsu_step{tag}%=:")
+    a(f"s_bitcmp1_b32 s{D + 3}, 31")                 # a bin with several classes in this step: hand it to the C++ step
     a("s_cbranch_scc1 .Lsu_out%=")
+    # the step behind this one: T at byte s69, D at byte s70 (the scan rows wrap: (i + shift) mod nb)
+    a("s_add_u32 s69, s65, 32")
+    a("s_add_u32 s70, s66, 64")
+    a("s_sub_u32 s71, s68, 1")
+    a(f"s_cbranch_scc0 .Lsu_nw{tag}%=")
+    a("s_mov_b32 s70, 0")
+    a("s_mov_b32 s71, %[wrapm1]")
+    a(f".Lsu_nw{tag}%=:")
+    a(f"s_load_dwordx8 s[{TN}:{TN + 7}], %[tb], s69")
+    a(f"s_load_dwordx16 s[{DN}:{DN + 15}], %[db], s70")
     # ---- phase A: cells of the four samples (top_down_map_polar.cpp:28-31)
     def coords(us):
         for u in us:
-            p, t = 8 + 2 * u, 40 + 2 * u
+            p, t = 8 + 2 * u, T + 2 * u
             if uscale:
                 a(f"v_pk_add_f32 v[{p}:{p + 1}], %[offv], s[{t}:{t + 1}]")
         if not uscale:
             for u in us:
-                p, t = 8 + 2 * u, 40 + 2 * u
+                p, t = 8 + 2 * u, T + 2 * u
                 a(f"v_pk_mul_f32 v[{p}:{p + 1}], %[scale2], s[{t}:{t + 1}]")   # (tab * scale)
             for u in us:
                 p = 8 + 2 * u
@@ -96,9 +122,9 @@ def loop_text(uscale, clamp, mask=True):
             a(f"ds_read_b32 v{28 + u}, v{16 + u}")
     # the record dword of every non-empty bin (cmap_offset with the dword folded into its constant)
     for u in range(4):
-        code, ckc = 48 + 4 * u, 50 + 4 * u
+        code, ckc = D + 4 * u, D + 2 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
-        a(f"s_cbranch_scc1 .Lsu_a{u}%=")
+        a(f"s_cbranch_scc1 .Lsu_a{u}{tag}%=")
         if not mask:
             coords([u])
         a(f"v_ashrrev_i32 v{20 + u}, 2, v{9 + 2 * u}")
@@ -111,7 +137,7 @@ def loop_text(uscale, clamp, mask=True):
         a("s_nop 0")
         # (never into its own address register: a load that is replayed reads its address again)
         a(f"global_load_dword v{24 + u}, v{20 + u}, %[crec]")
-        a(f".Lsu_a{u}%=:")
+        a(f".Lsu_a{u}{tag}%=:")
     # ---- phase B
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     if mask:
@@ -126,9 +152,9 @@ def loop_text(uscale, clamp, mask=True):
     else:   # every cell the sector can reach is known: four more known samples, nothing to look up
         a("v_add_u32 %[known], 4, %[known]")
     for u in range(4):
-        code, val, sh = 48 + 4 * u, 49 + 4 * u, 51 + 4 * u
+        code, val, sh = D + 4 * u, D + 1 + 4 * u, D + 3 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
-        a(f"s_cbranch_scc1 .Lsu_b{u}%=")
+        a(f"s_cbranch_scc1 .Lsu_b{u}{tag}%=")
         if mask:
             a(f"v_and_b32 v20, s{val}, v{16 + u}")                               # the bin's sum x known (:141-142)
         a(f"v_lshrrev_b32 v21, s{sh}, v{24 + u}")                                # the class's dictionary index * 4
@@ -142,50 +168,41 @@ def loop_text(uscale, clamp, mask=True):
         a("s_waitcnt lgkmcnt(0)")
         # acc[class] += value * distance (state_particle.cpp:136-139): a tree of wave-uniform branches over the class
         a(f"s_cmp_lt_u32 s{code}, 4")
-        a(f"s_cbranch_scc1 .Lsu_c{u}lo%=")
+        a(f"s_cbranch_scc1 .Lsu_c{u}lo{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 5")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k3%=")
+        a(f"s_cbranch_scc1 .Lsu_c{u}k3{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 6")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k4%=")
+        a(f"s_cbranch_scc1 .Lsu_c{u}k4{tag}%=")
         a(f"v_fmac_f32 v37, s{val}, v21")
-        a(f"s_branch .Lsu_b{u}%=")
-        a(f".Lsu_c{u}k4%=:")
+        a(f"s_branch .Lsu_b{u}{tag}%=")
+        a(f".Lsu_c{u}k4{tag}%=:")
         a(f"v_fmac_f32 v36, s{val}, v21")
-        a(f"s_branch .Lsu_b{u}%=")
-        a(f".Lsu_c{u}k3%=:")
+        a(f"s_branch .Lsu_b{u}{tag}%=")
+        a(f".Lsu_c{u}k3{tag}%=:")
         a(f"v_fmac_f32 v35, s{val}, v21")
-        a(f"s_branch .Lsu_b{u}%=")
-        a(f".Lsu_c{u}lo%=:")
+        a(f"s_branch .Lsu_b{u}{tag}%=")
+        a(f".Lsu_c{u}lo{tag}%=:")
         a(f"s_cmp_lt_u32 s{code}, 2")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k0%=")
+        a(f"s_cbranch_scc1 .Lsu_c{u}k0{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 3")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k1%=")
+        a(f"s_cbranch_scc1 .Lsu_c{u}k1{tag}%=")
         a(f"v_fmac_f32 v34, s{val}, v21")
-        a(f"s_branch .Lsu_b{u}%=")
-        a(f".Lsu_c{u}k1%=:")
+        a(f"s_branch .Lsu_b{u}{tag}%=")
+        a(f".Lsu_c{u}k1{tag}%=:")
         a(f"v_fmac_f32 v33, s{val}, v21")
-        a(f"s_branch .Lsu_b{u}%=")
-        a(f".Lsu_c{u}k0%=:")
+        a(f"s_branch .Lsu_b{u}{tag}%=")
+        a(f".Lsu_c{u}k0{tag}%=:")
         a(f"v_fmac_f32 v32, s{val}, v21")
-        a(f".Lsu_b{u}%=:")
+        a(f".Lsu_b{u}{tag}%=:")
     # ---- next step
-    a("s_add_u32 s65, s65, 32")
-    a("s_add_u32 s66, s66, 64")
-    a("s_sub_u32 s68, s68, 1")
-    a("s_cbranch_scc0 .Lsu_nw%=")
-    a("s_mov_b32 s66, 0")                                                        # the scan rows wrap: (i + shift) mod nb
-    a("s_mov_b32 s68, %[wrapm1]")
-    a(".Lsu_nw%=:")
+    a("s_mov_b32 s65, s69")
+    a("s_mov_b32 s66, s70")
+    a("s_mov_b32 s68, s71")
     a("s_sub_u32 s67, s67, 1")
-    a("s_cbranch_scc0 .Lsu_step%=")
-    a(".Lsu_out%=:")
-    for k in range(6):
-        a(f"v_mov_b32 %[a{k}], v{32 + k}")
-    a("v_mov_b32 %[toff], s65")
-    a("v_mov_b32 %[doff], s66")
-    a("v_mov_b32 %[nleft], s67")
-    a("v_mov_b32 %[wleft], s68")
-    return L
+    if tag == "e":
+        a("s_cbranch_scc1 .Lsu_out%=")               # (falls through into the other copy)
+    else:
+        a(f"s_cbranch_scc0 .Lsu_step{nxt}%=")
 
 
 def main():
@@ -202,7 +219,7 @@ def main():
             out.append("")
     out.append('#define SU_ASM_CLOBBERS                                                                                      \\')
     vregs = ", ".join(f'"v{i}"' for i in range(8, 38))
-    sregs = ", ".join(f'"s{i}"' for i in range(40, 69))
+    sregs = ", ".join(f'"s{i}"' for i in range(40, 96))
     out.append(f"  {vregs}, \\")
     out.append(f'  {sregs}, "vcc", "memory"')
     out.append("#endif  // TDR_SCORE_SU_ASM_H_")
