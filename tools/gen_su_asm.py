@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Writes top_down_renderer_amd/csrc/tdr_score_su_asm.h: the hand-scheduled gfx950 inner loop of score_polar_su_kernel
 (records of two dwords: 4-6 classes) as inline-assembly text, in six variants — uniform / per-lane scale x {general, without
-the clamp of the coordinates into the map's guard ring, without clamp and known-mask lookups (every reachable cell known)}.  The text is generated so that the four samples of a step and the
-variants cannot drift apart.
+the clamp of the coordinates into the map's guard ring, without clamp and known-mask lookups (every reachable cell known)}.
+The text is generated so that the four samples of a step, the two copies of the loop body and the variants cannot drift apart.
 
     python3 tools/gen_su_asm.py        (re-run after editing; the header is committed)
 
@@ -12,10 +12,11 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v20..v23  scratch
   v24..v27  sample u: the record dword
   v32..v37  accumulators of classes 0..5
-  s40..s47  the step's sample offsets {tx, ty} x 4
-  s48..s63  the step's descriptors {code, value, ckc, shift | flag} x 4 (su_prep_kernel)
+  s40..s47 / s72..s79   the step's sample offsets {tx, ty} x 4           (even / odd steps: the loop body exists twice and
+  s48..s63 / s80..s95   the step's descriptors {code, value, ckc, shift | flag} x 4 (su_prep_kernel)   requests the next
+                        step's scalars into the other set before it works on its own)
   s65 / s66 byte offsets of the step in the offset / descriptor streams, s67 steps left - 1,
-            s68 steps until the scan rows wrap - 1
+            s68 steps until the scan rows wrap - 1;  s69..s71 the same offsets / count for the step behind it
 Cost model behind the schedule (tools/valu_cost.hip, tools/ta_cost.hip; per CU): scalar instructions issue 1 per cycle,
 plain VOP2 2 cycles per SIMD, VOP3 / packed / conversions 4, a 64-lane gather >= 16 cycles of the L1 address path.
 Dependent vector instructions are kept at least one instruction apart (s_nop 0 where nothing else fits), as hipcc's own
