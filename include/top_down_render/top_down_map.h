@@ -26,9 +26,9 @@ class TopDownMap {
   };
   // src/top_down_map.cpp:9-64.  An empty map_path is the dynamic-map case (the map arrives through updateMap).  A static
   // map is taken from the reference's own cache — ~/.ros/xview_cache, written by the reference or by saveCachedMaps() —
-  // when its (map_path, num_classes, resolution) match (:18-20, :226-261).  Parsing SVG / decoding PNG (nanosvg, OpenCV:
-  // load-time work outside the per-scan path) is not done here: without a matching cache the map stays empty until
-  // setDistanceMaps() / updateMap() provide it.
+  // when its (map_path, num_classes, resolution) match (:18-20, :226-261), else from a raster-cache directory of class<i>.png
+  // (:42-46).  Parsing SVG / decoding colour images (nanosvg, OpenCV: load-time work outside the per-scan path) is not done
+  // here: without either the map stays empty until setDistanceMaps() / updateMap() provide it.
   explicit TopDownMap(const Params& params, const char* cache_dir = nullptr) : params_(params) {
     if (tdr_map_create(&m_) != TDR_OK) throw std::runtime_error(std::string("TopDownMap: ") + tdr_last_error());
     if (!params_.map_path.empty() && params_.num_classes > 0) {
@@ -39,7 +39,24 @@ class TopDownMap {
         tdr_map_destroy(m_);
         throw std::runtime_error(msg);
       }
+      // a map_path that is neither .svg nor .png / .jpg names a raster-cache directory (:42-46): class<i>.png, read
+      // over zlib, distance transforms on the GPU; then the cache is written like the reference does (:61)
+      const std::string& mp = params_.map_path;
+      const std::string ext = mp.size() >= 4 ? mp.substr(mp.size() - 4) : std::string();
+      if (!loaded && ext != ".svg" && ext != ".png" && ext != ".jpg" &&
+          tdr_map_load_rasters(m_, mp.c_str(), params_.num_classes, params_.resolution, 0, 0) == TDR_OK)
+        (void)tdr_map_save_cache(m_, cache_dir, mp.c_str());
     }
+  }
+  // saveRasterizedMaps / loadRasterizedMaps (:197-224): a directory of class<i>.png (8-bit grey, 0 inside the class,
+  // flipped like the reference stores them); load = rasters -> geometric layers -> distance maps, on the GPU
+  void saveRasterizedMaps(const std::string& path) {
+    if (tdr_map_save_rasters(m_, path.c_str()) != TDR_OK)
+      throw std::runtime_error(std::string("saveRasterizedMaps: ") + tdr_last_error());
+  }
+  void loadRasterizedMaps(const std::string& map_path) {
+    if (tdr_map_load_rasters(m_, map_path.c_str(), params_.num_classes, params_.resolution, map_center_[0], map_center_[1]) != TDR_OK)
+      throw std::runtime_error(std::string("loadRasterizedMaps: ") + tdr_last_error());
   }
   // saveCachedMaps (:263-286): the cache the constructor above (and the reference) reads
   void saveCachedMaps(const std::string& map_path, const char* cache_dir = nullptr) {

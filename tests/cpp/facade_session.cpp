@@ -91,6 +91,31 @@ int main(int argc, char** argv) {
       dump(dir + "/out_window.bin", w.data(), w.size());
     }
 
+    // the raster cache (src/top_down_map.cpp:197-224): saveRasterizedMaps, then a SECOND map constructed from that
+    // directory (map_path without .svg / .png / .jpg, :42-46) must hold the same map: the same window, value for value
+    {
+      const std::string rdir = dir + "/site_raster_cache";
+      map_->saveRasterizedMaps(rdir);
+      TopDownMap::Params p2 = map_params;
+      p2.map_path = rdir;
+      const std::string cdir = dir + "/xview_cache";
+      TopDownMapPolar m2(p2, cdir.c_str());
+      if (!m2.haveMap()) throw std::runtime_error("the raster-cache directory did not load");
+      m2.samplePtsPolar(Eigen::Vector2i(nb, nr), ang_res);
+      std::vector<Eigen::ArrayXXf> da, db;
+      for (int c = 0; c < ncls; c++) { da.push_back(Eigen::ArrayXXf(nb, nr)); db.push_back(Eigen::ArrayXXf(nb, nr)); }
+      Eigen::ArrayXXc ma(nb, nr), mb(nb, nr);
+      const Eigen::Vector2f ctr(st0[0].init_x_px, st0[0].init_y_px);
+      map_->getLocalMap(ctr, 1.3f, res, da, ma);
+      m2.getLocalMap(ctr, 1.3f, res, db, mb);
+      for (int c = 0; c < ncls; c++)
+        if (std::memcmp(da[c].data(), db[c].data(), (size_t)nb * nr * sizeof(float)) != 0)
+          throw std::runtime_error("raster cache: distance maps differ");
+      if (std::memcmp(ma.data(), mb.data(), (size_t)nb * nr) != 0) throw std::runtime_error("raster cache: masks differ");
+      std::ifstream cached(cdir + "/cached_data.txt");   // (the constructor wrote the .eig cache behind it, :61)
+      if (!cached) throw std::runtime_error("raster cache: no cached_data.txt written");
+    }
+
     // the Cartesian pair: ScanRenderer::renderSemanticTopDown (src/scan_renderer.cpp:55-78) and
     // TopDownMap::getLocalMap(center, rot, res, ...) (src/top_down_map.cpp:429-459) on a 40 x 56 window
     {
