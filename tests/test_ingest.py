@@ -267,3 +267,12 @@ def test_raster_cache_round_trip_and_overlapping_classes(tmp_path):
     assert np.array_equal(got[:, :, rf - 1] == 0, unknown)
     L.tdr_map_destroy(m)
     L.tdr_map_destroy(m2)
+    # the Python classes: the same round trip through TopDownMap.saveRasterizedMaps / loadRasterizedMaps
+    import top_down_renderer_amd as pkg
+    pm = pkg.TopDownMap(pkg.Params(resolution=1.0, num_classes=ncls, flatten_lut=list(range(ncls))), kernels=k)
+    pm.loadCompressedRasterMap(img)
+    pd = str(tmp_path / "py_raster_cache")
+    pm.saveRasterizedMaps(pd)
+    pm2 = pkg.TopDownMap(pkg.Params(resolution=1.0, num_classes=ncls), kernels=k)
+    pm2.loadRasterizedMaps(pd)
+    assert torch.equal(pm.dev.rec, pm2.dev.rec)

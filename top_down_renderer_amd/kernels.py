@@ -146,6 +146,34 @@ class HipKernels:
         m.compact(self)
         return m
 
+    def make_map_from_rasters(self, planes, resolution):
+        """planes: (ncls, rows, cols) uint8, the class<i>.png images of a raster cache as stored (row 0 = top).  Runs
+        loadRasterizedMaps' flip + computeDists on the device (tdr_k_map_from_rasters)."""
+        planes = np.ascontiguousarray(planes, np.uint8)
+        ncls, rows, cols = planes.shape
+        pl_d = self.to_device(planes.reshape(-1))
+        rec = self.empty((int(self.lib.tdr_map_rec_floats_total(ncls, rows, cols)),))
+        ws = self.empty((int(self.lib.tdr_map_ingest_workspace_bytes(ncls, rows, cols)),), torch.uint8)
+        check(self.lib.tdr_k_map_from_rasters(_ptr(pl_d), ncls, rows, cols, C.c_float(resolution), _ptr(rec), _ptr(ws),
+                                              self.stream()))
+        self.synchronize()
+        m = DeviceMap(rec, ncls, rows, cols, resolution)
+        m.compact(self)
+        return m
+
+    def png_read_gray8(self, path):
+        w, h = C.c_int(0), C.c_int(0)
+        rc = self.lib.tdr_png_read_gray8_host(str(path).encode(), None, 0, C.byref(w), C.byref(h))   # size query
+        if w.value < 1 or h.value < 1:
+            check(rc)
+        out = np.empty((h.value, w.value), np.uint8)
+        check(self.lib.tdr_png_read_gray8_host(str(path).encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(w), C.byref(h)))
+        return out
+
+    def png_write_gray8(self, path, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        check(self.lib.tdr_png_write_gray8_host(str(path).encode(), img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0]))
+
     def unpack_map(self, m):
         """Device map -> the reference's host layout: class maps (ncls, cols, rows) i.e. column-major, mask (cols, rows)."""
         maps = self.empty((m.ncls, m.cols, m.rows))

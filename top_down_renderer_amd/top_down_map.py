@@ -86,6 +86,31 @@ class TopDownMap:
         if old is not None and getattr(old, "nb", 0):
             self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
 
+    # top_down_map.cpp:197-224 — the raster cache: a directory of class<i>.png (8-bit grey, 0 inside the class, flipped)
+    def saveRasterizedMaps(self, path):
+        import os
+        os.makedirs(path, exist_ok=True)
+        maps_cm, mask_cm = self.k.unpack_map(self.dev)
+        for c in range(self.dev.ncls):
+            inside = (maps_cm[c].T == 0) & (mask_cm.T == 0)                  # [row][col], row 0 = bottom
+            self.k.png_write_gray8(os.path.join(path, f"class{c}.png"), np.where(inside, 0, 255).astype(np.uint8)[::-1])
+
+    def loadRasterizedMaps(self, map_path, map_center=(0, 0)):
+        """The constructor's path for a raster-cache directory (:42-58): rasters -> distance maps on the GPU."""
+        import os
+        p = self.params_
+        planes = np.stack([self.k.png_read_gray8(os.path.join(map_path, f"class{c}.png")) for c in range(p.num_classes)])
+        old = self.dev
+        self.geo_constant_one_ = False
+        self.dev = self.k.make_map_from_rasters(planes, p.resolution)
+        self.rows, self.cols = self.dev.rows, self.dev.cols
+        maps_cm, _ = self.k.unpack_map(self.dev)
+        self.maps_cm_host = maps_cm
+        self.map_center_ = (int(map_center[0]), int(map_center[1]))
+        self.have_map_ = True                                                # :63
+        if old is not None and getattr(old, "nb", 0):
+            self.k.set_polar_table(self.dev, old.nb, old.nr, old.ang_res)
+
     # top_down_map.cpp:159-175
     def getClassesAtPoint(self, center):
         cx, cy = center
