@@ -341,6 +341,11 @@ int tdr_config_cart_skip(int on);
  * floats in two groups of 8 slots); 0 forces the vector-unit search (A/B measurements, tests), 1 restores the default,
  * < 0 only queries.  Only the choice among rotations whose costs tie to rounding can differ.  Env TDR_INIT_MFMA. */
 int tdr_config_init_mfma(int on);
+/* The weight statistics of at most 32 768 particles (src/particle_filter.cpp:107-147) evaluate their two serial float
+ * chains wave by wave: predicted wave-chunks in parallel, the rest carried through by one wave without workgroup barriers
+ * (csrc/tdr_prefix.hip); 0 forces the chunk-by-chunk evaluation on the whole workgroup (A/B measurements, tests), 1
+ * restores the default, < 0 only queries.  Same bits either way.  Env TDR_UW_WAVES. */
+int tdr_config_uw_waves(int on);
 /* diagnostics: scoring launches of this process that took the shift-uniform kernel */
 int64_t tdr_shift_uniform_launches(void);
 

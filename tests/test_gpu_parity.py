@@ -831,6 +831,44 @@ def test_update_weights_serial_chains_bit_exact(tdr, oracle, kind, n):
     assert np.allclose(w.cpu().numpy(), ref, rtol=3e-6, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [1, 7, 511, 512, 513, 4096, 4097, 20_000, 32_767, 32_768])
+def test_uw_small_wave_chains_equal_workgroup_chains(tdr, oracle, n):
+    """The two evaluations of the statistics chains for n <= 32 768 — wave by wave (default) and chunk by chunk on the
+    whole workgroup (tdr_config_uw_waves(0)) — write the same bytes, and both are the oracle's serial chains, on weights
+    chosen against the wave path: zero runs at the start and across whole wave-chunks, negative and infinite weights (real
+    additions in the middle of predicted chunks), a binade crossing at every chunk end, half-ulp ties in bulk."""
+    pkg, k = tdr
+    f32 = np.float32
+    rng = np.random.default_rng(4200 + n)
+    cases = []
+    a = np.zeros(n, f32); a[n // 2:] = rng.random(n - n // 2).astype(f32); cases.append(a)            # zeros, then weights
+    a = rng.random(n).astype(f32); a[512:1536] = 0; cases.append(a)                                   # a hole of two chunks
+    a = rng.random(n).astype(f32) + f32(0.25); a[rng.random(n) < 0.01] *= f32(-1.0); cases.append(a)  # negatives
+    a = np.full(n, f32(1.0), f32); a[::2] = f32(1.0 + 2.0 ** -23); cases.append(a)                    # ties against a growing sum
+    a = (rng.random(n) * 1e-3).astype(f32); a[511::512] = f32(40.0); cases.append(a)                  # a jump at every chunk end
+    a = rng.random(n).astype(f32); a[n // 3] = np.inf; cases.append(a)                                # inf in the middle
+    a = np.exp(rng.normal(0, 8, n)).astype(f32); a[rng.random(n) < 0.3] = np.nan; cases.append(a)
+    before = k.lib.tdr_config_uw_waves(-1)
+    try:
+        for ci, raw in enumerate(cases):
+            ld = rng.random(n).astype(f32)
+            out = []
+            for on in (1, 0):
+                k.lib.tdr_config_uw_waves(on)
+                w, info = k.zeros((n,)), k.zeros((65536,))
+                k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
+                out.append((w.cpu().numpy(), info[:8].cpu().numpy().tobytes(), info[1:4].cpu().numpy()))
+            # the chains and the counts bit for bit; the two normalisation sums are double sums in another order (the
+            # reference leaves their order to Eigen), so the weights agree to rounding
+            assert out[0][1] == out[1][1], f"case {ci}"
+            assert np.allclose(out[0][0], out[1][0], rtol=1e-6, atol=0, equal_nan=True), f"case {ci}"
+            with np.errstate(all="ignore"):
+                _, _, stats = oracle.update_weights(raw, ld)
+            assert np.array_equal(out[0][2], np.asarray(stats[:3], f32), equal_nan=True), (ci, out[0][2], stats[:3])
+    finally:
+        k.lib.tdr_config_uw_waves(before)
+
+
 def test_gather_states_and_aos_roundtrip(tdr, g):
     pkg, k = tdr
     import torch

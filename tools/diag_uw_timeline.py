@@ -31,4 +31,5 @@ for n in (1000, 5000, 20000, 32768):
     print(f"n={n}: total {(t[9] - t[0]) / 100:.1f} us")
     for i, nm in enumerate(names):
         print(f"   {nm:24s} {(t[i + 1] - t[i]) / 100:7.1f} us")
-    print(f"   walk iterations: sum chain {tl[10]}, stddev chain {tl[11]}")
+    print(f"   walk iterations: sum chain {tl[10]}, stddev chain {tl[11]}; chunks (both chains): predicted {tl[12]}, "
+          f"crossing chunks lane by lane {tl[13]}, carried through {tl[14]}")

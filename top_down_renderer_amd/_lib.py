@@ -45,6 +45,7 @@ SIGNATURES = {
     "tdr_config_shift_uniform_span": (C.c_float, [C.c_float]),
     "tdr_config_cart_skip": (_i, [_i]),
     "tdr_config_init_mfma": (_i, [_i]),
+    "tdr_config_uw_waves": (_i, [_i]),
     "tdr_shift_uniform_launches": (_i64, []),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),

@@ -922,8 +922,10 @@ extern "C" int tdr_debug_read_uw_timeline(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uw_tl), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
 #define UW_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) g_uw_tl[k] = wall_clock64(); } while (0)
+#define UW_COUNT(k) do { if (threadIdx.x == 0) g_uw_tl[k]++; } while (0)
 #else
 #define UW_STAMP(k) do { } while (0)
+#define UW_COUNT(k) do { } while (0)
 #endif
 // FROM_LDS: the raw weights sit in the kernel's dynamic LDS array (uw_small_kernel) instead of global memory
 __device__ __forceinline__ int uws_idx(int e) { return e + (e >> 5); }   // one pad word per 32: bank spread for strided runs
@@ -1128,32 +1130,353 @@ __device__ __forceinline__ float uws_chain_total(int kind, int n, float mean) {
   }
   return r;
 }
+// ---- the same chains, wave by wave (default) --------------------------------------------------------------------------
+// The weights are cut into wave-chunks of 512 (one wave, 8 consecutive addends a lane).  The pass before the chain (the
+// count of valid weights / of weights below the mean) leaves the double sum of every wave-chunk's addends behind; from the
+// sums before a chunk every wave predicts the binade the chain is in when it enters and leaves it.  Then, side by side:
+//   * wave 0 adds the first wave-chunk one by one (the sum starts at zero and doubles every few addends);
+//   * the other waves summarise their chunks: a chunk predicted to stay in one binade as its parity pair (D0, D1) there;
+//     a chunk predicted to cross into the next binade as the parity pairs of every LANE (8 addends) in both binades.
+// One barrier later wave 0 walks the chunk list with the exact running sum, with register-level moves only — no workgroup
+// barrier inside the serial part: a one-binade chunk whose prediction holds is one integer add; in a crossing chunk a
+// scan of the lane pairs of the first binade finds the lane the sum crosses in, that lane's 8 addends are really added,
+// and a scan of the lane pairs of the second binade carries the sum to the chunk's end.  Whatever fits neither (a wrong
+// prediction, irregular addends, two crossings in one chunk) is carried through element by element by uws_wave_walk.
+// The bits are the serial chain's whatever was predicted, as in the multi-workgroup path.
+#define UWS_WC (64 * CHAIN_K)   // addends per wave-chunk
+#define UWS_THREADS 1024
+#define UWS_DUAL_SLOTS 8        // crossing chunks summarised lane by lane (the sum doubles log2(n / 512) times behind the head)
+#define UWS_DUAL_FLAG 0x100
+struct UwsShared {
+  double csum[64];                       // double sum of every wave-chunk's addends
+  int code[64];                          // -1: carried through; binade; binade | UWS_DUAL_FLAG | slot << 16
+  unsigned d0[64], d1[64];               // parity pair of a one-binade chunk
+  uint4 dual[UWS_DUAL_SLOTS][64];        // crossing chunks: scans of the lane pairs in the binade entered (x, y) / the next (z, w)
+  double shd[UWS_THREADS / 64];
+  float total;
+};
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int uws_min_dpp(int v) {
+  return min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ int uws_wave_min(int v) {   // minimum over the wave, in every lane (uniform)
+  v = uws_min_dpp<0x111, 0xF>(v);
+  v = uws_min_dpp<0x112, 0xF>(v);
+  v = uws_min_dpp<0x114, 0xF>(v);
+  v = uws_min_dpp<0x118, 0xF>(v);
+  v = uws_min_dpp<0x142, 0xA>(v);
+  v = uws_min_dpp<0x143, 0xC>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double uws_add_dpp(double v) {   // lanes without a source add 0.0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uws_wave_scan_d(double v) {   // inclusive sum over the lanes before and this one
+  v = uws_add_dpp<0x111, 0xF>(v);
+  v = uws_add_dpp<0x112, 0xF>(v);
+  v = uws_add_dpp<0x114, 0xF>(v);
+  v = uws_add_dpp<0x118, 0xF>(v);
+  v = uws_add_dpp<0x142, 0xA>(v);
+  v = uws_add_dpp<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ double uws_readlane_d(double v, int lane) {   // lane: wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// addend e of the chain if `take`, else 0.0 — the LDS read is unconditional (n: number of weights staged)
+__device__ __forceinline__ double uws_addend_if(int kind, int e, bool take, int n, float mean) {
+  const double x = uws_addend(kind, min(e, n - 1), mean);
+  return take ? x : 0.0;
+}
+__device__ __forceinline__ float uws_mant(unsigned re, unsigned state) { return __uint_as_float((re << 23) | (state & 0x7FFFFFu)); }
+// wave-chunk [lo, lo + cnt) carried through by the calling wave from its element `pos` on, entered with the running sum r
+// (wave-uniform): chain_walk_chunk on one wave
+__device__ __forceinline__ float uws_wave_walk(int kind, int lo, int cnt, float mean, float r, int pos) {
+  const int t0 = (threadIdx.x & 63) * CHAIN_K;
+  double xv[CHAIN_K];
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) xv[k] = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, lo + cnt, mean);
+  while (pos < cnt) {
+#ifdef TDR_UW_TIMELINE
+    if ((threadIdx.x & 63) == 0) g_uw_tl[10 + kind]++;
+#endif
+    const unsigned rb = __float_as_uint(r);
+    const unsigned re = rb >> 23;   // sign included
+    int first = cnt;
+    unsigned st[CHAIN_K] = {};
+    const bool regular = re >= PFXM_RE_MIN && re <= PFXM_RE_MAX;
+    if (!regular) {
+      // zero / tiny / huge / inf / NaN running sum: zero addends change nothing, the next other one is really added
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && xv[k] != 0.0) first = min(first, li);
+      }
+    } else {
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      unsigned f[CHAIN_K];
+      unsigned tiebits = 0u;
+      PfxPair mine = {0u, 0u};
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        const int li = t0 + k;
+        bool bad, tie;
+        chain_classify(xv[k], re, f[k], tie, bad);
+        if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
+        if (bad) first = min(first, li);
+        tiebits |= tie ? (1u << k) : 0u;
+        mine = pfx_compose(mine, pfx_element_pair(f[k], tie));
+      }
+      const PfxPair ex = pfx_pair_dpp<0x138, 0xF>(pfx_pair_wave_scan(mine));   // exclusive: wave_shr:1
+      unsigned state = R + ((R & 1u) ? ex.a1 : ex.a0);
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
+        st[k] = state;
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && state >= (1u << 24)) first = min(first, li);
+      }
+    }
+    const int stop = uws_wave_min(first);   // first addend that is really added (cnt: none)
+    unsigned sv = 0u;   // in the lane that holds it: the mantissa before the stop, the addend at the stop
+    double xs = 0.0;
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      if (t0 + k == stop - 1) sv = st[k];
+      if (t0 + k == stop) xs = xv[k];
+    }
+    if (regular && stop > pos) r = uws_mant(re, (unsigned)__builtin_amdgcn_readlane((int)sv, (stop - 1) / CHAIN_K));
+    if (stop < cnt) {
+      const double x = uws_readlane_d(xs, stop / CHAIN_K);
+      r = (float)((double)r + x);   // one real addition, in the reference's types
+      pos = stop + 1;
+    } else {
+      pos = cnt;
+    }
+  }
+  return r;
+}
+// a chunk summarised lane by lane — the inclusive scans of the lanes' parity pairs in the binade predicted at its entry
+// (x, y) and in the next one (z, w) — entered with r; pos: the element of the chunk the returned sum stands before (cnt: the
+// chunk is done, else uws_wave_walk takes over there)
+__device__ __forceinline__ float uws_wave_dual(int kind, int lo, int cnt, float mean, float r, const uint4* pq, int& pos) {
+  const int lane = threadIdx.x & 63, t0 = lane * CHAIN_K;
+  const unsigned rb = __float_as_uint(r), re = rb >> 23, R = (rb & 0x7FFFFFu) | 0x800000u;
+  const uint4 v = pq[lane];
+  const unsigned after = R + ((R & 1u) ? v.y : v.x);   // mantissa behind this lane's addends, while below 2^24
+  const unsigned long long cross = __ballot(after >= (1u << 24));
+  pos = cnt;
+  if (cross == 0ull) return uws_mant(re, (unsigned)__builtin_amdgcn_readlane((int)after, 63));
+  const int L = __ffsll((long long)cross) - 1;   // the lane the sum leaves the binade in: its addends are really added
+  float rl = uws_mant(re, L > 0 ? (unsigned)__builtin_amdgcn_readlane((int)after, L - 1) : R);   // exact before lane L
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, lo + cnt, mean));
+  const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rl), L));
+  const unsigned rb2 = __float_as_uint(r2), R2 = (rb2 & 0x7FFFFFu) | 0x800000u;
+  const int next = (L + 1) * CHAIN_K;
+  if (next >= cnt) return r2;
+  pos = next;
+  if ((rb2 >> 23) != re + 1u) return r2;
+  // the lanes behind L in the next binade: scan(63) = scan(L) + rest((p + scan(L)) & 1) for an entering parity p, so a
+  // scan(L) that is the same for both parities gives the rest for both
+  const unsigned qL = (unsigned)__builtin_amdgcn_readlane((int)v.z, L);
+  if (qL != (unsigned)__builtin_amdgcn_readlane((int)v.w, L)) return r2;
+  const unsigned q63 = (unsigned)__builtin_amdgcn_readlane((int)(((R2 + qL) & 1u) ? v.w : v.z), 63);
+  if (q63 >= PFXM_SAT || R2 + (q63 - qL) >= (1u << 24)) return r2;
+  pos = cnt;
+  return uws_mant(re + 1u, R2 + (q63 - qL));
+}
+// the first hn addends one by one: 64 at a time into the lanes, then every lane runs the same chain over them
+__device__ __forceinline__ float uws_head(int kind, int hn, float mean) {
+  const int lane = threadIdx.x & 63;
+  float run = 0.f;
+  if (kind == 0) {
+    // float + float: (float)((double)a + (double)b) == a + b for every pair of floats (53 >= 2 * 24 + 2 bits)
+    float nxt = (float)uws_addend_if(0, lane, lane < hn, hn, 0.f);
+    for (int b = 0; b < hn; b += 64) {
+      const int cur = (int)__float_as_uint(nxt);
+      nxt = (float)uws_addend_if(0, b + 64 + lane, b + 64 + lane < hn, hn, 0.f);
+#pragma unroll
+      for (int j = 0; j < 64; j++) run += __uint_as_float((unsigned)__builtin_amdgcn_readlane(cur, j));
+    }
+  } else {
+    double nxt = uws_addend_if(1, lane, lane < hn, hn, mean);
+    for (int b = 0; b < hn; b += 64) {
+      const double cur = nxt;
+      nxt = uws_addend_if(1, b + 64 + lane, b + 64 + lane < hn, hn, mean);
+#pragma unroll
+      for (int j = 0; j < 64; j++) run = (float)((double)run + uws_readlane_d(cur, j));
+    }
+  }
+  return run;
+}
+// sh.csum holds the chunks' double sums and a barrier has passed since they were written
+__device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float mean, UwsShared& sh) {
+  constexpr int NW = UWS_THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t0 = lane * CHAIN_K;
+  const int nwc = (n + UWS_WC - 1) / UWS_WC;   // <= 64
+  float r = 0.f;
+  if (wave == 0) {
+    r = uws_head(kind, min(UWS_WC, n), mean);
+  } else {
+    // the running double sum before / after each chunk -> what is predicted for it (lane c: chunk c)
+    int my_code;
+    {
+      const double own = lane < nwc ? sh.csum[lane] : 0.0;
+      const double after = uws_wave_scan_d(own), before = after - own;
+      const int re_b = (int)(__float_as_uint((float)before) >> 23), re_a = (int)(__float_as_uint((float)after) >> 23);   // sign included
+      const bool inr = lane >= 1 && lane < nwc && re_b >= PFXM_RE_MIN && re_a <= PFXM_RE_MAX;
+      const bool dualc = inr && re_a == re_b + 1;
+      const unsigned long long dm = __ballot(dualc);
+      const int slot = __popcll(dm & ((1ull << lane) - 1ull));
+      my_code = (inr && re_a == re_b) ? re_b : (dualc && slot < UWS_DUAL_SLOTS) ? (re_b | UWS_DUAL_FLAG | (slot << 16)) : -1;
+    }
+    for (int c = wave; c < nwc; c += NW - 1) {   // chunks 1 .. nwc - 1 over waves 1 .. NW - 1
+      const int code = __builtin_amdgcn_readlane(my_code, c);
+      const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
+      PfxPair P = {0u, 0u}, Q = {0u, 0u};
+      bool anybad = false;
+      if (code >= 0) {
+        const unsigned re = (unsigned)(code & 0xFF);
+        const bool dual = (code & UWS_DUAL_FLAG) != 0;
+#pragma unroll
+        for (int k = 0; k < CHAIN_K; k++) {
+          const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, n, mean);
+          unsigned f; bool tie, bad;
+          chain_classify(x, re, f, tie, bad);
+          anybad |= bad;
+          P = pfx_compose(P, pfx_element_pair(f, tie));
+          if (dual) {
+            chain_classify(x, re + 1u, f, tie, bad);
+            anybad |= bad;
+            Q = pfx_compose(Q, pfx_element_pair(f, tie));
+          }
+        }
+        P = pfx_pair_wave_scan(P);
+        if (dual) {
+          Q = pfx_pair_wave_scan(Q);
+          sh.dual[code >> 16][lane] = make_uint4(P.a0, P.a1, Q.a0, Q.a1);
+        }
+      }
+      const bool ok = code >= 0 && __ballot(anybad) == 0ull;
+      if (lane == 63) {
+        sh.code[c] = (ok && ((code & UWS_DUAL_FLAG) || (P.a0 < (1u << 24) && P.a1 < (1u << 24)))) ? code : -1;
+        sh.d0[c] = P.a0; sh.d1[c] = P.a1;
+      }
+    }
+  }
+  pfx_sync();
+  UW_STAMP(kind ? 5 : 2);
+  if (wave == 0) {   // the walk
+    const int v_code = (lane >= 1 && lane < nwc) ? sh.code[lane] : -1;
+    const unsigned v_d0 = (lane >= 1 && lane < nwc) ? sh.d0[lane] : 0u, v_d1 = (lane >= 1 && lane < nwc) ? sh.d1[lane] : 0u;
+    for (int c = 1; c < nwc; c++) {
+      const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
+      const int code = __builtin_amdgcn_readlane(v_code, c);
+      const unsigned rb = __float_as_uint(r);
+      const int re = (int)(rb >> 23);
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      int pos = 0;
+      if (code == re) {
+        const unsigned D = (unsigned)__builtin_amdgcn_readlane((R & 1u) ? (int)v_d1 : (int)v_d0, c);
+        if (R + D < (1u << 24)) { r = uws_mant((unsigned)re, R + D); UW_COUNT(12); continue; }
+      } else if (code >= 0 && re <= PFXM_RE_MAX && (code & 0x1FF) == (re | UWS_DUAL_FLAG)) {
+        r = uws_wave_dual(kind, lo, cnt, mean, r, sh.dual[code >> 16], pos);
+        UW_COUNT(13);
+      }
+      if (pos < cnt) {
+        UW_COUNT(14);
+        r = uws_wave_walk(kind, lo, cnt, mean, r, pos);
+      }
+    }
+    if (lane == 0) sh.total = r;
+  }
+  pfx_sync();
+  return sh.total;
+}
+template <int NT>
 __device__ __forceinline__ double uws_sum_d(double v, double* sh) {   // block sum, fixed order: a pure function of the inputs
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   pfx_sync();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   pfx_sync();
   double t = 0;
-  for (int w = 0; w < PFXW_THREADS / 64; w++) t += sh[w];
+  for (int w = 0; w < NT / 64; w++) t += sh[w];
   return t;
 }
-__global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __restrict__ raw,
+template <bool WAVES>
+__global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_kernel(const float* __restrict__ raw,
                                                                 const float* __restrict__ last_dist, int n,
                                                                 float* __restrict__ w, float* __restrict__ info) {
   extern __shared__ float uws_lraw[];   // [uws_idx(n)]: the raw weights, later the weights being normalised
   float* const lraw = uws_lraw;
-  __shared__ double shd[PFXW_THREADS / 64];
-  __shared__ float sh_best[PFXW_THREADS / 64];
-  __shared__ int sh_besti[PFXW_THREADS / 64];
+  constexpr int nt = WAVES ? UWS_THREADS : PFXW_THREADS;
+  __shared__ UwsShared ush;
+  double* const shd = ush.shd;
+  __shared__ float sh_best[nt / 64];
+  __shared__ int sh_besti[nt / 64];
   const int tid = threadIdx.x;
-  constexpr int nt = PFXW_THREADS;
 #ifdef TDR_UW_TIMELINE
   if (tid == 0) { for (int k = 10; k < 16; k++) g_uw_tl[k] = 0; }
 #endif
   UW_STAMP(0);
-  // stage (four loads in flight per thread), count the valid weights on the way (:108-116)
-  double cnt = 0;
-  {
+  float sum = 0.f, mean = 0.f, bsum = 0.f;
+  long long num_valid = 0, num_under = 0;
+  if constexpr (WAVES) {
+    // the two chains in one loop body (one copy of the code: a single launch runs every instruction once, from a cold
+    // instruction cache).  chain 0: stage the weights and count the valid ones (:108-116), `sum`; chain 1: count the
+    // weights below the mean, `bottom_stddev` (:118-126).  Either pass works wave-chunk by wave-chunk and leaves the
+    // chunks' double sums behind for the chain's predictions.
+    const int lane = tid & 63, nwc = (n + UWS_WC - 1) / UWS_WC;
+#pragma nounroll
+    for (int kind = 0; kind < 2; kind++) {
+      double cnt = 0;
+      for (int c = tid >> 6; c < nwc; c += nt / 64) {
+        const int base = c * UWS_WC + lane;
+        float v[CHAIN_K];
+        if (kind == 0) {   // (eight loads of 64 consecutive weights in flight per wave)
+#pragma unroll
+          for (int m = 0; m < CHAIN_K; m++) v[m] = base + 64 * m < n ? raw[base + 64 * m] : __uint_as_float(0x7FC00000u);
+#pragma unroll
+          for (int m = 0; m < CHAIN_K; m++)
+            if (base + 64 * m < n) lraw[uws_idx(base + 64 * m)] = v[m];
+        } else {
+#pragma unroll
+          for (int m = 0; m < CHAIN_K; m++) {
+            const float x = lraw[uws_idx(min(base + 64 * m, n - 1))];
+            v[m] = base + 64 * m < n ? x : __uint_as_float(0x7FC00000u);
+          }
+        }
+        double acc = 0;
+#pragma unroll
+        for (int m = 0; m < CHAIN_K; m++) {
+          const bool take = kind == 0 ? v[m] == v[m] : (v[m] == v[m] && v[m] < mean);
+          double x = (double)(kind == 0 ? v[m] : v[m] - mean);
+          if (kind) x = x * x;
+          cnt += take ? 1.0 : 0.0;
+          acc += take ? x : 0.0;
+        }
+        acc = uws_wave_scan_d(acc);
+        if (lane == 63) ush.csum[c] = acc;
+      }
+      const long long count = (long long)uws_sum_d<nt>(cnt, shd);   // (its barriers also publish the staged weights)
+      UW_STAMP(kind ? 4 : 1);
+      const float total = uws_chain_total_waves(kind, n, mean, ush);   // serial float chain, exact
+      UW_STAMP(kind ? 6 : 3);
+      if (kind == 0) {
+        sum = total; num_valid = count;
+        mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
+      } else {
+        bsum = total; num_under = count;
+      }
+    }
+  } else {
+    // stage (four loads in flight per thread), count the valid weights on the way (:108-116)
+    double cnt = 0;
     int i = tid;
     for (; i + 3 * nt < n; i += 4 * nt) {
       const float v0 = raw[i], v1 = raw[i + nt], v2 = raw[i + 2 * nt], v3 = raw[i + 3 * nt];
@@ -1165,22 +1488,22 @@ __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __r
       lraw[uws_idx(i)] = v;
       cnt += (v == v) ? 1.0 : 0.0;
     }
+    num_valid = (long long)uws_sum_d<nt>(cnt, shd);   // (its barriers also publish the staged weights)
+    UW_STAMP(1);
+    sum = uws_chain_total(0, n, 0.f);   // serial float chain, exact
+    UW_STAMP(3);
+    mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
+    // :118-126  bottom_stddev (serial float chain with double addends, exact) and the count below the mean
+    double cu = 0;
+    for (int i = tid; i < n; i += nt) {
+      const float v = lraw[uws_idx(i)];
+      cu += (v == v && v < mean) ? 1.0 : 0.0;
+    }
+    num_under = (long long)uws_sum_d<nt>(cu, shd);
+    UW_STAMP(4);
+    bsum = uws_chain_total(1, n, mean);
+    UW_STAMP(6);
   }
-  const long long num_valid = (long long)uws_sum_d(cnt, shd);   // (its barriers also publish the staged weights)
-  UW_STAMP(1);
-  const float sum = uws_chain_total(0, n, 0.f);   // serial float chain, exact
-  UW_STAMP(3);
-  const float mean = sum / (float)num_valid;  // :117 (0/0 -> NaN like the reference)
-  // :118-126  bottom_stddev (serial float chain with double addends, exact) and the count below the mean
-  double cu = 0;
-  for (int i = tid; i < n; i += nt) {
-    const float v = lraw[uws_idx(i)];
-    cu += (v == v && v < mean) ? 1.0 : 0.0;
-  }
-  const long long num_under = (long long)uws_sum_d(cu, shd);
-  UW_STAMP(4);
-  const float bsum = uws_chain_total(1, n, mean);
-  UW_STAMP(6);
   const float bottom = sqrtf(bsum / (float)num_under);
   const bool fallback = (sum == 0.f || num_under < 1);  // :129
   const float fill = mean - bottom;                      // :133
@@ -1192,7 +1515,7 @@ __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __r
     lraw[uws_idx(i)] = v;
     s1a += (double)v;
   }
-  const float fs1 = (float)uws_sum_d(s1a, shd);
+  const float fs1 = (float)uws_sum_d<nt>(s1a, shd);
   UW_STAMP(7);
   const float fn = (float)n;
   double s2 = 0;
@@ -1211,7 +1534,7 @@ __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __r
     }
     for (; i < n; i += nt) one(i, last_dist[i]);
   }
-  const float fs2 = (float)uws_sum_d(s2, shd);
+  const float fs2 = (float)uws_sum_d<nt>(s2, shd);
   UW_STAMP(8);
   float best = -INFINITY;
   int besti = 0x7fffffff;
@@ -1238,6 +1561,14 @@ __global__ __launch_bounds__(PFXW_THREADS) void uw_small_kernel(const float* __r
   }
   UW_STAMP(9);
 }
+static int g_uw_waves = [] {
+  const char* e = getenv("TDR_UW_WAVES");   // 0 = the chains chunk by chunk on the whole workgroup (A/B and debugging)
+  return (e && atoi(e) == 0) ? 0 : 1;
+}();
+extern "C" int tdr_config_uw_waves(int on) {   // < 0: query only
+  if (on >= 0) g_uw_waves = on ? 1 : 0;
+  return g_uw_waves;
+}
 int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st) {
   if (n < 1 || n > 32768) return fail(TDR_ERR_ARG, "uw_small: n out of range");
   const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1) * sizeof(float);
@@ -1245,12 +1576,17 @@ int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, 
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
   if (dev >= 64 || !attr_set[dev]) {   // more than the default 64 KB of dynamic LDS
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(uw_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            150 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(uw_small_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 133 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(uw_small_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 133 * 1024) != hipSuccess)
       return fail(TDR_ERR_HIP, "uw_small: cannot raise the dynamic LDS limit");
     if (dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(uw_small_kernel, dim3(1), dim3(PFXW_THREADS), lds, st, raw, last_dist, (int)n, w, info);
+  if (g_uw_waves)
+    hipLaunchKernelGGL(uw_small_kernel<true>, dim3(1), dim3(UWS_THREADS), lds, st, raw, last_dist, (int)n, w, info);
+  else
+    hipLaunchKernelGGL(uw_small_kernel<false>, dim3(1), dim3(PFXW_THREADS), lds, st, raw, last_dist, (int)n, w, info);
   return TDR_OK;
 }
 
