@@ -1183,13 +1183,28 @@ __device__ __forceinline__ double uws_wave_scan_d(double v) {   // inclusive sum
   v = uws_add_dpp<0x143, 0xC>(v);
   return v;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned uws_addu_dpp(unsigned v) {
+  return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned uws_wave_scan_u(unsigned v) {
+  v = uws_addu_dpp<0x111, 0xF>(v);
+  v = uws_addu_dpp<0x112, 0xF>(v);
+  v = uws_addu_dpp<0x114, 0xF>(v);
+  v = uws_addu_dpp<0x118, 0xF>(v);
+  v = uws_addu_dpp<0x142, 0xA>(v);
+  v = uws_addu_dpp<0x143, 0xC>(v);
+  return v;
+}
 __device__ __forceinline__ double uws_readlane_d(double v, int lane) {   // lane: wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 // addend e of the chain if `take`, else 0.0 — the LDS read is unconditional (n: number of weights staged)
-__device__ __forceinline__ double uws_addend_if(int kind, int e, bool take, int n, float mean) {
-  const double x = uws_addend(kind, min(e, n - 1), mean);
+// (the staged array ends in UWS_PAD unused words, so a read up to that far behind the last weight stays inside it)
+#define UWS_PAD 16
+__device__ __forceinline__ double uws_addend_if(int kind, int e, bool take, float mean) {
+  const double x = uws_addend(kind, e, mean);
   return take ? x : 0.0;
 }
 __device__ __forceinline__ float uws_mant(unsigned re, unsigned state) { return __uint_as_float((re << 23) | (state & 0x7FFFFFu)); }
@@ -1199,7 +1214,7 @@ __device__ __forceinline__ float uws_wave_walk(int kind, int lo, int cnt, float 
   const int t0 = (threadIdx.x & 63) * CHAIN_K;
   double xv[CHAIN_K];
 #pragma unroll
-  for (int k = 0; k < CHAIN_K; k++) xv[k] = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, lo + cnt, mean);
+  for (int k = 0; k < CHAIN_K; k++) xv[k] = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
   while (pos < cnt) {
 #ifdef TDR_UW_TIMELINE
     if ((threadIdx.x & 63) == 0) g_uw_tl[10 + kind]++;
@@ -1274,7 +1289,7 @@ __device__ __forceinline__ float uws_wave_dual(int kind, int lo, int cnt, float 
   const int L = __ffsll((long long)cross) - 1;   // the lane the sum leaves the binade in: its addends are really added
   float rl = uws_mant(re, L > 0 ? (unsigned)__builtin_amdgcn_readlane((int)after, L - 1) : R);   // exact before lane L
 #pragma unroll
-  for (int k = 0; k < CHAIN_K; k++) rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, lo + cnt, mean));
+  for (int k = 0; k < CHAIN_K; k++) rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean));
   const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rl), L));
   const unsigned rb2 = __float_as_uint(r2), R2 = (rb2 & 0x7FFFFFu) | 0x800000u;
   const int next = (L + 1) * CHAIN_K;
@@ -1296,18 +1311,18 @@ __device__ __forceinline__ float uws_head(int kind, int hn, float mean) {
   float run = 0.f;
   if (kind == 0) {
     // float + float: (float)((double)a + (double)b) == a + b for every pair of floats (53 >= 2 * 24 + 2 bits)
-    float nxt = (float)uws_addend_if(0, lane, lane < hn, hn, 0.f);
+    float nxt = (float)uws_addend_if(0, min(lane, hn - 1), lane < hn, 0.f);
     for (int b = 0; b < hn; b += 64) {
       const int cur = (int)__float_as_uint(nxt);
-      nxt = (float)uws_addend_if(0, b + 64 + lane, b + 64 + lane < hn, hn, 0.f);
+      nxt = (float)uws_addend_if(0, min(b + 64 + lane, hn - 1), b + 64 + lane < hn, 0.f);
 #pragma unroll
       for (int j = 0; j < 64; j++) run += __uint_as_float((unsigned)__builtin_amdgcn_readlane(cur, j));
     }
   } else {
-    double nxt = uws_addend_if(1, lane, lane < hn, hn, mean);
+    double nxt = uws_addend_if(1, min(lane, hn - 1), lane < hn, mean);
     for (int b = 0; b < hn; b += 64) {
       const double cur = nxt;
-      nxt = uws_addend_if(1, b + 64 + lane, b + 64 + lane < hn, hn, mean);
+      nxt = uws_addend_if(1, min(b + 64 + lane, hn - 1), b + 64 + lane < hn, mean);
 #pragma unroll
       for (int j = 0; j < 64; j++) run = (float)((double)run + uws_readlane_d(cur, j));
     }
@@ -1343,24 +1358,41 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
       if (code >= 0) {
         const unsigned re = (unsigned)(code & 0xFF);
         const bool dual = (code & UWS_DUAL_FLAG) != 0;
+        // without a rounding tie in the chunk a lane's pair is (s, s), s the plain sum of its increments
+        bool anytie = false;
 #pragma unroll
         for (int k = 0; k < CHAIN_K; k++) {
-          const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, n, mean);
+          const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
           unsigned f; bool tie, bad;
           chain_classify(x, re, f, tie, bad);
-          anybad |= bad;
-          P = pfx_compose(P, pfx_element_pair(f, tie));
+          anybad |= bad; anytie |= tie;
+          P.a0 += f;   // (f < 2^22: no overflow in a lane, none below 2^31 in a wave)
           if (dual) {
             chain_classify(x, re + 1u, f, tie, bad);
-            anybad |= bad;
-            Q = pfx_compose(Q, pfx_element_pair(f, tie));
+            anybad |= bad; anytie |= tie;
+            Q.a0 += f;
           }
         }
-        P = pfx_pair_wave_scan(P);
-        if (dual) {
-          Q = pfx_pair_wave_scan(Q);
-          sh.dual[code >> 16][lane] = make_uint4(P.a0, P.a1, Q.a0, Q.a1);
+        if (__ballot(anytie) == 0ull) {
+          P.a0 = P.a1 = uws_wave_scan_u(P.a0);
+          if (dual) Q.a0 = Q.a1 = uws_wave_scan_u(Q.a0);
+        } else {
+          P = PfxPair{0u, 0u}; Q = PfxPair{0u, 0u};
+#pragma unroll
+          for (int k = 0; k < CHAIN_K; k++) {
+            const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
+            unsigned f; bool tie, bad;
+            chain_classify(x, re, f, tie, bad);
+            P = pfx_compose(P, pfx_element_pair(f, tie));
+            if (dual) {
+              chain_classify(x, re + 1u, f, tie, bad);
+              Q = pfx_compose(Q, pfx_element_pair(f, tie));
+            }
+          }
+          P = pfx_pair_wave_scan(P);
+          if (dual) Q = pfx_pair_wave_scan(Q);
         }
+        if (dual) sh.dual[code >> 16][lane] = make_uint4(P.a0, P.a1, Q.a0, Q.a1);
       }
       const bool ok = code >= 0 && __ballot(anybad) == 0ull;
       if (lane == 63) {
@@ -1571,7 +1603,7 @@ extern "C" int tdr_config_uw_waves(int on) {   // < 0: query only
 }
 int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st) {
   if (n < 1 || n > 32768) return fail(TDR_ERR_ARG, "uw_small: n out of range");
-  const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1) * sizeof(float);
+  const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1 + UWS_PAD) * sizeof(float);
   static bool attr_set[64] = {false};   // per device: the attribute lives with the device's copy of the code object
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
