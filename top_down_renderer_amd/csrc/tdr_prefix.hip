@@ -1207,6 +1207,39 @@ __device__ __forceinline__ double uws_addend_if(int kind, int e, bool take, floa
   const double x = uws_addend(kind, e, mean);
   return take ? x : 0.0;
 }
+// the `sum` chain's addends are floats: pfx_classify's float arithmetic (exact, see there) with chain_classify's bound
+__device__ __forceinline__ float uws_addend_f(int e, bool take) {
+  extern __shared__ float uws_lraw[];
+  const float v = uws_lraw[uws_idx(e)];
+  return (take && v == v) ? v : 0.f;   // :111-115
+}
+__device__ __forceinline__ void uws_classify_f(float wv, unsigned re, unsigned& f, bool& tie, bool& bad) {
+  const float t = wv * __uint_as_float((277u - re) << 23);   // w / u, u = 2^(re - 150)
+  bad = !(wv >= 0.f) || !(t < 4194304.f);
+  const float fl = floorf(t);
+  const float fr = t - fl;
+  tie = fr == 0.5f;
+  f = (unsigned)fl + (fr > 0.5f ? 1u : 0u);
+  if (bad) { f = 0; tie = false; }
+}
+// addend e of chain `kind` (a compile-time constant where it matters) against the binades re and, if `dual`, re + 1
+struct UwsCls { unsigned f, f2; bool tie, tie2, bad; };
+__device__ __forceinline__ UwsCls uws_classify_at(int kind, int e, bool take, float mean, unsigned re, bool dual) {
+  UwsCls c;
+  c.f2 = 0u; c.tie2 = false;
+  bool bad2 = false;
+  if (kind == 0) {
+    const float x = uws_addend_f(e, take);
+    uws_classify_f(x, re, c.f, c.tie, c.bad);
+    if (dual) uws_classify_f(x, re + 1u, c.f2, c.tie2, bad2);
+  } else {
+    const double x = uws_addend_if(kind, e, take, mean);
+    chain_classify(x, re, c.f, c.tie, c.bad);
+    if (dual) chain_classify(x, re + 1u, c.f2, c.tie2, bad2);
+  }
+  c.bad |= bad2;
+  return c;
+}
 __device__ __forceinline__ float uws_mant(unsigned re, unsigned state) { return __uint_as_float((re << 23) | (state & 0x7FFFFFu)); }
 // wave-chunk [lo, lo + cnt) carried through by the calling wave from its element `pos` on, entered with the running sum r
 // (wave-uniform): chain_walk_chunk on one wave
@@ -1289,7 +1322,10 @@ __device__ __forceinline__ float uws_wave_dual(int kind, int lo, int cnt, float 
   const int L = __ffsll((long long)cross) - 1;   // the lane the sum leaves the binade in: its addends are really added
   float rl = uws_mant(re, L > 0 ? (unsigned)__builtin_amdgcn_readlane((int)after, L - 1) : R);   // exact before lane L
 #pragma unroll
-  for (int k = 0; k < CHAIN_K; k++) rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean));
+  for (int k = 0; k < CHAIN_K; k++) {
+    if (kind == 0) rl += uws_addend_f(lo + t0 + k, t0 + k < cnt);   // float + float: the same sum as through double
+    else rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean));
+  }
   const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rl), L));
   const unsigned rb2 = __float_as_uint(r2), R2 = (rb2 & 0x7FFFFFu) | 0x800000u;
   const int next = (L + 1) * CHAIN_K;
@@ -1362,16 +1398,10 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
         bool anytie = false;
 #pragma unroll
         for (int k = 0; k < CHAIN_K; k++) {
-          const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
-          unsigned f; bool tie, bad;
-          chain_classify(x, re, f, tie, bad);
-          anybad |= bad; anytie |= tie;
-          P.a0 += f;   // (f < 2^22: no overflow in a lane, none below 2^31 in a wave)
-          if (dual) {
-            chain_classify(x, re + 1u, f, tie, bad);
-            anybad |= bad; anytie |= tie;
-            Q.a0 += f;
-          }
+          const UwsCls c = uws_classify_at(kind, lo + t0 + k, t0 + k < cnt, mean, re, dual);
+          anybad |= c.bad; anytie |= c.tie | c.tie2;
+          P.a0 += c.f;   // (f < 2^22: no overflow in a lane, none below 2^31 in a wave)
+          Q.a0 += c.f2;
         }
         if (__ballot(anytie) == 0ull) {
           P.a0 = P.a1 = uws_wave_scan_u(P.a0);
@@ -1380,14 +1410,9 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
           P = PfxPair{0u, 0u}; Q = PfxPair{0u, 0u};
 #pragma unroll
           for (int k = 0; k < CHAIN_K; k++) {
-            const double x = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
-            unsigned f; bool tie, bad;
-            chain_classify(x, re, f, tie, bad);
-            P = pfx_compose(P, pfx_element_pair(f, tie));
-            if (dual) {
-              chain_classify(x, re + 1u, f, tie, bad);
-              Q = pfx_compose(Q, pfx_element_pair(f, tie));
-            }
+            const UwsCls c = uws_classify_at(kind, lo + t0 + k, t0 + k < cnt, mean, re, dual);
+            P = pfx_compose(P, pfx_element_pair(c.f, c.tie));
+            if (dual) Q = pfx_compose(Q, pfx_element_pair(c.f2, c.tie2));
           }
           P = pfx_pair_wave_scan(P);
           if (dual) Q = pfx_pair_wave_scan(Q);
@@ -1459,12 +1484,11 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
   float sum = 0.f, mean = 0.f, bsum = 0.f;
   long long num_valid = 0, num_under = 0;
   if constexpr (WAVES) {
-    // the two chains in one loop body (one copy of the code: a single launch runs every instruction once, from a cold
-    // instruction cache).  chain 0: stage the weights and count the valid ones (:108-116), `sum`; chain 1: count the
-    // weights below the mean, `bottom_stddev` (:118-126).  Either pass works wave-chunk by wave-chunk and leaves the
-    // chunks' double sums behind for the chain's predictions.
+    // chain 0: stage the weights and count the valid ones (:108-116), `sum`; chain 1: count the weights below the mean,
+    // `bottom_stddev` (:118-126).  Either pass works wave-chunk by wave-chunk and leaves the chunks' double sums behind
+    // for the chain's predictions.  (Unrolled: `kind` is a constant in each copy — 47 us against 53 with one copy.)
     const int lane = tid & 63, nwc = (n + UWS_WC - 1) / UWS_WC;
-#pragma nounroll
+#pragma unroll
     for (int kind = 0; kind < 2; kind++) {
       double cnt = 0;
       for (int c = tid >> 6; c < nwc; c += nt / 64) {
