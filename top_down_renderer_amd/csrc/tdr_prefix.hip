@@ -1222,23 +1222,16 @@ __device__ __forceinline__ void uws_classify_f(float wv, unsigned re, unsigned& 
   f = (unsigned)fl + (fr > 0.5f ? 1u : 0u);
   if (bad) { f = 0; tie = false; }
 }
-// addend e of chain `kind` (a compile-time constant where it matters) against the binades re and, if `dual`, re + 1
-struct UwsCls { unsigned f, f2; bool tie, tie2, bad; };
-__device__ __forceinline__ UwsCls uws_classify_at(int kind, int e, bool take, float mean, unsigned re, bool dual) {
-  UwsCls c;
-  c.f2 = 0u; c.tie2 = false;
-  bool bad2 = false;
-  if (kind == 0) {
-    const float x = uws_addend_f(e, take);
-    uws_classify_f(x, re, c.f, c.tie, c.bad);
-    if (dual) uws_classify_f(x, re + 1u, c.f2, c.tie2, bad2);
-  } else {
-    const double x = uws_addend_if(kind, e, take, mean);
-    chain_classify(x, re, c.f, c.tie, c.bad);
-    if (dual) chain_classify(x, re + 1u, c.f2, c.tie2, bad2);
-  }
-  c.bad |= bad2;
-  return c;
+// an addend of chain `kind` (a compile-time constant where it matters): a float in the `sum` chain, else a double
+struct UwsX { float f; double d; };
+__device__ __forceinline__ UwsX uws_load_x(int kind, int e, bool take, float mean) {
+  UwsX x;
+  x.f = 0.f; x.d = 0.0;
+  if (kind == 0) x.f = uws_addend_f(e, take); else x.d = uws_addend_if(kind, e, take, mean);
+  return x;
+}
+__device__ __forceinline__ void uws_classify_x(int kind, const UwsX& x, unsigned re, unsigned& f, bool& tie, bool& bad) {
+  if (kind == 0) uws_classify_f(x.f, re, f, tie, bad); else chain_classify(x.d, re, f, tie, bad);
 }
 __device__ __forceinline__ float uws_mant(unsigned re, unsigned state) { return __uint_as_float((re << 23) | (state & 0x7FFFFFu)); }
 // wave-chunk [lo, lo + cnt) carried through by the calling wave from its element `pos` on, entered with the running sum r
@@ -1321,10 +1314,13 @@ __device__ __forceinline__ float uws_wave_dual(int kind, int lo, int cnt, float 
   if (cross == 0ull) return uws_mant(re, (unsigned)__builtin_amdgcn_readlane((int)after, 63));
   const int L = __ffsll((long long)cross) - 1;   // the lane the sum leaves the binade in: its addends are really added
   float rl = uws_mant(re, L > 0 ? (unsigned)__builtin_amdgcn_readlane((int)after, L - 1) : R);   // exact before lane L
+  UwsX x[CHAIN_K];
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) x[k] = uws_load_x(kind, lo + t0 + k, t0 + k < cnt, mean);
 #pragma unroll
   for (int k = 0; k < CHAIN_K; k++) {
-    if (kind == 0) rl += uws_addend_f(lo + t0 + k, t0 + k < cnt);   // float + float: the same sum as through double
-    else rl = (float)((double)rl + uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean));
+    if (kind == 0) rl += x[k].f;   // float + float: the same sum as through double
+    else rl = (float)((double)rl + x[k].d);
   }
   const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rl), L));
   const unsigned rb2 = __float_as_uint(r2), R2 = (rb2 & 0x7FFFFFu) | 0x800000u;
@@ -1394,14 +1390,25 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
       if (code >= 0) {
         const unsigned re = (unsigned)(code & 0xFF);
         const bool dual = (code & UWS_DUAL_FLAG) != 0;
+        UwsX x[CHAIN_K];   // (all eight reads in flight before the first use)
+#pragma unroll
+        for (int k = 0; k < CHAIN_K; k++) x[k] = uws_load_x(kind, lo + t0 + k, t0 + k < cnt, mean);
         // without a rounding tie in the chunk a lane's pair is (s, s), s the plain sum of its increments
         bool anytie = false;
+        unsigned f; bool tie, bad;
 #pragma unroll
         for (int k = 0; k < CHAIN_K; k++) {
-          const UwsCls c = uws_classify_at(kind, lo + t0 + k, t0 + k < cnt, mean, re, dual);
-          anybad |= c.bad; anytie |= c.tie | c.tie2;
-          P.a0 += c.f;   // (f < 2^22: no overflow in a lane, none below 2^31 in a wave)
-          Q.a0 += c.f2;
+          uws_classify_x(kind, x[k], re, f, tie, bad);
+          anybad |= bad; anytie |= tie;
+          P.a0 += f;   // (f < 2^22: no overflow in a lane, none below 2^31 in a wave)
+        }
+        if (dual) {
+#pragma unroll
+          for (int k = 0; k < CHAIN_K; k++) {
+            uws_classify_x(kind, x[k], re + 1u, f, tie, bad);
+            anybad |= bad; anytie |= tie;
+            Q.a0 += f;
+          }
         }
         if (__ballot(anytie) == 0ull) {
           P.a0 = P.a1 = uws_wave_scan_u(P.a0);
@@ -1410,12 +1417,18 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
           P = PfxPair{0u, 0u}; Q = PfxPair{0u, 0u};
 #pragma unroll
           for (int k = 0; k < CHAIN_K; k++) {
-            const UwsCls c = uws_classify_at(kind, lo + t0 + k, t0 + k < cnt, mean, re, dual);
-            P = pfx_compose(P, pfx_element_pair(c.f, c.tie));
-            if (dual) Q = pfx_compose(Q, pfx_element_pair(c.f2, c.tie2));
+            uws_classify_x(kind, x[k], re, f, tie, bad);
+            P = pfx_compose(P, pfx_element_pair(f, tie));
           }
           P = pfx_pair_wave_scan(P);
-          if (dual) Q = pfx_pair_wave_scan(Q);
+          if (dual) {
+#pragma unroll
+            for (int k = 0; k < CHAIN_K; k++) {
+              uws_classify_x(kind, x[k], re + 1u, f, tie, bad);
+              Q = pfx_compose(Q, pfx_element_pair(f, tie));
+            }
+            Q = pfx_pair_wave_scan(Q);
+          }
         }
         if (dual) sh.dual[code >> 16][lane] = make_uint4(P.a0, P.a1, Q.a0, Q.a1);
       }
