@@ -266,14 +266,18 @@ int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, 
 
 /* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
 /* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum.
- * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  With a workspace and n >= 32768 the chain
- * is evaluated by many workgroups (per-chunk parity summaries, see csrc/tdr_prefix.hip); without one, by one workgroup.
- * The bits written are the serial chain's either way. */
+ * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  From 1024 to 32 768 weights — the
+ * reference's operating point — everything is one launch of one workgroup with the weights in LDS; above, with a
+ * workspace, the chain is evaluated by many workgroups (per-chunk parity summaries, see csrc/tdr_prefix.hip); without
+ * one, by one workgroup.  The bits written are the serial chain's either way.  tdr_config_prefix_small(0) takes the
+ * one-launch kernel out of the choice (A/B measurements, tests), 1 restores the default, < 0 only queries; env
+ * TDR_PFX_SMALL. */
+int tdr_config_prefix_small(int on);
 int64_t tdr_prefix_workspace_bytes(int64_t n);
 int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream);
 /* Same, choosing the implementation: mode 0 = one wave adding in index order, 1 = the exact parallel kernel in one
- * workgroup (integer increments per binade), 2 = the multi-workgroup scan (workspace required); all give identical
- * bits.  prefix_out (optional, modes 1 and 2) = raw sums. */
+ * workgroup (integer increments per binade), 2 = the multi-workgroup scan (workspace required), 3 = the one-launch
+ * kernel (n <= 32 768); all give identical bits.  prefix_out (optional, modes 1 to 3) = raw sums. */
 int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out, void* workspace,
                       void* stream);
 /* idx_out[i - i_begin] = first j with prefix_j > (float(i)+shift)/n_new, else n-1, for i in [i_begin, i_end). */

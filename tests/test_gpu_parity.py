@@ -711,6 +711,19 @@ def _prefix_cases():
     cases["zeros then data"] = np.concatenate([np.zeros(9000, f32), rng.random(5000).astype(f32) * f32(1e-4),
                                                np.zeros(100, f32)])
     cases["negatives"] = ((rng.random(20_000).astype(f32) - f32(0.2)) * f32(1e-4)).astype(f32)
+    # sizes of the one-launch kernel (n <= 32 768): ragged chunk ends, ties, crossings at chunk ends, irregular weights
+    for n in (513, 4096, 20_000, 32_767, 32_768):
+        w = rng.random(n).astype(f32) ** 2
+        cases[f"normalised n={n}"] = (w / w.sum()).astype(f32)
+    cases["20k dyadic ties"] = (rng.integers(0, 64, 20_000) * f32(2.0 ** -22)).astype(f32)
+    w = (rng.random(30_000) * 1e-6).astype(f32); w[511::512] = f32(0.01); cases["30k a jump at every chunk end"] = w
+    w = (rng.random(25_000).astype(f32) / f32(12_500)); w[[700, 9000, 9001, 24_999]] = f32(-0.125); w[13_000] = f32(3.0)
+    cases["25k negatives and a jump"] = w
+    w = np.full(20_000, f32(5e-5)); w[rng.random(20_000) < 0.1] = f32(-3e-6); cases["20k nan-fill negative"] = w
+    w = rng.random(20_000).astype(f32); w[12_345] = f32(np.inf); w[15_000] = f32(-np.inf); cases["20k inf then -inf"] = w
+    w = rng.random(20_000).astype(f32); w[12_345] = f32(np.nan); cases["20k nan inside"] = w
+    cases["20k zeros"] = np.zeros(20_000, f32)
+    w = np.zeros(20_000, f32); w[15_000:] = f32(1e-3); cases["20k zeros then data"] = w
     cases["nan-fill negative"] = np.where(rng.random(60_000) < 0.1, f32(-3e-6), rng.random(60_000).astype(f32) * 4e-5).astype(f32)
     cases["wide dynamic range"] = (10.0 ** rng.uniform(-12, -2, 50_000)).astype(f32)
     cases["subnormals"] = (rng.random(3000) * 1e-41).astype(f32)
@@ -752,7 +765,9 @@ def test_exact_parallel_prefix_is_the_serial_float_chain(tdr):
             refmax = np.maximum.accumulate(np.where(np.isnan(ref), -np.inf, ref)).astype(np.float32)
         wd = k.to_device(w)
         ws = k.prefix_workspace(n)
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
+            if mode == 3 and n > 32768:
+                continue
             rm, pf = k.zeros((n,)), k.zeros((n,))
             assert k.lib.tdr_k_prefix_mode(C.c_void_p(wd.data_ptr()), n, mode, C.c_void_p(rm.data_ptr()),
                                            C.c_void_p(pf.data_ptr()) if mode else None,

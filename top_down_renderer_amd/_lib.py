@@ -46,6 +46,7 @@ SIGNATURES = {
     "tdr_config_cart_skip": (_i, [_i]),
     "tdr_config_init_mfma": (_i, [_i]),
     "tdr_config_uw_waves": (_i, [_i]),
+    "tdr_config_prefix_small": (_i, [_i]),
     "tdr_shift_uniform_launches": (_i64, []),
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),

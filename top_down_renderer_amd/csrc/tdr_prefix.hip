@@ -932,6 +932,7 @@ __device__ __forceinline__ int uws_idx(int e) { return e + (e >> 5); }   // one 
 __device__ __forceinline__ double uws_addend(int kind, int e, float mean) {
   extern __shared__ float uws_lraw[];
   const float v = uws_lraw[uws_idx(e)];
+  if (kind == 2) return (double)v;                                          // :179 (the running sum of the resample)
   if (kind == 0) return (v != v) ? 0.0 : (double)v;                         // :111-115
   if (v != v || !(v < mean)) return 0.0;                                    // :120
   const double d = (double)(v - mean);                                      // float subtraction, then pow(double, 2)
@@ -1208,10 +1209,10 @@ __device__ __forceinline__ double uws_addend_if(int kind, int e, bool take, floa
   return take ? x : 0.0;
 }
 // the `sum` chain's addends are floats: pfx_classify's float arithmetic (exact, see there) with chain_classify's bound
-__device__ __forceinline__ float uws_addend_f(int e, bool take) {
+__device__ __forceinline__ float uws_addend_f(int kind, int e, bool take) {
   extern __shared__ float uws_lraw[];
   const float v = uws_lraw[uws_idx(e)];
-  return (take && v == v) ? v : 0.f;   // :111-115
+  return (take && (kind == 2 || v == v)) ? v : 0.f;   // :111-115 (`sum` skips NaN weights; the running sum, kind 2, does not)
 }
 __device__ __forceinline__ void uws_classify_f(float wv, unsigned re, unsigned& f, bool& tie, bool& bad) {
   const float t = wv * __uint_as_float((277u - re) << 23);   // w / u, u = 2^(re - 150)
@@ -1227,11 +1228,11 @@ struct UwsX { float f; double d; };
 __device__ __forceinline__ UwsX uws_load_x(int kind, int e, bool take, float mean) {
   UwsX x;
   x.f = 0.f; x.d = 0.0;
-  if (kind == 0) x.f = uws_addend_f(e, take); else x.d = uws_addend_if(kind, e, take, mean);
+  if (kind != 1) x.f = uws_addend_f(kind, e, take); else x.d = uws_addend_if(kind, e, take, mean);
   return x;
 }
 __device__ __forceinline__ void uws_classify_x(int kind, const UwsX& x, unsigned re, unsigned& f, bool& tie, bool& bad) {
-  if (kind == 0) uws_classify_f(x.f, re, f, tie, bad); else chain_classify(x.d, re, f, tie, bad);
+  if (kind != 1) uws_classify_f(x.f, re, f, tie, bad); else chain_classify(x.d, re, f, tie, bad);
 }
 __device__ __forceinline__ float uws_mant(unsigned re, unsigned state) { return __uint_as_float((re << 23) | (state & 0x7FFFFFu)); }
 // wave-chunk [lo, lo + cnt) carried through by the calling wave from its element `pos` on, entered with the running sum r
@@ -1243,19 +1244,23 @@ __device__ __forceinline__ float uws_wave_walk(int kind, int lo, int cnt, float 
   for (int k = 0; k < CHAIN_K; k++) xv[k] = uws_addend_if(kind, lo + t0 + k, t0 + k < cnt, mean);
   while (pos < cnt) {
 #ifdef TDR_UW_TIMELINE
-    if ((threadIdx.x & 63) == 0) g_uw_tl[10 + kind]++;
+    if ((threadIdx.x & 63) == 0 && kind < 2) g_uw_tl[10 + kind]++;
 #endif
     const unsigned rb = __float_as_uint(r);
     const unsigned re = rb >> 23;   // sign included
     int first = cnt;
     unsigned st[CHAIN_K] = {};
     const bool regular = re >= PFXM_RE_MIN && re <= PFXM_RE_MAX;
+    if (r != r) return r;   // NaN stays NaN
     if (!regular) {
-      // zero / tiny / huge / inf / NaN running sum: zero addends change nothing, the next other one is really added
+      // zero / tiny / huge / inf running sum: zero addends change nothing (an infinite sum: finite ones), the next other
+      // one is really added
+      const bool isinf = (rb & 0x7FFFFFFFu) == 0x7F800000u;
 #pragma unroll
       for (int k = 0; k < CHAIN_K; k++) {
         const int li = t0 + k;
-        if (li >= pos && li < cnt && xv[k] != 0.0) first = min(first, li);
+        const bool acts = isinf ? !(fabs(xv[k]) < INFINITY) : (xv[k] != 0.0);
+        if (li >= pos && li < cnt && acts) first = min(first, li);
       }
     } else {
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
@@ -1319,7 +1324,7 @@ __device__ __forceinline__ float uws_wave_dual(int kind, int lo, int cnt, float 
   for (int k = 0; k < CHAIN_K; k++) x[k] = uws_load_x(kind, lo + t0 + k, t0 + k < cnt, mean);
 #pragma unroll
   for (int k = 0; k < CHAIN_K; k++) {
-    if (kind == 0) rl += x[k].f;   // float + float: the same sum as through double
+    if (kind != 1) rl += x[k].f;   // float + float: the same sum as through double
     else rl = (float)((double)rl + x[k].d);
   }
   const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(rl), L));
@@ -1361,14 +1366,35 @@ __device__ __forceinline__ float uws_head(int kind, int hn, float mean) {
   }
   return run;
 }
-// sh.csum holds the chunks' double sums and a barrier has passed since they were written
-__device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float mean, UwsShared& sh) {
+// the running sum of the resample: the same head, and every lane keeps the running sum behind its own addend, which
+// replaces the weight in the staged array
+__device__ __forceinline__ float pfs_head(int hn) {
+  extern __shared__ float uws_lraw[];
+  const int lane = threadIdx.x & 63;
+  float run = 0.f;
+  float nxt = uws_addend_f(2, min(lane, hn - 1), lane < hn);
+  for (int b = 0; b < hn; b += 64) {
+    const int cur = (int)__float_as_uint(nxt);
+    nxt = uws_addend_f(2, min(b + 64 + lane, hn - 1), b + 64 + lane < hn);
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      run += __uint_as_float((unsigned)__builtin_amdgcn_readlane(cur, j));
+      mine = (lane == j) ? run : mine;
+    }
+    if (b + lane < hn) uws_lraw[uws_idx(b + lane)] = mine;
+  }
+  return run;
+}
+// sh.csum holds the chunks' double sums and a barrier has passed since they were written; rin (kind 2): the running sum
+// in front of every wave-chunk
+__device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float mean, UwsShared& sh, float* rin = nullptr) {
   constexpr int NW = UWS_THREADS / 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t0 = lane * CHAIN_K;
   const int nwc = (n + UWS_WC - 1) / UWS_WC;   // <= 64
   float r = 0.f;
   if (wave == 0) {
-    r = uws_head(kind, min(UWS_WC, n), mean);
+    r = kind == 2 ? pfs_head(min(UWS_WC, n)) : uws_head(kind, min(UWS_WC, n), mean);
   } else {
     // the running double sum before / after each chunk -> what is predicted for it (lane c: chunk c)
     int my_code;
@@ -1444,9 +1470,11 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
   if (wave == 0) {   // the walk
     const int v_code = (lane >= 1 && lane < nwc) ? sh.code[lane] : -1;
     const unsigned v_d0 = (lane >= 1 && lane < nwc) ? sh.d0[lane] : 0u, v_d1 = (lane >= 1 && lane < nwc) ? sh.d1[lane] : 0u;
+    float v_rin = 0.f;   // lane c: the running sum in front of chunk c
     for (int c = 1; c < nwc; c++) {
       const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
       const int code = __builtin_amdgcn_readlane(v_code, c);
+      if (kind == 2) v_rin = (lane == c) ? r : v_rin;
       const unsigned rb = __float_as_uint(r);
       const int re = (int)(rb >> 23);
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
@@ -1463,6 +1491,7 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
         r = uws_wave_walk(kind, lo, cnt, mean, r, pos);
       }
     }
+    if (kind == 2) rin[lane] = v_rin;
     if (lane == 0) sh.total = r;
   }
   pfx_sync();
@@ -1659,10 +1688,224 @@ int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, 
   return TDR_OK;
 }
 
+// ---- the running sum of the resample for small particle sets, in ONE launch ------------------------------------------
+// `running_sum += weights_[j]` (src/particle_filter.cpp:179) for n <= 32 768 with the machinery of the statistics chains:
+// the weights staged in LDS, wave-chunks predicted and summarised side by side with the one-by-one head, one wave walking
+// the chunk list with the exact sum (it notes the sum in front of every chunk), then every wave redoes its chunks from
+// their exact starting sums and leaves each addend's running sum in place of the weight; a last pass takes the running
+// maximum (the running sum itself when no weight is negative or NaN) and writes the outputs.
+struct PfsShared {
+  UwsShared u;
+  float rin[64];    // running sum in front of every wave-chunk
+  float cmax[64];   // largest running sum inside it (NaN skipped)
+  int irregular;    // a negative or NaN weight exists: the running sum is not its own running maximum
+};
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pfs_max_dpp(float v) {
+  return fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)0xFF800000u, (int)__float_as_uint(v), CTRL,
+                                                                        ROW_MASK, 0xF, false)));
+}
+__device__ __forceinline__ float pfs_wave_scan_max(float v) {   // inclusive maximum over the lanes before and this one
+  v = pfs_max_dpp<0x111, 0xF>(v);
+  v = pfs_max_dpp<0x112, 0xF>(v);
+  v = pfs_max_dpp<0x114, 0xF>(v);
+  v = pfs_max_dpp<0x118, 0xF>(v);
+  v = pfs_max_dpp<0x142, 0xA>(v);
+  v = pfs_max_dpp<0x143, 0xC>(v);
+  return v;
+}
+// wave-chunk [lo, lo + cnt) from its exact starting sum r: every addend's running sum, in place of the weight
+__device__ __forceinline__ void pfs_wave_fill(int lo, int cnt, float r) {
+  extern __shared__ float uws_lraw[];
+  const int t0 = (threadIdx.x & 63) * CHAIN_K;
+  float x[CHAIN_K], pv[CHAIN_K];
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++) { x[k] = uws_addend_f(2, lo + t0 + k, t0 + k < cnt); pv[k] = 0.f; }
+  int pos = 0;
+  while (pos < cnt) {
+    const unsigned rb = __float_as_uint(r);
+    const unsigned re = rb >> 23;   // sign included
+    if (r != r) {                   // NaN stays NaN
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++)
+        if (t0 + k >= pos) pv[k] = r;
+      break;
+    }
+    int first = cnt;
+    unsigned st[CHAIN_K] = {};
+    const bool regular = re >= PFXM_RE_MIN && re <= PFXM_RE_MAX;
+    if (!regular) {
+      const bool isinf = (rb & 0x7FFFFFFFu) == 0x7F800000u;
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        const int li = t0 + k;
+        const bool acts = isinf ? !(fabsf(x[k]) < INFINITY) : (x[k] != 0.f);
+        if (li >= pos && li < cnt && acts) first = min(first, li);
+      }
+    } else {
+      const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      unsigned f[CHAIN_K];
+      unsigned tiebits = 0u, lane_sum = 0u;
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        const int li = t0 + k;
+        bool bad, tie;
+        uws_classify_f(x[k], re, f[k], tie, bad);
+        if (li < pos || li >= cnt) { f[k] = 0u; tie = false; bad = false; }
+        if (bad) first = min(first, li);
+        tiebits |= tie ? (1u << k) : 0u;
+        lane_sum += f[k];
+      }
+      unsigned state;
+      if (__ballot(tiebits != 0u) == 0ull) {   // no rounding tie: plain sums
+        state = R + (uws_wave_scan_u(lane_sum) - lane_sum);
+      } else {
+        PfxPair mine = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < CHAIN_K; k++) mine = pfx_compose(mine, pfx_element_pair(f[k], ((tiebits >> k) & 1u) != 0u));
+        const PfxPair ex = pfx_pair_dpp<0x138, 0xF>(pfx_pair_wave_scan(mine));   // exclusive: wave_shr:1
+        state = R + ((R & 1u) ? ex.a1 : ex.a0);
+      }
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++) {
+        state += f[k] + (((tiebits >> k) & 1u) ? ((state + f[k]) & 1u) : 0u);
+        st[k] = state;
+        const int li = t0 + k;
+        if (li >= pos && li < cnt && state >= (1u << 24)) first = min(first, li);
+      }
+    }
+    const int stop = uws_wave_min(first);   // first addend that is really added (cnt: none)
+    unsigned sv = 0u;
+    float xs = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      const int li = t0 + k;
+      if (li >= pos && li < stop) pv[k] = regular ? uws_mant(re, st[k]) : r;
+      if (li == stop - 1) sv = st[k];
+      if (li == stop) xs = x[k];
+    }
+    if (regular && stop > pos) r = uws_mant(re, (unsigned)__builtin_amdgcn_readlane((int)sv, (stop - 1) / CHAIN_K));
+    if (stop < cnt) {
+      r += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xs), stop / CHAIN_K));   // one real addition
+#pragma unroll
+      for (int k = 0; k < CHAIN_K; k++)
+        if (t0 + k == stop) pv[k] = r;
+      pos = stop + 1;
+    } else {
+      pos = cnt;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CHAIN_K; k++)
+    if (t0 + k < cnt) uws_lraw[uws_idx(lo + t0 + k)] = pv[k];
+}
+__global__ __launch_bounds__(UWS_THREADS) void pfx_small_kernel(const float* __restrict__ w, int n,
+                                                                float* __restrict__ runmax, float* __restrict__ prefix_opt) {
+  extern __shared__ float uws_lraw[];
+  float* const lraw = uws_lraw;
+  __shared__ PfsShared sh;
+  constexpr int nt = UWS_THREADS, NW = UWS_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwc = (n + UWS_WC - 1) / UWS_WC;
+  if (tid == 0) sh.irregular = 0;
+  pfx_sync();
+  // stage wave-chunk by wave-chunk; their double sums for the predictions
+  bool irr = false;
+  for (int c = wave; c < nwc; c += NW) {
+    const int base = c * UWS_WC + lane;
+    float v[CHAIN_K];
+#pragma unroll
+    for (int m = 0; m < CHAIN_K; m++) v[m] = base + 64 * m < n ? w[base + 64 * m] : 0.f;
+    double acc = 0;
+#pragma unroll
+    for (int m = 0; m < CHAIN_K; m++) {
+      if (base + 64 * m < n) lraw[uws_idx(base + 64 * m)] = v[m];
+      irr |= !(v[m] >= 0.f);
+      acc += (double)v[m];
+    }
+    acc = uws_wave_scan_d(acc);
+    if (lane == 63) sh.u.csum[c] = acc;
+  }
+  if (__ballot(irr) != 0ull && lane == 0) atomicOr(&sh.irregular, 1);
+  pfx_sync();
+  (void)uws_chain_total_waves(2, n, 0.f, sh.u, sh.rin);   // (ends in a barrier)
+  // every chunk again from its exact starting sum (the first one was filled by the head)
+  for (int c = 1 + wave; c < nwc; c += NW) pfs_wave_fill(c * UWS_WC, min(UWS_WC, n - c * UWS_WC), sh.rin[c]);
+  pfx_sync();
+  if (sh.irregular == 0) {   // the running sum never falls: it is its own running maximum
+    for (int i = tid; i < n; i += nt) {
+      const float v = lraw[uws_idx(i)];
+      runmax[i] = v;
+      if (prefix_opt) prefix_opt[i] = v;
+    }
+    return;
+  }
+  const int t0 = lane * CHAIN_K;
+  for (int c = wave; c < nwc; c += NW) {
+    const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      const float v = lraw[uws_idx(lo + t0 + k)];
+      if (t0 + k < cnt && v == v) m = fmaxf(m, v);
+    }
+    m = pfs_wave_scan_max(m);
+    if (lane == 63) sh.cmax[c] = m;
+  }
+  pfx_sync();
+  const float before = pfs_wave_scan_max(lane < nwc ? sh.cmax[lane] : -INFINITY);   // lane c: maximum up to chunk c's end
+  for (int c = wave; c < nwc; c += NW) {
+    const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
+    const float carry = c > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(before), c - 1)) : -INFINITY;
+    float pv[CHAIN_K], lm[CHAIN_K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++) {
+      pv[k] = lraw[uws_idx(lo + t0 + k)];
+      if (t0 + k < cnt && pv[k] == pv[k]) m = fmaxf(m, pv[k]);
+      lm[k] = m;
+    }
+    const float incl = pfs_wave_scan_max(m);
+    float ex = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)0xFF800000u, (int)__float_as_uint(incl), 0x138, 0xF, 0xF, false));
+    ex = fmaxf(ex, carry);
+#pragma unroll
+    for (int k = 0; k < CHAIN_K; k++)
+      if (t0 + k < cnt) {
+        runmax[lo + t0 + k] = fmaxf(lm[k], ex);
+        if (prefix_opt) prefix_opt[lo + t0 + k] = pv[k];
+      }
+  }
+}
+#define TDR_PFX_SMALL_MAX_N 32768
+static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt, hipStream_t st) {
+  if (n < 1 || n > TDR_PFX_SMALL_MAX_N) return fail(TDR_ERR_ARG, "pfx_small: n out of range");
+  const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1 + UWS_PAD) * sizeof(float);
+  static bool attr_set[64] = {false};   // per device: the attribute lives with the device's copy of the code object
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  if (dev >= 64 || !attr_set[dev]) {   // more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pfx_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            133 * 1024) != hipSuccess)
+      return fail(TDR_ERR_HIP, "pfx_small: cannot raise the dynamic LDS limit");
+    if (dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(pfx_small_kernel, dim3(1), dim3(UWS_THREADS), lds, st, w, (int)n, runmax, prefix_opt);
+  return TDR_OK;
+}
+
 // Dispatch (tools/bench_prefix_modes.py on MI355X; us at n = 1k / 4k / 8k / 20k / 100k: one wave 16 / 43 / 84 / 208 /
 // 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 53 / 74 / 101):
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
 #define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
+#define TDR_PFX_SMALL_MIN_N 1024     // the one-launch kernel from here up to TDR_PFX_SMALL_MAX_N
+static int g_pfx_small = [] {
+  const char* e = getenv("TDR_PFX_SMALL");   // 0 = without the one-launch kernel (A/B and debugging)
+  return (e && atoi(e) == 0) ? 0 : 1;
+}();
+extern "C" int tdr_config_prefix_small(int on) {   // < 0: query only
+  if (on >= 0) g_pfx_small = on ? 1 : 0;
+  return g_pfx_small;
+}
 extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
   return n < 1 ? 0 : (int64_t)sizeof(PfxChunk) * cdiv(n, (int64_t)PFXM_CHUNK);
 }
@@ -1687,7 +1930,10 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
 }
 extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* workspace, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix: bad arguments");
-  if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
+  if (g_pfx_small && n >= TDR_PFX_SMALL_MIN_N && n <= TDR_PFX_SMALL_MAX_N) {
+    const int rc = pfx_small(w, n, runmax_out, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+  } else if (workspace && n >= TDR_PFX_MULTI_MIN_N) {
     const int rc = prefix_multi(w, n, runmax_out, nullptr, workspace, (hipStream_t)stream);
     if (rc) return rc;
   } else if (n < TDR_PFX_EXACT_MIN_N)
@@ -1699,13 +1945,16 @@ extern "C" int tdr_k_prefix(const float* w, int64_t n, float* runmax_out, void* 
   return TDR_OK;
 }
 // Test / diagnostic entry: mode 0 = serial kernel, 1 = exact parallel kernel in one workgroup, 2 = the multi-workgroup
-// scan (needs a workspace of tdr_prefix_workspace_bytes(n)); prefix_out (optional, modes 1 and 2) receives the raw
-// running sums.
+// scan (needs a workspace of tdr_prefix_workspace_bytes(n)), 3 = the one-launch kernel for n <= 32 768; prefix_out
+// (optional, modes 1 to 3) receives the raw running sums.
 extern "C" int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, float* prefix_out,
                                  void* workspace, void* stream) {
   if (!w || !runmax_out || n < 1) return fail(TDR_ERR_ARG, "prefix_mode: bad arguments");
   if (mode == 2 && !workspace) return fail(TDR_ERR_ARG, "prefix_mode: mode 2 needs a workspace");
-  if (mode == 0)
+  if (mode == 3) {
+    const int rc = pfx_small(w, n, runmax_out, prefix_out, (hipStream_t)stream);
+    if (rc) return rc;
+  } else if (mode == 0)
     hipLaunchKernelGGL(prefix_serial_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, n, runmax_out);
   else if (mode == 2) {
     const int rc = prefix_multi(w, n, runmax_out, prefix_out, workspace, (hipStream_t)stream);
