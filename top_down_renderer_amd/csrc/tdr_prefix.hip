@@ -1471,18 +1471,45 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
     const int v_code = (lane >= 1 && lane < nwc) ? sh.code[lane] : -1;
     const unsigned v_d0 = (lane >= 1 && lane < nwc) ? sh.d0[lane] : 0u, v_d1 = (lane >= 1 && lane < nwc) ? sh.d1[lane] : 0u;
     float v_rin = 0.f;   // lane c: the running sum in front of chunk c
-    for (int c = 1; c < nwc; c++) {
-      const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
-      const int code = __builtin_amdgcn_readlane(v_code, c);
-      if (kind == 2) v_rin = (lane == c) ? r : v_rin;
+    int c = 1;
+    while (c < nwc) {
       const unsigned rb = __float_as_uint(r);
       const int re = (int)(rb >> 23);
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
+      bool overflow = false;   // chunk c was predicted to stay in this binade and does not
+      // the run of chunks from c on that were summarised in the binade the sum is in: one scan of their pairs (plain
+      // sums when none of them holds a rounding tie) carries the sum through all of them
+      const unsigned long long other = ~__ballot(lane < nwc && v_code == re) & (~0ull << c);
+      const int cend = other ? __ffsll((long long)other) - 1 : 64;   // the run is [c, cend)
+      if (cend > c) {
+        const bool in_run = lane >= c && lane < cend;
+        unsigned after;   // lane l: mantissa behind chunk l, while below 2^24
+        if (__ballot(in_run && v_d0 != v_d1) == 0ull) {
+          after = R + uws_wave_scan_u(in_run ? v_d0 : 0u);
+        } else {
+          const PfxPair in = pfx_pair_wave_scan(in_run ? PfxPair{v_d0, v_d1} : PfxPair{0u, 0u});
+          after = R + ((R & 1u) ? in.a1 : in.a0);
+        }
+        const unsigned long long cross = __ballot(in_run && after >= (1u << 24));
+        const int c1 = cross ? __ffsll((long long)cross) - 1 : cend;   // chunks [c, c1) are taken
+        if (kind == 2) {
+          const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)after, 0x138, 0xF, 0xF, false);   // wave_shr:1
+          if (lane >= c && lane < c1) v_rin = lane == c ? r : uws_mant((unsigned)re, prev);
+        }
+        if (c1 > c) r = uws_mant((unsigned)re, (unsigned)__builtin_amdgcn_readlane((int)after, c1 - 1));
+#ifdef TDR_UW_TIMELINE
+        if (threadIdx.x == 0) g_uw_tl[12] += c1 - c;
+#endif
+        c = c1;
+        if (c1 == cend) continue;
+        overflow = true;
+      }
+      const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
+      const int code = __builtin_amdgcn_readlane(v_code, c);
+      if (kind == 2) v_rin = (lane == c) ? r : v_rin;
       int pos = 0;
-      if (code == re) {
-        const unsigned D = (unsigned)__builtin_amdgcn_readlane((R & 1u) ? (int)v_d1 : (int)v_d0, c);
-        if (R + D < (1u << 24)) { r = uws_mant((unsigned)re, R + D); UW_COUNT(12); continue; }
-      } else if (code >= 0 && re <= PFXM_RE_MAX && (code & 0x1FF) == (re | UWS_DUAL_FLAG)) {
+      const int re_now = (int)(__float_as_uint(r) >> 23);
+      if (!overflow && code >= 0 && re_now <= PFXM_RE_MAX && (code & 0x1FF) == (re_now | UWS_DUAL_FLAG)) {
         r = uws_wave_dual(kind, lo, cnt, mean, r, sh.dual[code >> 16], pos);
         UW_COUNT(13);
       }
@@ -1490,6 +1517,7 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
         UW_COUNT(14);
         r = uws_wave_walk(kind, lo, cnt, mean, r, pos);
       }
+      c++;
     }
     if (kind == 2) rin[lane] = v_rin;
     if (lane == 0) sh.total = r;
