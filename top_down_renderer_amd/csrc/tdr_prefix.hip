@@ -1527,9 +1527,9 @@ __device__ __forceinline__ float uws_chain_total_waves(int kind, int n, float me
 }
 template <int NT>
 __device__ __forceinline__ double uws_sum_d(double v, double* sh) {   // block sum, fixed order: a pure function of the inputs
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  v = uws_wave_scan_d(v);   // lane 63: the wave's sum
   pfx_sync();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
   pfx_sync();
   double t = 0;
   for (int w = 0; w < NT / 64; w++) t += sh[w];
@@ -1553,6 +1553,7 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
   UW_STAMP(0);
   float sum = 0.f, mean = 0.f, bsum = 0.f;
   long long num_valid = 0, num_under = 0;
+  double valid_sum = 0.0;   // WAVES: the valid weights summed in double (the sum of the wave-chunks' sums)
   if constexpr (WAVES) {
     // chain 0: stage the weights and count the valid ones (:108-116), `sum`; chain 1: count the weights below the mean,
     // `bottom_stddev` (:118-126).  Either pass works wave-chunk by wave-chunk and leaves the chunks' double sums behind
@@ -1560,7 +1561,7 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
     const int lane = tid & 63, nwc = (n + UWS_WC - 1) / UWS_WC;
 #pragma unroll
     for (int kind = 0; kind < 2; kind++) {
-      double cnt = 0;
+      int cnt = 0;
       for (int c = tid >> 6; c < nwc; c += nt / 64) {
         const int base = c * UWS_WC + lane;
         float v[CHAIN_K];
@@ -1583,13 +1584,14 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
           const bool take = kind == 0 ? v[m] == v[m] : (v[m] == v[m] && v[m] < mean);
           double x = (double)(kind == 0 ? v[m] : v[m] - mean);
           if (kind) x = x * x;
-          cnt += take ? 1.0 : 0.0;
+          cnt += take ? 1 : 0;
           acc += take ? x : 0.0;
         }
         acc = uws_wave_scan_d(acc);
         if (lane == 63) ush.csum[c] = acc;
       }
-      const long long count = (long long)uws_sum_d<nt>(cnt, shd);   // (its barriers also publish the staged weights)
+      const long long count = (long long)uws_sum_d<nt>((double)cnt, shd);   // (its barriers also publish the staged weights)
+      if (kind == 0) valid_sum = uws_readlane_d(uws_wave_scan_d(lane < nwc ? ush.csum[lane] : 0.0), 63);
       UW_STAMP(kind ? 4 : 1);
       const float total = uws_chain_total_waves(kind, n, mean, ush);   // serial float chain, exact
       UW_STAMP(kind ? 6 : 3);
@@ -1633,19 +1635,43 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
   const float bottom = sqrtf(bsum / (float)num_under);
   const bool fallback = (sum == 0.f || num_under < 1);  // :129
   const float fill = mean - bottom;                      // :133
-  pfx_sync();                                            // every thread is done reading the raw weights
-  double s1a = 0;
-  for (int i = tid; i < n; i += nt) {
-    float v = lraw[uws_idx(i)];
-    v = fallback ? 1.f : (v != v ? fill : v);
-    lraw[uws_idx(i)] = v;
-    s1a += (double)v;
-  }
-  const float fs1 = (float)uws_sum_d<nt>(s1a, shd);
-  UW_STAMP(7);
   const float fn = (float)n;
+  float fs1;
   double s2 = 0;
-  {
+  if constexpr (WAVES) {
+    // :130-135 without a pass of its own: the filled weights sum to the valid ones plus `fill` for every NaN (all ones in
+    // the fallback); the fill itself happens where the weight is read next.  The last travel distances are requested
+    // sixteen per thread at a time, ahead of the divisions.
+    fs1 = (float)(fallback ? (double)n : valid_sum + (double)(n - num_valid) * (double)fill);
+    UW_STAMP(7);
+    for (int i0 = tid; i0 < n; i0 += 16 * nt) {
+      float ld[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) ld[j] = i0 + j * nt < n ? last_dist[i0 + j * nt] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int i = i0 + j * nt;
+        if (i < n) {   // :135, :138-141
+          float v = lraw[uws_idx(i)];
+          v = (fallback ? 1.f : (v != v ? fill : v)) / fs1;
+          const float d = fminf(ld[j] * 5.f, 1.f);
+          v = d * v + (1.f - d) / fn;
+          lraw[uws_idx(i)] = v;
+          s2 += (double)v;
+        }
+      }
+    }
+  } else {
+    pfx_sync();                                            // every thread is done reading the raw weights
+    double s1a = 0;
+    for (int i = tid; i < n; i += nt) {
+      float v = lraw[uws_idx(i)];
+      v = fallback ? 1.f : (v != v ? fill : v);
+      lraw[uws_idx(i)] = v;
+      s1a += (double)v;
+    }
+    fs1 = (float)uws_sum_d<nt>(s1a, shd);
+    UW_STAMP(7);
     auto one = [&](int i, float ld) {   // :135, :138-141
       float v = lraw[uws_idx(i)] / fs1;
       const float d = fminf(ld * 5.f, 1.f);
