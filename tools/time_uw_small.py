@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 from top_down_renderer_amd.kernels import HipKernels
 
 k = HipKernels()
-for n in (1000, 5000, 20000, 32768):
+for n in (300, 1000, 5000, 20000, 32768):
     rng = np.random.default_rng(n)
     raw = (1.0 / (rng.random(n) * 20 + 0.15)).astype(np.float32)
     raw[rng.integers(0, n, n // 50)] = np.nan
@@ -31,13 +31,15 @@ for n in (1000, 5000, 20000, 32768):
         e1.record()
         k.synchronize()
         line += f"  statistics ({'waves' if on else 'workgroup'}) {e0.elapsed_time(e1) / reps * 1e3:7.1f} us"
-    for _ in range(5):
-        k.prefix(w, n, runmax)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(200):
-        k.prefix(w, n, runmax)
-    e1.record()
-    k.synchronize()
-    line += f"  running sum {e0.elapsed_time(e1) / 200 * 1e3:7.1f} us"
+    for on in (0, 1):
+        k.lib.tdr_config_prefix_small(on)
+        for _ in range(5):
+            k.prefix(w, n, runmax)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            k.prefix(w, n, runmax)
+        e1.record()
+        k.synchronize()
+        line += f"  running sum ({'one launch' if on else 'as before'}) {e0.elapsed_time(e1) / 200 * 1e3:7.1f} us"
     print(line)

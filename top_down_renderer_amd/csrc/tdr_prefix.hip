@@ -1951,7 +1951,7 @@ static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt
 // 1036, one workgroup 60 / 129 / 156 / 235 / 417, multi-workgroup 38 / 59 / 53 / 74 / 101):
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
 #define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
-#define TDR_PFX_SMALL_MIN_N 1024     // the one-launch kernel from here up to TDR_PFX_SMALL_MAX_N
+#define TDR_PFX_SMALL_MIN_N 256     // the one-launch kernel from here up to TDR_PFX_SMALL_MAX_N
 static int g_pfx_small = [] {
   const char* e = getenv("TDR_PFX_SMALL");   // 0 = without the one-launch kernel (A/B and debugging)
   return (e && atoi(e) == 0) ? 0 : 1;

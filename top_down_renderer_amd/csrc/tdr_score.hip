@@ -595,10 +595,13 @@ struct FinalizeArgs {
   int gnchunks;
   float gsum0, gsum1;
   int only_uninit;      // mode 1: slots whose particle already has a heading are left alone
+  int tlog;             // 2^tlog neighbouring lanes share a slot's chunks (launch_finalize)
 };
 
 __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = 1 << a.tlog, t = (int)(gid & (T - 1));
+  const int64_t slot = gid >> a.tlog;
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if (slot >= nact) return;
   const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
@@ -611,16 +614,20 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
     return;
   }
   if (a.mode == 1 && a.only_uninit && a.st[TDR_ST_HAVE_INIT * a.cap + p] != 0.f) return;
-  // Per-chunk partial sums -> double totals, chunk order ascending for every slot.  The loads of FIN_B chunks x all
-  // slots are issued together (independent addresses, coalesced over the particles) before the dependent additions.
+  // Per-chunk partial sums -> double totals, chunk order ascending.  The loads of FIN_B chunks x all slots are issued
+  // together (independent addresses, coalesced over the particles) before the dependent additions.  A small particle
+  // set has many chunks and few slots — 128 x 1000 at the reference's test size — and one lane per slot would wait for
+  // memory 32 times in a row: there 2^tlog neighbouring lanes take a contiguous share of a slot's chunks each and
+  // their double totals are added up in a fixed butterfly.
   constexpr int FIN_B = 4, FIN_S = TDR_MAX_CLASSES + 2;   // slots: ncls class dots, normalisation, known count
   double tot[FIN_S];
 #pragma unroll
   for (int k = 0; k < FIN_S; k++) tot[k] = 0;
   const int64_t cstride = (int64_t)(a.rf + 1) * a.npad;
   auto slot_row = [&](int k) { return k < a.ncls ? k : (k == a.ncls ? a.rf - 1 : a.rf); };
-  int c0 = 0;
-  for (; c0 + FIN_B <= a.nchunks; c0 += FIN_B) {
+  const int share = (a.nchunks + T - 1) >> a.tlog, cend = min(a.nchunks, (t + 1) * share);
+  int c0 = t * share;
+  for (; c0 + FIN_B <= cend; c0 += FIN_B) {
     float v[FIN_B][FIN_S];
 #pragma unroll
     for (int b = 0; b < FIN_B; b++)
@@ -633,10 +640,17 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
       for (int k = 0; k < FIN_S; k++)
         if (k < a.ncls + 2) tot[k] += (double)v[b][k];
   }
-  for (; c0 < a.nchunks; c0++) {
+  for (; c0 < cend; c0++) {
 #pragma unroll
     for (int k = 0; k < FIN_S; k++)
       if (k < a.ncls + 2) tot[k] += (double)a.part[(int64_t)c0 * cstride + (int64_t)slot_row(k) * a.npad + slot];
+  }
+  if (T > 1) {   // (the lanes of a slot left or stayed together above)
+    for (int sft = T >> 1; sft >= 1; sft >>= 1)
+#pragma unroll
+      for (int k = 0; k < FIN_S; k++)
+        if (k < a.ncls + 2) tot[k] += __shfl_xor(tot[k], sft, 64);
+    if (t != 0) return;
   }
   double known = 0, norm = 0;
 #pragma unroll
@@ -677,6 +691,14 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
     a.best_cost[slot] = best;
     a.best_theta[slot] = bt;
   }
+}
+
+// nslots: slots the launch covers (a.n / a.count still bound the active ones)
+static void launch_finalize(FinalizeArgs& f, int64_t nslots, hipStream_t s) {
+  int tl = 0;
+  while (tl < 4 && (f.nchunks >> (tl + 1)) >= 4 && (nslots << (tl + 1)) <= 131072) tl++;
+  f.tlog = tl;
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(nslots << tl, 256)), dim3(256), 0, s, f);
 }
 
 // The 40-rotation initialisation search of state_particle.cpp:195-206 in ONE pass over the window: the candidate
@@ -1994,11 +2016,11 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
       HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
     }
     f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = counts + 2;
-    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(W.npad_part, 256)), dim3(256), 0, s, f);
+    launch_finalize(f, W.npad_part, s);
   } else {
     rc = launch_score(a, map, rf, map->ncls, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+    launch_finalize(f, n, s);
   }
   LAUNCH_CHECK("score_finalize");
   if (init_search) {
@@ -2099,7 +2121,7 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
       if ((rc = launch_score(a, map, rf, map->ncls, s))) return rc;
       if ((rc = launch_score(g, geo_map, 4, 2, s))) return rc;
       f.first = k == 0; f.theta_override = t;
-      hipLaunchKernelGGL(score_finalize_kernel, fgrid, fblock, 0, s, f);
+      launch_finalize(f, n, s);
       LAUNCH_CHECK("score_finalize(geo init)");
       k++;
     }
@@ -2112,7 +2134,7 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
   if ((rc = launch_score(a, map, rf, map->ncls, s))) return rc;
   if ((rc = launch_score(g, geo_map, 4, 2, s))) return rc;
   f.mode = 0; f.first = 0; f.theta_override = 0.f; f.only_uninit = 0;
-  hipLaunchKernelGGL(score_finalize_kernel, fgrid, fblock, 0, s, f);
+  launch_finalize(f, n, s);
   LAUNCH_CHECK("score_finalize(geo)");
   if (init_search) {
     hipLaunchKernelGGL(init_fixup_kernel, fgrid, fblock, 0, s, (const float*)res_flag, n, fp->regularization, raw_w);
@@ -2199,7 +2221,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   f.P = (int64_t)rows * cols; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
   f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
-  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, f);
+  launch_finalize(f, n, s);
   LAUNCH_CHECK("score_finalize(cart)");
   return TDR_OK;
 }
