@@ -884,6 +884,43 @@ def test_uw_small_wave_chains_equal_workgroup_chains(tdr, oracle, n):
         k.lib.tdr_config_uw_waves(before)
 
 
+@pytest.mark.parametrize("n", [32_768, 32_769, 40_000, 100_000, 300_017])
+def test_heads_of_the_long_chains_through_the_one_workgroup_kernels(tdr, oracle, n):
+    """Above 32 768 weights the first 32 768 addends of the statistics chains and of the running sum go through the
+    one-workgroup kernels (chain_head_kernel, pfx_small_kernel) and the chunk walk starts behind them;
+    tdr_config_prefix_small(0) walks the chunks from the first addend on.  Same `sum`, `mean`, `bottom_stddev`, same
+    running maxima, bit for bit, and both the oracle's / numpy's serial chains."""
+    pkg, k = tdr
+    import ctypes as C
+    f32 = np.float32
+    rng = np.random.default_rng(5100 + n)
+    cases = [(1.0 / (rng.random(n) * 20 + 0.15)).astype(f32), np.exp(rng.normal(0, 4, n)).astype(f32),
+             (rng.integers(0, 64, n) * 2.0 ** -9).astype(f32)]
+    cases[0][rng.random(n) < 0.05] = np.nan
+    a = np.zeros(n, f32); a[30_000:] = rng.random(n - 30_000).astype(f32); cases.append(a)   # the head sums to zero
+    before = k.lib.tdr_config_prefix_small(-1)
+    try:
+        for ci, raw in enumerate(cases):
+            ld = rng.random(n).astype(f32)
+            got = []
+            for on in (1, 0):
+                k.lib.tdr_config_prefix_small(on)
+                w, info = k.zeros((n,)), k.zeros((65536,))
+                k.update_weights(k.to_device(raw), k.to_device(ld), n, w, info)
+                rm = k.zeros((n,))
+                k.prefix(w, n, rm)
+                got.append((info[:8].cpu().numpy().tobytes(), w.cpu().numpy(), rm.cpu().numpy()))
+            assert got[0][0] == got[1][0], f"case {ci}: statistics"
+            assert np.array_equal(got[0][1], got[1][1], equal_nan=True) and np.array_equal(got[0][2], got[1][2]), f"case {ci}"
+            with np.errstate(all="ignore"):
+                _, _, stats = oracle.update_weights(raw, ld)
+                ref = np.cumsum(got[0][1], dtype=f32)
+            assert np.array_equal(np.frombuffer(got[0][0], f32)[1:4], np.asarray(stats[:3], f32), equal_nan=True), ci
+            assert np.array_equal(got[0][2], np.maximum.accumulate(np.where(np.isnan(ref), -np.inf, ref)).astype(f32)), ci
+    finally:
+        k.lib.tdr_config_prefix_small(before)
+
+
 def test_gather_states_and_aos_roundtrip(tdr, g):
     pkg, k = tdr
     import torch

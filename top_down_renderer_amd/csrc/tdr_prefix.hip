@@ -557,11 +557,11 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_sum_kernel(const float
 }
 
 __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const float* __restrict__ w, int64_t n,
-                                                                         PfxChunk* __restrict__ ch) {
+                                                                         PfxChunk* __restrict__ ch, int c_first) {
   __shared__ double shd[PFXM_THREADS / 64];
   __shared__ PfxPair shp[PFXM_THREADS / 64];
   __shared__ int s_bad;
-  const int c = blockIdx.x;
+  const int c = blockIdx.x + c_first;   // (the chunks before c_first are not walked, see prefix_multi)
   const long long lo = (long long)c * PFXM_CHUNK;
   const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
   // predicted running sum before the chunk: the double sums of the chunks before it, in chunk order per thread
@@ -707,11 +707,13 @@ __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long
 __global__ __launch_bounds__(PFXW_THREADS) void pfx_walk_kernel(const float* __restrict__ w, int64_t n,
                                                                PfxChunk* __restrict__ ch, int nch,
                                                                float* __restrict__ runmax,
-                                                               float* __restrict__ prefix_opt, int head_len) {
+                                                               float* __restrict__ prefix_opt, int head_len,
+                                                               int c_first, const float* __restrict__ tail) {
   __shared__ int sm_re[PFXW_BLOCK], sm_acc[PFXW_BLOCK];
   __shared__ unsigned sm_d0[PFXW_BLOCK], sm_d1[PFXW_BLOCK];
   __shared__ float sm_r0[PFXW_BLOCK], sm_c0[PFXW_BLOCK];
-  float r = 0.f, carry = -INFINITY;   // workgroup-uniform
+  // workgroup-uniform; chunks [0, c_first) were done by pfx_small_kernel, which left the sum and the maximum behind them
+  float r = c_first > 0 ? tail[0] : 0.f, carry = c_first > 0 ? tail[1] : -INFINITY;
   for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
     pfx_sync();
     for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXW_THREADS) {
@@ -721,6 +723,7 @@ __global__ __launch_bounds__(PFXW_THREADS) void pfx_walk_kernel(const float* __r
     pfx_sync();
     const int ce = min(nch, cb + PFXW_BLOCK);
     for (int c = cb; c < ce; c++) {
+      if (c < c_first) { sm_acc[c - cb] = 0; continue; }
       const unsigned rb = __float_as_uint(r);
       const int re = (int)(rb >> 23);                   // sign bit included: a negative sum never matches
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
@@ -869,11 +872,12 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_sum_kernel(ChainSrc s, int
     ch[blockIdx.x].sum = t;
   }
 }
-__global__ __launch_bounds__(PFXW_THREADS) void chain_summary_kernel(ChainSrc s, int64_t n, PfxChunk* __restrict__ ch) {
+__global__ __launch_bounds__(PFXW_THREADS) void chain_summary_kernel(ChainSrc s, int64_t n, PfxChunk* __restrict__ ch,
+                                                                    int c_first) {
   __shared__ double shd[PFXW_THREADS / 64];
   __shared__ PfxPair shp[PFXW_THREADS / 64];
   __shared__ int s_bad;
-  const int c = blockIdx.x;
+  const int c = blockIdx.x + c_first;   // (the chunks before c_first are not walked, see tdr_chain_total)
   const long long lo = (long long)c * PFXM_CHUNK;
   const int cnt = (int)min((long long)PFXM_CHUNK, (long long)n - lo);
   double acc = 0.0;
@@ -1033,7 +1037,8 @@ __device__ __forceinline__ void chain_walk_chunk(const ChainSrc& s, long long lo
   }
 }
 __global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, int64_t n, const PfxChunk* __restrict__ ch,
-                                                                 int nch, float* __restrict__ total_out) {
+                                                                 int nch, float* __restrict__ total_out, int c_first,
+                                                                 const float* __restrict__ r_first) {
   __shared__ int sm_re[PFXW_BLOCK];
   __shared__ unsigned sm_d0[PFXW_BLOCK], sm_d1[PFXW_BLOCK];
   const float mean = s.kind ? *s.mean : 0.f;
@@ -1041,17 +1046,18 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, in
   // thousand addends — so those are added one by one by a single thread out of LDS
   __shared__ double head[CHAIN_HEAD];
   __shared__ float s_head_r;
-  const int hn = (int)min((long long)CHAIN_HEAD, (long long)n);
+  // (c_first > 0: chunks [0, c_first) were summed by chain_head_kernel, which left the sum behind them in *r_first)
+  const int hn = c_first > 0 ? 0 : (int)min((long long)CHAIN_HEAD, (long long)n);
   for (int t = threadIdx.x; t < hn; t += PFXW_THREADS) head[t] = chain_addend(s, t, mean);
   pfx_sync();
   if (threadIdx.x == 0) {
-    float run = 0.f;
+    float run = c_first > 0 ? *r_first : 0.f;
     for (int t = 0; t < hn; t++) run = (float)((double)run + head[t]);
     s_head_r = run;
   }
   pfx_sync();
   float r = s_head_r;   // workgroup-uniform
-  for (int cb = 0; cb < nch; cb += PFXW_BLOCK) {
+  for (int cb = (c_first / PFXW_BLOCK) * PFXW_BLOCK; cb < nch; cb += PFXW_BLOCK) {
     pfx_sync();
     for (int t = threadIdx.x; t < PFXW_BLOCK && cb + t < nch; t += PFXW_THREADS) {
       const PfxChunk x = ch[cb + t];
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, in
     }
     pfx_sync();
     const int ce = min(nch, cb + PFXW_BLOCK);
-    for (int c = cb; c < ce; c++) {
+    for (int c = max(cb, c_first); c < ce; c++) {
       const unsigned rb = __float_as_uint(r);
       const int re = (int)(rb >> 23);
       const unsigned R = (rb & 0x7FFFFFu) | 0x800000u;
@@ -1074,6 +1080,19 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, in
   }
   if (threadIdx.x == 0) *total_out = r;
 }
+static int g_pfx_small = [] {
+  const char* e = getenv("TDR_PFX_SMALL");   // 0 = without the one-launch kernel (A/B and debugging)
+  return (e && atoi(e) == 0) ? 0 : 1;
+}();
+extern "C" int tdr_config_prefix_small(int on) {   // < 0: query only
+  if (on >= 0) g_pfx_small = on ? 1 : 0;
+  return g_pfx_small;
+}
+#define CHAIN_HEAD_N 32768
+// whole chunks at the start that the one-workgroup machinery takes (0: none; tdr_config_prefix_small(0) switches it off
+// for the running sum AND the statistics chains: the chunk walk from the first addend on, for A/B and debugging)
+static int chain_head_chunks(int64_t n) { return (g_pfx_small && n >= CHAIN_HEAD_N) ? CHAIN_HEAD_N / PFXM_CHUNK : 0; }
+static int chain_head_launch(const float* raw, const float* mean_dev, int kind, int n_head, float* r_out, hipStream_t st);
 // raw: [n] raw weights; kind 0: total = serial float sum of the non-NaN weights; kind 1: total = serial
 // float-accumulated sum of pow(w - *mean_dev, 2) over the non-NaN weights below *mean_dev.  workspace: chunk headers,
 // tdr_prefix_workspace_bytes(n).  total_out: one device float.
@@ -1084,9 +1103,19 @@ int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n
   const int nch = (int)nch64;
   PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
   ChainSrc s{raw, mean_dev, kind};
+  // The first 32 768 addends — where the sum crosses most of its binades — go through the one-workgroup machinery of
+  // uw_small_kernel (chain_head_kernel, below); the chunk walk starts behind them.
+  const int c_first = chain_head_chunks(n);
   hipLaunchKernelGGL(chain_sum_kernel, dim3(nch), dim3(PFXW_THREADS), 0, st, s, n, ch);
-  hipLaunchKernelGGL(chain_summary_kernel, dim3(nch), dim3(PFXW_THREADS), 0, st, s, n, ch);
-  hipLaunchKernelGGL(chain_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, s, n, (const PfxChunk*)ch, nch, total_out);
+  if (nch > c_first)
+    hipLaunchKernelGGL(chain_summary_kernel, dim3(nch - c_first), dim3(PFXW_THREADS), 0, st, s, n, ch, c_first);
+  float* r_first = reinterpret_cast<float*>(&ch[0].r0);   // (a header slot the chains do not use)
+  if (c_first > 0) {
+    const int rc = chain_head_launch(raw, mean_dev, kind, c_first * PFXM_CHUNK, r_first, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(chain_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, s, n, (const PfxChunk*)ch, nch, total_out,
+                     c_first, (const float*)r_first);
   return TDR_OK;
 }
 
@@ -1854,7 +1883,8 @@ __device__ __forceinline__ void pfs_wave_fill(int lo, int cnt, float r) {
     if (t0 + k < cnt) uws_lraw[uws_idx(lo + t0 + k)] = pv[k];
 }
 __global__ __launch_bounds__(UWS_THREADS) void pfx_small_kernel(const float* __restrict__ w, int n,
-                                                                float* __restrict__ runmax, float* __restrict__ prefix_opt) {
+                                                                float* __restrict__ runmax, float* __restrict__ prefix_opt,
+                                                                float* __restrict__ tail) {   // tail (optional): sum, maximum
   extern __shared__ float uws_lraw[];
   float* const lraw = uws_lraw;
   __shared__ PfsShared sh;
@@ -1882,11 +1912,12 @@ __global__ __launch_bounds__(UWS_THREADS) void pfx_small_kernel(const float* __r
   }
   if (__ballot(irr) != 0ull && lane == 0) atomicOr(&sh.irregular, 1);
   pfx_sync();
-  (void)uws_chain_total_waves(2, n, 0.f, sh.u, sh.rin);   // (ends in a barrier)
+  const float total = uws_chain_total_waves(2, n, 0.f, sh.u, sh.rin);   // (ends in a barrier)
   // every chunk again from its exact starting sum (the first one was filled by the head)
   for (int c = 1 + wave; c < nwc; c += NW) pfs_wave_fill(c * UWS_WC, min(UWS_WC, n - c * UWS_WC), sh.rin[c]);
   pfx_sync();
   if (sh.irregular == 0) {   // the running sum never falls: it is its own running maximum
+    if (tail && tid == 0) { tail[0] = total; tail[1] = total; }
     for (int i = tid; i < n; i += nt) {
       const float v = lraw[uws_idx(i)];
       runmax[i] = v;
@@ -1908,6 +1939,7 @@ __global__ __launch_bounds__(UWS_THREADS) void pfx_small_kernel(const float* __r
   }
   pfx_sync();
   const float before = pfs_wave_scan_max(lane < nwc ? sh.cmax[lane] : -INFINITY);   // lane c: maximum up to chunk c's end
+  if (tail && tid == 63) { tail[0] = total; tail[1] = before; }
   for (int c = wave; c < nwc; c += NW) {
     const int lo = c * UWS_WC, cnt = min(UWS_WC, n - lo);
     const float carry = c > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(before), c - 1)) : -INFINITY;
@@ -1931,7 +1963,7 @@ __global__ __launch_bounds__(UWS_THREADS) void pfx_small_kernel(const float* __r
   }
 }
 #define TDR_PFX_SMALL_MAX_N 32768
-static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt, hipStream_t st) {
+static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt, hipStream_t st, float* tail = nullptr) {
   if (n < 1 || n > TDR_PFX_SMALL_MAX_N) return fail(TDR_ERR_ARG, "pfx_small: n out of range");
   const size_t lds = ((size_t)n + (size_t)(n >> 5) + 1 + UWS_PAD) * sizeof(float);
   static bool attr_set[64] = {false};   // per device: the attribute lives with the device's copy of the code object
@@ -1943,7 +1975,57 @@ static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt
       return fail(TDR_ERR_HIP, "pfx_small: cannot raise the dynamic LDS limit");
     if (dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(pfx_small_kernel, dim3(1), dim3(UWS_THREADS), lds, st, w, (int)n, runmax, prefix_opt);
+  hipLaunchKernelGGL(pfx_small_kernel, dim3(1), dim3(UWS_THREADS), lds, st, w, (int)n, runmax, prefix_opt, tail);
+  return TDR_OK;
+}
+
+// The head of a statistics chain over more than 32 768 weights: its first n_head addends (whole 4096-chunks, at most
+// 32 768) staged into LDS and summed by uws_chain_total_waves; the chunk walk of chain_walk_kernel starts behind them.
+template <int KIND>
+__global__ __launch_bounds__(UWS_THREADS) void chain_head_kernel(const float* __restrict__ raw, const float* __restrict__ mean_dev,
+                                                                 int n, float* __restrict__ r_out) {
+  extern __shared__ float uws_lraw[];
+  __shared__ UwsShared ush;
+  const int tid = threadIdx.x, lane = tid & 63, nwc = (n + UWS_WC - 1) / UWS_WC;
+  const float mean = KIND ? *mean_dev : 0.f;
+  for (int c = tid >> 6; c < nwc; c += UWS_THREADS / 64) {
+    const int base = c * UWS_WC + lane;
+    float v[CHAIN_K];
+#pragma unroll
+    for (int m = 0; m < CHAIN_K; m++) v[m] = base + 64 * m < n ? raw[base + 64 * m] : __uint_as_float(0x7FC00000u);
+    double acc = 0;
+#pragma unroll
+    for (int m = 0; m < CHAIN_K; m++) {
+      if (base + 64 * m < n) uws_lraw[uws_idx(base + 64 * m)] = v[m];
+      const bool take = KIND == 0 ? v[m] == v[m] : (v[m] == v[m] && v[m] < mean);
+      double x = (double)(KIND == 0 ? v[m] : v[m] - mean);
+      if (KIND) x = x * x;
+      acc += take ? x : 0.0;
+    }
+    acc = uws_wave_scan_d(acc);
+    if (lane == 63) ush.csum[c] = acc;
+  }
+  pfx_sync();
+  const float r = uws_chain_total_waves(KIND, n, mean, ush);
+  if (tid == 0) *r_out = r;
+}
+static int chain_head_launch(const float* raw, const float* mean_dev, int kind, int n_head, float* r_out, hipStream_t st) {
+  const size_t lds = ((size_t)n_head + (size_t)(n_head >> 5) + 1 + UWS_PAD) * sizeof(float);
+  static bool attr_set[64] = {false};   // per device: the attribute lives with the device's copy of the code object
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  if (dev >= 64 || !attr_set[dev]) {   // more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            133 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            133 * 1024) != hipSuccess)
+      return fail(TDR_ERR_HIP, "chain_head: cannot raise the dynamic LDS limit");
+    if (dev < 64) attr_set[dev] = true;
+  }
+  if (kind == 0)
+    hipLaunchKernelGGL(chain_head_kernel<0>, dim3(1), dim3(UWS_THREADS), lds, st, raw, mean_dev, n_head, r_out);
+  else
+    hipLaunchKernelGGL(chain_head_kernel<1>, dim3(1), dim3(UWS_THREADS), lds, st, raw, mean_dev, n_head, r_out);
   return TDR_OK;
 }
 
@@ -1952,14 +2034,6 @@ static int pfx_small(const float* w, int64_t n, float* runmax, float* prefix_opt
 #define TDR_PFX_MULTI_MIN_N 6144    // with a workspace: the multi-workgroup scan from here on, one wave below
 #define TDR_PFX_EXACT_MIN_N 24576   // without a workspace: one workgroup from here on, one wave below
 #define TDR_PFX_SMALL_MIN_N 256     // the one-launch kernel from here up to TDR_PFX_SMALL_MAX_N
-static int g_pfx_small = [] {
-  const char* e = getenv("TDR_PFX_SMALL");   // 0 = without the one-launch kernel (A/B and debugging)
-  return (e && atoi(e) == 0) ? 0 : 1;
-}();
-extern "C" int tdr_config_prefix_small(int on) {   // < 0: query only
-  if (on >= 0) g_pfx_small = on ? 1 : 0;
-  return g_pfx_small;
-}
 extern "C" int64_t tdr_prefix_workspace_bytes(int64_t n) {
   return n < 1 ? 0 : (int64_t)sizeof(PfxChunk) * cdiv(n, (int64_t)PFXM_CHUNK);
 }
@@ -1969,15 +2043,23 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
   if (nch64 > (1 << 24)) return fail(TDR_ERR_ARG, "prefix: n too large");
   const int nch = (int)nch64;
   PfxChunk* ch = reinterpret_cast<PfxChunk*>(workspace);
+  // the first 32 768 weights through pfx_small_kernel, the chunk walk behind them (see tdr_chain_total)
+  const int c_first = chain_head_chunks(n);
+  float* tail = reinterpret_cast<float*>(&ch[0].sum);   // (chunk 0's sum is not read once the summaries are made)
   hipLaunchKernelGGL(pfx_chunk_sum_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
-  hipLaunchKernelGGL(pfx_chunk_summary_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, ch);
+  if (nch > c_first)
+    hipLaunchKernelGGL(pfx_chunk_summary_kernel, dim3(nch - c_first), dim3(PFXM_THREADS), 0, st, w, n, ch, c_first);
+  if (c_first > 0) {
+    const int rc = pfx_small(w, (int64_t)c_first * PFXM_CHUNK, runmax_out, prefix_out, st, tail);
+    if (rc) return rc;
+  }
   static const int head_len = [] {
     const char* e = getenv("TDR_PFX_HEAD");
     const int v = e ? atoi(e) : PFXW_HEAD;
     return v < 1 ? 1 : (v > PFX_HEAD ? PFX_HEAD : v);
   }();
   hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
-                     head_len);
+                     head_len, c_first, (const float*)tail);
   hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,
                      runmax_out, prefix_out);
   return TDR_OK;
