@@ -356,17 +356,26 @@ __global__ __launch_bounds__(256) void uw_pass5(int64_t n, const UwScratch* s4, 
 }
 __global__ __launch_bounds__(256) void uw_pass6(int64_t n, const UwScratch* s1, const UwScratch* s2,
                                                 const UwScratch* s5, const UwExact* ex, float* info) {
-  __shared__ float sb[UW_G];
-  __shared__ long long si[UW_G];
-  for (int g = threadIdx.x; g < UW_G; g += blockDim.x) { sb[g] = (float)s5->a[g]; si[g] = (long long)s5->b[g]; }
+  static_assert(UW_G == 256, "one candidate per thread");
+  __shared__ float sb[4];
+  __shared__ long long si[4];
+  // first maximum over the workgroups' candidates (:145-147): largest value, smallest index among equals; a NaN never
+  // wins (one thread per candidate and a tree instead of a serial loop over LDS: 23 -> 5 us)
+  float best = (float)s5->a[threadIdx.x];
+  long long besti = (long long)s5->b[threadIdx.x];
+  if (best != best) { best = -INFINITY; besti = 0x7fffffffffffffffll; }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_down(best, o, 64);
+    const long long oi = __shfl_down(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = besti; }
   const float sum = ex->sum, mean = ex->mean;
-  const long long nv = (long long)uw_total(s1->b), nu = (long long)uw_total(s2->b);
+  const long long nv = (long long)uw_total(s1->b), nu = (long long)uw_total(s2->b);   // (barriers inside)
   const float bottom = sqrtf(ex->bsum / (float)nu);
   if (threadIdx.x != 0) return;
-  float best = -INFINITY;
-  long long besti = 0x7fffffffffffffffll;
-  for (int g = 0; g < UW_G; g++)
-    if (sb[g] > best || (sb[g] == best && si[g] < besti)) { best = sb[g]; besti = si[g]; }
+  for (int k = 1; k < 4; k++)
+    if (sb[k] > best || (sb[k] == best && si[k] < besti)) { best = sb[k]; besti = si[k]; }
   if (besti == 0x7fffffffffffffffll) besti = 0;
   info[0] = __int_as_float((int)besti);
   info[1] = sum; info[2] = mean; info[3] = bottom; info[4] = (sum == 0.f || nu < 1) ? 1.f : 0.f;
