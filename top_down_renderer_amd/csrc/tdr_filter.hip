@@ -2,6 +2,9 @@
 #include <random>
 
 #include <rocprim/device/device_radix_sort.hpp>
+// rocPRIM sorts up to 2^20 pairs by merging sorted blocks; 2048-item blocks instead of its 1024 save a merge launch
+// (20 000 keys: 40 -> 30 us; 8192-item blocks: 35 us, its radix sort proper — merge limit 0 — 90 us)
+using TdrSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 4>, rocprim::default_config>;
 
 #include "tdr_common.h"
 #include "tdr_sincosf.h"
@@ -927,7 +930,7 @@ static size_t radix_tmp_bytes(int64_t n) {
   size_t bytes = 0;
   uint32_t* k = nullptr;
   int32_t* v = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, 32u, (hipStream_t)0, false);
+  hipError_t e = rocprim::radix_sort_pairs<TdrSortConfig>(nullptr, bytes, k, k, v, v, (size_t)n, 0u, 32u, (hipStream_t)0, false);
   if (e != hipSuccess || bytes == 0) bytes = (size_t)(n + 4096) * 16;  // no device to ask: a generous bound
   return bytes;
 }
@@ -955,7 +958,7 @@ extern "C" int tdr_k_locality_order(const float* st, int64_t cap, int64_t n, int
   LAUNCH_CHECK("loc_key");
   unsigned bits = 2;
   while ((1u << (bits / 2)) < (unsigned)(2 * std::max(map_rows, map_cols)) && bits < 32) bits += 2;
-  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm_out, (size_t)n, 0u, bits, s,
+  HIP_TRY(rocprim::radix_sort_pairs<TdrSortConfig>(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm_out, (size_t)n, 0u, bits, s,
                                     false));
   return TDR_OK;
 }
