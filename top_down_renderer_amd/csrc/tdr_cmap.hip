@@ -101,11 +101,10 @@ extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
 }
 __global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
                                                          uint32_t* __restrict__ kmask) {
-  const int tcols = kmask_tcols(cols);
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // word t = tile t / 32, row t % 32 of the tile
-  if (t >= (int64_t)kmask_trows(rows) * tcols * 32) return;
-  const int64_t tile = t >> 5;
-  const int r = (int)(tile / tcols) * 32 + (int)(t & 31) - 32, c0 = (int)(tile % tcols) * 32 - 32;
+  const int colw = kmask_trows(rows) * 32;                            // words of a tile column
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // word t = tile column t / colw, row t % colw of it
+  if (t >= (int64_t)colw * kmask_tcols(cols)) return;
+  const int r = (int)(t % colw) - 32, c0 = (int)(t / colw) * 32 - 32;
   uint32_t bits = 0;
   if (r >= 0 && r < rows)
     for (int b = 0; b < 32; b++) {

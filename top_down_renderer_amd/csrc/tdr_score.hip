@@ -37,7 +37,7 @@ struct ScoreArgs {
   // the map's known mask (tdr_cmap.hip, layout: kmask_offset), read by the SKIP instantiations: its byte offset from
   // crec, bytes per row of its tiles
   unsigned kmask_off;
-  int kmask_row;
+  int kmask_row;         // bytes of one tile column of it
 };
 
 #include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const tdr_v2f offv = {off0, off1};
   unsigned moff[SKIP ? U : 1];   // SKIP: byte offset (from crec) of the known-mask word of sample u's cell ...
   int mbit[SKIP ? U : 1];        // ... and the cell's column (its low 5 bits: the bit in that word)
-  const int mconst = (int)a.kmask_off + 128;               // kmask_offset
+  const int mconst = (int)a.kmask_off + a.kmask_row + 128;   // kmask_offset
   auto cell_offset = [&](float2 t, int u) -> unsigned {
     tdr_v2f pv = {t.x, t.y};
     if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
@@ -2009,7 +2009,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
       const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
       r.ctiles_r = (map->rows >> lc) + 2;
       r.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
-      r.kmask_row = kmask_tcols(map->cols) * 128;
+      r.kmask_row = kmask_trows(map->rows) * 128;
       if ((rc = launch_score_form<true>(r, rf, map->ncls, side->s))) return rc;
       HIP_TRY(hipEventRecord(side->join, side->s));
       if ((rc = tdr_su_score(L, W.suw, s))) return rc;

@@ -25,7 +25,7 @@ struct CartArgs {
   // tdr_score_cart.hip only
   const uint32_t* desc;  // [cols][rows][4]: scan descriptor of every bin (cart_prep_kernel)
   unsigned kmask_off;    // byte offset of the known mask from crec
-  int kmask_row;         // bytes per row of its tiles (kmask_offset, tdr_score_dev.h)
+  int kmask_row;         // bytes of one tile column of it (kmask_offset, tdr_score_dev.h)
 };
 
 // dwords of workspace the descriptors take (behind the partial sums of tdr_score_cart_workspace_floats)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
   const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
   const uint32_t* __restrict__ crec = a.crec;
   const int ckcol = a.ctiles_r * 128 - 16 * CW, ckconst = a.ctiles_r * 128 + 128;   // cmap_offset
-  const int mrow = a.kmask_row, mconst = (int)a.kmask_off + 128;                     // kmask_offset
+  const int mrow = a.kmask_row, mconst = (int)a.kmask_off + a.kmask_row + 128;       // kmask_offset
   typedef const float __attribute__((address_space(4))) * tdr_const_f;
   typedef const uint32_t __attribute__((address_space(4))) * tdr_const_u;
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
@@ -266,7 +266,7 @@ int tdr_cart_skip_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* 
   LAUNCH_CHECK("cart_prep");
   a.desc = desc_ws;
   a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
-  a.kmask_row = kmask_tcols(map->cols) * 128;
+  a.kmask_row = kmask_trows(map->rows) * 128;
   const dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, rf);
 #define TDR_LAUNCH_CART_SKIP(NV4)                                                           \

@@ -61,16 +61,18 @@ __device__ __forceinline__ void cmap_load(const char* __restrict__ crecb, unsign
 // ---- the known mask behind the compact tiles (tdr_cmap.hip): 1 bit per cell in 32 x 32-cell tiles of 32 words — 128 bytes,
 // one cache line: lanes whose cells are a few cells apart, in whatever direction, read the same line.  With r' = r + 32
 // and c' = c + 32 (a guard band of unknown cells around the map) cell (r, c), r in [-1, rows], c in [-1, cols], is bit c & 31
-// of word r' & 31 of tile (r' >> 5, c' >> 5); the tiles are stored row by row, kmask_tcols(cols) per row.
+// of word r' & 31 of tile (r' >> 5, c' >> 5); the tiles are stored COLUMN by column, kmask_trows(rows) per tile column, so
+// the words of one tile column are simply its rows in order: word index = (c' >> 5) * 32 kmask_trows + r'.
 __host__ __device__ inline int kmask_tcols(int cols) { return (cols >> 5) + 2; }
 __host__ __device__ inline int kmask_trows(int rows) { return (rows >> 5) + 2; }
-// Byte offset of the cell's word: tile_row_bytes = 128 * kmask_tcols, kconst = (byte offset of the mask) + 128
-__device__ __forceinline__ unsigned kmask_offset(int ri, int ci, int tile_row_bytes, int kconst) {
-  const int rp = ri + 32;
-  int off, cq = ci >> 5, rq = rp >> 5, r5 = rp & 31;
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(rq), "s"(tile_row_bytes), "v"(kconst));
-  asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(off) : "v"(cq), "v"(off));
-  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(r5), "v"(off));
+// Byte offset of the cell's word: col_bytes = 128 * kmask_trows (a tile column), kconst = (byte offset of the mask) +
+// col_bytes + 128 — the two guard bands folded in: (c + 32) >> 5 = (c >> 5) + 1 and 4 (r + 32) = 4 r + 128.  Three integer
+// ops (the row-by-row order of the tiles this replaced took seven).
+__device__ __forceinline__ unsigned kmask_offset(int ri, int ci, int col_bytes, int kconst) {
+  int off;
+  const int cq = ci >> 5;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(off) : "v"(cq), "s"(col_bytes), "v"(kconst));
+  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(ri), "v"(off));
   return (unsigned)off;
 }
 

@@ -47,7 +47,7 @@
 struct SuArgs {
   const uint32_t* crec;    // compact records (narrow form)
   const uint32_t* kmask;   // the map's known mask (behind the tiles of crec)
-  int ktcols;              // its tiles per tile row (kmask_tcols)
+  int kcolw;               // words of one of its tile columns (32 kmask_trows)
   unsigned kmask_off;      // its byte offset from crec
   const float* dict;
   int dict_n, ctiles_r;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     uint32_t cbits[(4 * NS + 5) / 6];   // the column's low 5 bits of every sample (the bit of its mask word), six per word
 #pragma unroll
     for (int q = 0; q < (4 * NS + 5) / 6; q++) cbits[q] = 0;
-    const int mtrb = a.ktcols * 128, mconst = (int)a.kmask_off + 128;   // kmask_offset
+    const int mtrb = a.kcolw * 4, mconst = (int)a.kmask_off + a.kcolw * 4 + 128;   // kmask_offset
     int ii = i, jx = jj;
 #pragma unroll
     for (int d = 0; d < NS; d++) {
@@ -610,11 +610,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     uint32_t every = 0xFFFFFFFFu;   // AND of the words this thread staged
     if (fits) {
       const int total = H * Wb;
-      // (row fastest: consecutive threads read consecutive words of one 32 x 32-cell tile of the mask, kmask_offset)
+      // (row fastest: consecutive threads read consecutive words of one tile column of the mask, kmask_offset)
       for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int wc = idx / H, row = idx - wc * H;
-        const int rp = rlo + row + 32;
-        const uint32_t wv = kmask[((int64_t)(rp >> 5) * a.ktcols + (wlo + wc)) * 32 + (rp & 31)];
+        const uint32_t wv = kmask[(int64_t)(wlo + wc) * a.kcolw + (rlo + row + 32)];
         lds.bits[row * Wb + wc] = wv;
         every &= wv;
       }
@@ -750,7 +749,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.desc = reinterpret_cast<const uint32_t*>(base + W.desc);
   u.bbox = reinterpret_cast<const float*>(base + W.bbox);
   u.kmask = map->crec + tdr_cmap_tile_words(map->ncls, map->rows, map->cols);
-  u.ktcols = kmask_tcols(map->cols);
+  u.kcolw = kmask_trows(map->rows) * 32;
   u.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
   u.scan_pk = L.scan_pk;
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
