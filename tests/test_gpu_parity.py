@@ -998,6 +998,64 @@ def test_full_step_c1_vs_oracle(tdr, oracle):
                             s["theta"], s["scale"]], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("waves", [1, 0])
+def test_full_step_at_the_reference_defaults_vs_oracle(tdr, oracle, waves):
+    """The reference node's own operating point (src/top_down_render.cpp:53: 20 000 particles, a 100 x 25 polar image, 6
+    classes): one step — propagate, render, update — against the oracle over ALL particles: raw weights to 1e-5, the NaN
+    pattern, the statistics chains bit for bit given the same raw weights, the normalised weights, the arg-max, and the
+    resample indices bit for bit given the same weights.  waves = 1: the one-workgroup statistics evaluate their chains
+    wave by wave and the running sum is the one-launch kernel (the defaults); 0: the round-2 evaluations."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    import torch
+    sc = synth.make_scene("ref")
+    cfg = sc.cfg
+    n = len(sc.states)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    r.renderSemanticTopDown(sc.pts, cfg.res, cfg.ang_res)
+    b_uw, b_px = k.lib.tdr_config_uw_waves(-1), k.lib.tdr_config_prefix_small(-1)
+    try:
+        k.lib.tdr_config_uw_waves(waves)
+        k.lib.tdr_config_prefix_small(waves)
+        f = pkg.ParticleFilter(n, m, pkg.FilterParams(fixed_scale=1.0), seed=9, kernels=k, init_particles=False,
+                               locality_every=1)   # parity RNG: the reference's mt19937 stream
+        f.set_states(sc.states)
+        f.propagate((1.0, 0.0), 0.01)
+        f.update(r.last_scan(), None, cfg.res, shift=0.61)
+        raw, w, idx, amax = f.raw_weights(), f.weights(), f.resample_indices(), f._argmax()
+        # the oracle's step on the same inputs
+        fpo = oracle.make_params(cfg.ncls)
+        st = sc.states.copy()
+        last = oracle.propagate(st, 1.0, 0.0, 0.01, True, fpo, oracle.Rng(9))
+        scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
+        ref_raw = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, cfg.map_resolution),
+                                         oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, cfg.map_resolution), cfg.nb, cfg.nr,
+                                         scan, cfg.res, fpo, st)
+        _assert_weights(raw, ref_raw)
+        ref_w, ref_argmax, ref_stats = oracle.update_weights(ref_raw, last)
+        assert np.allclose(w, ref_w, rtol=2e-5, atol=0)
+        assert amax == ref_argmax or abs(w[ref_argmax] - w.max()) <= 2e-5 * w.max()
+        # the device's statistics on the ORACLE's raw weights: the serial chains bit for bit
+        wd, info = k.zeros((n,)), k.zeros((65536,))
+        k.update_weights(k.to_device(ref_raw), k.to_device(last), n, wd, info)
+        assert np.array_equal(info[1:4].cpu().numpy(), np.asarray(ref_stats[:3], np.float32), equal_nan=True)
+        # resampling the ORACLE's weights on the device: the oracle's indices bit for bit
+        ref_idx = oracle.resample_prefix(ref_w, n, 0.61)
+        runmax = k.empty((n,))
+        k.prefix(k.to_device(ref_w), n, runmax)
+        out = k.zeros((n,), torch.int32)
+        k.resample(runmax, n, n, 0.61, 0, n, out)
+        assert np.array_equal(out.cpu().numpy(), ref_idx)
+        mism = int((idx != ref_idx).sum())
+        assert mism <= 2 + n // 200, f"{mism} resample indices differ"
+    finally:
+        k.lib.tdr_config_uw_waves(b_uw)
+        k.lib.tdr_config_prefix_small(b_px)
+
+
 def test_full_step_with_an_empty_scan_vs_oracle(tdr, oracle):
     """A scan without a single usable return: every class image is zero, every cost is 0/0, every weight NaN — the
     statistics take the reference's `sum == 0 || num_under_mean < 1` branch (src/particle_filter.cpp:129-131: all weights
