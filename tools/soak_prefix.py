@@ -1,5 +1,5 @@
 """Soak test of the running-sum kernels: random weight vectors (dynamic range, dyadic values that force rounding ties,
-zero runs, rare negatives / NaN / inf) of random length, all three implementations against numpy's sequential float32
+zero runs, rare negatives / NaN / inf) of random length, all four implementations against numpy's sequential float32
 cumsum.  usage: PYTHONPATH=. python tools/soak_prefix.py [cases=300] (GPU box)"""
 import ctypes as C
 import sys
@@ -14,7 +14,8 @@ rng = np.random.default_rng(12345)
 f32 = np.float32
 bad = 0
 for case in range(cases):
-    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 7000), rng.integers(7000, 70000), rng.integers(70000, 400000)]))
+    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 7000), rng.integers(7000, 32769), rng.integers(32769, 70000),
+                        rng.integers(70000, 400000)]))
     kind = rng.integers(0, 6)
     if kind == 0:
         w = np.exp(rng.normal(0, rng.uniform(0.1, 6), n))
@@ -41,7 +42,9 @@ for case in range(cases):
         refmax = np.maximum.accumulate(np.where(np.isnan(ref), -np.inf, ref)).astype(f32)
     wd = k.to_device(w)
     ws = k.prefix_workspace(n)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):   # (2: the chunk walk, its first 32 768 weights through the one-launch kernel; 3: that kernel)
+        if mode == 3 and n > 32768:
+            continue
         rm, pf = k.zeros((n,)), k.zeros((n,))
         rc = k.lib.tdr_k_prefix_mode(C.c_void_p(wd.data_ptr()), n, mode, C.c_void_p(rm.data_ptr()),
                                      C.c_void_p(pf.data_ptr()) if mode else None, C.c_void_p(ws.data_ptr()), k.stream())
