@@ -174,6 +174,22 @@ class OracleKernels:
         else:
             dst[:, :n_new] = src[:, j]
 
+    def save_ml_state(self, info, st, n, out12, src_shard=0):
+        j = int(info[:1].view(torch.int32).item())
+        if j < 0 or j >= n:
+            j = 0
+        if src_shard:
+            full = st.view(-1, 7, src_shard).permute(1, 0, 2).reshape(7, -1)
+            f = full[:, j]
+        else:
+            f = st[:, j]
+        out12[:7] = f
+        out12[7] = 0.0
+        out12[8] = f[2] * f[5] + f[0]
+        out12[9] = f[3] * f[5] + f[1]
+        out12[10] = f[4]
+        out12[11] = f[5]
+
     def mean_cov(self, st, n, about=None):
         a = soa_to_aos(st, n)
         mean, cov = oracle.mean_cov(a)

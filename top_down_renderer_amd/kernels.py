@@ -308,6 +308,12 @@ class HipKernels:
         check(self.lib.tdr_k_gather_states(_ptr(src), src_cap, src_shard, _ptr(idx), n_new, _ptr(dst), dst.shape[1],
                                            self.stream()))
 
+    def save_ml_state(self, info, st, n, out12, src_shard=0):
+        """out12[:7] = the SoA fields of particle argmax (info[0]), out12[8:12] its mlState; st: the [7][cap] planes, or
+        with src_shard > 0 the all-gathered [rank][7][src_shard] buffer (particle_filter.cpp:145-147)."""
+        cap = st.shape[1] if (st.dim() == 2 and src_shard == 0) else 0
+        check(self.lib.tdr_k_save_ml_state(_ptr(info), _ptr(st), cap, src_shard, n, _ptr(out12), self.stream()))
+
     def mean_cov(self, st, n, about=None):
         """about: optional device tensor of 4 floats (computeCov about that mlState); None = about the mean."""
         out = self.empty((4800,))   # TDR_MEAN_COV_FLOATS: 24 results + reduction scratch

@@ -130,6 +130,7 @@ class ParticleFilter:
         self._maybe_uninit = True
         self._uniform_scale = 0.0
         self._ml_fields = None
+        self._ml_buf = None
         self.num_gaussians_ = 1   # :7
         self.gmm_means_ = np.zeros((0, 3), np.float32)
         self.gmm_covs_ = np.zeros((0, 3, 3), np.float32)
@@ -333,13 +334,13 @@ class ParticleFilter:
         tensor of the filter's own (device-side gather, no host round trip).  A view into st_all / self.st would be
         overwritten by the next all-gather of the resampled states (meanLikelihood, computeMeanCov, computeCov,
         computeGMM and freezeScale all gather) or by the next update."""
-        j = self.info[:1].view(torch.int32).to(torch.int64)          # argmax of update_weights, stays on the device
+        if self._ml_buf is None:
+            self._ml_buf = self.k.zeros((12,))
         if st_all is not None:
-            r = torch.div(j, nl, rounding_mode="floor")
-            flat = st_all.view(self.comm.world, 7, nl)
-            self._ml_fields = flat[r, :, j - r * nl].reshape(7).clone()
+            self.k.save_ml_state(self.info, st_all, self.num_particles_, self._ml_buf, src_shard=nl)
         else:
-            self._ml_fields = self.st.index_select(1, j).reshape(7).clone()
+            self.k.save_ml_state(self.info, self.st, self.num_particles_, self._ml_buf)
+        self._ml_fields = self._ml_buf[:7]   # (one small kernel; the buffer is rewritten by the next update only)
 
     def resample_indices(self):
         """Global source index of every particle of this rank's shard after the last update (for parity tests)."""
