@@ -328,13 +328,19 @@ int tdr_config_compact(int on);
 /* The polar scoring kernel has a second form that processes particles in (heading bin, Morton) order, every bin padded
  * to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes are skipped
  * wave-wide (csrc/tdr_score_su.hip).  Per launch the DENSE particles take it — those whose 64 neighbours in the locality
- * order lie within tdr_config_shift_uniform_span map cells (default 24; 0 = every particle counts as dense) — and the
+ * order lie within the SPAN, a number of map cells (0 = every particle counts as dense) — and the
  * others the lane-shift kernel, side by side: same partial sums, bit for bit, whichever kernel scores a particle.
  * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
  * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow
- * compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM / TDR_SU_SPAN set the initial values. */
+ * compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
+ * The span: by default it is TUNED WHILE THE FILTER RUNS — 8, 12, 16, 24 and 40 cells are timed over one scoring call
+ * each (HIP events on the caller's stream), the fastest is kept and the trial is repeated every 4000 calls; which one wins
+ * depends on how far the same-heading neighbours of moderately dense particles lie apart (config 2: 8, config 5: 16, a
+ * cluster with one heading: 24 or more).  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env
+ * TDR_SU_SPAN fix it (no timing, no host wait on the previous call's event); -1 only returns the span in use; -2 goes
+ * back to tuning. */
 int tdr_config_shift_uniform(int mode);
-float tdr_config_shift_uniform_span(float cells);   /* < 0 only returns it */
+float tdr_config_shift_uniform_span(float cells);
 /* The Cartesian scoring has a second kernel that reads the scan side of a sample as a scalar descriptor and gives an empty
  * scan bin one 4-byte gather from the map's known mask instead of the record gather, decode and FMAs
  * (csrc/tdr_score_cart.hip); same partial sums, bit for bit.  It is used whenever the map has narrow compact records;

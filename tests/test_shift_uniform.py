@@ -33,7 +33,7 @@ def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False,
     """Raw weights (and the states after scoring) of the lane-shift kernel (mode 0) and the shift-uniform one (mode 2).
     span 0: every particle through the shift-uniform kernel; > 0: particles farther than that from their neighbours in
     the locality order stay with the lane-shift kernel (the mixed launch)."""
-    before, before_span = k.lib.tdr_config_shift_uniform(-1), k.lib.tdr_config_shift_uniform_span(-1.0)
+    before = k.lib.tdr_config_shift_uniform(-1)
     out = []
     try:
         k.lib.tdr_config_shift_uniform_span(span)
@@ -56,7 +56,7 @@ def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False,
             out.append((f.raw_w[:n].cpu().numpy(), k.states_to_host(f.st, n, pkg.STATE_DTYPE)))
     finally:
         k.lib.tdr_config_shift_uniform(before)
-        k.lib.tdr_config_shift_uniform_span(before_span)
+        k.lib.tdr_config_shift_uniform_span(-2.0)   # back to the default: tuned while running
     return out
 
 
@@ -267,3 +267,47 @@ def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
     assert np.array_equal(out.cpu().numpy(), ref_idx)
     mism = int((idx != ref_idx).sum())
     assert mism <= 2 + n // 200, f"{mism} resample indices differ"
+
+
+def test_span_tuned_while_running_never_changes_the_weights(tdr, oracle):
+    """By default the span that routes particles between the two kernels of a mixed launch is tuned while the filter runs
+    (five candidates, one timed scoring call each, repeated now and then): twelve calls on the same particles — through
+    the skipped calls, every candidate and the settled state — give the lane-shift kernel's raw weights, bit for bit."""
+    from top_down_renderer_amd import synth
+    import torch
+    pkg, k = tdr
+    sc = synth.make_scene("c1", n_particles=512)
+    cfg = sc.cfg
+    st = synth.make_particles(cfg, sc.lab, sc.pose, np.random.default_rng(12), n=24_576)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((cfg.nb, cfg.nr), cfg.ang_res)
+    r = pkg.ScanRendererPolar(sc.lut, kernels=k)
+    r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    r.renderSemanticTopDown(sc.pts, cfg.res, cfg.ang_res)
+    before = k.lib.tdr_config_shift_uniform(-1)
+    try:
+        k.lib.tdr_config_shift_uniform_span(-2.0)   # tuning (the default)
+        ref = None
+        spans = set()
+        for mode, reps in ((0, 1), (2, 12)):
+            k.lib.tdr_config_shift_uniform(mode)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
+                                   locality_every=1)
+            f.set_states(st)
+            perm = k.zeros((f.cap_local,), torch.int32)
+            k.locality_order(f.st, len(st), m.rows, m.cols, perm)
+            for _ in range(reps):
+                launches = int(k.lib.tdr_shift_uniform_launches())
+                k.score(m.dev, m.scan_handle(r.last_scan()), float(cfg.res), f.fp_c, f.st, len(st), f.raw_w, perm=perm,
+                        uniform_scale=f._uniform_scale, n_total=len(st))
+                k.synchronize()
+                assert int(k.lib.tdr_shift_uniform_launches()) - launches == (1 if mode else 0)
+                got = f.raw_w[: len(st)].cpu().numpy()
+                if ref is None:
+                    ref = got
+                assert np.array_equal(got, ref, equal_nan=True)
+                spans.add(float(k.lib.tdr_config_shift_uniform_span(-1.0)))
+        assert len(spans) >= 1
+    finally:
+        k.lib.tdr_config_shift_uniform(before)
+        k.lib.tdr_config_shift_uniform_span(-2.0)

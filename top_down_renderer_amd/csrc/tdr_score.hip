@@ -1993,6 +1993,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
     L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
+    L.span = tdr_su_span_begin(((int64_t)n << 24) ^ ((int64_t)nb << 12) ^ nr ^ ((int64_t)map->rows << 40), s);
     if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &counts))) return rc;
     {
       // dense particles by heading bin through the shift-uniform kernel, sparse ones — in their locality order, behind the
@@ -2017,6 +2018,7 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
     }
     f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = counts + 2;
     launch_finalize(f, W.npad_part, s);
+    tdr_su_span_end(s);
   } else {
     rc = launch_score(a, map, rf, map->ncls, s);
     if (rc) return rc;

@@ -28,11 +28,19 @@ struct SuLaunch {
   int64_t npad;              // slot capacity = stride of part (su_npad)
   float* part;
   int32_t* ws;               // tdr_su_ws(...).total words
+  float span;                // map cells the 64 locality neighbours of a dense particle may span (tdr_su_span_begin)
 };
 // ordering passes + descriptors (everything but the scoring kernels).  slots_out: the slot list — the dense particles
 // by heading bin, every bin padded to whole waves (-1), then the sparse particles in the caller's order (su_key_kernel);
 // counts_out: device words {slots of the heading bins, sparse particles behind them, both together (what finalize walks)}
 int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out);
+// The span for this launch.  With a fixed span (tdr_config_shift_uniform_span, TDR_SU_SPAN) that one; otherwise it is tuned
+// while the filter runs: a few candidates are timed over one launch each (events on `s` around the whole scoring call,
+// tdr_su_span_end closes the measurement), the fastest is kept, and the trial is repeated every few thousand launches
+// (`shape`: anything that identifies the launch's sizes; a change restarts the trial).  The span only routes particles
+// between two kernels that produce identical partial sums: results do not depend on it.
+float tdr_su_span_begin(int64_t shape, hipStream_t s);
+void tdr_su_span_end(hipStream_t s);
 // the shift-uniform kernel over the heading bins' slots
 int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 #endif  // TDR_SCORE_SU_H_

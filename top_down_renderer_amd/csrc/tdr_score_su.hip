@@ -648,13 +648,74 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
   return g_su_mode;
 }
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
-static float g_su_span = [] {   // map cells the 64 locality neighbours of a "dense" particle may span
+// map cells the 64 locality neighbours of a "dense" particle may span: fixed (env TDR_SU_SPAN / the config call), or — the
+// default — tuned while running, starting from SU_SPAN_START
+#define SU_SPAN_START 16.f
+static bool g_su_span_fixed = getenv("TDR_SU_SPAN") != nullptr;
+static float g_su_span = [] {
   const char* e = getenv("TDR_SU_SPAN");
-  return e ? (float)atof(e) : 24.f;
+  return e ? (float)atof(e) : SU_SPAN_START;
 }();
-extern "C" float tdr_config_shift_uniform_span(float cells) {   // < 0: query only; 0: every particle counts as dense
-  if (cells >= 0.f) g_su_span = cells;
+extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it (0: every particle counts as dense);
+  if (cells >= 0.f) { g_su_span = cells; g_su_span_fixed = true; }   // -1: query only; below -1.5: back to tuning
+  else if (cells < -1.5f) { g_su_span = SU_SPAN_START; g_su_span_fixed = false; }
   return g_su_span;
+}
+// Which span is fastest depends on the particle set (how far the same-heading neighbours of a moderately dense particle
+// lie apart): measured on MI355X, config 2 wants 8 (7.00 against 7.29 ms at 24), config 5 wants 16 (15.9 against 17.7 at 8),
+// a cluster with a single heading wants 24 or more (4.6 against 6.9 ms at 8).
+namespace {
+constexpr float kSpanCand[] = {8.f, 12.f, 16.f, 24.f, 40.f};
+constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
+constexpr int kSpanSkip = 2;          // launches of a new shape that are not timed (first-use allocations, cold caches)
+constexpr int kSpanRetune = 4000;     // launches between two trials
+struct SpanTuner {
+  int64_t shape = -1;
+  int phase = -kSpanSkip;             // < 0: skipping; < kSpanCands: timing that candidate; else settled
+  int settled_launches = 0;
+  float best = SU_SPAN_START, best_ms = 3.0e38f;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool open = false, pending = false;
+};
+SpanTuner* span_tuner() {
+  static SpanTuner tab[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SpanTuner* t = &tab[dev];
+  if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return nullptr;
+  return t;
+}
+}  // namespace
+float tdr_su_span_begin(int64_t shape, hipStream_t s) {
+  if (g_su_span_fixed) return g_su_span;
+  SpanTuner* t = span_tuner();
+  if (!t) return g_su_span;
+  if (shape != t->shape) { t->shape = shape; t->phase = -kSpanSkip; t->best_ms = 3.0e38f; t->pending = false; }
+  if (t->pending) {   // the candidate timed by the previous launch
+    float ms = 0.f;
+    if (hipEventSynchronize(t->e1) == hipSuccess && hipEventElapsedTime(&ms, t->e0, t->e1) == hipSuccess && ms > 0.f &&
+        ms < t->best_ms) {
+      t->best_ms = ms;
+      t->best = kSpanCand[t->phase];
+    }
+    t->pending = false;
+    t->phase++;
+    if (t->phase >= kSpanCands) { t->settled_launches = 0; g_su_span = t->best; }
+  }
+  if (t->phase < 0) { t->phase++; return g_su_span; }
+  if (t->phase >= kSpanCands) {
+    if (++t->settled_launches < kSpanRetune) return t->best;
+    t->phase = 0;   // try them again: the particle set changes as the filter converges
+    t->best_ms = 3.0e38f;
+  }
+  t->open = hipEventRecord(t->e0, s) == hipSuccess;
+  return kSpanCand[t->phase];
+}
+void tdr_su_span_end(hipStream_t s) {
+  SpanTuner* t = g_su_span_fixed ? nullptr : span_tuner();
+  if (!t || !t->open) return;
+  t->open = false;
+  t->pending = hipEventRecord(t->e1, s) == hipSuccess;
 }
 static int64_t g_su_launches = 0;
 extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches; }
@@ -711,7 +772,7 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * nkeys + 3), s));
   HIP_TRY(hipMemsetAsync(slots, 0xFF, sizeof(int32_t) * (size_t)L.npad, s));
   hipLaunchKernelGGL(su_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), sizeof(int) * (size_t)nkeys, s, L.st, L.cap, n,
-                     L.perm, L.nb, g_su_span, keys_in, vals_in, cnt);
+                     L.perm, L.nb, L.span, keys_in, vals_in, cnt);
   LAUNCH_CHECK("su_key");
   hipLaunchKernelGGL(su_offsets_kernel, dim3(1), dim3(256), 0, s, (const int*)cnt, nkeys, start, slot_start, counts);
   LAUNCH_CHECK("su_offsets");
