@@ -305,6 +305,8 @@ def main():
                                  "score_polar_su_kernel for the dense particles, score_polar_kernel for the scattered ones — "
                                  "and `avg_launch_ms` spans both",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
+                         # polar configs: the dense / scattered split of the mixed launch the library's tuner settled on
+                         "shift_uniform_span_cells": float(k.lib.tdr_config_shift_uniform_span(-1.0)) if cfg.polar else None,
                          "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
                                          "frac": alg_gbps / 8000.0}},
         }
