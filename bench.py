@@ -58,7 +58,59 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch / rendezvous / collect path only: every rank joins the group, all-reduces a one and rank 0 "
+                         "prints a line — no GPU is touched (CPU test of the self-launch; use with --backend gloo)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: this process — which has not touched the GPU and never will — starts
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD (no exec: a process
+    must not be replaced once anything initialised the GPU, and a child keeps that rule trivially true), relays rank 0's
+    JSON line and exits with the child's code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        rc = 1
+    raise SystemExit(rc)
+
+
+def plumbing_only(a, world, rank):
+    """The N > 1 launch path up to the first collective, on the CPU."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "particle-updates/sec (render+score+resample)", "value": None, "plumbing_only": True,
+                          "n_gpus": world, "ranks_in_allreduce": int(t.item()), "backend": a.backend}), flush=True)
+    dist.destroy_process_group()
 
 
 def host_threads():
@@ -138,15 +190,18 @@ def measured_traffic(cfg_name, kernel, n_local):
 
 def main():
     a = parse()
-    import numpy as np
-    import torch
-
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)          # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
+    if a.plumbing_only:
+        return plumbing_only(a, world, rank)
+    import numpy as np
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
     if a.same_device:
@@ -161,6 +216,10 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
         group = dist.group.WORLD
+        # how many ranks the backend really joined: a one on every rank's device through one all-reduce
+        ones = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(ones)
+        ranks_joined = int(ones.item())
 
     import top_down_renderer_amd as pkg
     from top_down_renderer_amd import synth
@@ -310,6 +369,8 @@ def main():
                          "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
                                          "frac": alg_gbps / 8000.0}},
         }
+        if world > 1:
+            out["rccl_ranks" if a.backend == "nccl" else a.backend + "_ranks"] = ranks_joined
         if init_step_ms is not None:
             out["config"]["init_search_first_step_ms"] = init_step_ms
             out["config"]["init_search_first_step_cold_ms"] = init_cold_ms
