@@ -8,8 +8,8 @@
 //   * the mixture behind the adaptive particle count (:151-157, 245-318) is fitted on demand by computeGMM() with a
 //     deterministic EM (csrc/tdr_gmm.cpp) instead of cv::ml::EM in a detached thread; getGMM() returns it;
 //     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides;
-//   * visualize(cv::Mat&) (:373-423) is drawing code: with OpenCV present it draws the particles / mixture / best
-//     particle from a host copy of the states; without OpenCV it is a no-op (there is nothing to draw with);
+//   * visualize(cv::Mat&) (:373-423) is drawing code and not rebuilt: the call forwards a host snapshot of the
+//     particle set to a hook the host may set (setVisualizer), and is a no-op otherwise;
 //   * top_down_geo is accepted and ignored like in the reference's score, whose geometric block is commented out
 //     (src/state_particle.cpp:145-152); setGeometricCost(true) switches that block on.
 #ifndef PARTICLE_FILTER_H_
@@ -150,50 +150,29 @@ class ParticleFilter {
     for (int r = 0; r < map.rows; r++) std::memcpy(packed.data() + (size_t)r * map.cols, map.ptr<uint8_t>(r), (size_t)map.cols);
     updateMap(packed.data(), map.rows, map.cols, lut, map_center);
   }
-  // visualize (:373-423, call site src/top_down_render.cpp:431): particles as red arrows (green dots when outside the
-  // image), the mixture of the last computeGMM as blue ellipses, the max-likelihood particle as a blue arrow.
+  // visualize (call site src/top_down_render.cpp:431).  Drawing is out of scope here and this library
+  // links no image library: the call hands the host a copy of the particle states, the mixture of the last computeGMM
+  // and the max-likelihood state through the hook set with setVisualizer(), and does nothing when none is set.
+  struct Snapshot {
+    std::vector<State> particles;
+    std::vector<Eigen::Vector3f> gmm_means;
+    std::vector<Eigen::Matrix3f> gmm_covs;
+    bool have_best = false;
+    Eigen::Vector4f best;   // mlState of the max-likelihood particle (valid after the first update)
+  };
+  typedef void (*Visualizer)(cv::Mat& img, const Snapshot& snap, void* user);
+  void setVisualizer(Visualizer fn, void* user = nullptr) { visualizer_ = fn; visualizer_user_ = user; }
   void visualize(cv::Mat& img) {
-#ifdef TDR_HAVE_OPENCV
-    const int H = img.size().height, W = img.size().width;
-    for (const State& p : states()) {
-      const float x = p.dx_m * p.scale + p.init_x_px, y = p.dy_m * p.scale + p.init_y_px;   // mlState (:98-102)
-      cv::Point pt((int)x, (int)((float)H - y));
-      if (pt.x < 0 || pt.x > W || pt.y < 0 || pt.y > H) {
-        pt.x = std::min(std::max(pt.x, 5), W - 5);
-        pt.y = std::min(std::max(pt.y, 5), H - 5);
-        cv::circle(img, pt, 2, cv::Scalar(0, 255, 0), -1);
-      } else {
-        const cv::Point dir((int)(std::cos(p.theta) * 5), (int)(-std::sin(p.theta) * 5));
-        cv::arrowedLine(img, pt - dir, pt + dir, cv::Scalar(0, 0, 255), 2, cv::LINE_AA, 0, 0.3);
-      }
-    }
-    std::vector<Eigen::Vector3f> means;
-    std::vector<Eigen::Matrix3f> covs;
-    getGMM(means, covs);
-    for (size_t i = 0; i < means.size(); i++) {
-      // eigen-decomposition of the symmetric 2x2 position block in closed form (ascending eigenvalues)
-      const float a = covs[i](0, 0), b = covs[i](0, 1), d = covs[i](1, 1);
-      const float tr = a + d, disc = std::sqrt(std::max(0.f, (a - d) * (a - d) / 4 + b * b));
-      const float l0 = tr / 2 - disc, l1 = tr / 2 + disc;
-      if (l0 < 0 || l1 < 0) break;
-      float vx = b, vy = l0 - a;                       // eigenvector of l0
-      if (std::fabs(vx) + std::fabs(vy) < 1e-12f) { vx = 1; vy = 0; }
-      const float angle = std::atan2(-vy, vx);
-      const cv::Point center((int)means[i][0], (int)((float)H - means[i][1]));
-      cv::ellipse(img, center, cv::Size((int)std::sqrt(l0), (int)std::sqrt(l1)) * 2, angle * 180 / M_PI, 0, 360,
-                  cv::Scalar(255, 0, 0), 2);
-      const cv::Point dir((int)(std::cos(means[i][2]) * 5), (int)(-std::sin(means[i][2]) * 5));
-      cv::arrowedLine(img, center - dir, center + dir, cv::Scalar(255, 0, 0), 2, cv::LINE_AA, 0, 0.3);
-    }
+    if (!visualizer_) return;
+    Snapshot snap;
+    snap.particles = states();
+    getGMM(snap.gmm_means, snap.gmm_covs);
     float s[4], c[16];
     if (tdr_filter_mean_cov(f_, 1, s, c) == TDR_OK) {   // fails before the first update: no best particle yet
-      const cv::Point pt((int)s[0], (int)((float)H - s[1]));
-      const cv::Point dir((int)(std::cos(s[2]) * 5), (int)(-std::sin(s[2]) * 5));
-      cv::arrowedLine(img, pt - dir, pt + dir, cv::Scalar(255, 0, 0), 2, cv::LINE_AA, 0, 0.3);
+      snap.have_best = true;
+      for (int i = 0; i < 4; i++) snap.best[i] = s[i];
     }
-#else
-    (void)img;   // no OpenCV in this build: nothing to draw with
-#endif
+    visualizer_(img, snap, visualizer_user_);
   }
 
   // --- beyond the reference's surface -------------------------------------------------------------------------------
@@ -237,6 +216,8 @@ class ParticleFilter {
   int target_count_ = -1;
   bool adaptive_ = false;
   bool geometric_cost_ = false;
+  Visualizer visualizer_ = nullptr;
+  void* visualizer_user_ = nullptr;
   TopDownMapPolar* map_;
   FilterParams params_;
   tdr_filter* f_ = nullptr;

@@ -262,7 +262,13 @@ int main(int argc, char** argv) {
       extra[0] = after[0].init_x_px - before[0].init_x_px;      // +2 against the centre (7, -3) set above
       extra[1] = after[0].init_y_px - before[0].init_y_px;      // +2
       cv::Mat canvas(rows, cols, labels.data());
-      filter_->visualize(canvas);                                // drawing code: a no-op without OpenCV, must not throw
+      filter_->visualize(canvas);                                // no hook set: a no-op, must not throw
+      // with a hook the host gets a snapshot of what the reference's drawing code reads: states, mixture, best state
+      filter_->setVisualizer([](cv::Mat&, const ParticleFilter::Snapshot& s, void* user) {
+        *static_cast<float*>(user) = (float)s.particles.size() + (s.have_best ? 0.5f : 0.f);
+      }, &extra[7]);
+      filter_->visualize(canvas);
+      extra[7] -= (float)filter_->numParticles();                // 0.5 left: every particle + a best state arrived
     }
     {   // update() refuses images that do not have the shape given to samplePtsPolar instead of reading past them
       std::vector<Eigen::ArrayXXf> wrong, geo2;

@@ -258,6 +258,7 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     # cost with zero geometric images == the plain cost
     assert extra[4] == 1.0 and extra[6] == 768.0
     assert extra[5] <= 1e-6
+    assert extra[7] == 0.5     # visualize() handed every particle and a best state to the host's hook
     geo = np.stack([rd("out_geo_render.bin", np.float32), rd("out_geo_render1.bin", np.float32)])
     pts4 = np.ascontiguousarray(sc.pts[:, :4])
     assert np.array_equal(geo, oracle.raster_geo_polar(pts4, len(pts4), 1, cfg.res, cfg.ang_res, cfg.nb, cfg.nr))

@@ -206,7 +206,78 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a(f"s_cbranch_scc0 .Lsu_step{nxt}%=")
 
 
+# ---- static guard -------------------------------------------------------------------------------------------------
+# The loop names its registers itself; the compiler only knows what the statement's operand and clobber lists say.  Three
+# rules keep the two in step (a violation showed up once as memory faults at full size only):
+#   1. the text begins by draining the compiler's own loads in flight (s_waitcnt vmcnt(0) lgkmcnt(0));
+#   2. every register an instruction WRITES is a fixed register of the clobber list or a named operand the statement
+#      declares as an output ("+v" / "=v" in SU_ASM_OPERANDS of tdr_score_su.hip);
+#   3. every fixed register an instruction READS is inside the clobber list too (nothing outside the plan is touched), and
+#      the named inputs are never written.
+CLOBBER_V = range(8, 38)
+CLOBBER_S = range(40, 96)
+NO_DEST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch_", "s_cmp_", "s_bitcmp")   # write nothing / SCC only
+
+
+def statement_operands():
+    """(outputs, inputs) named in SU_ASM_OPERANDS of the kernel source."""
+    import re
+    src = open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su.hip")).read()
+    blk = src[src.index("#define SU_ASM_OPERANDS"):src.index(": SU_ASM_CLOBBERS")]
+    ops = re.findall(r'\[(\w+)\]\s*"([^"]+)"', blk)
+    return {n for n, c in ops if c[0] in "+="}, {n for n, c in ops if c[0] not in "+="}
+
+
+def regs_of(tok):
+    """Fixed registers a textual operand names: 'v12' -> [('v', 12)], 's[40:47]' -> s40..s47; named / literal -> []."""
+    import re
+    m = re.fullmatch(r"([vs])(\d+)", tok)
+    if m:
+        return [(m.group(1), int(m.group(2)))]
+    m = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", tok)
+    if m:
+        return [(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)]
+    return []
+
+
+def check_text(lines, outputs, inputs):
+    import re
+    assert lines[0] == "s_waitcnt vmcnt(0) lgkmcnt(0)", "the loop must begin by draining the loads in flight"
+    named_written = set()
+    for ln in lines:
+        if ln.endswith(":"):
+            continue
+        mn, _, rest = ln.partition(" ")
+        toks = [t.strip() for t in re.split(r",(?![^\[]*\])", rest)] if rest else []
+        writes_dest = not mn.startswith(NO_DEST)
+        for k, t in enumerate(toks):
+            named = re.fullmatch(r"%\[(\w+)\]", t)
+            is_dest = writes_dest and k == 0
+            if named:
+                assert named.group(1) in outputs | inputs, f"unknown operand in: {ln}"
+                if is_dest:
+                    assert named.group(1) in outputs, f"writes an input operand: {ln}"
+                    named_written.add(named.group(1))
+                continue
+            for kind, i in regs_of(t):
+                ok = i in (CLOBBER_V if kind == "v" else CLOBBER_S)
+                assert ok, f"{'writes' if is_dest else 'reads'} {kind}{i}, which is outside the clobber list: {ln}"
+    return named_written
+
+
+def check_all():
+    outputs, inputs = statement_operands()
+    n = 0
+    for uscale in (True, False):
+        for clamp, mask in ((True, True), (False, True), (False, False)):
+            written = check_text(loop_text(uscale, clamp, mask), outputs, inputs)
+            assert written <= outputs
+            n += 1
+    return n
+
+
 def main():
+    check_all()
     out = ["// tdr_score_su_asm.h — GENERATED by tools/gen_su_asm.py; do not edit.",
            "// The inner loop of score_polar_su_kernel for two-dword compact records (4-6 classes), see the generator for the",
            "// register plan and the schedule's cost model.",
