@@ -10,7 +10,12 @@
  * Conventions
  *  - plain C, no torch / Eigen / PCL types; every function returns an int status (TDR_OK == 0), never throws;
  *  - "tdr_k_*" entry points are stateless launchers: every pointer is a DEVICE pointer unless the name says
- *    `_host`, `stream` is a hipStream_t (NULL = default stream), nothing is allocated, nothing synchronises;
+ *    `_host`, `stream` is a hipStream_t (NULL = default stream), nothing is allocated, nothing synchronises, and no
+ *    state is kept between calls.  The one thing a launcher may be GIVEN is a caller-owned tdr_score_ctx (below):
+ *    a side stream and a tuner that then belong to that caller alone.  Load-time entry points (tdr_k_compact_map,
+ *    tdr_k_map_from_*) say so where they synchronise.  The tdr_config_* calls and the TDR_* environment variables they
+ *    mirror are PROCESS-WIDE switches for A/B measurements and tests (set them before the first launch, not while
+ *    another thread launches); results never depend on them unless a comment says so;
  *  - images follow the reference's Eigen::ArrayXXf layout: column-major float32, element (i,j) at i + rows*j,
  *    one image per class, images of one scan contiguous: [ncls][rows*cols];
  *  - particle state on the device is a structure of arrays `float st[TDR_ST_FIELDS][cap]` (plane stride `cap`),
@@ -112,10 +117,20 @@ int tdr_k_pack_map(const float* class_maps, const uint8_t* class_mask, int ncls,
 #define TDR_CMAP_WIDE_MAX_DICT 4096   /* ... of the wide form (16-bit fields; tdr_k_compact_map_wide) */
 #define TDR_CMAP_WORKSPACE_BYTES (16384 * 4 + 16384 * 2 + 256)
 int tdr_cmap_words(int ncls);
-/* dwords behind crec: the tiles (tdr_cmap_tile_words) followed by the map's known mask, one bit per cell, rows -1..rows of
- * (cols >> 5) + 2 words, cell (r, c) in word (r + 1) * wpr + (c >> 5) + 1 at bit c & 31 */
+/* dwords behind crec, three parts:
+ *  - the record tiles (tdr_cmap_tile_words);
+ *  - the map's KNOWN MASK, one bit per cell in 32 x 32-cell tiles of 32 words (one 128-byte line), the tiles stored tile
+ *    column by tile column with a guard band of 32 unknown cells around the map: with r' = r + 32, c' = c + 32 cell (r, c)
+ *    is bit c & 31 of word (c' >> 5) * 32 * ((rows >> 5) + 2) + r' (csrc/tdr_score_dev.h: kmask_offset);
+ *  - from dword tdr_cmap_plane_offset_words on, the CLASS PLANES (tdr_cmap_plane_words dwords each, 0 = none: the map is
+ *    too large for 32-bit offsets): per class one 16-bit value per cell — dictionary index in bits 0-9, known in bit 15 —
+ *    in tiles of 8 x 8 cells, tile column by tile column, a guard band of 8 cells (csrc/tdr_score_dev.h: plane_offset).
+ * Behind the float dictionary, `dict` also carries the dictionary as integers (narrow form): entries [1024, 2048) =
+ * value * 2^q as uint32, [2048] = q, [2049] = 1 when every value has that form (csrc/tdr_cmap.hip). */
 size_t tdr_cmap_words_total(int ncls, int rows, int cols);
 size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
+size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
+size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
 int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream);
 size_t tdr_cmap_wide_words_total(int ncls, int rows, int cols);   /* 0: no wide form for this class count */
 int tdr_k_compact_map_wide(tdr_map_desc* map, uint32_t* wrec_out, float* dict_out, void* workspace, void* stream);
@@ -206,6 +221,22 @@ int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* sc
                       const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
                       const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,
                       void* stream);
+/* The same with a caller-owned context.  A large launch runs two kernels — dense particles through the shift-uniform
+ * kernel, scattered ones through the ray-mapped kernel (tdr_config_shift_uniform below) — and chooses the split between
+ * them by timing; the context gives the call a stream of its own to run the two side by side (forked from and joined back
+ * into `stream` through events inside the call: the caller sees plain stream order) and keeps the tuner's state from call to
+ * call.  One context per filter (or per caller thread); it is bound to the device current at creation; calls that share a
+ * context must not overlap.  ctx == NULL: tdr_k_score_polar — the kernels one after the other on `stream`, the configured
+ * span, no state.  Results never depend on the context.  Nothing waits on the host either way (the tuner polls its events).
+ * tdr_score_ctx_span: the split the context's tuner has settled on so far (map cells). */
+typedef struct tdr_score_ctx tdr_score_ctx;
+int tdr_score_ctx_create(tdr_score_ctx** out);
+void tdr_score_ctx_destroy(tdr_score_ctx* ctx);
+float tdr_score_ctx_span(const tdr_score_ctx* ctx);
+int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
+                          const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
+                          const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,
+                          tdr_score_ctx* ctx, void* stream);
 
 /* Scoring WITH the geometric term of getCostForRot (src/state_particle.cpp:145-152: commented out in the reference, whose
  * geometric images are all-zero anyway; opt-in here): cost += (geo_i . shifted geo_cls_i).sum() * 0.01 and
@@ -325,22 +356,31 @@ int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void
  * forces the dense records (A/B measurements, tests), 1 restores the default, < 0 only queries.  Results never depend on
  * it: both forms decode to the same operands.  Returns the value in force.  (Environment: TDR_COMPACT=0.) */
 int tdr_config_compact(int on);
-/* The polar scoring kernel has a second form that processes particles in (heading bin, Morton) order, every bin padded
- * to whole waves, so that the scan side of a sample is a scalar operand and empty scan bins / absent classes are skipped
- * wave-wide (csrc/tdr_score_su.hip).  Per launch the DENSE particles take it — those whose 64 neighbours in the locality
- * order lie within the SPAN, a number of map cells (0 = every particle counts as dense) — and the
- * others the lane-shift kernel, side by side: same partial sums, bit for bit, whichever kernel scores a particle.
+/* Large polar launches take the INTEGER form of the score.  A scan count is an integer and a distance value of the map
+ * an integer multiple of 2^-q (tdr_cmap_words_total above), so a class's product sum is accumulated as a 64-bit integer:
+ * exact, hence independent of the order of the additions and of the kernel that forms it.  Two kernels share a launch:
+ *  - DENSE particles — those whose 64 neighbours in the locality order lie within the SPAN, a number of map cells (0 =
+ *    every particle counts as dense, a very large span = none) — go in (heading bin, Morton) order, every bin padded to
+ *    whole waves, lane = particle: the scan side of a sample is a scalar operand and empty scan bins / absent classes are
+ *    skipped wave-wide (csrc/tdr_score_su.hip);
+ *  - the others one WAVE per particle, lanes = consecutive samples along a ray, gathering 2-byte cells of per-class
+ *    planes (csrc/tdr_score_ray.hip).
+ * Whichever kernel scores a particle, its weight is the same bits; the float kernel (score_polar_kernel: small filters,
+ * shapes and maps the integer form does not cover, scans with fractional or non-finite counts — detected on the device)
+ * agrees with it to rounding (<= 1e-6 relative).
  * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
  * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow
- * compact records); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
- * The span: by default it is TUNED WHILE THE FILTER RUNS — 8, 12, 16, 24 and 40 cells are timed over one scoring call
- * each (HIP events on the caller's stream), the fastest is kept and the trial is repeated every 4000 calls; which one wins
- * depends on how far the same-heading neighbours of moderately dense particles lie apart (config 2: 8, config 5: 16, a
- * cluster with one heading: 24 or more).  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env
- * TDR_SU_SPAN fix it (no timing, no host wait on the previous call's event); -1 only returns the span in use; -2 goes
+ * compact records and class planes); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
+ * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — 8, 12, 16, 24 and 40 cells are timed over one
+ * scoring call each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
+ * repeated every 4000 calls.  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env TDR_SU_SPAN fix
+ * it for every caller; -1 only returns the configured span (16 by default: what a launch without a context uses); -2 goes
  * back to tuning. */
 int tdr_config_shift_uniform(int mode);
 float tdr_config_shift_uniform_span(float cells);
+/* Waves a scattered particle's window is split over in the ray-mapped kernel (1 .. 8; 0 = chosen per launch from its size,
+ * the default; < 0 only queries).  The sums are exact integers: results never depend on it (tests). */
+int tdr_config_ray_split(int k);
 /* The Cartesian scoring has a second kernel that reads the scan side of a sample as a scalar descriptor and gives an empty
  * scan bin one 4-byte gather from the map's known mask instead of the record gather, decode and FMAs
  * (csrc/tdr_score_cart.hip); same partial sums, bit for bit.  It is used whenever the map has narrow compact records;

@@ -113,7 +113,10 @@ class OracleKernels:
     def propagate_normals(self, rng, n, scale_freeze):
         return oracle.propagate_normals(n, bool(scale_freeze), rng)
 
-    def score(self, m, scan, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0):
+    def score_ctx_create(self):
+        return None   # (the device kernels' side stream and tuner: nothing to keep here)
+
+    def score(self, m, scan, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0, ctx=None):
         self.calls.append(("score", n))
         a = soa_to_aos(st, n)
         fpo = oracle.FilterParams.from_buffer_copy(bytes(fp))

@@ -1,5 +1,7 @@
-"""The shift-uniform scoring kernel (csrc/tdr_score_su.hip) against the lane-shift kernel (array equality: both produce
-the same partial sums) and against the CPU oracle (1e-5, BASELINE.json north_star).  Run with `pytest -m gpu`.
+"""The integer form of a polar launch — the shift-uniform kernel (csrc/tdr_score_su.hip) for dense particles, the ray-mapped
+kernel (csrc/tdr_score_ray.hip) for scattered ones — against itself (array equality: the integer sums are exact, whichever
+kernel forms them), against the float kernel (score_polar_kernel: equal to rounding) and against the CPU oracle (1e-5,
+BASELINE.json north_star).  Run with `pytest -m gpu`.
 
 Small launches are scored as SHARDS of a large filter (n_total = 10^6): the ring groups then have the size a large
 filter gets, which is what the kernel needs (groups of a multiple of 4 rings), and tdr_config_shift_uniform(2) takes the
@@ -29,10 +31,23 @@ def _assert_weights(w, ref, rtol=1e-5):
     assert err.max(initial=0.0) <= rtol, f"max rel err {err.max():.3e}"
 
 
-def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False, span=0.0):
-    """Raw weights (and the states after scoring) of the lane-shift kernel (mode 0) and the shift-uniform one (mode 2).
+ALL_RAY = 1e-6   # a span no two distinct particles fit in: every particle counts as scattered
+
+
+def _assert_float_form_agrees(raw_float, raw_int, rtol=3e-6):
+    """The float kernel adds a window's products up in float, group by group; the integer form is exact: same NaN / zero
+    pattern, values equal to the float kernel's rounding."""
+    assert np.array_equal(np.isnan(raw_float), np.isnan(raw_int))
+    ok = ~np.isnan(raw_int)
+    assert np.array_equal(raw_float[ok] == 0, raw_int[ok] == 0)
+    err = np.abs(raw_float[ok] - raw_int[ok]) / np.maximum(np.abs(raw_int[ok]), 1e-30)
+    assert err.max(initial=0.0) <= rtol, f"float form off by {err.max():.3e}"
+
+
+def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False, span=0.0, ctx=None):
+    """Raw weights (and the states after scoring) of the float kernel (mode 0) and of the integer form (mode 2).
     span 0: every particle through the shift-uniform kernel; > 0: particles farther than that from their neighbours in
-    the locality order stay with the lane-shift kernel (the mixed launch)."""
+    the locality order go through the ray-mapped kernel (the mixed launch); ALL_RAY: all of them."""
     before = k.lib.tdr_config_shift_uniform(-1)
     out = []
     try:
@@ -49,7 +64,7 @@ def _score_both(pkg, k, m, scan, res, st, params, locality=1, init_search=False,
                 k.locality_order(f.st, n, m.rows, m.cols, perm)
             launches = int(k.lib.tdr_shift_uniform_launches())
             k.score(m.dev, m.scan_handle(scan), float(res), f.fp_c, f.st, n, f.raw_w, perm=perm, init_search=init_search,
-                    uniform_scale=f._uniform_scale, n_total=N_TOTAL)
+                    uniform_scale=f._uniform_scale, n_total=N_TOTAL, ctx=ctx)
             k.synchronize()
             took = int(k.lib.tdr_shift_uniform_launches()) - launches
             assert took == (1 if mode == 2 else 0), f"mode {mode}: {took} shift-uniform launches"
@@ -96,11 +111,14 @@ def test_shift_uniform_equals_lane_shift_kernel_and_oracle(tdr, oracle, ncls, nb
                                  oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
                                  oracle.make_params(cfg.ncls, **params), st.copy())
     (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality)
-    assert np.array_equal(raw0, raw2, equal_nan=True)
+    _assert_float_form_agrees(raw0, raw2)
     _assert_weights(raw2, ref)
-    # mixed launch: the particles with neighbours within 3 cells through the shift-uniform kernel, the others not
-    (_, _), (raw3, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality, span=3.0)
-    assert np.array_equal(raw0, raw3, equal_nan=True)
+    # mixed launch: the particles with neighbours within 3 cells through the shift-uniform kernel, the others through the
+    # ray-mapped kernel (here on a stream of its own: a caller's context); then every particle through the ray-mapped kernel
+    (_, _), (raw3, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality, span=3.0, ctx=k.score_ctx_create())
+    assert np.array_equal(raw2, raw3, equal_nan=True)
+    (_, _), (raw4, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, locality, span=ALL_RAY)
+    assert np.array_equal(raw2, raw4, equal_nan=True)
 
 
 @pytest.mark.parametrize("holes", ["none", "one far corner"])
@@ -131,14 +149,17 @@ def test_shift_uniform_on_a_fully_known_map(tdr, oracle, holes):
     ref = oracle.compute_weights(oracle.OracleMap(maps, mask, 1.0), oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res),
                                  cfg.nb, cfg.nr, scan, cfg.res, oracle.make_params(cfg.ncls, **params), st.copy())
     (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, params)
-    assert np.array_equal(raw0, raw2, equal_nan=True)
+    _assert_float_form_agrees(raw0, raw2)
     _assert_weights(raw2, ref)
+    (_, _), (raw4, _) = _score_both(pkg, k, m, scan, cfg.res, st, params, span=ALL_RAY)
+    assert np.array_equal(raw2, raw4, equal_nan=True)
 
 
 @pytest.mark.parametrize("kind", ["empty", "dense", "fractional", "one bin"])
 def test_shift_uniform_scan_contents(tdr, oracle, kind):
     """Descriptor classes: every bin empty; most bins holding several classes; counts that are not integers and negative
-    ones (ParticleFilter::update is handed images, not counts); a single occupied bin."""
+    ones (ParticleFilter::update is handed images, not counts: such a scan has no integer form, the device notices and the
+    float kernel does the launch); a single occupied bin."""
     from top_down_renderer_amd import synth
     pkg, k = tdr
     cfg = synth.Config("suc", 3000, 6, 40, 16, 200, 900, seed=4300)
@@ -163,7 +184,13 @@ def test_shift_uniform_scan_contents(tdr, oracle, kind):
                                      oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
                                      oracle.make_params(cfg.ncls), st.copy())
     (raw0, _), (raw2, _) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0))
-    assert np.array_equal(raw0, raw2, equal_nan=True)
+    (_, _), (raw3, _) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0), span=4.0)
+    (_, _), (raw4, _) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0), span=ALL_RAY)
+    assert np.array_equal(raw2, raw3, equal_nan=True) and np.array_equal(raw2, raw4, equal_nan=True)
+    if kind == "fractional":
+        assert np.array_equal(raw0, raw2, equal_nan=True)   # the float kernel ran in both modes
+    else:
+        _assert_float_form_agrees(raw0, raw2)
     if kind != "fractional":   # sums of mixed signs cancel: the 1e-5 bound is for counts
         fin = np.isfinite(ref)
         _assert_weights(raw2[fin], ref[fin])
@@ -171,8 +198,8 @@ def test_shift_uniform_scan_contents(tdr, oracle, kind):
 
 
 def test_shift_uniform_keeps_zero_times_infinity(tdr, oracle):
-    """A map value of +inf makes 0 * inf = NaN in the reference's products (state_particle.cpp:136-139): with such a value
-    in the dictionary nothing is skipped, and both kernels agree on every NaN."""
+    """A map value of +inf makes 0 * inf = NaN in the reference's products (state_particle.cpp:136-139): a dictionary holding
+    such a value has no integer form, the float kernel does the launch in either mode and multiplies every product out."""
     from top_down_renderer_amd import synth
     pkg, k = tdr
     cfg = synth.Config("sui", 3000, 6, 32, 16, 160, 800, seed=4400)
@@ -208,13 +235,14 @@ def test_shift_uniform_after_the_init_search(tdr, oracle):
     scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, cfg.nb, cfg.nr)
     (raw0, st0), (raw2, st2) = _score_both(pkg, k, m, scan, cfg.res, st, dict(fixed_scale=1.0), init_search=True)
     assert np.array_equal(st0["theta"], st2["theta"]) and st2["have_init"].all()
-    assert np.array_equal(raw0, raw2, equal_nan=True)
+    _assert_float_form_agrees(raw0, raw2)
 
 
 def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
     """BASELINE configs[1] at full size: one step (propagate, render, update) with the default kernel choice — the
-    shift-uniform kernel at this size — against the lane-shift kernel (equality) and against the oracle over ALL 100 000
-    particles: raw weights to 1e-5, the NaN pattern, the normalised weights, the arg-max and the resample indices."""
+    integer form at this size, dense and scattered particles side by side — against the float kernel (to rounding) and
+    against the oracle over ALL 100 000 particles: raw weights to 1e-5, the NaN pattern, the normalised weights, the
+    arg-max and the resample indices."""
     from top_down_renderer_amd import synth
     pkg, k = tdr
     sc = synth.make_scene("c2")
@@ -241,8 +269,8 @@ def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
     finally:
         k.lib.tdr_config_shift_uniform(before)
     raw, w, idx, _ = res[1]
-    assert np.array_equal(res[0][0], raw, equal_nan=True)
-    assert np.array_equal(res[0][1], w) and np.array_equal(res[0][2], idx)
+    _assert_float_form_agrees(res[0][0], raw)
+    assert np.allclose(res[0][1], w, rtol=1e-5, atol=0) and int((res[0][2] != idx).sum()) <= 2 + n // 200
     # the oracle's step on the same inputs
     fpo = oracle.make_params(cfg.ncls)
     st = sc.states.copy()
@@ -270,9 +298,10 @@ def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
 
 
 def test_span_tuned_while_running_never_changes_the_weights(tdr, oracle):
-    """By default the span that routes particles between the two kernels of a mixed launch is tuned while the filter runs
-    (five candidates, one timed scoring call each, repeated now and then): twelve calls on the same particles — through
-    the skipped calls, every candidate and the settled state — give the lane-shift kernel's raw weights, bit for bit."""
+    """A caller that brings a context has the span that routes particles between the two kernels of a mixed launch tuned
+    while the filter runs (five candidates, one timed scoring call each, repeated now and then): sixteen calls on the same
+    particles — through the skipped calls, every candidate and the settled state — give the same raw weights, bit for bit,
+    and two contexts on one device (two filters of different shapes, called in turn) each settle for themselves."""
     from top_down_renderer_amd import synth
     import torch
     pkg, k = tdr
@@ -287,27 +316,32 @@ def test_span_tuned_while_running_never_changes_the_weights(tdr, oracle):
     before = k.lib.tdr_config_shift_uniform(-1)
     try:
         k.lib.tdr_config_shift_uniform_span(-2.0)   # tuning (the default)
-        ref = None
-        spans = set()
-        for mode, reps in ((0, 1), (2, 12)):
-            k.lib.tdr_config_shift_uniform(mode)
-            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
+        k.lib.tdr_config_shift_uniform(2)
+        filters = []
+        for n_f in (len(st), len(st) - 4096):   # two filters of different sizes on one device, a context each
+            f = pkg.ParticleFilter(n_f, m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
                                    locality_every=1)
-            f.set_states(st)
+            f.set_states(st[:n_f])
             perm = k.zeros((f.cap_local,), torch.int32)
-            k.locality_order(f.st, len(st), m.rows, m.cols, perm)
-            for _ in range(reps):
+            k.locality_order(f.st, n_f, m.rows, m.cols, perm)
+            filters.append((f, perm, n_f, k.score_ctx_create(), [None], set()))
+        for _ in range(16):
+            for f, perm, n_f, ctx, ref, spans in filters:   # in turn: neither disturbs the other's tuner
                 launches = int(k.lib.tdr_shift_uniform_launches())
-                k.score(m.dev, m.scan_handle(r.last_scan()), float(cfg.res), f.fp_c, f.st, len(st), f.raw_w, perm=perm,
-                        uniform_scale=f._uniform_scale, n_total=len(st))
+                k.score(m.dev, m.scan_handle(r.last_scan()), float(cfg.res), f.fp_c, f.st, n_f, f.raw_w, perm=perm,
+                        uniform_scale=f._uniform_scale, n_total=n_f, ctx=ctx)
                 k.synchronize()
-                assert int(k.lib.tdr_shift_uniform_launches()) - launches == (1 if mode else 0)
-                got = f.raw_w[: len(st)].cpu().numpy()
-                if ref is None:
-                    ref = got
-                assert np.array_equal(got, ref, equal_nan=True)
-                spans.add(float(k.lib.tdr_config_shift_uniform_span(-1.0)))
-        assert len(spans) >= 1
+                assert int(k.lib.tdr_shift_uniform_launches()) - launches == 1
+                got = f.raw_w[:n_f].cpu().numpy()
+                if ref[0] is None:
+                    ref[0] = got
+                assert np.array_equal(got, ref[0], equal_nan=True)
+                spans.add(ctx.span())
+        for f, perm, n_f, ctx, ref, spans in filters:
+            assert ctx.span() in (8.0, 12.0, 16.0, 24.0, 40.0)
+            assert len(spans) >= 1
+        # the same particles in both filters: the same weights
+        assert np.array_equal(filters[0][4][0][: filters[1][2]], filters[1][4][0], equal_nan=True)
     finally:
         k.lib.tdr_config_shift_uniform(before)
         k.lib.tdr_config_shift_uniform_span(-2.0)

@@ -11,12 +11,17 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
   v20..v23  scratch
   v24..v27  sample u: the record dword
-  v32..v37  accumulators of classes 0..5
+  (the accumulators of classes 0..5 — 64-bit integers, see below — , the normalisation and the known count are operands
+   of the statement: the register allocator places them)
   s40..s47 / s72..s79   the step's sample offsets {tx, ty} x 4           (even / odd steps: the loop body exists twice and
   s48..s63 / s80..s95   the step's descriptors {code, value, ckc, shift | flag} x 4 (su_prep_kernel)   requests the next
                         step's scalars into the other set before it works on its own)
   s65 / s66 byte offsets of the step in the offset / descriptor streams, s67 steps left - 1,
             s68 steps until the scan rows wrap - 1;  s69..s71 the same offsets / count for the step behind it
+Arithmetic: EXACT.  A scan count is an integer and a dictionary value an integer multiple of 2^-q (tdr_cmap.hip), so a
+class's product sum is accumulated as a 64-bit integer — v_mad_u64_u32, one instruction at the cost of the v_fmac_f32 it
+replaces (tools/valu_cost.hip) — and does not depend on the order of the additions: every kernel, launch and shard gives
+the same bits.
 Cost model behind the schedule (tools/valu_cost.hip, tools/ta_cost.hip; per CU): scalar instructions issue 1 per cycle,
 plain VOP2 2 cycles per SIMD, VOP3 / packed / conversions 4, a 64-lane gather >= 16 cycles of the L1 address path.
 Dependent vector instructions are kept at least one instruction apart (s_nop 0 where nothing else fits), as hipcc's own
@@ -41,8 +46,6 @@ def loop_text(uscale, clamp, mask=True):
     a("v_readfirstlane_b32 s66, %[doff]")
     a("v_readfirstlane_b32 s67, %[nleft]")
     a("v_readfirstlane_b32 s68, %[wleft]")
-    for k in range(6):
-        a(f"v_mov_b32 v{32 + k}, %[a{k}]")
     a("s_load_dwordx8 s[40:47], %[tb], s65")
     a("s_load_dwordx16 s[48:63], %[db], s66")
     a("s_waitcnt lgkmcnt(0)")
@@ -52,8 +55,6 @@ def loop_text(uscale, clamp, mask=True):
     step(a, uscale, clamp, mask, T=72, D=80, TN=40, DN=48, tag="o", nxt="e")
     a(".Lsu_out%=:")
     a("s_waitcnt lgkmcnt(0)")                        # (a request for the step behind the last one may still be in flight)
-    for k in range(6):
-        a(f"v_mov_b32 %[a{k}], v{32 + k}")
     a("v_mov_b32 %[toff], s65")
     a("v_mov_b32 %[doff], s66")
     a("v_mov_b32 %[nleft], s67")
@@ -157,43 +158,43 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a(f"s_cmp_eq_u32 s{code}, 0")
         a(f"s_cbranch_scc1 .Lsu_b{u}{tag}%=")
         if mask:
-            a(f"v_and_b32 v20, s{val}, v{16 + u}")                               # the bin's sum x known (:141-142)
+            a(f"v_and_b32 v20, s{val}, v{16 + u}")                               # the bin's count x known (:141-142)
         a(f"v_lshrrev_b32 v21, s{sh}, v{24 + u}")                                # the class's dictionary index * 4
         if mask:
-            a("v_add_f32 %[norm], %[norm], v20")
+            a("v_add_u32 %[norm], %[norm], v20")
         else:
-            a(f"v_add_f32 %[norm], s{val}, %[norm]")
+            a(f"v_add_u32 %[norm], s{val}, %[norm]")
         a("v_and_b32 v21, 0xffc, v21")
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                # the dictionary sits at LDS address 0
         a("s_waitcnt lgkmcnt(0)")
-        # acc[class] += value * distance (state_particle.cpp:136-139): a tree of wave-uniform branches over the class
+        # acc[class] += count * distance (state_particle.cpp:136-139), as integers: a tree of wave-uniform branches over the class
         a(f"s_cmp_lt_u32 s{code}, 4")
         a(f"s_cbranch_scc1 .Lsu_c{u}lo{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 5")
         a(f"s_cbranch_scc1 .Lsu_c{u}k3{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 6")
         a(f"s_cbranch_scc1 .Lsu_c{u}k4{tag}%=")
-        a(f"v_fmac_f32 v37, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a5], vcc, s{val}, v21, %[a5]")
         a(f"s_branch .Lsu_b{u}{tag}%=")
         a(f".Lsu_c{u}k4{tag}%=:")
-        a(f"v_fmac_f32 v36, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a4], vcc, s{val}, v21, %[a4]")
         a(f"s_branch .Lsu_b{u}{tag}%=")
         a(f".Lsu_c{u}k3{tag}%=:")
-        a(f"v_fmac_f32 v35, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a3], vcc, s{val}, v21, %[a3]")
         a(f"s_branch .Lsu_b{u}{tag}%=")
         a(f".Lsu_c{u}lo{tag}%=:")
         a(f"s_cmp_lt_u32 s{code}, 2")
         a(f"s_cbranch_scc1 .Lsu_c{u}k0{tag}%=")
         a(f"s_cmp_lt_u32 s{code}, 3")
         a(f"s_cbranch_scc1 .Lsu_c{u}k1{tag}%=")
-        a(f"v_fmac_f32 v34, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a2], vcc, s{val}, v21, %[a2]")
         a(f"s_branch .Lsu_b{u}{tag}%=")
         a(f".Lsu_c{u}k1{tag}%=:")
-        a(f"v_fmac_f32 v33, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a1], vcc, s{val}, v21, %[a1]")
         a(f"s_branch .Lsu_b{u}{tag}%=")
         a(f".Lsu_c{u}k0{tag}%=:")
-        a(f"v_fmac_f32 v32, s{val}, v21")
+        a(f"v_mad_u64_u32 %[a0], vcc, s{val}, v21, %[a0]")
         a(f".Lsu_b{u}{tag}%=:")
     # ---- next step
     a("s_mov_b32 s65, s69")
@@ -214,7 +215,7 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
 #      declares as an output ("+v" / "=v" in SU_ASM_OPERANDS of tdr_score_su.hip);
 #   3. every fixed register an instruction READS is inside the clobber list too (nothing outside the plan is touched), and
 #      the named inputs are never written.
-CLOBBER_V = range(8, 38)
+CLOBBER_V = range(8, 32)
 CLOBBER_S = range(40, 96)
 NO_DEST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch_", "s_cmp_", "s_bitcmp")   # write nothing / SCC only
 
@@ -290,8 +291,8 @@ def main():
                 out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
             out.append("")
     out.append('#define SU_ASM_CLOBBERS                                                                                      \\')
-    vregs = ", ".join(f'"v{i}"' for i in range(8, 38))
-    sregs = ", ".join(f'"s{i}"' for i in range(40, 96))
+    vregs = ", ".join(f'"v{i}"' for i in CLOBBER_V)
+    sregs = ", ".join(f'"s{i}"' for i in CLOBBER_S)
     out.append(f"  {vregs}, \\")
     out.append(f'  {sregs}, "vcc", "memory"')
     out.append("#endif  // TDR_SCORE_SU_ASM_H_")

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tdr_config_compact": (_i, [_i]),
     "tdr_config_shift_uniform": (_i, [_i]),
     "tdr_config_shift_uniform_span": (C.c_float, [C.c_float]),
+    "tdr_config_ray_split": (_i, [_i]),
     "tdr_config_cart_skip": (_i, [_i]),
     "tdr_config_init_mfma": (_i, [_i]),
     "tdr_config_uw_waves": (_i, [_i]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     "tdr_cmap_words": (_i, [_i]),
     "tdr_cmap_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_cmap_tile_words": (C.c_size_t, [_i, _i, _i]),
+    "tdr_cmap_plane_offset_words": (C.c_size_t, [_i, _i, _i]),
+    "tdr_cmap_plane_words": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
     "tdr_cmap_wide_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map_wide": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
@@ -82,6 +85,11 @@ SIGNATURES = {
     "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
                                _i64, _vp, _f, _i, _vp, _vp, _vp]),
+    "tdr_score_ctx_create": (_i, [C.POINTER(_vp)]),
+    "tdr_score_ctx_destroy": (None, [_vp]),
+    "tdr_score_ctx_span": (C.c_float, [_vp]),
+    "tdr_k_score_polar_ctx": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
+                                   _i64, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "tdr_score_geo_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar_geo": (_i, [C.POINTER(MapDescC), C.POINTER(MapDescC), _vp, _vp, _vp, _f, _f, _i, _i, _f,
                                    C.POINTER(FilterParamsC), _vp, _i64, _i64, _i64, _vp, _f, _i, _vp, _vp, _vp]),

@@ -94,10 +94,31 @@ extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols) {
   const CmapGeom g = cmap_geom(cw, rows, cols);
   return (size_t)g.tiles_r * g.tiles_c * 32;   // 128 bytes per tile
 }
-extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
+// dwords of the tiles + the known mask (+ 4 words: a lane of score_polar_kernel<SKIP> reads a whole record's worth of
+// dwords at a mask word), rounded up to whole 128-byte lines: where the class planes start
+extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols) {
   const size_t tiles = tdr_cmap_tile_words(ncls, rows, cols);
-  // (+ 4 words: a lane of score_polar_kernel<SKIP> reads a whole record's worth of dwords at a mask word)
-  return tiles ? tiles + (size_t)kmask_trows(rows) * kmask_tcols(cols) * 32 + 4 : 0;
+  if (!tiles) return 0;
+  return (tiles + (size_t)kmask_trows(rows) * kmask_tcols(cols) * 32 + 4 + 31) / 32 * 32;
+}
+// Behind the mask sit the CLASS PLANES (layout: plane_offset, tdr_score_dev.h): per class one 16-bit value per cell —
+// the class's dictionary index in bits 0-9, `known` in bit 15 — in tiles of 8 x 8 cells = one 128-byte line, the tiles
+// column by column with a guard band like the mask's.  A sample whose scan bin holds ONE class needs 2 bytes of the map,
+// and a ray of the polar window crosses 8 cells of a plane's line where it crosses 4 of a record tile's: the kernel that
+// scores scattered particles one wave per particle (tdr_score_ray.hip) pulls a third of the lines through the fabric
+// (measured on the config-2 scene: 2 400 lines per window against 6 700).  0: the map is too large for the kernels'
+// 32-bit byte offsets — it then has no planes and the scattered particles stay with score_polar_kernel.
+extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols) {
+  const size_t off = tdr_cmap_plane_offset_words(ncls, rows, cols);
+  if (!off) return 0;
+  const size_t per = (size_t)plane_trows(rows) * plane_tcols(cols) * 32;
+  if ((off + per * (size_t)ncls) * 4 > 0xFFFFFF00ull || (size_t)plane_trows(rows) * 128 >= (1u << 23) || per * 4 / 128 >= (1u << 24))
+    return 0;
+  return per;
+}
+extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
+  const size_t off = tdr_cmap_plane_offset_words(ncls, rows, cols);
+  return off ? off + tdr_cmap_plane_words(ncls, rows, cols) * (size_t)ncls : 0;
 }
 __global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
                                                          uint32_t* __restrict__ kmask) {
@@ -112,6 +133,28 @@ __global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict
       if (c >= 0 && c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) bits |= 1u << b;
     }
   kmask[t] = bits;
+}
+
+// one thread per cell of one class plane (tile-major: coalesced stores); blockIdx.y = class
+__global__ __launch_bounds__(256) void cmap_plane_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
+                                                         const unsigned* __restrict__ hash, const uint16_t* __restrict__ hidx,
+                                                         size_t plane_words, uint16_t* __restrict__ planes) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y, tr_n = plane_trows(rows);
+  if (t >= (int64_t)plane_words * 2) return;
+  const int64_t tile = t >> 6;
+  const int within = (int)(t & 63);
+  const int tc = (int)(tile / tr_n), tr = (int)(tile - (int64_t)tc * tr_n);
+  const int r = ((tr - 1) << 3) + (within >> 3), c = ((tc - 1) << 3) + (within & 7);
+  uint16_t v = 0;   // outside the map: index 0 (distance 0), unknown — the guard record
+  if (r >= 0 && r < rows && c >= 0 && c < cols) {
+    const float* src = rec + ((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf;
+    const unsigned bits = __float_as_uint(src[k]);
+    unsigned h = cmap_hash(bits);
+    while (hash[h] != bits) h = (h + 1) & (CMAP_HASH_SLOTS - 1);
+    v = (uint16_t)(hidx[h] | (src[rf - 1] != 0.f ? 0x8000u : 0u));
+  }
+  planes[(size_t)k * plane_words * 2 + t] = v;
 }
 
 // wide: 16-bit fields, two per dword (the wide form, below) instead of 10-bit fields, three per dword
@@ -189,6 +232,36 @@ static int cmap_dictionary(const tdr_map_desc* map, float* dict_out, void* works
   for (int h = 0; h < CMAP_HASH_SLOTS; h++)
     if (hh[h] != CMAP_EMPTY && hh[h] != 0u)
       hx[h] = (uint16_t)(std::lower_bound(vals.begin() + 1, vals.end(), hh[h]) - vals.begin());
+  // The dictionary as INTEGERS (narrow form): every value a non-negative multiple of 2^-q below 2^32 - then a product
+  // sum of integer scan counts with these values is an integer sum: exact, whatever the order it is added up in
+  // (tdr_score_su.hip, tdr_score_ray.hip).  Entries [1024, 2048) = value * 2^q as u32, [2048] = q, [2049] = 1 when
+  // the map qualifies (distance maps of resolution >= ~0.2: min(50, resolution * sqrt(d2)) >= 2^-3 ... 50).
+  if ((int)vals.size() <= TDR_CMAP_MAX_DICT) {
+    int q = 0;
+    bool ok = true;
+    for (size_t i = 1; i < vals.size() && ok; i++) {
+      float v;
+      std::memcpy(&v, &vals[i], 4);
+      if (!(v > 0.f) || !(v <= 3.402823466e+38f)) { ok = false; break; }
+      int e;
+      const double m = std::frexp((double)v, &e);                     // v = m 2^e, m in [0.5, 1): m 2^24 is an integer
+      uint32_t mi = (uint32_t)std::ldexp(m, 24);
+      int tz = 0;
+      while (!(mi & 1u)) { mi >>= 1; tz++; }
+      q = std::max(q, 24 - tz - e);                                    // v = mi 2^(e - 24 + tz)
+    }
+    std::vector<uint32_t> di(TDR_CMAP_MAX_DICT, 0u);
+    for (size_t i = 1; i < vals.size() && ok; i++) {
+      float v;
+      std::memcpy(&v, &vals[i], 4);
+      const double x = std::ldexp((double)v, q);
+      if (!(x < 4294967296.0)) { ok = false; break; }
+      di[i] = (uint32_t)x;
+    }
+    std::memcpy(dict.data() + TDR_CMAP_MAX_DICT, di.data(), sizeof(uint32_t) * TDR_CMAP_MAX_DICT);
+    const uint32_t tail[2] = {(uint32_t)q, ok ? 1u : 0u};
+    std::memcpy(dict.data() + 2 * TDR_CMAP_MAX_DICT, tail, sizeof(tail));
+  }
   HIP_TRY(hipMemcpyAsync(dict_out, dict.data(), sizeof(float) * TDR_CMAP_WIDE_MAX_DICT, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(hidx, hx.data(), sizeof(uint16_t) * CMAP_HASH_SLOTS, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));   // dict / hx live on this stack frame until the copies are done
@@ -210,6 +283,14 @@ static int cmap_pack(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, voi
     hipLaunchKernelGGL(cmap_kmask_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, s, map->rec, map->rows, map->cols,
                        map->rec_floats, crec_out + (size_t)g.tiles_r * g.tiles_c * 32);
     LAUNCH_CHECK("cmap_kmask");
+    const size_t pw = tdr_cmap_plane_words(map->ncls, map->rows, map->cols);
+    if (pw) {   // the class planes behind the mask
+      uint16_t* planes = reinterpret_cast<uint16_t*>(crec_out + tdr_cmap_plane_offset_words(map->ncls, map->rows, map->cols));
+      hipLaunchKernelGGL(cmap_plane_kernel, dim3((unsigned)cdiv((int64_t)pw * 2, 256), (unsigned)map->ncls), dim3(256), 0, s,
+                         map->rec, map->rows, map->cols, map->rec_floats, (const unsigned*)hash, (const uint16_t*)hidx, pw,
+                         planes);
+      LAUNCH_CHECK("cmap_plane");
+    }
   }
   HIP_TRY(hipStreamSynchronize(s));
   map->crec = crec_out;

@@ -126,6 +126,7 @@ struct tdr_filter {
   DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
   bool have_ml = false;
   hipStream_t stream = nullptr;
+  tdr_score_ctx* score_ctx = nullptr;   // this filter's own side stream and span tuner for its scoring launches (tdr.h)
   // Sharded over the ranks of `comm` (one process per GPU; NULL = the whole filter lives here).  n / n_max stay the
   // GLOBAL counts; this rank holds particles [rank * nl, (rank + 1) * nl), nl = n / world, in st[7][cap] with
   // cap = n_max / world.  raw_glob / ld_glob / w / runmax are global arrays, identical on every rank.
@@ -679,6 +680,7 @@ static int filter_create(tdr_map* map, int n_max, const tdr_filter_params* fp, u
     if (rc == TDR_OK) rc = f->st_glob.resize(TDR_ST_FIELDS * N);
   }
   if (rc == TDR_OK && hipMemset(f->last_dist.p, 0, cap * sizeof(float)) != hipSuccess) rc = failh(TDR_ERR_HIP, "memset");
+  if (rc == TDR_OK) rc = tdr_score_ctx_create(&f->score_ctx);
   if (rc != TDR_OK) {
     tdr_filter_destroy(f);
     return rc;
@@ -699,6 +701,7 @@ int64_t tdr_filter_num_local(const tdr_filter* f) { return f ? f->nl() : 0; }
 void tdr_filter_destroy(tdr_filter* f) {
   if (!f) return;
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
+  tdr_score_ctx_destroy(f->score_ctx);   // (waits for its side stream)
   delete f;
 }
 
@@ -948,8 +951,8 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
       m->desc.rec16 = m->rec16.p;
     }
   }
-  TTRY(tdr_k_score_polar(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, f->n, perm, f->uniform_scale,
-                         f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->stream));
+  TTRY(tdr_k_score_polar_ctx(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, f->n, perm, f->uniform_scale,
+                             f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->score_ctx, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised
   if (f->maybe_uninit && !(f->fp.force_on_map || f->fp.fixed_scale < 0)) f->maybe_uninit = false;
   return TDR_OK;

@@ -38,6 +38,8 @@ struct ScoreArgs {
   // crec, bytes per row of its tiles
   unsigned kmask_off;
   int kmask_row;         // bytes of one tile column of it
+  const int32_t* run_if = nullptr; // optional device words (int_form_off): the launch runs only then (the float form of a launch whose
+                         // integer form — tdr_score_su.hip, tdr_score_ray.hip — applies)
 };
 
 #include "tdr_score_dev.h"   // rot_shift_dev, the coordinate rounding, compact-record geometry / load / decode
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256, COMPACT ? (WIDE ? 3 : 5) : 1) void score_polar
   const unsigned bx = blockIdx.x;
 #endif
   const int64_t slot = ((int64_t)bx * 4 + wave) * 64 + lane;
+  if (a.run_if && !int_form_off(a.run_if)) return;  // (uniform)
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if ((int64_t)bx * 256 >= nact) return;  // whole workgroup idle (uniform)
   const bool valid = slot < nact;
@@ -596,12 +599,20 @@ struct FinalizeArgs {
   float gsum0, gsum1;
   int only_uninit;      // mode 1: slots whose particle already has a heading are left alone
   int tlog;             // 2^tlog neighbouring lanes share a slot's chunks (launch_finalize)
+  const int32_t* run_if = nullptr;   // optional device words: run only when the integer form is off (see ScoreArgs)
+  // the integer form (score_finalize_exact_kernel): `part` holds 64-bit integer sums
+  const uint32_t* ipart = nullptr;   // [chunks][2 ncls + 2][npad]
+  const uint32_t* dict_tail = nullptr;   // {q, ...}: a sum is a multiple of 2^-q
+  const int32_t* counts = nullptr;   // {slots of the dense share: nchunks chunk rows each; ...; all slots}: the others have ray_split rows
+  const int32_t* inexact = nullptr;
+  int ray_split = 1;
 };
 
 __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int T = 1 << a.tlog, t = (int)(gid & (T - 1));
   const int64_t slot = gid >> a.tlog;
+  if (a.run_if && !int_form_off(a.run_if)) return;
   const int64_t nact = a.count ? (int64_t)*a.count : a.n;
   if (slot >= nact) return;
   const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
@@ -691,6 +702,55 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
     a.best_cost[slot] = best;
     a.best_theta[slot] = bt;
   }
+}
+
+// The integer form of a launch (tdr_score_su.hip, tdr_score_ray.hip): a slot's chunk rows hold, per class, the 64-bit
+// integer sum of count x (distance 2^q) over the chunk's samples, and the normalisation and the known-cell count as
+// integers.  Integer sums are exact: whatever kernel, split or order produced the rows, their total is the same number, and
+// so is the weight.  dot_c = total 2^-q rounded to float once (the reference: a float sum of float products in Eigen's
+// order, state_particle.cpp:136-138), then the reference's own arithmetic (:136-139, 154, 212).
+__global__ __launch_bounds__(256) void score_finalize_exact_kernel(FinalizeArgs a) {
+  if (int_form_off(a.inexact)) return;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (int64_t)a.counts[2]) return;
+  const int64_t p = a.order[slot];
+  if (p < 0) return;   // a padding slot of the shift-uniform order
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  if (particle_gated(a.gate, cx, cy, scale)) {
+    a.raw_w[p] = 0.f;
+    return;
+  }
+  const int rows = 2 * a.ncls + 2;
+  const int nch = slot < (int64_t)a.counts[0] ? a.nchunks : a.ray_split;
+  unsigned long long tot[TDR_MAX_CLASSES], norm = 0, known = 0;
+#pragma unroll
+  for (int k = 0; k < TDR_MAX_CLASSES; k++) tot[k] = 0;
+  for (int c = 0; c < nch; c++) {
+    const uint32_t* o = a.ipart + (int64_t)c * rows * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls)
+        tot[k] += (unsigned long long)o[(int64_t)(2 * k) * a.npad] | ((unsigned long long)o[(int64_t)(2 * k + 1) * a.npad] << 32);
+    norm += o[(int64_t)(2 * a.ncls) * a.npad];
+    known += o[(int64_t)(2 * a.ncls + 1) * a.npad];
+  }
+  float cost;
+  if ((float)known / (float)a.P < 0.5) {   // state_particle.cpp:117-120
+    cost = __builtin_nanf("");
+  } else {
+    const int q = (int)a.dict_tail[0];
+    cost = 0.f;
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls) {
+        const float dot = (float)ldexp((double)tot[k], -q);
+        cost = (float)((double)cost + (double)dot * 0.01 * (double)a.fp.class_weights[k]);  // :136-139
+      }
+    cost = cost / (float)norm;  // :154
+  }
+  a.raw_w[p] = (float)(1. / (double)(cost + a.fp.regularization));  // :212
 }
 
 // nslots: slots the launch covers (a.n / a.count still bound the active ones)
@@ -1656,7 +1716,10 @@ static ScoreWs score_ws(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   w.npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   w.su = tdr_su_shape_ok(nb, nr, w.group, n_total) && tdr_cmap_words(ncls) != 0;
   w.npad_part = w.su ? su_npad(std::max<int64_t>(n, 1), nb) : w.npad;
-  w.off_aux = (int64_t)w.nchunks * (rf + 1) * w.npad_part;
+  // partial sums: [chunks][rows][slots] — float form rf + 1 rows; integer form (tdr_score_su.hip) 2 ncls + 2 rows of
+  // words and room for the chunk rows of a scattered particle's window (tdr_score_ray.hip)
+  w.off_aux = w.su ? (int64_t)std::max(w.nchunks, TDR_RAY_MAX_SPLIT) * std::max(rf + 1, 2 * ncls + 2) * w.npad_part
+                   : (int64_t)w.nchunks * (rf + 1) * w.npad_part;
   w.off_utab = w.off_aux + 3 * w.npad + 64;
   w.off_su = (w.off_utab + 2 * (int64_t)nb * nr + 63) / 64 * 64;
   w.total = w.off_su;
@@ -1689,8 +1752,8 @@ static size_t g_prof_used = 0;
 struct ScoreProfScope {
   hipStream_t s;
   hipEvent_t stop = nullptr;
-  explicit ScoreProfScope(hipStream_t s_) : s(s_) {
-    if (!g_prof_on) return;
+  explicit ScoreProfScope(hipStream_t s_, bool on = true) : s(s_) {
+    if (!g_prof_on || !on) return;
     if (g_prof_used == g_prof_events.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -1794,9 +1857,9 @@ static bool map_has_compact(const tdr_map_desc* map, int rf) {
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   return (int64_t)((map->rows >> lc) + 2) * 128 < (1 << 23) && map->cols < (1 << 24);   // cmap_offset: 24-bit operands
 }
-static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s) {
+static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, hipStream_t s, bool profile = true) {
   a.crec = nullptr; a.dict = nullptr; a.dict_n = 0; a.ctiles_r = 0;
-  ScoreProfScope prof(s);
+  ScoreProfScope prof(profile ? s : nullptr, profile);
   if (!map_has_compact(map, rf)) return launch_score_form<false>(a, rf, ncls, s);
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   a.crec = map->crec;
@@ -1817,33 +1880,81 @@ static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, 
   return launch_score_form<true>(a, rf, ncls, s);
 }
 
-// A stream of the library's own (one per device) for work that runs beside the caller's stream inside one call; joined
-// again through events before the call's last kernel, so the caller sees plain stream order.
-struct SideStream {
-  hipStream_t s;
-  hipEvent_t fork, join;
+// tdr_score_ctx (tdr.h): what a scoring call keeps BETWEEN calls and BESIDE the caller's stream — a stream of its own for
+// the second kernel of a mixed launch (joined again through events before the call's last kernel, so the caller sees
+// plain stream order) and the span tuner of tdr_score_su.h.  It belongs to one caller (a filter handle): nothing of it is
+// shared between filters, threads or devices.  Without a context a call runs its kernels one after the other on the
+// caller's stream with the configured span.
+struct tdr_score_ctx {
+  int device = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  SpanTuner tuner;
 };
-static SideStream* side_stream() {
-  static SideStream* tab[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!tab[dev]) {
-    SideStream* x = new SideStream;
-    const hipError_t rc = hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking);
-    if (rc != hipSuccess || hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&x->join, hipEventDisableTiming) != hipSuccess) {
-      delete x;
-      return nullptr;
-    }
-    tab[dev] = x;
+extern "C" int tdr_score_ctx_create(tdr_score_ctx** out) {
+  if (!out) return fail(TDR_ERR_ARG, "score_ctx_create: null pointer");
+  *out = nullptr;
+  tdr_score_ctx* c = new (std::nothrow) tdr_score_ctx;
+  if (!c) return fail(TDR_ERR_NOMEM, "score_ctx_create: out of memory");
+  hipError_t e = hipGetDevice(&c->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    tdr_score_ctx_destroy(c);
+    return fail(TDR_ERR_HIP, "score_ctx_create: %s", hipGetErrorString(e));
   }
-  return tab[dev];
+  *out = c;
+  return TDR_OK;
 }
+extern "C" void tdr_score_ctx_destroy(tdr_score_ctx* c) {
+  if (!c) return;
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->join) (void)hipEventDestroy(c->join);
+  if (c->tuner.e0) (void)hipEventDestroy(c->tuner.e0);
+  if (c->tuner.e1) (void)hipEventDestroy(c->tuner.e1);
+  delete c;
+}
+extern "C" float tdr_score_ctx_span(const tdr_score_ctx* c) {   // the span the context's tuner has settled on so far
+  return c ? c->tuner.best : tdr_config_shift_uniform_span(-1.f);
+}
+// Fork onto the context's stream and join again — on EVERY way out of the scope, so that a failed launch never leaves the
+// side stream running against buffers the caller may free, nor the tuner's measurement open.
+struct SideScope {
+  tdr_score_ctx* c;
+  hipStream_t s;
+  bool forked = false;
+  SideScope(tdr_score_ctx* c_, hipStream_t s_) : c(c_), s(s_) {}
+  hipStream_t fork() {   // the stream the second kernel goes to: the context's, ordered behind what `s` holds so far
+    if (!c) return s;
+    if (hipEventRecord(c->fork, s) != hipSuccess || hipStreamWaitEvent(c->side, c->fork, 0) != hipSuccess) return s;
+    forked = true;
+    return c->side;
+  }
+  void join() {
+    if (!forked) return;
+    forked = false;
+    if (hipEventRecord(c->join, c->side) == hipSuccess) (void)hipStreamWaitEvent(s, c->join, 0);
+    else (void)hipStreamSynchronize(c->side);
+  }
+  ~SideScope() {
+    join();
+    if (c) tdr_su_span_end(&c->tuner, s);
+  }
+};
 
 extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
                                  float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
                                  int64_t n_total, const int32_t* perm, float uniform_scale, int init_search,
                                  float* raw_w, float* workspace, void* stream) {
+  return tdr_k_score_polar_ctx(map, tab, scan_pk, nb, nr, res, fp, st, cap, n, n_total, perm, uniform_scale, init_search,
+                               raw_w, workspace, nullptr, stream);
+}
+extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr,
+                                     float res, const tdr_filter_params* fp, float* st, int64_t cap, int64_t n,
+                                     int64_t n_total, const int32_t* perm, float uniform_scale, int init_search,
+                                     float* raw_w, float* workspace, tdr_score_ctx* ctx, void* stream) {
   if (!map || !map->rec || !tab || !scan_pk || !fp || !st || !raw_w || !workspace)
     return fail(TDR_ERR_ARG, "score: null pointer");
   if (n_total <= 0) n_total = n;
@@ -1984,41 +2095,47 @@ extern "C" int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, cons
   f.P = (int64_t)nb * nr; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
   f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
-  if (W.su && map_has_compact(map, rf) && !map_is_wide(map, rf)) {
-    // shift-uniform order (tdr_score_su.h): same partial sums, slot-indexed over the padded order
+  if (W.su && map_has_compact(map, rf) && !map_is_wide(map, rf) && tdr_ray_map_ok(map)) {
+    // The INTEGER form of the launch (tdr_score_su.h): dense particles by heading bin through the shift-uniform kernel,
+    // scattered ones — behind the bins in the same slot list — one wave each through the ray-mapped kernel; both form exact
+    // integer sums, so a particle's weight does not depend on which of the two scored it.  The two run side by side when the
+    // caller brought a context (one is bound by vector issue, the other by the memory system).  A scan or a map without
+    // an integer form (fractional or non-finite counts; a dictionary finer than 2^-q) raises the device word `inexact`:
+    // the integer kernels then return at once and the float kernel below does the launch — nothing is decided on the host.
     const int32_t* slots = nullptr;
-    const int32_t* counts = nullptr;   // device words {slots of the shift-uniform share, lane-shift share, both}
+    const int32_t* counts = nullptr;   // device words {slots of the dense share, scattered particles behind them, both}
     SuLaunch L;
     L.map = map; L.tab = a.utab ? a.utab : a.tab; L.uniform_scale = a.utab != nullptr; L.scan_pk = scan_pk;
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
     L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
+    L.ray_split = tdr_ray_splits(nb, nr, n);
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
-    L.span = tdr_su_span_begin(((int64_t)n << 24) ^ ((int64_t)nb << 12) ^ nr ^ ((int64_t)map->rows << 40), s);
+    SideScope side(ctx, s);   // (closes the tuner's measurement and joins the side stream on every way out)
+    L.span = tdr_su_span_begin(ctx ? &ctx->tuner : nullptr,
+                               ((int64_t)n << 24) ^ ((int64_t)nb << 12) ^ nr ^ ((int64_t)map->rows << 40), s);
     if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &counts))) return rc;
+    if ((rc = tdr_ray_prepare(L, W.suw, s))) return rc;
+    const int32_t* inexact = counts + 4;
     {
-      // dense particles by heading bin through the shift-uniform kernel, sparse ones — in their locality order, behind the
-      // bins in the same slot list — through the lane-shift kernel: identical partial sums either way.  The two launches
-      // run side by side (a stream of the library's own): one is bound by vector issue, the other by the memory system.
       ScoreProfScope prof(s);
-      SideStream* side = side_stream();
-      if (!side) return fail(TDR_ERR_HIP, "score: cannot create the side stream");
-      HIP_TRY(hipEventRecord(side->fork, s));
-      HIP_TRY(hipStreamWaitEvent(side->s, side->fork, 0));
-      ScoreArgs r = a;
-      r.order = slots; r.slot_base = counts; r.count = counts + 1; r.npad = W.npad_part;
-      r.crec = map->crec; r.dict = map->dict; r.dict_n = map->dict_n;
-      const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-      r.ctiles_r = (map->rows >> lc) + 2;
-      r.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
-      r.kmask_row = kmask_trows(map->rows) * 128;
-      if ((rc = launch_score_form<true>(r, rf, map->ncls, side->s))) return rc;
-      HIP_TRY(hipEventRecord(side->join, side->s));
+      hipStream_t s2 = side.fork();
+      if ((rc = tdr_ray_score(L, W.suw, s2))) return rc;
       if ((rc = tdr_su_score(L, W.suw, s))) return rc;
-      HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
+      side.join();
+      // the float form, for the launches the integer form does not cover
+      ScoreArgs r = a;
+      r.run_if = inexact;
+      if ((rc = launch_score(r, map, rf, map->ncls, s, false))) return rc;
     }
-    f.npad = W.npad_part; f.n = W.npad_part; f.order = slots; f.count = counts + 2;
-    launch_finalize(f, W.npad_part, s);
-    tdr_su_span_end(s);
+    FinalizeArgs fx = f;
+    fx.npad = W.npad_part; fx.order = slots; fx.counts = counts; fx.inexact = inexact;
+    fx.ipart = reinterpret_cast<const uint32_t*>(a.part);
+    fx.dict_tail = reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT;
+    fx.nchunks = W.nchunks; fx.ray_split = L.ray_split;
+    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(W.npad_part, 256)), dim3(256), 0, s, fx);
+    LAUNCH_CHECK("score_finalize_exact");
+    f.run_if = inexact;
+    launch_finalize(f, n, s);
   } else {
     rc = launch_score(a, map, rf, map->ncls, s);
     if (rc) return rc;

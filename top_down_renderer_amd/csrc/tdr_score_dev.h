@@ -76,6 +76,28 @@ __device__ __forceinline__ unsigned kmask_offset(int ri, int ci, int col_bytes, 
   return (unsigned)off;
 }
 
+// ---- the class planes behind the mask (tdr_cmap.hip): per class a 16-bit value per cell (dictionary index | known << 15)
+// in tiles of 8 x 8 cells (128 bytes), tiles column by column, plane_trows per tile column, a guard band of 8 cells.  With
+// r' = r + 8, c' = c + 8 the cell's byte offset inside its plane is (c' >> 3) * CS + r' * 16 + (c' & 7) * 2, CS = 128
+// plane_trows; as the row part is linear:  (c >> 3) * (CS - 16) + 2 c + 16 r + (CS + 128).
+__host__ __device__ inline int plane_trows(int rows) { return (rows >> 3) + 2; }
+__host__ __device__ inline int plane_tcols(int cols) { return (cols >> 3) + 2; }
+__device__ __forceinline__ unsigned plane_offset(int ri, int ci, int pkcol, int pkconst) {   // pkcol = CS - 16, pkconst = base + CS + 128
+  int t1, off;
+  const int cq = ci >> 3;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "s"(pkcol), "v"(pkconst));
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t1) : "v"(ci), "v"(t1));
+  asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ri), "v"(t1));
+  return (unsigned)off;
+}
+
+// The two device words that decide between the integer and the float form of a launch (ray_prep_kernel writes them):
+// flags[0] != 0: a scan count or the dictionary has no integer form; flags[1]: an upper bound of (the scan's total count) /
+// 256 — below 2^24 the total stays below 2^32, the normalisation sums fit 32 bits and the class sums 64.
+__device__ __forceinline__ bool int_form_off(const int32_t* flags) {
+  return flags[0] != 0 || (uint32_t)flags[1] >= (1u << 24);
+}
+
 // one compact record -> the RF operands the dense record would have delivered, bit for bit (ldict: the dictionary in LDS)
 template <int RF, bool KSLOT>
 __device__ __forceinline__ void cmap_decode(const uint32_t (&w)[CmapShape<RF, KSLOT>::CW], const float* ldict, float (&m)[RF]) {

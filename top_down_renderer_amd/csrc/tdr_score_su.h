@@ -1,4 +1,5 @@
-// tdr_score_su.h — host interface of the shift-uniform polar scoring path (tdr_score_su.hip), used by tdr_score.hip.
+// tdr_score_su.h — host interface of the integer polar scoring path: the shift-uniform kernel for dense particles
+// (tdr_score_su.hip) and the ray-mapped kernel for scattered ones (tdr_score_ray.hip), used by tdr_score.hip.
 #ifndef TDR_SCORE_SU_H_
 #define TDR_SCORE_SU_H_
 #include "tdr_common.h"
@@ -9,9 +10,11 @@ static inline int64_t su_npad(int64_t n, int nb) { return cdiv(n + 63 * std::min
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
 // The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
 struct SuWs {
-  int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, total;
-  // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3]
+  int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, ray_tab, ray_desc, ray_multi, total;
+  // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3][n_multi][inexact][mass bound]  (int_form_off)
 };
+#define TDR_SU_TAIL_INTS 6        // the words of `ints` behind the three per-key tables
+#define TDR_RAY_MAX_SPLIT 8       // waves a particle's window may be split over (tdr_ray_splits): chunk rows of `part`
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
 
 struct SuLaunch {
@@ -26,7 +29,8 @@ struct SuLaunch {
   const int32_t* perm;       // caller's locality order (NULL = identity)
   int group, nchunks;
   int64_t npad;              // slot capacity = stride of part (su_npad)
-  float* part;
+  float* part;               // integer partial sums, [chunks][2 ncls + 2][npad] words (tdr_score_su.hip)
+  int ray_split;             // waves per scattered particle (tdr_ray_splits)
   int32_t* ws;               // tdr_su_ws(...).total words
   float span;                // map cells the 64 locality neighbours of a dense particle may span (tdr_su_span_begin)
 };
@@ -39,8 +43,24 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
 // tdr_su_span_end closes the measurement), the fastest is kept, and the trial is repeated every few thousand launches
 // (`shape`: anything that identifies the launch's sizes; a change restarts the trial).  The span only routes particles
 // between two kernels that produce identical partial sums: results do not depend on it.
-float tdr_su_span_begin(int64_t shape, hipStream_t s);
-void tdr_su_span_end(hipStream_t s);
+// The tuner's state belongs to the caller's tdr_score_ctx (tdr.h); without one the span is the configured / default one.
+// Nothing here waits on the host: a trial whose events have not completed when the next call arrives is repeated.
+struct SpanTuner {
+  int64_t shape = -1;
+  int phase = -2;                     // < 0: skipping; < number of candidates: timing that candidate; else settled
+  int settled_launches = 0;
+  float best = 16.f, best_ms = 3.0e38f;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool open = false, pending = false;
+};
+float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s);
+void tdr_su_span_end(SpanTuner* t, hipStream_t s);
 // the shift-uniform kernel over the heading bins' slots
 int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
+// the ray-mapped kernel (tdr_score_ray.hip): whether the map carries what it reads (class planes, integer dictionary
+// space), the split of a window over waves, its tables / the `inexact` flag (before either scoring kernel), the launch
+bool tdr_ray_map_ok(const tdr_map_desc* map);
+int tdr_ray_splits(int nb, int nr, int64_t n);
+int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s);
+int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 #endif  // TDR_SCORE_SU_H_

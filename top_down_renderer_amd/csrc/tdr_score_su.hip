@@ -35,6 +35,8 @@
 // serialises the four record loads of a step as soon as one of them is conditional.
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <atomic>
+
 #include "tdr_score_dev.h"
 #include "tdr_score_su.h"
 #include "tdr_score_su_asm.h"
@@ -49,8 +51,9 @@ struct SuArgs {
   const uint32_t* kmask;   // the map's known mask (behind the tiles of crec)
   int kcolw;               // words of one of its tile columns (32 kmask_trows)
   unsigned kmask_off;      // its byte offset from crec
-  const float* dict;
+  const uint32_t* dict_int;   // the dictionary as integers: value * 2^q (tdr_cmap.hip)
   int dict_n, ctiles_r;
+  const int32_t* inexact;  // device words (int_form_off): this scan / map has no exact integer form, the launch does nothing
   int rows, cols;          // map
   float resolution;
   const float* tab_su;     // [nchunks][nb][group][2]: (tab*scale)*res (USCALE) or tab
@@ -65,13 +68,13 @@ struct SuArgs {
   const int32_t* nslots;   // device word: slots in use (a multiple of 64)
   int group, nchunks, ncls;
   int64_t npad;            // stride of `part`
-  float* part;             // [nchunks][rf+1][npad]
+  uint32_t* part;          // [nchunks][2 ncls + 2][npad]: class k's integer sum as {low, high} words, normalisation, known count
 };
 
 // Scan descriptor of a bin, four dwords:
 //   [0] code: 0 = every class zero; c + 1 = class c alone is non-zero; SU_CODE_FULL = several classes;
 //       SU_CODE_FULL_ALL = a non-finite dictionary / scan value: no skipping in this bin
-//   [1] the bin's sum over the classes (float bits; slot rf-1 of the packed record) — for a single class: its value
+//   [1] the bin's count summed over the classes, as an integer — for a single class: its count
 //   [2] the constant of the record offset (cmap_offset) advanced to the dword the class lives in: ckconst + 4 * (c / 3)
 //   [3] bits 0-4: the bit offset of the class's field in that dword minus 2 (10 * (c % 3)); bit 31, on the first bin of a
 //       step (4 consecutive rings) only: one of the step's bins is SU_CODE_FULL / SU_CODE_FULL_ALL
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
         nz++;
       }
     }
+    // (a non-finite or fractional count: the launch runs in its float form instead — ray_prep_kernel raises `inexact`)
     if (dict_bad || !finite) { code = SU_CODE_FULL_ALL; val = r[rf - 1]; }
     else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc += 4u * (uint32_t)(first / 3); sh = 10u * (uint32_t)(first % 3); }
     else if (nz > 1) { code = SU_CODE_FULL; val = r[rf - 1]; }
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
   tab_su[2 * t] = tx;
   tab_su[2 * t + 1] = ty;
   desc[4 * t] = code;
-  desc[4 * t + 1] = __float_as_uint(val);
+  desc[4 * t + 1] = (uint32_t)val;
   desc[4 * t + 2] = ckc;
   desc[4 * t + 3] = sh | (((jj & 3) == 0 && anyfull) ? 0x80000000u : 0u);
 }
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
 
 // LDS of the scoring kernel, ONE object so that the dictionary sits at LDS address 0 (the assembly loop reads it there)
 struct SuLds {
-  float dict[TDR_CMAP_MAX_DICT];
+  uint32_t dict[TDR_CMAP_MAX_DICT];   // integer dictionary
   uint32_t bits[SU_BOX_WORDS];   // the staged known mask: rows rlo..rhi of words wlo..whi of the map's mask
   int box[4];
 };
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW;
   constexpr bool ASM_LOOP = CW == 2 && ND == 6;   // tdr_score_su_asm.h: two-dword records
   __shared__ SuLds lds;
-  for (int t = threadIdx.x; t < a.dict_n; t += 256) lds.dict[t] = a.dict[t];
+  if (int_form_off(a.inexact)) return;   // (uniform) no integer form of this scan / map: score_polar_kernel does the launch in floats
+  for (int t = threadIdx.x; t < a.dict_n; t += 256) lds.dict[t] = a.dict_int[t];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
   const int64_t nsl = (int64_t)__builtin_amdgcn_readfirstlane(*a.nslots);
   if ((int64_t)blockIdx.x * 256 >= nsl) return;   // the whole workgroup is beyond the slots in use (uniform)
@@ -288,32 +293,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));
   const tdr_v2f offv = {off0, off1};
   const bool weird = !(fabsf(off0) <= 1e9f) || !(fabsf(off1) <= 1e9f) || (!USCALE && !(fabsf(scale * a.res) <= 1e9f));
-  auto field = [&](const uint32_t (&w)[CW], int k) -> float {   // distance k of a compact record (cmap_decode, one field)
+  auto field = [&](const uint32_t (&w)[CW], int k) -> uint32_t {   // distance k of a compact record (cmap_decode, one field)
     const uint32_t ww = w[k / 3];
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.dict) + boff);
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds.dict) + boff);
   };
-  auto field1 = [&](uint32_t ww, int k) -> float {   // ... when the sample loaded only the dword class k lives in
+  auto field1 = [&](uint32_t ww, int k) -> uint32_t {   // ... when the sample loaded only the dword class k lives in
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.dict) + boff);
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds.dict) + boff);
   };
 
-  float acc[ND];
+  // integer sums (see the file comment: exact, so independent of the order and of the kernel that forms them)
+  uint64_t acc[ND];
 #pragma unroll
-  for (int k = 0; k < ND; k++) acc[k] = 0.f;
-  float norm = 0.f;
+  for (int k = 0; k < ND; k++) acc[k] = 0;
+  uint32_t norm = 0;
   uint32_t known = 0;
 
   // per-class accumulate of a bin that holds class cd - 1 only: a switch over a wave-uniform value
-  auto single_class = [&](uint32_t cd, float v, uint32_t ww) {
+  auto single_class = [&](uint32_t cd, uint32_t v, uint32_t ww) {
     switch (cd) {
 #define SU_CASE(K)                                                                                 \
   case K + 1:                                                                                      \
     if constexpr (K < ND) {                                                                        \
-      const float m = field1(ww, K < ND ? K : 0);                                                  \
-      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m));          \
+      const uint32_t m = field1(ww, K < ND ? K : 0);                                               \
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m) : "vcc"); \
     }                                                                                              \
     break;
       SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
@@ -323,13 +329,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
   };
   // a bin with several classes (or a non-finite value in play): the whole record against the packed scan record
-  auto full_bin = [&](uint32_t cd, float v, const uint32_t (&wr)[CW], int kbit, int64_t bin) {
+  auto full_bin = [&](uint32_t cd, uint32_t v, const uint32_t (&wr)[CW], int kbit, int64_t bin) {
     const tdr_const_f S = scanc + bin * RF;
-    norm = __builtin_fmaf(v, (float)kbit, norm);
+    norm += v & (0u - (uint32_t)kbit);
 #pragma unroll
     for (int k = 0; k < ND; k++) {
       const float sk = S[k];
-      if (cd == SU_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
+      if (sk != 0.f) acc[k] += (uint64_t)(uint32_t)sk * (uint64_t)field(wr, k);
     }
   };
   // cell of one sample (top_down_map_polar.cpp:28-31)
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   auto cpp_step = [&](int i, int r, int jj, int krow4, int kconst) {
     const tdr_const_f T = tbase + ((int64_t)i * G + jj) * 2;
     const tdr_const_u D = dbase + ((int64_t)r * G + jj) * 4;
-    float val[4];
+    uint32_t val[4];
     uint32_t code[4];
     uint32_t w[4], bits[4];
     int cis[4];
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       code[u] = D[4 * u];
-      val[u] = __uint_as_float(D[4 * u + 1]);
+      val[u] = D[4 * u + 1];
       const uint32_t ckc = D[4 * u + 2];
       int ri, ci;
       cell(T[2 * u], T[2 * u + 1], ri, ci);
@@ -388,8 +394,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const uint32_t cd = code[u];
       if (cd != 0) {   // wave-uniform
         if (cd < SU_CODE_FULL_ALL) {
-          // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
-          norm = norm + __uint_as_float((uint32_t)kmsk & __float_as_uint(val[u]));
+          // the bin's count x known (state_particle.cpp:141-142)
+          norm += (uint32_t)kmsk & val[u];
           single_class(cd, val[u], w[u]);
         } else {
           uint32_t wr[CW];
@@ -460,9 +466,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const uint32_t kb = cd == 0 ? (ww >> ((cbits[sidx / 6] >> (5 * (sidx % 6))) & 31u)) & 1u : (ww & 1u);
         known += kb;
         if (cd != 0) {   // wave-uniform
-          const float v = __uint_as_float(D[4 * u + 1]);
+          const uint32_t v = D[4 * u + 1];
           if (cd < SU_CODE_FULL_ALL) {
-            norm = norm + __uint_as_float((0u - kb) & __float_as_uint(v));
+            norm += (0u - kb) & v;
             single_class(cd, v, ww);
           } else {
             // the other dwords of the record: its offset again (rare: ~1 % of the bins hold several classes)
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const uint64_t res2 = (uint64_t)__float_as_uint(a.res) * 0x100000001ull;   // {res, res} in an SGPR pair
         while (nleft != 0xFFFFFFFFu) {
 #define SU_ASM_OPERANDS                                                                                               \
-          : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),             \
+          : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),   /* 64-bit */ \
             [a5] "+v"(acc[ND > 5 ? 5 : 0]), [norm] "+v"(norm), [known] "+v"(known), [toff] "+v"(toff), [doff] "+v"(doff), \
             [nleft] "+v"(nleft), [wleft] "+v"(wleft)                                                                   \
           : [offv] "v"(offv), [krow4] "v"(krow4), [ckcol] "v"(ckcol), [tb] "s"(tbase), [db] "s"(dbase),              \
@@ -628,12 +634,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   }
   if (active) {
     const int64_t slot = base + lane;
-    float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
+    uint32_t* o = a.part + (int64_t)blockIdx.y * (2 * a.ncls + 2) * a.npad + slot;
 #pragma unroll
     for (int k = 0; k < ND; k++)
-      if (k < a.ncls) o[(int64_t)k * a.npad] = acc[k];
-    o[(int64_t)(RF - 1) * a.npad] = norm;
-    o[(int64_t)RF * a.npad] = (float)known;
+      if (k < a.ncls) {
+        o[(int64_t)(2 * k) * a.npad] = (uint32_t)acc[k];
+        o[(int64_t)(2 * k + 1) * a.npad] = (uint32_t)(acc[k] >> 32);
+      }
+    o[(int64_t)(2 * a.ncls) * a.npad] = norm;
+    o[(int64_t)(2 * a.ncls + 1) * a.npad] = known;
   }
 }
 
@@ -667,42 +676,24 @@ extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it 
 namespace {
 constexpr float kSpanCand[] = {8.f, 12.f, 16.f, 24.f, 40.f};
 constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
-constexpr int kSpanSkip = 2;          // launches of a new shape that are not timed (first-use allocations, cold caches)
 constexpr int kSpanRetune = 4000;     // launches between two trials
-struct SpanTuner {
-  int64_t shape = -1;
-  int phase = -kSpanSkip;             // < 0: skipping; < kSpanCands: timing that candidate; else settled
-  int settled_launches = 0;
-  float best = SU_SPAN_START, best_ms = 3.0e38f;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  bool open = false, pending = false;
-};
-SpanTuner* span_tuner() {
-  static SpanTuner tab[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SpanTuner* t = &tab[dev];
-  if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return nullptr;
-  return t;
-}
 }  // namespace
-float tdr_su_span_begin(int64_t shape, hipStream_t s) {
-  if (g_su_span_fixed) return g_su_span;
-  SpanTuner* t = span_tuner();
-  if (!t) return g_su_span;
-  if (shape != t->shape) { t->shape = shape; t->phase = -kSpanSkip; t->best_ms = 3.0e38f; t->pending = false; }
-  if (t->pending) {   // the candidate timed by the previous launch
+float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
+  if (g_su_span_fixed || !t) return g_su_span;
+  if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return g_su_span;
+  if (shape != t->shape) { t->shape = shape; t->phase = -2; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
+  if (t->pending) {   // the candidate timed by an earlier launch — if its events are not through yet, ask again next time
+    if (hipEventQuery(t->e1) != hipSuccess) return t->best;
     float ms = 0.f;
-    if (hipEventSynchronize(t->e1) == hipSuccess && hipEventElapsedTime(&ms, t->e0, t->e1) == hipSuccess && ms > 0.f &&
-        ms < t->best_ms) {
+    if (hipEventElapsedTime(&ms, t->e0, t->e1) == hipSuccess && ms > 0.f && ms < t->best_ms) {
       t->best_ms = ms;
       t->best = kSpanCand[t->phase];
     }
     t->pending = false;
     t->phase++;
-    if (t->phase >= kSpanCands) { t->settled_launches = 0; g_su_span = t->best; }
+    if (t->phase >= kSpanCands) t->settled_launches = 0;
   }
-  if (t->phase < 0) { t->phase++; return g_su_span; }
+  if (t->phase < 0) { t->phase++; return t->best; }
   if (t->phase >= kSpanCands) {
     if (++t->settled_launches < kSpanRetune) return t->best;
     t->phase = 0;   // try them again: the particle set changes as the filter converges
@@ -711,14 +702,13 @@ float tdr_su_span_begin(int64_t shape, hipStream_t s) {
   t->open = hipEventRecord(t->e0, s) == hipSuccess;
   return kSpanCand[t->phase];
 }
-void tdr_su_span_end(hipStream_t s) {
-  SpanTuner* t = g_su_span_fixed ? nullptr : span_tuner();
-  if (!t || !t->open) return;
+void tdr_su_span_end(SpanTuner* t, hipStream_t s) {
+  if (g_su_span_fixed || !t || !t->open) return;
   t->open = false;
   t->pending = hipEventRecord(t->e1, s) == hipSuccess;
 }
-static int64_t g_su_launches = 0;
-extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches; }
+static std::atomic<int64_t> g_su_launches{0};   // diagnostics only
+extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches.load(); }
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total) {
   if (g_su_mode == 0) return false;
@@ -747,9 +737,12 @@ SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   w.keys_out = take(n);
   w.vals_in = take(n);
   w.vals_out = take(n);
-  w.ints = take(3 * ((int64_t)nb + 1) + 4);   // [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3]
+  w.ints = take(3 * ((int64_t)nb + 1) + TDR_SU_TAIL_INTS);   // [cnt][start][slot_start] nb + 1 each, [counts 3][n_multi][inexact][mass bound]
   w.slots = take(su_npad(n, nb));
   w.sort_tmp = take((int64_t)((su_sort_tmp_bytes(n) + 3) / 4));
+  w.ray_tab = take(2 * (int64_t)nb * nr);      // tdr_score_ray.hip: sample table and scan descriptors in ray order,
+  w.ray_desc = take((int64_t)nb * nr);         // the list of bins that hold several classes
+  w.ray_multi = take(2 * (int64_t)nb * nr);
   w.total = o;
   return w;
 }
@@ -769,7 +762,7 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   int* counts = slot_start + nkeys;
   int32_t* slots = base + W.slots;
   const int64_t n = L.n;
-  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * nkeys + 3), s));
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(3 * nkeys + TDR_SU_TAIL_INTS), s));
   HIP_TRY(hipMemsetAsync(slots, 0xFF, sizeof(int32_t) * (size_t)L.npad, s));
   hipLaunchKernelGGL(su_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), sizeof(int) * (size_t)nkeys, s, L.st, L.cap, n,
                      L.perm, L.nb, L.span, keys_in, vals_in, cnt);
@@ -804,7 +797,9 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   int* nslots = base + W.ints + 3 * (L.nb + 1);   // counts[0]
   SuArgs u;
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
-  u.crec = map->crec; u.dict = map->dict; u.dict_n = map->dict_n; u.ctiles_r = (map->rows >> lc) + 2;
+  u.crec = map->crec; u.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
+  u.dict_n = map->dict_n; u.ctiles_r = (map->rows >> lc) + 2;
+  u.inexact = nslots + 4;
   u.rows = map->rows; u.cols = map->cols; u.resolution = map->resolution;
   u.tab_su = reinterpret_cast<const float*>(base + W.tab_su);
   u.desc = reinterpret_cast<const uint32_t*>(base + W.desc);
@@ -815,7 +810,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.scan_pk = L.scan_pk;
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
-  u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = L.part;
+  u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = reinterpret_cast<uint32_t*>(L.part);
   const dim3 grid((unsigned)cdiv(L.npad, 256), (unsigned)L.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, L.rf), us = L.uniform_scale;
 #define TDR_LAUNCH_SU(NV4)                                                                         \
@@ -831,6 +826,6 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   }
 #undef TDR_LAUNCH_SU
   LAUNCH_CHECK("score_polar_su");
-  g_su_launches++;
+  g_su_launches.fetch_add(1);
   return TDR_OK;
 }

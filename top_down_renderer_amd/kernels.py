@@ -18,6 +18,24 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class ScoreCtx:
+    """Owner of a tdr_score_ctx (include/tdr.h): one per filter."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def span(self):
+        return float(self.lib.tdr_score_ctx_span(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.tdr_score_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class DeviceMap:
     """Device-resident interleaved map (tdr_map_desc) + the polar sampling table."""
 
@@ -249,15 +267,23 @@ class HipKernels:
             self._ws = self.empty((need,))
         return self._ws
 
-    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0):
-        """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_polar; 0 = n."""
+    def score_ctx_create(self):
+        """A tdr_score_ctx: the side stream and the span tuner of ONE caller's scoring launches (include/tdr.h)."""
+        h = C.c_void_p(0)
+        check(self.lib.tdr_score_ctx_create(C.byref(h)))
+        return ScoreCtx(self.lib, h)
+
+    def score(self, m, scan_pk, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0, ctx=None):
+        """n_total: particle count of the whole (possibly sharded) filter, see tdr_k_score_polar; 0 = n.
+        ctx: the caller's ScoreCtx (None: the kernels of a launch one after the other on the caller's stream)."""
         ws = self._workspace(m.ncls, m.nb, m.nr, n, n_total)
         cap = st.shape[1]
         if init_search and max(n, n_total) >= int(self.lib.tdr_config_rec16_min_particles(-1)):
             m.init_scratch(self)
-        check(self.lib.tdr_k_score_polar(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
-                                         C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
-                                         int(bool(init_search)), _ptr(raw_w), _ptr(ws), self.stream()))
+        check(self.lib.tdr_k_score_polar_ctx(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
+                                             C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
+                                             int(bool(init_search)), _ptr(raw_w), _ptr(ws),
+                                             ctx.handle if ctx is not None else C.c_void_p(0), self.stream()))
 
     def score_geo(self, m, gm, scan_pk, geo_pk, geo_sums, res, fp, st, n, raw_w, perm=None, init_search=False,
                   uniform_scale=0.0):

@@ -124,6 +124,7 @@ class ParticleFilter:
         self.parity_rng = parity_rng
         self.locality_every = int(locality_every)
         self.seed = int(seed)
+        self.score_ctx = self.k.score_ctx_create()   # this filter's side stream + span tuner (include/tdr.h)
         self.gen_ = self.k.rng_create(seed)
         self.step_ = 0
         self.prop_calls_ = 0      # device RNG counter: every propagate call draws fresh noise
@@ -265,7 +266,7 @@ class ParticleFilter:
         elif getattr(m, "polar", True):
             k.score(m.dev, scan_pk, float(res), self.fp_c, self.st, nl, self.raw_w,
                     perm=self.perm if self.locality_every else None, init_search=self._maybe_uninit,
-                    uniform_scale=self._uniform_scale, n_total=n)
+                    uniform_scale=self._uniform_scale, n_total=n, ctx=self.score_ctx)
         else:   # Cartesian window (BASELINE config 4; definition in include/tdr.h:tdr_k_score_cart)
             rows, cols = m.window_shape()
             k.score_cart(m.dev, scan_pk, rows, cols, float(res), self.fp_c, self.st, nl, self.raw_w,
