@@ -18,19 +18,24 @@ for N > 1 every GPU holds the same number of particles (weak scaling; N = 8 with
 configs[2]).
 
 One JSON line on stdout (rank 0).  `roofline` prices the scoring launch (its average duration measured live with HIP
-events on its launch stream; a polar launch may run two kernels side by side, the events span both) against the 8 TB/s
-HBM peak:
-  * `traffic` = read bytes per launch the L2s request from the fabric, MEASURED with rocprofv3 --pmc
+events on its launch stream; a polar launch runs two kernels, the events span both) against the 8 TB/s HBM peak:
+  * `traffic` = read bytes per launch the L2s request from the fabric, measured with rocprofv3 --pmc
     TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum in a pass of its own over this same command (tools/traffic_from_pmc.py ->
-    profiles/score_traffic.json).  Hits in the Infinity Cache are among them: an upper bound on what HBM delivers.  The
-    record carries a hash of the kernel sources and the launch shape: when either differs from what runs now, `traffic`
-    and `issue` are null.
+    profiles/score_traffic.json) and REPLAYED here — `traffic_source` says so and carries the record's source hash; when
+    the kernel sources or the launch shape differ from the record's, `traffic` and `issue` are null.  Hits in the Infinity
+    Cache are among the requests: an upper bound on what HBM delivers.
   * `achieved` / `frac` = traffic / launch duration (/ peak) when traffic is known;
+  * `sparse_algorithmic` = the bytes the launch cannot do without, from THIS run's scan: per particle one mask byte per
+    window sample (the known-fraction gate reads every sample) + 4 bytes per non-empty scan bin (one dictionary value),
+    with `frac` against the peak and `traffic_over_sparse` = how much more the counters saw (cache lines, not bytes, are
+    what a gather moves);
   * `issue` = {valu_busy, lds_busy, insts_per_sample} from a second counter pass; `bound` = the busiest of
     {hbm: `frac`, valu, lds};
-  * `algorithmic` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the same
-    duration.  Particles share map cells, so L1/L2 serve much of it and this figure can exceed the peak: it is a
-    work-rate, kept under its own key; it becomes `achieved` (flagged by `basis`) only when no measured traffic exists.
+  * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, without the side
+    stream): shift-uniform kernel over the dense particles, ray-mapped kernel over the scattered ones, particles in each;
+  * `dense_work_rate` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the
+    same duration.  The launch does not move those bytes (compact records, empty bins skipped, shared lines): a WORK rate,
+    not a roofline figure — `x_hbm_peak` above 1 says exactly that.
 `cpu_baseline` times the CPU oracle (oracle/oracle.cpp, OpenMP over particles like the reference's parallel for_each)
 on a bounded sample of the same workload on this host's cores.
 """
@@ -48,8 +53,8 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400, help="default: a timed region of >= 2 s at configs[1]")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="", help="default: c2 on one GPU, c3 (125 000 particles per GPU) on several")
     ap.add_argument("--particles-per-gpu", type=int, default=0, help="default: the config's particle count (c3, c5: / 8)")
     ap.add_argument("--locality-every", type=int, default=1, help="recompute the cache-locality order every k steps (0 = off)")
@@ -168,7 +173,7 @@ def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
+    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_score_su.h", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
         h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -312,6 +317,25 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    shares = None
+    if rank == 0 and cfg.polar:
+        # the launch's two kernels on their own: one more scoring call, without the filter's context (no side stream)
+        try:
+            f.st[:, :nl].copy_(st0)   # the particle set every timed step starts from
+            if f.locality_every and f.perm is not None:
+                k.locality_order(f.st, nl, m.rows, m.cols, f.perm)
+            k.lib.tdr_profile_enable(1)
+            k.score(m.dev, r.last_scan()[1], float(cfg.res), f.fp_c, f.st, nl, f.raw_w,
+                    perm=f.perm if f.locality_every else None, uniform_scale=f._uniform_scale, n_total=n_global)
+            d_ms, s_ms, s_n = C.c_double(0), C.c_double(0), C.c_int64(0)
+            if k.lib.tdr_profile_shares(C.byref(d_ms), C.byref(s_ms), C.byref(s_n)) == 0:
+                shares = {"dense_ms": d_ms.value, "dense_particles": nl - int(s_n.value), "dense_kernel": "score_polar_su_kernel",
+                          "scattered_ms": s_ms.value, "scattered_particles": int(s_n.value),
+                          "scattered_kernel": "score_polar_ray_kernel",
+                          "how": "HIP events around each kernel, one after the other on one stream, on the particle set "
+                                 "every timed step starts from"}
+        finally:
+            k.lib.tdr_profile_enable(0)
     if rank == 0:
         P = cfg.nb * cfg.nr
         b_pu = P * (4 * cfg.ncls + 1) + 64
@@ -338,6 +362,13 @@ def main():
             util["valu"] = issue["valu_busy"] or 0.0
             util["lds"] = issue["lds_busy"] or 0.0
         bound = max(util, key=util.get)
+        # bytes the launch cannot do without, from this run's scan
+        nnz = int((r.last_images().sum(dim=0) > 0).sum().item())
+        sparse_bytes = n_local * (P + 4 * nnz)
+        sparse = {"bytes_per_launch": sparse_bytes, "nonempty_bins": nnz, "bins": P,
+                  "GBps": sparse_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                  "frac": sparse_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0 if avg_ms > 0 else None,
+                  "traffic_over_sparse": traffic / sparse_bytes if traffic is not None else None}
         out = {
             "metric": "particle-updates/sec (render+score+resample)",
             "value": n_global * a.steps / dt,
@@ -354,6 +385,9 @@ def main():
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
+                         "traffic_source": (f"replayed from profiles/score_traffic.json (kernel sources {kernel_source_hash()}): "
+                                            + traffic_note) if traffic is not None else None,
+                         "sparse_algorithmic": sparse, "shares": shares,
                          "traffic_is": "read requests the L2s send to the fabric (TCC_EA0_RDREQ), Infinity-Cache hits "
                                        "included: an upper bound on the bytes HBM itself delivers",
                          "issue": issue,
@@ -364,10 +398,12 @@ def main():
                                  "score_polar_su_kernel for the dense particles, score_polar_kernel for the scattered ones — "
                                  "and `avg_launch_ms` spans both",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
-                         # polar configs: the dense / scattered split of the mixed launch the library's tuner settled on
-                         "shift_uniform_span_cells": float(k.lib.tdr_config_shift_uniform_span(-1.0)) if cfg.polar else None,
-                         "algorithmic": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
-                                         "frac": alg_gbps / 8000.0}},
+                         # polar configs: the dense / scattered split of the mixed launch this filter's tuner settled on
+                         "shift_uniform_span_cells": f.score_ctx.span() if cfg.polar else None,
+                         "dense_work_rate": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
+                                             "x_hbm_peak": alg_gbps / 8000.0,
+                                             "what": "SURVEY 8(d) dense byte model over the launch duration: a work rate, "
+                                                     "not bytes moved"}},
         }
         if world > 1:
             out["rccl_ranks" if a.backend == "nccl" else a.backend + "_ranks"] = ranks_joined

@@ -123,14 +123,17 @@ int tdr_cmap_words(int ncls);
  *    column by tile column with a guard band of 32 unknown cells around the map: with r' = r + 32, c' = c + 32 cell (r, c)
  *    is bit c & 31 of word (c' >> 5) * 32 * ((rows >> 5) + 2) + r' (csrc/tdr_score_dev.h: kmask_offset);
  *  - from dword tdr_cmap_plane_offset_words on, the CLASS PLANES (tdr_cmap_plane_words dwords each, 0 = none: the map is
- *    too large for 32-bit offsets): per class one 16-bit value per cell — dictionary index in bits 0-9, known in bit 15 —
- *    in tiles of 8 x 8 cells, tile column by tile column, a guard band of 8 cells (csrc/tdr_score_dev.h: plane_offset).
+ *    too large for 32-bit offsets): per class one 16-bit value per cell — dictionary index * 4 in bits 2-11, known in bit
+ *    15 — in tiles of 8 x 8 cells, tile column by tile column, a guard band of 8 cells (csrc/tdr_score_dev.h:
+ *    plane_offset); behind them the COARSE MASK PLANE (tdr_cmap_cmask_words dwords), the same shape with a 16-bit cell
+ *    holding the known bits of columns 16 cc .. 16 cc + 15 of one row at cell (r, cc).
  * Behind the float dictionary, `dict` also carries the dictionary as integers (narrow form): entries [1024, 2048) =
  * value * 2^q as uint32, [2048] = q, [2049] = 1 when every value has that form (csrc/tdr_cmap.hip). */
 size_t tdr_cmap_words_total(int ncls, int rows, int cols);
 size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
 size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
 size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
+size_t tdr_cmap_cmask_words(int ncls, int rows, int cols);
 int tdr_k_compact_map(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, void* workspace, void* stream);
 size_t tdr_cmap_wide_words_total(int ncls, int rows, int cols);   /* 0: no wide form for this class count */
 int tdr_k_compact_map_wide(tdr_map_desc* map, uint32_t* wrec_out, float* dict_out, void* workspace, void* stream);
@@ -404,6 +407,23 @@ int64_t tdr_shift_uniform_launches(void);
  * tdr_profile_score_ms synchronises on them, returns the summed duration and the launch count, and resets. */
 int tdr_profile_enable(int on);
 int tdr_profile_score_ms(double* total_ms, int64_t* launches);
+/* While enabled, a polar launch of the integer form made WITHOUT a context (its two kernels then run one after the other)
+ * also brackets each of the two: the last such launch's durations — shift-uniform kernel over the dense particles,
+ * ray-mapped kernel over the scattered ones — and the number of scattered particles (synchronises).  Measurement state is
+ * process-wide like the switch itself: one measuring thread. */
+int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles);
+
+/* Environment variables (read once, when the library first needs them; each mirrors a tdr_config_* call where one exists;
+ * A/B measurements and debugging only — results never depend on them unless stated):
+ *   TDR_SHIFT_UNIFORM  initial tdr_config_shift_uniform mode          TDR_SU_SPAN     fixes tdr_config_shift_uniform_span
+ *   TDR_COMPACT        initial tdr_config_compact                     TDR_CART_SKIP   initial tdr_config_cart_skip
+ *   TDR_INIT_MFMA      initial tdr_config_init_mfma                   TDR_INIT_HALF   0: never use tdr_map_desc.rec16
+ *   TDR_INIT_AHEAD     record loads in flight in the init search (1-3)
+ *   TDR_PFX_SMALL      initial tdr_config_prefix_small                TDR_UW_WAVES    initial tdr_config_uw_waves
+ *   TDR_PFX_HEAD       0: the long chains walk from the first addend (no one-workgroup head)
+ *   TDR_SCORE_WAVES    waves the float scoring kernel aims for        TDR_SCORE_GROUP rings per workgroup of the float /
+ *                      shift-uniform kernels (changes the partition of the FLOAT kernel's sums: its results move in the
+ *                      last bits) */
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
 /* sinf / cosf on the device are the HOST libm's, bit for bit (csrc/tdr_sincosf.h: glibc >= 2.28's double-precision

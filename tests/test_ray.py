@@ -41,7 +41,8 @@ def test_class_planes_and_integer_dictionary_decode_to_the_map(tdr, ncls, rows, 
     assert m.dev.desc.cwords > 0
     off = int(lib.tdr_cmap_plane_offset_words(ncls, rows, cols))
     pw = int(lib.tdr_cmap_plane_words(ncls, rows, cols))
-    assert pw > 0 and int(lib.tdr_cmap_words_total(ncls, rows, cols)) == off + pw * ncls
+    cmw = int(lib.tdr_cmap_cmask_words(ncls, rows, cols))
+    assert pw > 0 and cmw > 0 and int(lib.tdr_cmap_words_total(ncls, rows, cols)) == off + pw * ncls + cmw
     crec = m.dev.crec.cpu().numpy().view(np.uint32)
     dic = m.dev.dict.cpu().numpy()
     n = int(m.dev.desc.dict_n)
@@ -59,11 +60,17 @@ def test_class_planes_and_integer_dictionary_decode_to_the_map(tdr, ncls, rows, 
     for kk in range(ncls):
         v = planes[kk * 2 * pw + el]
         assert np.array_equal(v >> 15, 1 - mask)
-        assert np.array_equal(fdict[v & 0x3FF], maps[kk])
+        assert np.array_equal(fdict[(v >> 2) & 0x3FF], maps[kk])
     # the guard band: unknown, distance 0
     gr = np.array([-1, -1, rows, rows, 5]); gc = np.array([-1, cols, -1, cols, -1])
     el = (((gc + 8) >> 3) * trows + ((gr + 8) >> 3)) * 64 + ((gr + 8) & 7) * 8 + ((gc + 8) & 7)
     assert (planes[el] == 0).all()
+    # the coarse mask plane behind the class planes: cell (r, c >> 4), bit c & 15
+    cm = crec[off + pw * ncls: off + pw * ncls + cmw].view(np.uint16)
+    ccp = (c >> 4) + 8
+    el = ((ccp >> 3) * trows + (rp >> 3)) * 64 + (rp & 7) * 8 + (ccp & 7)
+    assert np.array_equal((cm[el] >> (c & 15)) & 1, 1 - mask)
+    assert (cm[(((gc >> 4) + 8) >> 3) * trows * 64 + ((gr + 8) >> 3) * 64 + ((gr + 8) & 7) * 8 + (((gc >> 4) + 8) & 7)] >> (gc & 15) & 1 == 0).all()
 
 
 def test_a_map_without_an_integer_form_says_so(tdr, oracle):

@@ -5,7 +5,8 @@ splits between the two kernels (GPU box only):
     span 8 / 16  the mixed launch (dense particles shift-uniform, scattered ones ray-mapped), with a context (two streams)
     all ray      every particle through the ray-mapped kernel
     float        the float kernel (tdr_config_shift_uniform(0))
-Usage: python3 tools/time_int_form.py [config] [quick]"""
+Usage: python3 tools/time_int_form.py [config] [quick] [only=<distribution>] [ray|su]
+   ray / su: only the all-ray / all-shift-uniform launch, three times (counter passes: tools/pmc_ray_bound.sh)"""
 import os
 import sys
 import time
@@ -39,6 +40,9 @@ def main():
             "gauss5": synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, sigma_px=5.0, sigma_deg=2.0, uniform_frac=0.0)}
     if not quick:
         sets["gauss30"] = synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, uniform_frac=0.0)
+    only = [x[5:] for x in sys.argv if x.startswith("only=")]
+    if only:
+        sets = {k_: v for k_, v in sets.items() if only[0] in k_}
     fp = pkg.FilterParams(fixed_scale=1.0).to_c(cfg.ncls)
     st = k.zeros((7, n))
     raw = k.zeros((n,))
@@ -62,6 +66,24 @@ def main():
         row = []
         lib.tdr_config_shift_uniform(1)
         lib.tdr_config_ray_split(0)
+        if "mixed" in sys.argv:   # the mixed launch only (kernel traces)
+            lib.tdr_config_shift_uniform_span(16.0)
+            if "splits" in sys.argv:
+                for span in (8.0, 16.0, 24.0):
+                    lib.tdr_config_shift_uniform_span(span)
+                    for split in (1, 2, 4, 8):
+                        lib.tdr_config_ray_split(split)
+                        print(f"{sname:14s} span {span:g} split {split}: one stream {timed(5):6.2f}", flush=True)
+                lib.tdr_config_ray_split(0)
+                continue
+            print(f"{sname:14s} span 16 +ctx: {timed(6, ctx=ctx):6.2f}   one stream: {timed(6):6.2f}", flush=True)
+            lib.tdr_config_shift_uniform_span(-2.0)
+            continue
+        if "ray" in sys.argv or "su" in sys.argv:
+            lib.tdr_config_shift_uniform_span(1e-6 if "ray" in sys.argv else 0.0)
+            print(f"{sname:14s} {'all ray' if 'ray' in sys.argv else 'span 0'}: {timed(3):6.2f}", flush=True)
+            lib.tdr_config_shift_uniform_span(-2.0)
+            continue
         for label, span, c in (("span 0", 0.0, None), ("span 8 +ctx", 8.0, ctx), ("span 16 +ctx", 16.0, ctx),
                                ("span 16 one stream", 16.0, None), ("span 40 +ctx", 40.0, ctx), ("all ray", 1e-6, None)):
             lib.tdr_config_shift_uniform_span(span)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tdr_cmap_tile_words": (C.c_size_t, [_i, _i, _i]),
     "tdr_cmap_plane_offset_words": (C.c_size_t, [_i, _i, _i]),
     "tdr_cmap_plane_words": (C.c_size_t, [_i, _i, _i]),
+    "tdr_cmap_cmask_words": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
     "tdr_cmap_wide_words_total": (C.c_size_t, [_i, _i, _i]),
     "tdr_k_compact_map_wide": (_i, [C.POINTER(MapDescC), _vp, _vp, _vp, _vp]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "tdr_k_states_soa_to_aos": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "tdr_profile_enable": (_i, [_i]),
     "tdr_profile_score_ms": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tdr_profile_shares": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     # handle layer (csrc/tdr_host.cpp)
     "tdr_map_create": (_i, [C.POINTER(_vp)]),
     "tdr_map_destroy": (None, [_vp]),

@@ -102,7 +102,7 @@ extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols) {
   return (tiles + (size_t)kmask_trows(rows) * kmask_tcols(cols) * 32 + 4 + 31) / 32 * 32;
 }
 // Behind the mask sit the CLASS PLANES (layout: plane_offset, tdr_score_dev.h): per class one 16-bit value per cell —
-// the class's dictionary index in bits 0-9, `known` in bit 15 — in tiles of 8 x 8 cells = one 128-byte line, the tiles
+// the class's dictionary index times 4 in bits 2-11, `known` in bit 15 — in tiles of 8 x 8 cells = one 128-byte line, the tiles
 // column by column with a guard band like the mask's.  A sample whose scan bin holds ONE class needs 2 bytes of the map,
 // and a ray of the polar window crosses 8 cells of a plane's line where it crosses 4 of a record tile's: the kernel that
 // scores scattered particles one wave per particle (tdr_score_ray.hip) pulls a third of the lines through the fabric
@@ -112,13 +112,20 @@ extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols) {
   const size_t off = tdr_cmap_plane_offset_words(ncls, rows, cols);
   if (!off) return 0;
   const size_t per = (size_t)plane_trows(rows) * plane_tcols(cols) * 32;
-  if ((off + per * (size_t)ncls) * 4 > 0xFFFFFF00ull || (size_t)plane_trows(rows) * 128 >= (1u << 23) || per * 4 / 128 >= (1u << 24))
+  if ((off + per * (size_t)(ncls + 1)) * 4 > 0xFFFFFF00ull || (size_t)plane_trows(rows) * 128 >= (1u << 23) || per * 4 / 128 >= (1u << 24))
     return 0;
   return per;
 }
+// ... and behind the class planes the COARSE MASK PLANE: the known mask once more in the planes' own shape — a 16-bit cell
+// holds the known bits of 16 neighbouring columns of one row (cell (r, c >> 4), bit c & 15), tiles of 8 rows x 8 such cells —
+// so that the ray-mapped kernel addresses "the cell's known bit" and "the cell's class value" with one formula.
+extern "C" size_t tdr_cmap_cmask_words(int ncls, int rows, int cols) {
+  if (!tdr_cmap_plane_words(ncls, rows, cols)) return 0;
+  return (size_t)plane_trows(rows) * plane_tcols(cols >> 4) * 32;
+}
 extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
   const size_t off = tdr_cmap_plane_offset_words(ncls, rows, cols);
-  return off ? off + tdr_cmap_plane_words(ncls, rows, cols) * (size_t)ncls : 0;
+  return off ? off + tdr_cmap_plane_words(ncls, rows, cols) * (size_t)ncls + tdr_cmap_cmask_words(ncls, rows, cols) : 0;
 }
 __global__ __launch_bounds__(256) void cmap_kmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
                                                          uint32_t* __restrict__ kmask) {
@@ -152,9 +159,27 @@ __global__ __launch_bounds__(256) void cmap_plane_kernel(const float* __restrict
     const unsigned bits = __float_as_uint(src[k]);
     unsigned h = cmap_hash(bits);
     while (hash[h] != bits) h = (h + 1) & (CMAP_HASH_SLOTS - 1);
-    v = (uint16_t)(hidx[h] | (src[rf - 1] != 0.f ? 0x8000u : 0u));
+    v = (uint16_t)(((unsigned)hidx[h] << 2) | (src[rf - 1] != 0.f ? 0x8000u : 0u));   // index * 4: the dictionary's byte offset
   }
   planes[(size_t)k * plane_words * 2 + t] = v;
+}
+// one thread per cell of the coarse mask plane
+__global__ __launch_bounds__(256) void cmap_cmask_kernel(const float* __restrict__ rec, int rows, int cols, int rf,
+                                                         size_t words, uint16_t* __restrict__ cmask) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)words * 2) return;
+  const int tr_n = plane_trows(rows);
+  const int64_t tile = t >> 6;
+  const int within = (int)(t & 63);
+  const int tc = (int)(tile / tr_n), tr = (int)(tile - (int64_t)tc * tr_n);
+  const int r = ((tr - 1) << 3) + (within >> 3), cc = ((tc - 1) << 3) + (within & 7);
+  uint16_t v = 0;
+  if (r >= 0 && r < rows && cc >= 0)
+    for (int b = 0; b < 16; b++) {
+      const int c = cc * 16 + b;
+      if (c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) v |= (uint16_t)(1u << b);
+    }
+  cmask[t] = v;
 }
 
 // wide: 16-bit fields, two per dword (the wide form, below) instead of 10-bit fields, three per dword
@@ -290,6 +315,10 @@ static int cmap_pack(tdr_map_desc* map, uint32_t* crec_out, float* dict_out, voi
                          map->rec, map->rows, map->cols, map->rec_floats, (const unsigned*)hash, (const uint16_t*)hidx, pw,
                          planes);
       LAUNCH_CHECK("cmap_plane");
+      const size_t cw16 = tdr_cmap_cmask_words(map->ncls, map->rows, map->cols);
+      hipLaunchKernelGGL(cmap_cmask_kernel, dim3((unsigned)cdiv((int64_t)cw16 * 2, 256)), dim3(256), 0, s, map->rec, map->rows,
+                         map->cols, map->rec_floats, cw16, planes + (size_t)map->ncls * pw * 2);
+      LAUNCH_CHECK("cmap_cmask");
     }
   }
   HIP_TRY(hipStreamSynchronize(s));

@@ -1767,9 +1767,45 @@ struct ScoreProfScope {
     if (stop) (void)hipEventRecord(stop, s);
   }
 };
+// ... and, for a launch WITHOUT a context (its two kernels run one after the other on the caller's stream), of each of the two
+// kernels on its own: the last such launch's {dense, scattered} durations and the device words that say how many particles
+// each share held (tdr_profile_shares).
+static hipEvent_t g_share_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+static bool g_share_valid = false;
+static const int32_t* g_share_counts = nullptr;
+struct ShareProfScope {
+  hipStream_t s;
+  hipEvent_t stop = nullptr;
+  ShareProfScope(int which, hipStream_t s_, bool on) : s(s_) {
+    if (!g_prof_on || !on) return;
+    for (int k = 0; k < 2; k++)
+      if (!g_share_ev[which][k] && hipEventCreate(&g_share_ev[which][k]) != hipSuccess) return;
+    (void)hipEventRecord(g_share_ev[which][0], s);
+    stop = g_share_ev[which][1];
+  }
+  ~ShareProfScope() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
 extern "C" int tdr_profile_enable(int on) {
   g_prof_on = on != 0;
   g_prof_used = 0;
+  g_share_valid = false;
+  return TDR_OK;
+}
+extern "C" int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles) {
+  if (!dense_ms || !scattered_ms || !scattered_particles) return fail(TDR_ERR_ARG, "profile_shares: null pointer");
+  if (!g_share_valid || !g_share_counts) return fail(TDR_ERR_ARG, "profile_shares: no launch without a context was profiled");
+  float ms[2] = {0.f, 0.f};
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipEventSynchronize(g_share_ev[k][1]));
+    HIP_TRY(hipEventElapsedTime(&ms[k], g_share_ev[k][0], g_share_ev[k][1]));
+  }
+  int32_t counts[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpy(counts, g_share_counts, sizeof(counts), hipMemcpyDeviceToHost));
+  *scattered_ms = ms[0];
+  *dense_ms = ms[1];
+  *scattered_particles = counts[1];
   return TDR_OK;
 }
 extern "C" int tdr_profile_score_ms(double* total_ms, int64_t* launches) {
@@ -2119,8 +2155,15 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     {
       ScoreProfScope prof(s);
       hipStream_t s2 = side.fork();
-      if ((rc = tdr_ray_score(L, W.suw, s2))) return rc;
-      if ((rc = tdr_su_score(L, W.suw, s))) return rc;
+      {
+        ShareProfScope sp(0, s2, ctx == nullptr);
+        if ((rc = tdr_ray_score(L, W.suw, s2))) return rc;
+      }
+      {
+        ShareProfScope sp(1, s, ctx == nullptr);
+        if ((rc = tdr_su_score(L, W.suw, s))) return rc;
+      }
+      if (g_prof_on && !ctx) { g_share_valid = true; g_share_counts = counts; }
       side.join();
       // the float form, for the launches the integer form does not cover
       ScoreArgs r = a;

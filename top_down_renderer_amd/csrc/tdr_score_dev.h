@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned kmask_offset(int ri, int ci, int col_bytes, 
   return (unsigned)off;
 }
 
-// ---- the class planes behind the mask (tdr_cmap.hip): per class a 16-bit value per cell (dictionary index | known << 15)
+// ---- the class planes behind the mask (tdr_cmap.hip): per class a 16-bit value per cell (dictionary index << 2 | known << 15)
 // in tiles of 8 x 8 cells (128 bytes), tiles column by column, plane_trows per tile column, a guard band of 8 cells.  With
 // r' = r + 8, c' = c + 8 the cell's byte offset inside its plane is (c' >> 3) * CS + r' * 16 + (c' & 7) * 2, CS = 128
 // plane_trows; as the row part is linear:  (c >> 3) * (CS - 16) + 2 c + 16 r + (CS + 128).

@@ -1,4 +1,4 @@
-// tdr_score_ray.hip — the RAY-MAPPED polar scoring kernel: one WAVE per particle, lanes = consecutive samples along a ray.
+// tdr_score_ray.hip — the RAY-MAPPED polar scoring kernel: one WAVE per particle, lanes = consecutive rings of a direction.
 //
 // For whom.  The scattered particles of a launch (su_key_kernel, tdr_score_su.hip: the uniform tenth of the bench mix,
 // particle initialisation, the tails of a cluster).  With lane = particle (score_polar_kernel, score_polar_su_kernel) a
@@ -6,115 +6,150 @@
 // measured against 16 for <= 4 lines, tools/ta_cost.hip), every line used by ONE sample, and a window's lines are
 // requested once per ring group, far apart in time.  Here a wave walks ONE window from its first sample to its last:
 // 64 consecutive rings of one direction per step, i.e. 64 cells along a ray —
-//   * a gather touches 8-11 lines instead of 64 (a plane tile holds 8 x 8 cells),
+//   * a gather touches 8-11 lines instead of 64 (a plane tile holds 8 x 8 cells), 2-3 per 16 lanes: the address path's
+//     minimum of 16 cycles per instruction,
 //   * neighbouring directions follow each other in time: a line fetched for direction i is still in the L2 for i + 1,
 //   * what is fetched is the CLASS PLANE of the one class the scan bin holds (2 bytes per cell, tdr_cmap.hip) — or, for an
-//     empty bin, the word of the known mask: 2 400 lines per window on the config-2 scene where the 8-byte records of all
-//     classes take 6 700.
+//     empty bin, the 16 known bits around the cell from the coarse mask plane: 2 400 lines per window on the config-2 scene
+//     where the 8-byte records of all classes take 6 700.
 // Why it may: the product sums are EXACT integers (a scan count times a dictionary value that is an integer multiple of
 // 2^-q, accumulated in 64 bits), so they do not depend on the order of the additions — lane-major here, sample-major in
 // the lane = particle kernels — and a particle's weight is the same bits whichever kernel scored it
 // (tests/test_shift_uniform.py, tests/test_ray.py).
 //
-// Per launch: ray_prep_kernel (sample table and scan descriptors in ray order, the list of bins holding several classes,
-// the `inexact` flag), then score_polar_ray_kernel over the sparse share of the slot list; score_finalize_exact_kernel
-// (tdr_score.hip) turns the integer sums into weights.
+// What bounds it: the L1 address path (every vector memory instruction of a wave costs it >= 16 cycles) and vector issue,
+// about equally (the first version: three memory instructions and ~55 vector instructions per step, 53 CU cycles per step
+// measured).  So a step of 64 samples is ONE gather and ~21 vector instructions:
+//   * the scan descriptors of a lane's rings of one direction are 16 bits each — class code, count — packed side by side:
+//     one load per direction brings up to four steps' worth; the sample offsets likewise (two 16-byte loads);
+//   * everything that depends on the bin's class only — the byte offset of its plane (the coarse mask plane for an empty
+//     bin), the column shift that turns a cell into a mask cell, the bit the cell's `known` flag sits at, the accumulator the
+//     product goes to — comes out of a 16-entry table in LDS with one 16-byte read, so there is no branch and no select in
+//     the loop: an empty bin multiplies a count of zero;
+//   * mask plane and class planes share one offset formula (plane_offset: same tile shape, same tile-column stride);
+//   * a lane adds its products into its own 64-bit accumulators in LDS, one per class (ds_add_u64).
+// Bins that hold several classes, or a count beyond 12 bits, are "empty" to the loop and go through a list afterwards.
+//
+// Per launch: ray_prep_kernel (sample offsets and scan descriptors in ray order, the list, the `inexact` flag), then
+// score_polar_ray_kernel over the sparse share of the slot list; score_finalize_exact_kernel (tdr_score.hip) turns the
+// integer sums into weights.
 #include "tdr_score_dev.h"
 #include "tdr_score_su.h"
 
-#define RAY_U 8   // steps (of 64 samples) whose gathers a wave keeps in flight
+// ray order: a direction's rings in BLOCKS of GQ steps of 64 rings (GQ = 1, 2 or 4: ray_gq); "row" m = direction * blocks
+// + block.  Lane l of step g of block b is ring (b * GQ + g) * 64 + l.
+static inline int ray_gq(int nr) { return nr <= 64 ? 1 : (nr <= 128 ? 2 : 4); }
+static inline int ray_blocks(int nr) { return (int)cdiv(nr, 64 * ray_gq(nr)); }
+int64_t tdr_ray_padded_samples(int nb, int nr) { return (int64_t)nb * ray_blocks(nr) * ray_gq(nr) * 64; }
 
-// One thread per window sample in RAY order k' = i * nr + j (direction i, ring j; the reference's images are column-major,
-// k = i + nb * j).  tab_ray[k'] = the sample's offset; desc_ray[k'] = the scan bin (row i, ring j) as count | code << 24
-// — code 0: empty, c + 1: class c alone (count = its count), 0xFF: several classes (count = their sum; the bin goes on
-// the `multi` list as {k', j * nb + i}).  A window row i is paired with scan row (i + shift) mod nb: index
-// (k' + shift * nr) mod P of desc_ray.
-// `inexact` is raised when the scan has no integer form: a count that is negative, fractional, not finite or >= 2^24,
-// or a dictionary without one (tdr_cmap.hip) — the integer kernels then return at once and the float kernel runs.
+// One thread per (scan row, padded ring).  tab_ray[((i * blocks + b) * 64 + l) * GQ + g] = sample offset of (direction i,
+// ring j); desc_ray (16-bit) at the same index for scan row i, ring j: code << 12 | count — code 0: nothing for the loop
+// (an empty bin, or one that went on the list), c + 1: class c alone.  Rings beyond nr: an offset far outside the map (their
+// cell is the guard cell: unknown), descriptor 0.
+// `list`: bins holding several classes or a count >= 4096, as row << 16 | ring.
+// inexact[0] is raised when the scan has no integer form: a count that is negative, fractional, not finite or >= 2^24, or
+// a dictionary without one (tdr_cmap.hip); inexact[1] collects the bound on the total count (int_form_off).
 __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk, int nb,
-                                                       int nr, int rf, int ncls, const uint32_t* __restrict__ dict_tail,
-                                                       float* __restrict__ tab_ray, uint32_t* __restrict__ desc_ray,
-                                                       uint32_t* __restrict__ multi, int32_t* __restrict__ n_multi,
-                                                       int32_t* __restrict__ inexact) {
-  const int64_t P = (int64_t)nb * nr;
+                                                       int nr, int rf, int ncls, int gq, int blocks,
+                                                       const uint32_t* __restrict__ dict_tail, float* __restrict__ tab_ray,
+                                                       uint16_t* __restrict__ desc_ray, uint32_t* __restrict__ list,
+                                                       int32_t* __restrict__ n_list, int32_t* __restrict__ inexact) {
+  const int rpad = blocks * gq * 64;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0 && dict_tail[1] != 1u) atomicOr(inexact, 1);
-  // (inexact[1]: upper bound of the scan's total count / 256, see int_form_off)
+  const bool live = t < (int64_t)nb * rpad;
+  const int i = live ? (int)(t / rpad) : 0, j = live ? (int)(t - (int64_t)i * rpad) : 0;
+  const int64_t k = (int64_t)j * nb + i;
+  const bool real = live && j < nr;
   uint32_t mass = 0;
-  if (t < P) {
-    const float sum = scan_pk[((int64_t)(t % nr) * nb + t / nr) * rf + rf - 1];
+  if (real) {
+    const float sum = scan_pk[k * rf + rf - 1];
     if (sum >= 1.f && sum < 16777216.f) mass = ((uint32_t)sum >> 8) + 1u;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) mass += __shfl_xor(mass, d, 64);
   if ((threadIdx.x & 63) == 0 && mass) atomicAdd(reinterpret_cast<unsigned*>(inexact) + 1, mass);
-  if (t >= P) return;
-  const int i = (int)(t / nr), j = (int)(t - (int64_t)i * nr);
-  const int64_t k = (int64_t)j * nb + i;
-  tab_ray[2 * t] = tab[2 * k];
-  tab_ray[2 * t + 1] = tab[2 * k + 1];
-  const float* r = scan_pk + k * rf;
-  int nz = 0, first = 0;
-  bool ok = true;
-  for (int c = 0; c < ncls; c++) {
-    const float v = r[c];
-    ok &= v >= 0.f && v < 16777216.f && v == floorf(v);
-    if (v != 0.f) {
-      if (!nz) first = c;
-      nz++;
-    }
-  }
-  const float sum = r[rf - 1];
-  ok &= sum >= 0.f && sum < 16777216.f && sum == floorf(sum);
-  if (!ok) { atomicOr(inexact, 1); desc_ray[t] = 0; return; }
+  if (!live) return;
+  const int g = j >> 6, l = j & 63, b = g / gq;
+  const int64_t at = (((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq);
+  float tx = -1.0e30f, ty = -1.0e30f;
   uint32_t d = 0;
-  if (nz == 1) d = (uint32_t)r[first] | ((uint32_t)(first + 1) << 24);
-  else if (nz > 1) {
-    d = (uint32_t)sum | 0xFF000000u;
-    const int at = atomicAdd(n_multi, 1);   // (any order: the sums are exact)
-    multi[2 * at] = (uint32_t)t;
-    multi[2 * at + 1] = (uint32_t)k;
+  if (real) {
+    tx = tab[2 * k];
+    ty = tab[2 * k + 1];
+    const float* r = scan_pk + k * rf;
+    int nz = 0, first = 0;
+    bool ok = true;
+    for (int c = 0; c < ncls; c++) {
+      const float v = r[c];
+      ok &= v >= 0.f && v < 16777216.f && v == floorf(v);
+      if (v != 0.f) {
+        if (!nz) first = c;
+        nz++;
+      }
+    }
+    const float sum = r[rf - 1];
+    ok &= sum >= 0.f && sum < 16777216.f && sum == floorf(sum);
+    if (!ok) atomicOr(inexact, 1);
+    else if (nz == 1 && r[first] < 4096.f) d = (uint32_t)r[first] | ((uint32_t)(first + 1) << 12);
+    else if (nz >= 1) list[atomicAdd(n_list, 1)] = ((uint32_t)i << 16) | (uint32_t)j;   // (any order: the sums are exact)
   }
-  desc_ray[t] = d;
+  tab_ray[2 * at] = tx;
+  tab_ray[2 * at + 1] = ty;
+  desc_ray[at] = (uint16_t)d;
 }
 
 struct RayArgs {
-  const uint32_t* crec;     // compact map: tiles, known mask, class planes (byte offsets from here)
-  unsigned kmask_off;       // the mask's byte offset
-  int kmask_col;            // bytes of one of its tile columns
+  const uint32_t* crec;     // compact map: tiles, known mask, class planes, coarse mask plane (byte offsets from here)
   unsigned planes_off;      // byte offset of class plane 0
-  unsigned plane_units;     // bytes of a plane / 128
-  int pkcol;                // plane_offset: bytes of a tile column - 16
+  unsigned plane_bytes;     // bytes of a class plane
+  unsigned cmask_off;       // byte offset of the coarse mask plane
+  int pkcol;                // plane_offset: bytes of a tile column - 16 (the same for every plane)
   const uint32_t* dict_int;
   int dict_n;
   int rows, cols;
   float resolution;
+  const float* tab;         // [P][2] in the table's own order (the list pass)
   const float* tab_ray;
-  const uint32_t* desc_ray;
-  const uint32_t* multi;
-  const int32_t* n_multi;
+  const uint16_t* desc_ray;
+  const uint32_t* list;
+  const int32_t* n_list;
   const float* scan_pk;
-  int rf, ncls, nb, nr;
+  int rf, ncls, nb, nr, blocks;
   float res;
   const float* st;
   int64_t cap;
   const int32_t* slots;     // the launch's slot list; the sparse share is slots [counts[0], counts[0] + counts[1])
   const int32_t* counts;
   const int32_t* inexact;
-  int nsplit;               // waves per particle: each takes a contiguous share of the window and writes one chunk row
+  int nsplit;               // waves per particle: each takes a contiguous share of the directions and writes one chunk row
   int64_t npad;
   uint32_t* part;           // [>= nsplit][2 ncls + 2][npad], like score_polar_su_kernel
 };
 
-template <bool USCALE>
+template <int GQ, bool USCALE>
 __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   extern __shared__ unsigned long long lacc[];   // [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class)
   __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
+  __shared__ uint4 lut[16];                      // per class code: {plane constant, column shift, known-bit index, accumulator}
   if (int_form_off(a.inexact)) return;
   const int nsparse = a.counts[1];
   if ((int64_t)blockIdx.x * 4 >= (int64_t)nsparse * a.nsplit) return;   // whole workgroup idle (uniform)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict_int[t];
+  const unsigned pconst = (unsigned)(a.pkcol + 16) + 128u;   // plane_offset's constant without the plane's own offset
+  if (threadIdx.x < 16) {
+    const int code = threadIdx.x;
+    uint4 e;
+    if (code >= 1 && code <= a.ncls) {   // class code - 1 alone: its plane, cells as they are, `known` in bit 15
+      e.x = a.planes_off + (unsigned)(code - 1) * a.plane_bytes + pconst;
+      e.y = 0; e.z = 15; e.w = (unsigned)code * 512u;
+    } else {                             // nothing to multiply: the coarse mask plane (16 columns per cell), bit = column & 15
+      e.x = a.cmask_off + pconst;
+      e.y = 4; e.z = 0; e.w = 0;
+    }
+    lut[code] = e;
+  }
   unsigned long long* const my = lacc + (size_t)wave * (a.ncls + 1) * 64 + lane;
   for (int c = 0; c <= a.ncls; c++) my[c * 64] = 0;
   __syncthreads();
@@ -130,17 +165,12 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   const float off0 = cy / a.resolution;  // top_down_map_polar.cpp:29
   const float off1 = cx / a.resolution;  // :30
   const int shift = rot_shift_dev(a.st[TDR_ST_THETA * a.cap + p], a.nb);
-  const int P = a.nb * a.nr;
-  const int rot = shift * a.nr;   // window sample k' meets scan bin (k' + rot) mod P of desc_ray
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
   const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
-  const int mconst = (int)a.kmask_off + a.kmask_col + 128;                          // kmask_offset
-  const int pconst = (int)a.planes_off + (a.pkcol + 16) + 128;                      // plane_offset, plane 0
-  const float2* __restrict__ tab2 = reinterpret_cast<const float2*>(a.tab_ray);
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));
   const tdr_v2f offv = {off0, off1};
-  auto cell = [&](float2 t, int& ri, int& ci) {
-    tdr_v2f pv = {t.x, t.y};
+  auto cell = [&](float tx, float ty, int& ri, int& ci) {
+    tdr_v2f pv = {tx, ty};
     if constexpr (!USCALE) pv = (pv * scale) * a.res;  // top_down_map_polar.cpp:28
     pv = pv + offv;                                     // :29-30
     tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
@@ -148,80 +178,94 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
   };
-  auto plane_at = [&](int ri, int ci, uint32_t cls) -> unsigned {   // byte offset of the cell in class `cls`'s plane
-    return plane_offset(ri, ci, a.pkcol, pconst) + ((cls * a.plane_units) << 7);
-  };
 
-  // this wave's share of the window: whole steps of 64 samples
-  const int steps = (P + 63) >> 6, per = (steps + a.nsplit - 1) / a.nsplit;
-  const int k0 = part_id * per * 64, k1 = min(P, (part_id + 1) * per * 64);
+  // this wave's share of the window: rows m = direction * blocks + block; a window row meets scan row (m + shift * blocks)
+  // mod (nb * blocks)
+  const int rows_all = a.nb * a.blocks, per = (rows_all + a.nsplit - 1) / a.nsplit;
+  const int m0 = part_id * per, m1 = min(rows_all, m0 + per);
+  const int rot = shift * a.blocks;
   uint32_t known = 0, norm = 0;
-  for (int kb = k0; kb < k1; kb += 64 * RAY_U) {
-    float2 t[RAY_U];
-    uint32_t d[RAY_U];
+  constexpr int U = 8 / GQ;   // rows whose gathers are in flight together: 8 steps
+  typedef uint16_t desc_t __attribute__((ext_vector_type(GQ)));
+  typedef float tab_t __attribute__((ext_vector_type(2 * GQ)));
+  const desc_t* __restrict__ descv = reinterpret_cast<const desc_t*>(a.desc_ray);
+  const tab_t* __restrict__ tabv = reinterpret_cast<const tab_t*>(a.tab_ray);
+  auto rows_step = [&](auto cnt_c, int m) {
+    constexpr int N = decltype(cnt_c)::value;
+    desc_t dd[N];
+    tab_t tt[N];
 #pragma unroll
-    for (int u = 0; u < RAY_U; u++) {
-      const int k = kb + 64 * u + lane;
-      const bool valid = k < k1;
-      const int kk = valid ? k : k1 - 1;
-      t[u] = tab2[kk];
-      int dk = kk + rot;
-      dk -= dk >= P ? P : 0;
-      d[u] = a.desc_ray[dk];
-      if (!valid) d[u] = 0xFE000000u;   // no sample: counts nothing (code 0xFE)
+    for (int u = 0; u < N; u++) {
+      int mr = m + u + rot;
+      mr -= mr >= rows_all ? rows_all : 0;
+      dd[u] = descv[(int64_t)mr * 64 + lane];
+      tt[u] = tabv[(int64_t)(m + u) * 64 + lane];
     }
-    uint32_t v[RAY_U];
-    uint32_t sh[RAY_U];
+    uint32_t v[N * GQ], shb[N * GQ], cnt[N * GQ], acc_at[N * GQ];
 #pragma unroll
-    for (int u = 0; u < RAY_U; u++) {
-      int ri, ci;
-      cell(t[u], ri, ci);
-      const uint32_t code = d[u] >> 24;
-      const bool single = code - 1u < (uint32_t)a.ncls;
-      // one 2-byte gather per sample: the cell of the bin's class plane (its bit 15 = known), else the half of the known
-      // mask's word that holds the cell's bit
-      const unsigned moff = kmask_offset(ri, ci, a.kmask_col, mconst) + ((unsigned)(ci >> 3) & 2u);
-      const unsigned poff = plane_at(ri, ci, code - 1u);
-      const unsigned off = single ? poff : moff;
-      sh[u] = single ? 15u : ((uint32_t)ci & 15u);
-      v[u] = *reinterpret_cast<const uint16_t*>(crecb + off);
-    }
+    for (int u = 0; u < N; u++)
 #pragma unroll
-    for (int u = 0; u < RAY_U; u++) {
-      const uint32_t code = d[u] >> 24, cnt = d[u] & 0xFFFFFFu;
-      const bool single = code - 1u < (uint32_t)a.ncls;
-      const uint32_t kbit = code == 0xFEu ? 0u : (v[u] >> sh[u]) & 1u;
-      known += kbit;
-      norm += cnt & (0u - kbit);                                   // state_particle.cpp:141-142
-      if (single) {
-        const uint32_t D = ldict[v[u] & 0x3FFu];
-        my[code * 64] += (unsigned long long)cnt * D;              // :136-139, as integers
+      for (int g = 0; g < GQ; g++) {
+        const int s = u * GQ + g;
+        int ri, ci;
+        cell(tt[u][2 * g], tt[u][2 * g + 1], ri, ci);
+        const uint32_t d = dd[u][g];
+        cnt[s] = d & 0xFFFu;
+        // one 16-byte LDS read: everything that depends on the bin's class
+        const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
+        const int cc = ci >> (int)e.y;                       // a mask cell spans 16 columns
+        const unsigned off = plane_offset(ri, cc, a.pkcol, (int)e.x);
+        shb[s] = ((uint32_t)ci & 15u) | e.z;                 // bit of `known`: 15 in a class cell, the column's in a mask cell
+        acc_at[s] = e.w;
+        v[s] = *reinterpret_cast<const uint16_t*>(crecb + off);
       }
+#pragma unroll
+    for (int s = 0; s < N * GQ; s++) {
+      uint32_t kbit;
+      asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(v[s]), "v"(shb[s]));
+      known += kbit;
+      norm = __umul24(cnt[s], kbit) + norm;                  // state_particle.cpp:141-142
+      const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + (v[s] & 0xFFCu));
+      const unsigned long long prod = (unsigned long long)cnt[s] * D;   // :136-139, as integers (0 for an empty bin)
+      unsigned long long* const acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(my) + acc_at[s]);
+      __hip_atomic_fetch_add(acc, prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u64; the lane's own slot
     }
-  }
-  // the bins that hold several classes: their known bit and count went in above, here every class present meets its plane
+  };
+  int m = m0;
+  for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, m);
+  for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, m);
+
+  // the list: bins that hold several classes (or one large count).  The loop above saw them as empty bins — their cell's
+  // known bit is counted — ; here every class present meets its plane, and the bin's count enters the normalisation.
   {
-    const int nm = *a.n_multi, mper = (nm + a.nsplit - 1) / a.nsplit;
+    const int nm = *a.n_list, mper = (nm + a.nsplit - 1) / a.nsplit;
     const int e1 = min(nm, (part_id + 1) * mper);
     for (int e = part_id * mper + lane; e < e1; e += 64) {
-      int k = (int)a.multi[2 * e] - rot;   // the window sample that meets this scan bin
-      k += k < 0 ? P : 0;
-      const int64_t bin = a.multi[2 * e + 1];
+      const uint32_t w = a.list[e];
+      const int r = (int)(w >> 16), j = (int)(w & 0xFFFFu);
+      int i = r - shift;   // the window row that meets scan row r
+      i += i < 0 ? a.nb : 0;
+      const int64_t k = (int64_t)j * a.nb + i, bin = (int64_t)j * a.nb + r;
       int ri, ci;
-      cell(tab2[k], ri, ci);
+      cell(a.tab[2 * k], a.tab[2 * k + 1], ri, ci);
+      const unsigned cell_off = plane_offset(ri, ci, a.pkcol, (int)(a.planes_off + pconst));
+      uint32_t kbit = 0;
       for (int c = 0; c < a.ncls; c++) {
         const float s = a.scan_pk[bin * a.rf + c];
         if (s != 0.f) {
-          const uint32_t vv = *reinterpret_cast<const uint16_t*>(crecb + plane_at(ri, ci, (uint32_t)c));
-          my[(c + 1) * 64] += (unsigned long long)(uint32_t)s * ldict[vv & 0x3FFu];
+          const uint32_t vv = *reinterpret_cast<const uint16_t*>(crecb + cell_off + (unsigned)c * a.plane_bytes);
+          kbit = vv >> 15;
+          __hip_atomic_fetch_add(&my[(c + 1) * 64], (unsigned long long)(uint32_t)s * ldict[(vv & 0xFFCu) >> 2],
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      norm += (uint32_t)a.scan_pk[bin * a.rf + a.rf - 1] & (0u - kbit);
     }
   }
-  // lanes -> one sum per class
+  // lanes -> one sum per class (the rings a block pads a direction with fell on the guard cell — unknown — and counted nothing)
   uint32_t* o = a.part + (int64_t)part_id * (2 * a.ncls + 2) * a.npad + slot;
   for (int c = 0; c < a.ncls; c++) {
-    unsigned long long s = my[(c + 1) * 64];
+    unsigned long long s = __hip_atomic_load(&my[(c + 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
     if (lane == 0) {
@@ -241,7 +285,6 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);
 extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
 extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
 
@@ -256,22 +299,23 @@ extern "C" int tdr_config_ray_split(int k) {   // >= 1: force; 0: per launch (de
 }
 int tdr_ray_splits(int nb, int nr, int64_t n) {
   if (g_ray_split > 0) return g_ray_split;
-  // waves per particle: a window of P samples is P / 64 steps; small launches split it to fill the chip (the sums are
-  // exact: any split gives the same bits)
-  const int64_t steps = cdiv((int64_t)nb * nr, 64);
+  // waves per particle: a window is nb * blocks rows of up to four steps; small launches split it to fill the chip (the
+  // sums are exact: any split gives the same bits)
+  const int64_t rows = (int64_t)nb * ray_blocks(nr);
   int s = 1;
-  while (s < TDR_RAY_MAX_SPLIT && n * s < 32768 && steps / (2 * s) >= 8) s *= 2;
-  if (s == 1 && steps >= 512) s = 2;
+  while (s < TDR_RAY_MAX_SPLIT && n * s < 32768 && rows / (2 * s) >= 8) s *= 2;
+  if (s == 1 && rows >= 128) s = 2;
   return s;
 }
 
 int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   int32_t* base = L.ws;
-  int* ints = base + W.ints + 3 * (L.nb + 1);   // [counts 3][n_multi][inexact]
-  const int64_t P = (int64_t)L.nb * L.nr;
-  hipLaunchKernelGGL(ray_prep_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
-                     L.map->ncls, reinterpret_cast<const uint32_t*>(L.map->dict) + 2 * TDR_CMAP_MAX_DICT,
-                     reinterpret_cast<float*>(base + W.ray_tab), reinterpret_cast<uint32_t*>(base + W.ray_desc),
+  int* ints = base + W.ints + 3 * (L.nb + 1);   // [counts 3][n_list][inexact][mass bound]
+  const int gq = ray_gq(L.nr), blocks = ray_blocks(L.nr);
+  const int64_t T = tdr_ray_padded_samples(L.nb, L.nr);
+  hipLaunchKernelGGL(ray_prep_kernel, dim3((unsigned)cdiv(T, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
+                     L.map->ncls, gq, blocks, reinterpret_cast<const uint32_t*>(L.map->dict) + 2 * TDR_CMAP_MAX_DICT,
+                     reinterpret_cast<float*>(base + W.ray_tab), reinterpret_cast<uint16_t*>(base + W.ray_desc),
                      reinterpret_cast<uint32_t*>(base + W.ray_multi), ints + 3, ints + 4);
   LAUNCH_CHECK("ray_prep");
   return TDR_OK;
@@ -283,20 +327,21 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   int* ints = base + W.ints + 3 * (L.nb + 1);
   RayArgs r;
   r.crec = map->crec;
-  r.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
-  r.kmask_col = kmask_trows(map->rows) * 128;
+  const size_t pw = tdr_cmap_plane_words(map->ncls, map->rows, map->cols);
   r.planes_off = (unsigned)(tdr_cmap_plane_offset_words(map->ncls, map->rows, map->cols) * 4);
-  r.plane_units = (unsigned)(tdr_cmap_plane_words(map->ncls, map->rows, map->cols) * 4 / 128);
+  r.plane_bytes = (unsigned)(pw * 4);
+  r.cmask_off = r.planes_off + (unsigned)map->ncls * r.plane_bytes;
   r.pkcol = plane_trows(map->rows) * 128 - 16;
   r.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
   r.dict_n = map->dict_n;
   r.rows = map->rows; r.cols = map->cols; r.resolution = map->resolution;
+  r.tab = L.tab;
   r.tab_ray = reinterpret_cast<const float*>(base + W.ray_tab);
-  r.desc_ray = reinterpret_cast<const uint32_t*>(base + W.ray_desc);
-  r.multi = reinterpret_cast<const uint32_t*>(base + W.ray_multi);
-  r.n_multi = ints + 3;
+  r.desc_ray = reinterpret_cast<const uint16_t*>(base + W.ray_desc);
+  r.list = reinterpret_cast<const uint32_t*>(base + W.ray_multi);
+  r.n_list = ints + 3;
   r.scan_pk = L.scan_pk;
-  r.rf = L.rf; r.ncls = map->ncls; r.nb = L.nb; r.nr = L.nr; r.res = L.res;
+  r.rf = L.rf; r.ncls = map->ncls; r.nb = L.nb; r.nr = L.nr; r.blocks = ray_blocks(L.nr); r.res = L.res;
   r.st = L.st; r.cap = L.cap;
   r.slots = base + W.slots;
   r.counts = ints;
@@ -306,8 +351,15 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   r.part = reinterpret_cast<uint32_t*>(L.part);
   const dim3 grid((unsigned)cdiv(L.n * r.nsplit, 4)), block(256);
   const size_t lds = (size_t)4 * (map->ncls + 1) * 64 * sizeof(unsigned long long);
-  if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<true>), grid, block, lds, s, r);
-  else hipLaunchKernelGGL((score_polar_ray_kernel<false>), grid, block, lds, s, r);
+#define TDR_LAUNCH_RAY(GQ)                                                                              \
+  if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true>), grid, block, lds, s, r);  \
+  else hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false>), grid, block, lds, s, r);
+  switch (ray_gq(L.nr)) {
+    case 1: TDR_LAUNCH_RAY(1) break;
+    case 2: TDR_LAUNCH_RAY(2) break;
+    default: TDR_LAUNCH_RAY(4) break;
+  }
+#undef TDR_LAUNCH_RAY
   LAUNCH_CHECK("score_polar_ray");
   return TDR_OK;
 }

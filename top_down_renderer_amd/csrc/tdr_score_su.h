@@ -60,6 +60,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 // the ray-mapped kernel (tdr_score_ray.hip): whether the map carries what it reads (class planes, integer dictionary
 // space), the split of a window over waves, its tables / the `inexact` flag (before either scoring kernel), the launch
 bool tdr_ray_map_ok(const tdr_map_desc* map);
+int64_t tdr_ray_padded_samples(int nb, int nr);   // window samples with every direction padded to whole blocks of steps
 int tdr_ray_splits(int nb, int nr, int64_t n);
 int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s);
 int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
