@@ -49,6 +49,7 @@ struct SpanTuner {
   int64_t shape = -1;
   int phase = -2;                     // < 0: skipping; < number of candidates: timing that candidate; else settled
   int settled_launches = 0;
+  int trial = 0;                      // timed calls of the current candidate so far
   float best = 16.f, best_ms = 3.0e38f;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool open = false, pending = false;

@@ -674,14 +674,17 @@ extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it 
 // lie apart): measured on MI355X, config 2 wants 8 (7.00 against 7.29 ms at 24), config 5 wants 16 (15.9 against 17.7 at 8),
 // a cluster with a single heading wants 24 or more (4.6 against 6.9 ms at 8).
 namespace {
+// (measured on MI355X with the ray-mapped kernel taking the scattered share, ms per scoring call at 8 / 16 / 24 / 40 cells:
+// config 2's mix 5.88 / 5.55 / 5.51 / 5.67, uniform particles 10.7 / 11.0 / - / 11.7, a converged filter 3.1 / 3.05 / - / 3.0)
 constexpr float kSpanCand[] = {8.f, 12.f, 16.f, 24.f, 40.f};
 constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
+constexpr int kSpanTrials = 2;        // timed calls per candidate: the faster one counts (a single call is noisy)
 constexpr int kSpanRetune = 4000;     // launches between two trials
 }  // namespace
 float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
   if (g_su_span_fixed || !t) return g_su_span;
   if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return g_su_span;
-  if (shape != t->shape) { t->shape = shape; t->phase = -2; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
+  if (shape != t->shape) { t->shape = shape; t->phase = -2; t->trial = 0; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
   if (t->pending) {   // the candidate timed by an earlier launch — if its events are not through yet, ask again next time
     if (hipEventQuery(t->e1) != hipSuccess) return t->best;
     float ms = 0.f;
@@ -690,7 +693,7 @@ float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
       t->best = kSpanCand[t->phase];
     }
     t->pending = false;
-    t->phase++;
+    if (++t->trial >= kSpanTrials) { t->trial = 0; t->phase++; }
     if (t->phase >= kSpanCands) t->settled_launches = 0;
   }
   if (t->phase < 0) { t->phase++; return t->best; }
