@@ -340,6 +340,20 @@ int tdr_k_local_map_polar(const tdr_map_desc* map, const float* tab, int nb, int
 int tdr_k_local_map_cart(const tdr_map_desc* map, int rows, int cols, float cx, float cy, float rot, float res,
                          float* dists_out, uint8_t* mask_out, void* stream);
 
+/* ---- ActiveLocalizer (src/active_localizer.cpp; dead at its call sites src/particle_filter.cpp:77-78,316) -------------- */
+/* computeTotalDifference (:7-20) over getLocalMap (:22-42) for many candidates at once.  centres (device) [ncand][K][2]:
+ * position {x, y} of hypothesis i displaced by candidate q (:62-63); shifts (device) [K]: rot_shift of hypothesis i
+ * (:33-36); res: getLocalMap's resolution (2 at :30); (nb, nr) the shape of `tab` (100 x 25 in the reference).
+ * sums_out (device) [ncand] doubles: sum over pairs i > j, classes and samples of |L_i - L_j|; the reference's figure is
+ * sum / (K (K-1) / 2 * ncls).  K <= 32. */
+int tdr_k_active_diffs(const tdr_map_desc* map, const float* tab, int nb, int nr, float res, const float* centres,
+                       const int32_t* shifts, int K, int ncand, double* sums_out, void* stream);
+/* The candidates of getBestRelPos (:55-77) — distances 50, 75, 100, 125; directions by the float loop `theta += pi / 8`
+ * as written — for the HOST arrays preds [K][3] = {x, y, theta}: centres [4 * 17][K][2], dists / thetas [4 * 17] (candidate
+ * d * 17 + t), shifts [K]; *ntheta_out directions per distance, *ndist_out distances. */
+int tdr_active_candidates_host(const float* preds, int K, int nb, float* centres, float* dists, float* thetas,
+                               int32_t* shifts, int* ntheta_out, int* ndist_out);
+
 /* ---- per-step consumers (src/particle_filter.cpp:191-236, 325-334, 343-357) --------------------------------- */
 /* out (device, TDR_MEAN_COV_FLOATS floats; the first 24 are the result, the rest is scratch for the multi-workgroup
  * reductions): mean[4] (meanLikelihood :191-203), cov[16] row-major about the mean (computeMeanCov, about == NULL) or
@@ -485,6 +499,11 @@ int tdr_map_center(const tdr_map* m, int* center_x, int* center_y);             
 int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
                       float* dists_out, uint8_t* mask_out);
 int tdr_map_classes_at_point(const tdr_map* m, int px, int py, uint32_t* class_bits);    /* top_down_map.cpp:159-170 */
+/* ActiveLocalizer::getBestRelPos (src/active_localizer.cpp:44-82) on the map's table (tdr_map_sample_pts_polar; the
+ * reference's local maps are 100 x 25): preds HOST [K][3] = {x, y, theta} of the pose hypotheses (the mixture's means).
+ * best_rel_pos = {distance, direction} of the displacement whose local maps differ most, *best_diff that mean difference
+ * (0 and {0, 0} when nothing beats 0 — e.g. one hypothesis: the reference's 0 / 0 never wins). */
+int tdr_map_best_rel_pos(tdr_map* m, const float* preds, int K, float best_rel_pos[2], float* best_diff);
 /* getLocalGeoMap (top_down_map_polar.cpp:55-76 / top_down_map.cpp:461-481): the same window gathered from the two
  * geometric layers geo_maps_ — [0] distance to the nearest cell WITHOUT a geometric class (flattened class >= 3), [1]
  * to the nearest cell WITH one (getGeoRasterMap :410-427 + computeDists), as tdr_map_set derives them; after

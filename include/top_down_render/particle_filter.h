@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "top_down_render/active_localizer.h"   // like the reference's header (particle_filter.h:5)
 #include "top_down_render/scan_renderer.h"
 #include "top_down_render/state_particle.h"
 

@@ -197,6 +197,22 @@ def local_map_polar(m, tab, cx, cy, scale, res):
     return d, k
 
 
+def rot_shift(rot, num_bins):
+    """src/state_particle.cpp:123-128."""
+    return int(lib().orc_rot_shift(C.c_float(rot), C.c_int(num_bins)))
+
+
+def active_best_rel_pos(m, tab, nb, nr, preds):
+    """ActiveLocalizer::getBestRelPos (src/active_localizer.cpp:44-82): ((dist, theta), best_diff, diffs[4][17])."""
+    preds = np.ascontiguousarray(preds, np.float32).reshape(-1, 3)
+    out = np.zeros(2, np.float32)
+    best = C.c_float(0)
+    diffs = np.zeros((4, 17), np.float32)
+    lib().orc_active_best_rel_pos(C.byref(m.c), _p(tab), C.c_int(nb), C.c_int(nr), _p(preds), C.c_int(len(preds)), _p(out),
+                                  C.byref(best), _p(diffs))
+    return out, float(best.value), diffs
+
+
 def local_map_cart(m, cx, cy, rot, res, rows, cols):
     P = rows * cols
     d = np.empty((m.ncls, P), np.float32)

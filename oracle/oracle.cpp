@@ -766,6 +766,81 @@ long orc_initialize_particles(const orc_map* m, const orc_filter_params* fp, int
   return count;
 }
 
+// N4  ActiveLocalizer   (src/active_localizer.cpp; dead at its call sites src/particle_filter.cpp:77-78,316, built for
+// completeness).  Local maps are nb x nr images (the reference hard-codes 100 x 25, the shape its node gives the table,
+// src/top_down_render.cpp:115); `tab` is the map's sample table of that shape.
+// getLocalMap (:22-42): the window at state.head<2>() with res = 2 (scale 1, top_down_map_polar.cpp:78-82), rows rotated by
+// rot_shift = round(state[2] * nb / 2 / pi) (:32-36): out row a = window row (a - shift) mod nb (:38-41).
+static void orc_active_local_map(const orc_map* m, const float* tab, int nb, int nr, const float state[3], float* out) {
+  const long P = (long)nb * nr;
+  std::vector<float> orig((size_t)m->ncls * P);
+  std::vector<uint8_t> mask(P);
+  orc_local_map_polar(m, tab, P, state[0], state[1], 1.f, 2.f, orig.data(), mask.data());   // :30
+  int rot_shift = (int)std::round((double)(state[2] * (float)nb / 2) / M_PI);                 // :33
+  while (rot_shift >= nb) rot_shift -= nb;                                                    // :35-36
+  while (rot_shift < 0) rot_shift += nb;
+  for (int c = 0; c < m->ncls; c++)
+    for (int j = 0; j < nr; j++)
+      for (int a = 0; a < nb; a++) {
+        const int src = a < rot_shift ? nb - rot_shift + a : a - rot_shift;                   // :39-40
+        out[(size_t)c * P + a + (size_t)nb * j] = orig[(size_t)c * P + src + (size_t)nb * j];
+      }
+}
+// computeTotalDifference (:7-20): mean over pairs i > j and classes of sum |L_i - L_j| (Eigen float sums, order
+// unspecified: accumulated in double per block here, the running total in float like the reference's).
+static float orc_active_total_difference(const float* maps, int K, int ncls, long P) {
+  float total = 0;
+  int cnt = 0;
+  for (int i = 0; i < K; i++)
+    for (int j = 0; j < i; j++)
+      for (int c = 0; c < ncls; c++) {
+        const float* a = maps + ((size_t)i * ncls + c) * P;
+        const float* b = maps + ((size_t)j * ncls + c) * P;
+        double s = 0;
+        for (long k = 0; k < P; k++) s += (double)fabsf(a[k] - b[k]);
+        total += (float)s;                                                                    // :14
+        cnt += 1;
+      }
+  return total / (float)cnt;                                                                  // :19 (0 / 0 = NaN for one mode)
+}
+// getBestRelPos (:44-82).  preds: [K][3] = {x, y, theta}.  out = {dist, theta} of the best candidate, *best_diff its mean
+// difference; diffs_out (optional, [4][17]): every candidate's difference, NaN where the loops did not go.
+void orc_active_best_rel_pos(const orc_map* m, const float* tab, int nb, int nr, const float* preds, int K, float out[2],
+                             float* best_diff_out, float* diffs_out) {
+  const long P = (long)nb * nr;
+  std::vector<float> maps((size_t)K * m->ncls * P);
+  if (diffs_out)
+    for (int q = 0; q < 4 * 17; q++) diffs_out[q] = std::numeric_limits<float>::quiet_NaN();
+  float dist = 50, best_diff = 0;                                                             // :55-56
+  float best[2] = {0, 0};
+  int di = 0;
+  while (best_diff < 6000 && dist < 150) {                                                    // :58
+    int ti = 0;
+    for (float theta = 0; theta < 2 * M_PI; theta += M_PI / 8) {                              // :59
+      for (int i = 0; i < K; i++) {
+        float pos[3] = {preds[3 * i], preds[3 * i + 1], preds[3 * i + 2]};
+        const float ang = theta + pos[2];
+        pos[0] += dist * cosf(ang);                                                           // :63 (float overloads)
+        pos[1] += dist * sinf(ang);
+        orc_active_local_map(m, tab, nb, nr, pos, maps.data() + (size_t)i * m->ncls * P);
+      }
+      const float diff = orc_active_total_difference(maps.data(), K, m->ncls, P);             // :69
+      if (diffs_out && di < 4 && ti < 17) diffs_out[di * 17 + ti] = diff;
+      if (diff > best_diff) {                                                                 // :70-73
+        best_diff = diff;
+        best[0] = dist;
+        best[1] = theta;
+      }
+      ti++;
+    }
+    dist += 25;                                                                               // :76
+    di++;
+  }
+  out[0] = best[0];
+  out[1] = best[1];
+  if (best_diff_out) *best_diff_out = best_diff;
+}
+
 int orc_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

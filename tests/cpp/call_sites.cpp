@@ -70,6 +70,11 @@ struct Node {
     Eigen::Vector4f best;
     filter_->maxLikelihood(best);
     filter_->computeCov(cov);
+    // the two lines the reference keeps commented out (src/particle_filter.cpp:77-78, 316)
+    ActiveLocalizer* active_loc_ = new ActiveLocalizer(map_);
+    Eigen::Vector2f best_rel_pos_ = active_loc_->getBestRelPos(means);
+    (void)best_rel_pos_;
+    delete active_loc_;
   }
   void aerialMap(const cv::Mat& map_img) {                                    // :574-593
     Eigen::Vector2i map_loc_eig(10, 20);

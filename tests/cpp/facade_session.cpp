@@ -91,6 +91,37 @@ int main(int argc, char** argv) {
       dump(dir + "/out_window.bin", w.data(), w.size());
     }
 
+    // ActiveLocalizer (src/active_localizer.cpp): the best relative move for three pose hypotheses taken from the first
+    // particles, its helper methods on host images against the one-launch search
+    {
+      ActiveLocalizer al(map_);
+      std::vector<Eigen::Vector3f> preds;
+      for (int i = 0; i < 3; i++) {
+        const State& s = st0[(size_t)i * 7 % st0.size()];
+        preds.push_back(Eigen::Vector3f(s.dx_m * s.scale + s.init_x_px, s.dy_m * s.scale + s.init_y_px, s.theta + 0.4f * (float)i));
+      }
+      const Eigen::Vector2f best = al.getBestRelPos(preds);
+      float act[12] = {best[0], best[1], al.lastBestDiff(), 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 3; i++)
+        for (int d = 0; d < 3; d++) act[3 + 3 * i + d] = preds[i][d];
+      // the same candidate through the class's host-image methods (:7-42)
+      std::vector<std::vector<Eigen::ArrayXXf>> lms;
+      for (int i = 0; i < 3; i++) {
+        std::vector<Eigen::ArrayXXf> lm;
+        for (int c = 0; c < ncls; c++) lm.push_back(Eigen::ArrayXXf(nb, nr));
+        Eigen::Vector3f pos = preds[i];
+        pos[0] += best[0] * std::cos(best[1] + preds[i][2]);
+        pos[1] += best[0] * std::sin(best[1] + preds[i][2]);
+        al.getLocalMap(pos, lm);
+        lms.push_back(lm);
+      }
+      const float host_diff = al.computeTotalDifference(lms);
+      float act2[13];
+      std::memcpy(act2, act, sizeof(act));
+      act2[12] = host_diff;
+      dump(dir + "/out_active.bin", act2, 13);
+    }
+
     // the raster cache (src/top_down_map.cpp:197-224): saveRasterizedMaps, then a SECOND map constructed from that
     // directory (map_path without .svg / .png / .jpg, :42-46) must hold the same map: the same window, value for value
     {

@@ -86,6 +86,8 @@ SIGNATURES = {
     "tdr_score_workspace_floats": (C.c_size_t, [_i, _i, _i, _i64, _i64]),
     "tdr_k_score_polar": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,
                                _i64, _vp, _f, _i, _vp, _vp, _vp]),
+    "tdr_k_active_diffs": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, _vp, _vp, _i, _i, _vp, _vp]),
+    "tdr_active_candidates_host": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "tdr_score_ctx_create": (_i, [C.POINTER(_vp)]),
     "tdr_score_ctx_destroy": (None, [_vp]),
     "tdr_score_ctx_span": (C.c_float, [_vp]),
@@ -156,6 +158,7 @@ SIGNATURES = {
     "tdr_map_save_cache": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "tdr_k_geo_map_from_map": (_i, [C.POINTER(MapDescC), _i, _vp, _vp, _vp]),
     "tdr_map_classes_at_point": (_i, [_vp, _i, _i, C.POINTER(_u32)]),
+    "tdr_map_best_rel_pos": (_i, [_vp, _vp, _i, _vp, _vp]),
     "tdr_renderer_create": (_i, [_vp, C.POINTER(_vp)]),
     "tdr_renderer_destroy": (None, [_vp]),
     "tdr_renderer_render": (_i, [_vp, _i, _vp, _i, _i, _i64, _f, _f, _i, _i, _i, _vp]),

@@ -382,6 +382,43 @@ int tdr_map_local_map(tdr_map* m, int polar, float cx, float cy, float scale_or_
   return TDR_OK;
 }
 
+// ActiveLocalizer::getBestRelPos (src/active_localizer.cpp:44-82): every candidate's difference in one launch, then the
+// reference's sequential choice — strict `>` over the candidates in loop order, the next distance only while the best
+// difference is below 6000 (:58, 70-73).
+int tdr_map_best_rel_pos(tdr_map* m, const float* preds, int K, float best_rel_pos[2], float* best_diff) {
+  if (!m || !m->have_map || !preds || !best_rel_pos) return failh(TDR_ERR_ARG, "best_rel_pos: no map / null pointer");
+  if (m->nb < 1 || !m->tab.p) return failh(TDR_ERR_ARG, "best_rel_pos: samplePtsPolar was never called");
+  if (K < 1 || K > TDR_GMM_MAX_K) return failh(TDR_ERR_ARG, "best_rel_pos: %d hypotheses (1 .. %d)", K, TDR_GMM_MAX_K);
+  const int ncand_max = 4 * 17;
+  std::vector<float> centres((size_t)ncand_max * K * 2), dists(ncand_max), thetas(ncand_max);
+  std::vector<int32_t> shifts(K);
+  int nt = 0, nd = 0;
+  TTRY(tdr_active_candidates_host(preds, K, m->nb, centres.data(), dists.data(), thetas.data(), shifts.data(), &nt, &nd));
+  DevBuf<float> d_c;
+  DevBuf<int32_t> d_s;
+  DevBuf<double> d_out;
+  TTRY(d_c.resize(centres.size()));
+  TTRY(d_s.resize(K));
+  TTRY(d_out.resize(ncand_max));
+  HTRY(hipMemcpy(d_c.p, centres.data(), centres.size() * sizeof(float), hipMemcpyHostToDevice));
+  HTRY(hipMemcpy(d_s.p, shifts.data(), K * sizeof(int32_t), hipMemcpyHostToDevice));
+  HTRY(hipMemset(d_out.p, 0, ncand_max * sizeof(double)));
+  TTRY(tdr_k_active_diffs(&m->desc, m->tab.p, m->nb, m->nr, 2.f, d_c.p, d_s.p, K, ncand_max, d_out.p, nullptr));
+  std::vector<double> sums(ncand_max);
+  HTRY(hipMemcpy(sums.data(), d_out.p, ncand_max * sizeof(double), hipMemcpyDeviceToHost));
+  const int cnt = K * (K - 1) / 2 * m->desc.ncls;   // :15
+  float best = 0.f, bd = 0.f, bt = 0.f;
+  for (int di = 0; di < nd && best < 6000.f; di++)   // :58
+    for (int t = 0; t < nt; t++) {
+      const float diff = (float)sums[di * 17 + t] / (float)cnt;   // :19 (0 / 0 = NaN for one hypothesis: never wins)
+      if (diff > best) { best = diff; bd = dists[di * 17 + t]; bt = thetas[di * 17 + t]; }   // :70-73
+    }
+  best_rel_pos[0] = bd;
+  best_rel_pos[1] = bt;
+  if (best_diff) *best_diff = best;
+  return TDR_OK;
+}
+
 // getLocalGeoMap (top_down_map_polar.cpp:55-76, top_down_map.cpp:461-481): the window of one pose gathered from the two
 // geometric layers; dists_out HOST [2][rows*cols]
 int tdr_map_local_geo_map(tdr_map* m, int polar, float cx, float cy, float scale_or_rot, float res, int rows, int cols,
