@@ -278,6 +278,25 @@ void* tdr_rng_create(uint32_t seed);
 void tdr_rng_destroy(void* rng);
 float tdr_rng_uniform_host(void* rng);                      /* particle_filter.cpp:172-173 */
 int tdr_propagate_normals_host(void* rng, int64_t n, int scale_freeze, float* z4_out);
+/* The same stream on the DEVICE (csrc/tdr_rng.hip).  `state`: TDR_RNG_STATE_WORDS device words — a std::mt19937 in
+ * libstdc++'s own representation: [0, 624) the engine's state array, [624] the index of the next word (624: a twist comes
+ * first), [625] an error flag the kernels raise if a call runs out of its attempt budget (probability ~1e-23; then the state
+ * is left alone and tdr_rng_set_state_host refuses it).  tdr_rng_get_state_host / _set_state_host move a host engine's state
+ * into and out of that form (HOST arrays), so either side can continue the other's stream.
+ * tdr_k_rng_propagate_normals: z4_out (device) [hi - lo][4] = the standard normals {theta, dx, dy, scale} of particles
+ * [lo, hi) of a propagate call over n particles — bit for bit what tdr_propagate_normals_host draws for them — and the
+ * state moves on by the words the WHOLE call consumes (every rank of a sharded filter passes its own [lo, hi) and keeps
+ * the same state).  Marsaglia attempts are independent given the words, so only the generator's state recurrence is
+ * serial (one wave); acceptance, ranking and the normals themselves are data-parallel.  workspace: device scratch of
+ * tdr_rng_dev_workspace_bytes(n) bytes.  tdr_k_rng_uniform: *out_dev = std::uniform_real_distribution<float>(0, 1)(gen),
+ * the draw of the systematic resample (src/particle_filter.cpp:172-173).  Nothing synchronises. */
+#define TDR_RNG_STATE_WORDS 640
+size_t tdr_rng_dev_workspace_bytes(int64_t n);
+int tdr_k_rng_propagate_normals(uint32_t* state, int64_t n, int64_t lo, int64_t hi, int scale_freeze, float* z4_out,
+                                void* workspace, void* stream);
+int tdr_k_rng_uniform(uint32_t* state, float* out_dev, void* stream);
+int tdr_rng_get_state_host(void* rng, uint32_t* words);
+int tdr_rng_set_state_host(void* rng, const uint32_t* words);
 /* ParticleFilter::initializeParticles particle loop (src/particle_filter.cpp:57-71) with the StateParticle
  * constructor (src/state_particle.cpp:3-49): host-side, serial mt19937 draws with on-road rejection.
  * class_maps: HOST copy of class_maps_ (column-major [ncls][rows*cols]); out must hold max_num+16 states. */
@@ -317,6 +336,9 @@ int tdr_k_prefix_mode(const float* w, int64_t n, int mode, float* runmax_out, fl
 /* idx_out[i - i_begin] = first j with prefix_j > (float(i)+shift)/n_new, else n-1, for i in [i_begin, i_end). */
 int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, float shift, int64_t i_begin, int64_t i_end,
                    int32_t* idx_out, void* stream);
+/* The same with the shift read from device memory (tdr_k_rng_uniform): no host value in the step. */
+int tdr_k_resample_dev(const float* runmax, int64_t n, int64_t n_new, const float* shift_dev, int64_t i_begin, int64_t i_end,
+                       int32_t* idx_out, void* stream);
 /* new_particles_[i]->setState(particles_[j]->state()) (:184): dst[f][i] = src[f][idx[i]].
  * src_shard == 0: src is a plain [7][src_cap] SoA.  src_shard > 0: src is the all-gathered [rank][7][src_shard]
  * buffer of a sharded filter and idx holds global particle indices (rank*src_shard + local). */
@@ -450,6 +472,10 @@ int tdr_libm_variant(void);
 int tdr_libm_force_variant(int variant);
 int tdr_sincosf_host(const float* x, int64_t n, int variant, float* sin_out, float* cos_out);
 int tdr_k_selftest_sincos(const float* x, int64_t n, float* sin_out, float* cos_out, void* stream);
+/* logf on the device is the host libm's too (csrc/tdr_logf.h; glibc's two builds agree on every argument): the
+ * restatement on the host / on the device (libstdc++'s normal_distribution<float> calls it, csrc/tdr_rng.hip). */
+int tdr_logf_host(const float* x, int64_t n, float* out);
+int tdr_k_selftest_logf(const float* x, int64_t n, float* out, void* stream);
 /* Self-test hook: out[i] = the raster kernel's atan2f(y[i], x[i]) (bit-identical to glibc's atan2f). */
 int tdr_k_selftest_atan2(const float* y, const float* x, int64_t n, float* out, void* stream);
 

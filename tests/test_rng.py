@@ -1,0 +1,124 @@
+"""The reference's random stream on the device (csrc/tdr_rng.hip): std::mt19937 + libstdc++'s normal / uniform
+distributions reproduced word for word — the normals of a propagate call, the words it consumes and the generator state
+afterwards against the host's own engine (tdr_propagate_normals_host / tdr_rng_uniform_host, i.e. libstdc++ itself).
+Run with `pytest -m gpu`; the state conversion is checked on the CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _lib():
+    from top_down_renderer_amd import _lib
+    return _lib.load()
+
+
+def _host_normals(L, rng, n, freeze):
+    z = np.empty((n, 4), np.float32)
+    assert L.tdr_propagate_normals_host(rng, n, int(freeze), z.ctypes.data_as(C.c_void_p)) == 0
+    return z
+
+
+def test_engine_state_round_trip_on_the_host():
+    """get_state / set_state move a std::mt19937 through libstdc++'s own representation: an engine rebuilt from the words
+    continues the original's stream, wherever in a block it stood."""
+    L = _lib()
+    for seed, burn in ((1, 0), (5489, 1), (77, 623), (77, 624), (123456, 1000), (9, 3 * 624 + 5)):
+        a = C.c_void_p(L.tdr_rng_create(C.c_uint32(seed)))
+        for _ in range(burn):
+            L.tdr_rng_uniform_host(a)
+        words = np.zeros(640, np.uint32)
+        assert L.tdr_rng_get_state_host(a, words.ctypes.data_as(C.c_void_p)) == 0
+        assert words[624] <= 624 and not words[625:].any()
+        b = C.c_void_p(L.tdr_rng_create(C.c_uint32(424242)))
+        assert L.tdr_rng_set_state_host(b, words.ctypes.data_as(C.c_void_p)) == 0
+        za, zb = _host_normals(L, a, 300, False), _host_normals(L, b, 300, False)
+        assert np.array_equal(za.view(np.uint32), zb.view(np.uint32))
+        L.tdr_rng_destroy(a)
+        L.tdr_rng_destroy(b)
+    bad = np.zeros(640, np.uint32)
+    bad[625] = 1     # the device's "ran out of attempts" flag: the host refuses such a state
+    a = C.c_void_p(L.tdr_rng_create(C.c_uint32(1)))
+    assert L.tdr_rng_set_state_host(a, bad.ctypes.data_as(C.c_void_p)) != 0
+    L.tdr_rng_destroy(a)
+
+
+@pytest.fixture(scope="module")
+def k():
+    import torch
+    from top_down_renderer_amd.kernels import HipKernels
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return HipKernels()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,freeze,burn", [(1, False, 0), (1, True, 5), (2, False, 623), (7, False, 624), (64, True, 100),
+                                           (1000, False, 0), (1000, True, 311), (20_000, False, 7), (100_003, False, 12345),
+                                           (100_000, True, 1)])
+def test_device_normals_are_the_hosts_bit_for_bit(k, n, freeze, burn):
+    """One propagate call's normals for n particles: the device's [n][4] against libstdc++'s, bit for bit; the generator
+    state afterwards: an engine rebuilt from it draws what the host engine draws next; then the uniform of the resample."""
+    L = k.lib
+    seed = 1000 + n + burn
+    host = C.c_void_p(L.tdr_rng_create(C.c_uint32(seed)))
+    for _ in range(burn):
+        L.tdr_rng_uniform_host(host)
+    state = k.rng_state_to_device(host)
+    z_host = _host_normals(L, host, n, freeze)
+    z = k.zeros((n, 4))
+    k.rng_propagate_normals_dev(state, n, 0, n, freeze, z, n)
+    got = z.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), z_host.view(np.uint32))
+    # the uniform draw of the resample continues the stream on the device ...
+    u = k.zeros((64,))
+    k.rng_uniform_dev(state, u)
+    assert float(u[0].item()) == float(L.tdr_rng_uniform_host(host))
+    # ... a second call continues it further ...
+    z2_host = _host_normals(L, host, min(n, 500), not freeze)
+    z2 = k.zeros((min(n, 500), 4))
+    k.rng_propagate_normals_dev(state, min(n, 500), 0, min(n, 500), not freeze, z2, n)
+    assert np.array_equal(z2.cpu().numpy().view(np.uint32), z2_host.view(np.uint32))
+    # ... and the host engine rebuilt from the device state is where the host's own engine is
+    back = C.c_void_p(L.tdr_rng_create(C.c_uint32(0)))
+    k.rng_state_to_host(back, state)
+    a, b = _host_normals(L, host, 50, False), _host_normals(L, back, 50, False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for h in (host, back):
+        L.tdr_rng_destroy(h)
+
+
+@pytest.mark.gpu
+def test_a_rank_of_a_sharded_filter_keeps_its_slice_and_the_common_state(k):
+    """Ranks pass their own [lo, hi): each gets exactly its particles' normals, all end in the same generator state."""
+    L = k.lib
+    n, world = 4096, 4
+    host = C.c_void_p(L.tdr_rng_create(C.c_uint32(31)))
+    z_host = _host_normals(L, host, n, False)
+    states = []
+    for r in range(world):
+        g = C.c_void_p(L.tdr_rng_create(C.c_uint32(31)))
+        st = k.rng_state_to_device(g)
+        z = k.zeros((n // world, 4))
+        k.rng_propagate_normals_dev(st, n, r * n // world, (r + 1) * n // world, False, z, n)
+        assert np.array_equal(z.cpu().numpy().view(np.uint32), z_host[r * n // world:(r + 1) * n // world].view(np.uint32))
+        states.append(st.cpu().numpy()[:626].copy())
+        L.tdr_rng_destroy(g)
+    for s in states[1:]:
+        assert np.array_equal(s, states[0])
+    L.tdr_rng_destroy(host)
+
+
+@pytest.mark.gpu
+def test_many_uniform_draws_cross_the_blocks(k):
+    """1500 single-word draws on the device: over two twists of the state."""
+    L = k.lib
+    host = C.c_void_p(L.tdr_rng_create(C.c_uint32(2024)))
+    state = k.rng_state_to_device(host)
+    u = k.zeros((64,))
+    for i in range(1500):
+        k.rng_uniform_dev(state, u)
+        if i % 97 == 0 or 620 <= i <= 630 or 1244 <= i <= 1252:
+            assert float(u[0].item()) == float(L.tdr_rng_uniform_host(host)), i
+        else:
+            L.tdr_rng_uniform_host(host)
+    L.tdr_rng_destroy(host)

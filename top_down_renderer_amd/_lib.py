@@ -88,6 +88,14 @@ SIGNATURES = {
                                _i64, _vp, _f, _i, _vp, _vp, _vp]),
     "tdr_k_active_diffs": (_i, [C.POINTER(MapDescC), _vp, _i, _i, _f, _vp, _vp, _i, _i, _vp, _vp]),
     "tdr_active_candidates_host": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)]),
+    "tdr_logf_host": (_i, [_vp, _i64, _vp]),
+    "tdr_k_selftest_logf": (_i, [_vp, _i64, _vp, _vp]),
+    "tdr_rng_dev_workspace_bytes": (C.c_size_t, [_i64]),
+    "tdr_k_rng_propagate_normals": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
+    "tdr_k_rng_uniform": (_i, [_vp, _vp, _vp]),
+    "tdr_rng_get_state_host": (_i, [_vp, _vp]),
+    "tdr_rng_set_state_host": (_i, [_vp, _vp]),
+    "tdr_k_resample_dev": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "tdr_score_ctx_create": (_i, [C.POINTER(_vp)]),
     "tdr_score_ctx_destroy": (None, [_vp]),
     "tdr_score_ctx_span": (C.c_float, [_vp]),

@@ -448,6 +448,30 @@ extern "C" int tdr_k_resample(const float* runmax, int64_t n, int64_t n_new, flo
   return TDR_OK;
 }
 
+__global__ void resample_dev_kernel(const float* __restrict__ runmax, int64_t n, int64_t n_new, const float* __restrict__ shift_dev,
+                                    int64_t i_begin, int64_t i_end, int32_t* __restrict__ idx) {
+  const int64_t i = i_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i_end) return;
+  const float sample = ((float)i + *shift_dev) / (float)n_new;  // particle_filter.cpp:176
+  int64_t lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (runmax[mid] > sample) hi = mid; else lo = mid + 1;
+  }
+  idx[i - i_begin] = (int32_t)lo;
+}
+extern "C" int tdr_k_resample_dev(const float* runmax, int64_t n, int64_t n_new, const float* shift_dev, int64_t i_begin,
+                                  int64_t i_end, int32_t* idx_out, void* stream) {
+  if (!runmax || !idx_out || !shift_dev) return fail(TDR_ERR_ARG, "resample: null pointer");
+  if (n < 1 || n_new < 1 || i_begin < 0 || i_end > n_new || i_begin > i_end)
+    return fail(TDR_ERR_ARG, "resample: bad range");
+  if (i_begin == i_end) return TDR_OK;
+  hipLaunchKernelGGL(resample_dev_kernel, dim3((unsigned)cdiv(i_end - i_begin, 256)), dim3(256), 0, (hipStream_t)stream,
+                     runmax, n, n_new, shift_dev, i_begin, i_end, idx_out);
+  LAUNCH_CHECK("resample");
+  return TDR_OK;
+}
+
 __global__ void gather_states_kernel(const float* __restrict__ src, int64_t src_cap, int64_t src_shard,
                                      const int32_t* __restrict__ idx, int64_t n_new, float* __restrict__ dst,
                                      int64_t dst_cap) {

@@ -127,6 +127,14 @@ struct tdr_filter {
   bool have_ml = false;
   hipStream_t stream = nullptr;
   tdr_score_ctx* score_ctx = nullptr;   // this filter's own side stream and span tuner for its scoring launches (tdr.h)
+  // The reference's generator in parity mode: the host std::mt19937 `rng` and its copy on the device (csrc/tdr_rng.hip).
+  // Exactly one of them is current: propagate and the resample's uniform draw continue the stream on the device, the
+  // host engine takes it back when host code draws (particle initialisation).  A generator shared with the caller
+  // (tdr_filter_share_rng) stays on the host.
+  DevBuf<uint32_t> rng_dev;
+  DevBuf<uint8_t> rng_ws;
+  DevBuf<float> shift_dev;
+  bool rng_on_device = false;
   // Sharded over the ranks of `comm` (one process per GPU; NULL = the whole filter lives here).  n / n_max stay the
   // GLOBAL counts; this rank holds particles [rank * nl, (rank + 1) * nl), nl = n / world, in st[7][cap] with
   // cap = n_max / world.  raw_glob / ld_glob / w / runmax are global arrays, identical on every rank.
@@ -742,8 +750,10 @@ void tdr_filter_destroy(tdr_filter* f) {
   delete f;
 }
 
+static int rng_to_host(tdr_filter* f);   // (below, with the propagate step)
 int tdr_filter_configure(tdr_filter* f, int parity_rng, int locality_every) {
   if (!f) return failh(TDR_ERR_ARG, "filter_configure: null filter");
+  if (!parity_rng && f->rng_on_device) TTRY(rng_to_host(f));
   f->parity_rng = parity_rng != 0;
   f->locality_every = locality_every;
   return TDR_OK;
@@ -808,6 +818,7 @@ int tdr_filter_initialize_particles(tdr_filter* f) {
   }
   std::vector<tdr_state> states((size_t)f->n_max + 16);
   int64_t n = 0;
+  TTRY(rng_to_host(f));
   TTRY(tdr_init_particles_host(f->rng, m->maps_host.data(), m->desc.ncls, m->desc.rows, m->desc.cols,
                                m->desc.resolution, &p, (int)f->n_max, states.data(), &n));
   n = std::min<int64_t>(n, f->n_max);
@@ -815,14 +826,44 @@ int tdr_filter_initialize_particles(tdr_filter* f) {
   return tdr_filter_set_states(f, states.data(), n);
 }
 
+// the generator's stream continues on the device / on the host (see tdr_filter::rng_dev)
+static int rng_to_device(tdr_filter* f) {
+  if (f->rng_on_device) return TDR_OK;
+  uint32_t words[TDR_RNG_STATE_WORDS];
+  TTRY(tdr_rng_get_state_host(f->rng, words));
+  TTRY(f->rng_dev.resize(TDR_RNG_STATE_WORDS));
+  TTRY(f->shift_dev.resize(64));
+  HTRY(hipMemcpyAsync(f->rng_dev.p, words, sizeof(words), hipMemcpyHostToDevice, f->stream));
+  HTRY(hipStreamSynchronize(f->stream));   // `words` lives on this frame
+  f->rng_on_device = true;
+  return TDR_OK;
+}
+static int rng_to_host(tdr_filter* f) {
+  if (!f->rng_on_device) return TDR_OK;
+  uint32_t words[TDR_RNG_STATE_WORDS];
+  HTRY(hipMemcpyAsync(words, f->rng_dev.p, sizeof(words), hipMemcpyDeviceToHost, f->stream));
+  HTRY(hipStreamSynchronize(f->stream));
+  TTRY(tdr_rng_set_state_host(f->rng, words));
+  f->rng_on_device = false;
+  return TDR_OK;
+}
+static bool rng_device_capable(const tdr_filter* f) { return f->rng_owned && f->parity_rng; }
+
 // ParticleFilter::propagate (particle_filter.cpp:86-92)
 static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool scale_freeze) {
   if (f->n == 0) return TDR_OK;
   const int64_t nl = f->nl();
   const float* z = nullptr;
-  if (f->parity_rng) {
-    // the reference draws serially in GLOBAL particle order from one generator: every rank replays the whole stream
-    // (same seed) and uploads its own slice
+  if (rng_device_capable(f)) {
+    // the reference draws serially in GLOBAL particle order from one generator: every rank continues the same stream on
+    // its device (same state everywhere) and keeps the normals of its own particles — nothing is drawn on the host
+    TTRY(rng_to_device(f));
+    TTRY(f->rng_ws.resize(tdr_rng_dev_workspace_bytes(f->n_max)));
+    TTRY(tdr_k_rng_propagate_normals(f->rng_dev.p, f->n, (int64_t)f->rank * nl, (int64_t)(f->rank + 1) * nl, scale_freeze ? 1 : 0,
+                                     f->z4.p, f->rng_ws.p, f->stream));
+    z = f->z4.p;
+  } else if (f->parity_rng) {
+    // a generator shared with the caller (StateParticle's surface): the host draws, serially
     std::vector<float> zh((size_t)4 * f->n);
     TTRY(tdr_propagate_normals_host(f->rng, f->n, scale_freeze ? 1 : 0, zh.data()));
     HTRY(hipMemcpyAsync(f->z4.p, zh.data() + (size_t)4 * f->rank * nl, (size_t)4 * nl * sizeof(float),
@@ -847,6 +888,7 @@ int tdr_filter_propagate_freeze(tdr_filter* f, float tx, float ty, float omega, 
 // built with; it is not owned.
 int tdr_filter_share_rng(tdr_filter* f, void* mt19937) {
   if (!f || !mt19937) return failh(TDR_ERR_ARG, "filter_share_rng: bad arguments");
+  f->rng_on_device = false;   // (the filter's own stream ends here)
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
   f->rng = mt19937;
   f->rng_owned = false;
@@ -858,6 +900,7 @@ int tdr_filter_init_one(tdr_filter* f) {
   if (!f || !f->map || !f->map->have_map) return failh(TDR_ERR_ARG, "filter_init_one: no map");
   tdr_map* m = f->map;
   tdr_state st;
+  TTRY(rng_to_host(f));
   TTRY(tdr_init_particle_host(f->rng, m->maps_host.data(), m->desc.ncls, m->desc.rows, m->desc.cols, m->desc.resolution,
                               &f->fp, &st));
   return tdr_filter_set_states(f, &st, 1);
@@ -1001,11 +1044,17 @@ static int filter_resample(tdr_filter* f, int64_t n_target) {
   if (n_target >= 0) n_new = std::max<int64_t>(1, std::min<int64_t>(n_target, f->n_max));
   n_new = std::max<int64_t>(f->world, n_new - n_new % f->world);   // whole shards
   const int64_t nl_new = n_new / f->world, i0 = (int64_t)f->rank * nl_new;
-  const float shift = tdr_rng_uniform_host(f->rng);  // :172-173 (every rank owns an identically seeded generator)
   TTRY(f->ml_dev.resize(12));
   TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
-  // each rank draws its own slice [i0, i0 + nl_new) of the new set; idx holds GLOBAL source indices
-  TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, i0, i0 + nl_new, f->idx.p, f->stream));
+  // :172-173 (every rank owns an identically seeded generator); each rank draws its own slice [i0, i0 + nl_new) of the new
+  // set, idx holds GLOBAL source indices
+  if (f->rng_on_device) {   // the stream is on the device: so is the draw
+    TTRY(tdr_k_rng_uniform(f->rng_dev.p, f->shift_dev.p, f->stream));
+    TTRY(tdr_k_resample_dev(f->runmax.p, n, n_new, f->shift_dev.p, i0, i0 + nl_new, f->idx.p, f->stream));
+  } else {
+    const float shift = tdr_rng_uniform_host(f->rng);
+    TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, i0, i0 + nl_new, f->idx.p, f->stream));
+  }
   if (f->comm) {
     // the second all-gather: the pre-resample state planes, [rank][7][nl] (28 B x N)
     for (int k = 0; k < TDR_ST_FIELDS; k++)

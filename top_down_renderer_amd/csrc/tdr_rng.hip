@@ -1,0 +1,298 @@
+// tdr_rng.hip — the reference's random stream on the device: std::mt19937 + libstdc++'s std::normal_distribution<float> /
+// std::uniform_real_distribution<float>, word for word.
+//
+// ParticleFilter::propagate (src/particle_filter.cpp:86-92) walks the particles in index order and every
+// StateParticle::propagate (src/state_particle.cpp:64-73) draws from ONE shared std::mt19937 through fresh distribution
+// objects: N(0, theta_cov dist) once, N(0, pos_cov dist) twice, and — unless the scale is frozen — N(1, ...) once.
+// libstdc++'s normal_distribution is Marsaglia's polar method (bits/random.tcc): an ATTEMPT takes two 32-bit words
+// (generate_canonical<float, 24> = one word each), x = 2 c0 - 1, y = 2 c1 - 1, and is accepted when 0 < x^2 + y^2 <= 1;
+// an accepted attempt yields y * mult and keeps x * mult for the object's next call, mult = sqrt(-2 log(r2) / r2).  A fresh
+// object has nothing saved, so the stream of a propagate call is nothing but attempts, and particle p owns the accepted
+// attempts 3p (theta: y), 3p + 1 (dx: y, dy: the saved x), 3p + 2 (scale: y) — 2p, 2p + 1 with the scale frozen.  That
+// makes the stream parallel:
+//   mt_fill_kernel      the generator's untempered state blocks, one after the other (the only serial part: one wave,
+//                       a block of 624 words in four LDS round trips — 192 elements of a block depend on nothing younger
+//                       than 227 elements);
+//   mt_attempt_kernel   every attempt of the budget: tempering, the two canonical floats, accepted or not;
+//   rocPRIM             exclusive scan of the accepted flags = the rank of every accepted attempt;
+//   mt_normal_kernel    accepted attempt of rank a -> particle a / 3 (or a / 2), with glibc's logf restated (tdr_logf.h) and
+//                       correctly rounded division / square root; the attempt that completes the last particle records
+//                       how many words the call consumed;
+//   mt_advance_kernel   the generator state behind exactly those words.
+// The uniform draw of the systematic resample (src/particle_filter.cpp:172-173) is mt_uniform_kernel: one word.
+// The state lives on the device in libstdc++'s own representation (624 words + the index of the next word), so it moves
+// to and from a host std::mt19937 through the engine's stream operators (tdr_rng_get_state_host / _set_state_host) and the
+// host object can take over at any time (particle initialisation, a generator shared with the caller).
+// tests/test_rng.py: normals, consumed words and the state afterwards against the host's distributions for many sizes.
+#include <rocprim/device/device_scan.hpp>
+
+#include <random>
+#include <sstream>
+
+#include "tdr_common.h"
+#include "tdr_logf.h"
+
+#define MT_N 624
+#define MT_M 397
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);                    // (d = 0xffffffff)
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+// generate_canonical<float, 24>(mt19937) (bits/random.tcc): one word, float(u) / 2^32, clamped below 1
+__device__ __forceinline__ float mt_canonical(uint32_t u) {
+  float c = (float)u * 0x1p-32f;     // u32 -> float rounds to nearest; the scaling is exact
+  return c >= 1.f ? 0x1.fffffep-1f : c;
+}
+// One twist of the state in LDS (mersenne_twister_engine::_M_gen_rand), by ONE wave: elements in ascending order, 192 at
+// a time — element k needs the OLD x[k], x[k + 1] and, from 227 on, the NEW x[k - 227], written at least one batch earlier.
+__device__ __forceinline__ void mt_twist(uint32_t* x, int lane) {
+  for (int base = 0; base < MT_N; base += 192) {
+    uint32_t nv[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int k = base + 64 * s + lane;
+      if (k < MT_N) {
+        const int k1 = k + 1 == MT_N ? 0 : k + 1;
+        const uint32_t y = (x[k] & 0x80000000u) | (x[k1] & 0x7fffffffu);
+        const uint32_t src = k < MT_N - MT_M ? x[k + MT_M] : x[k - (MT_N - MT_M)];
+        nv[s] = src ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+      }
+    }
+    // element 623 reads the NEW x[0] (it is the last of the loop in the engine): its batch is the last one, x[0] is long
+    // written; every other read above is of values no store of this batch touches.  (One wave: the barriers are there for
+    // the compiler — loads of a batch before its stores, stores before the next batch's loads.)
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int k = base + 64 * s + lane;
+      if (k < MT_N) x[k] = nv[s];
+    }
+    __syncthreads();
+  }
+}
+
+// raw [nblocks][624]: block 0 = the state as it is, block b = the state b twists later (untempered words)
+__global__ __launch_bounds__(64) void mt_fill_kernel(const uint32_t* __restrict__ state, int nblocks, uint32_t* __restrict__ raw) {
+  __shared__ uint32_t x[MT_N];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < MT_N; k += 64) {
+    const uint32_t v = state[k];
+    x[k] = v;
+    raw[k] = v;
+  }
+  __syncthreads();
+  for (int b = 1; b < nblocks; b++) {
+    mt_twist(x, lane);
+    for (int k = lane; k < MT_N; k += 64) raw[(int64_t)b * MT_N + k] = x[k];
+  }
+}
+
+struct MtAttempt {
+  float x, y, r2;
+  bool ok;
+};
+__device__ __forceinline__ MtAttempt mt_attempt(const uint32_t* __restrict__ raw, int64_t g) {
+  MtAttempt a;
+  const float c0 = mt_canonical(mt_temper(raw[g])), c1 = mt_canonical(mt_temper(raw[g + 1]));
+  a.x = (float)((double)(2.0f * c0) - 1.0);   // result_type(2.0) * aurng() - 1.0: float product, double difference
+  a.y = (float)((double)(2.0f * c1) - 1.0);
+  a.r2 = a.x * a.x + a.y * a.y;               // (compiled with -ffp-contract=off: two roundings, like the host's)
+  a.ok = !((double)a.r2 > 1.0 || (double)a.r2 == 0.0);
+  return a;
+}
+// attempt t uses words p0 + 2t, p0 + 2t + 1 of the raw stream
+__global__ __launch_bounds__(256) void mt_attempt_kernel(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ state,
+                                                         int64_t nattempts, uint32_t* __restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nattempts) return;
+  flags[t] = mt_attempt(raw, (int64_t)state[MT_N] + 2 * t).ok ? 1u : 0u;
+}
+// per: accepted attempts a particle owns (3, or 2 with the scale frozen); particles [lo, hi) of n are written, to z4[p - lo]
+__global__ __launch_bounds__(256) void mt_normal_kernel(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ state,
+                                                        const uint32_t* __restrict__ flags, const uint32_t* __restrict__ rank,
+                                                        int64_t nattempts, int64_t n, int per, int64_t lo, int64_t hi,
+                                                        float* __restrict__ z4, uint32_t* __restrict__ consumed) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nattempts || !flags[t]) return;
+  const int64_t a = rank[t];
+  if (a >= n * per) return;
+  if (a == n * per - 1) *consumed = (uint32_t)(2 * (t + 1));
+  const int64_t p = a / per;
+  const int slot = (int)(a - p * per);
+  if (p < lo || p >= hi) return;
+  const MtAttempt at = mt_attempt(raw, (int64_t)state[MT_N] + 2 * t);
+  // std::sqrt(-2 * std::log(r2) / r2): the float overloads (glibc logf, IEEE division and square root)
+  const float mult = sqrtf(-2.f * tdr_libm::logf_t<true>(at.r2) / at.r2);
+  float* z = z4 + 4 * (p - lo);
+  const float vy = at.y * mult * 1.f + 0.f, vx = at.x * mult * 1.f + 0.f;   // ret * stddev + mean of the {0, 1} objects
+  if (slot == 0) z[0] = vy;                       // theta: a fresh object's first value; its saved one is dropped
+  else if (slot == 1) { z[1] = vy; z[2] = vx; }   // dx, dy: one object, two calls
+  else z[3] = vy;                                 // scale
+  if (per == 2 && slot == 1) z[3] = 0.f;
+}
+// the state behind `consumed` words of the raw stream; error word: 1 when the budget of attempts did not suffice
+__global__ __launch_bounds__(64) void mt_advance_kernel(const uint32_t* __restrict__ raw, int nblocks,
+                                                        const uint32_t* __restrict__ consumed, uint32_t* __restrict__ state) {
+  const uint32_t c = *consumed;
+  if (c == 0xFFFFFFFFu) {   // not enough accepted attempts inside the budget: leave the state, raise the flag
+    if (threadIdx.x == 0) state[MT_N + 1] = 1u;
+    return;
+  }
+  const int64_t q = (int64_t)state[MT_N] + c;
+  int b = (int)(q / MT_N), p = (int)(q % MT_N);
+  if (p == 0 && b > 0) { b--; p = MT_N; }   // "all of block b - 1 is used" is the same state as "none of block b"
+  if (b >= nblocks) {
+    if (threadIdx.x == 0) state[MT_N + 1] = 1u;
+    return;
+  }
+  uint32_t v[(MT_N + 63) / 64];
+  for (int k = threadIdx.x, i = 0; k < MT_N; k += 64, i++) v[i] = raw[(int64_t)b * MT_N + k];
+  for (int k = threadIdx.x, i = 0; k < MT_N; k += 64, i++) state[k] = v[i];
+  if (threadIdx.x == 0) state[MT_N] = (uint32_t)p;
+}
+// std::uniform_real_distribution<float>(0, 1)(gen): one word
+__global__ __launch_bounds__(64) void mt_uniform_kernel(uint32_t* __restrict__ state, float* __restrict__ out) {
+  __shared__ uint32_t x[MT_N];
+  const int lane = threadIdx.x;
+  uint32_t p = state[MT_N];
+  uint32_t word;
+  if (p >= MT_N) {   // (uniform) the block is used up: twist first
+    for (int k = lane; k < MT_N; k += 64) x[k] = state[k];
+    __syncthreads();
+    mt_twist(x, lane);
+    for (int k = lane; k < MT_N; k += 64) state[k] = x[k];
+    p = 0;
+    word = x[0];
+  } else {
+    word = state[p];
+  }
+  if (lane == 0) {
+    *out = mt_canonical(mt_temper(word)) * (1.f - 0.f) + 0.f;   // (b - a) * canonical + a
+    state[MT_N] = p + 1;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// attempts a call may look at: the expected 3.82 per particle-normal... (acceptance pi / 4) plus 5 % and ten standard
+// deviations: running out has probability ~1e-23 (and is reported, never silent)
+static int64_t mt_attempt_budget(int64_t need) {
+  return (int64_t)std::ceil((double)need / 0.7853981633974483 * 1.05 + 12.0 * std::sqrt((double)need + 1.0) + 64.0);
+}
+static size_t mt_scan_bytes(int64_t nattempts) {
+  size_t bytes = 0;
+  uint32_t* p = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, bytes, p, p, 0u, (size_t)nattempts, rocprim::plus<uint32_t>(), (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) bytes = (size_t)nattempts / 16 + 65536;
+  return (bytes + 255) / 256 * 256;
+}
+struct MtWs {
+  int64_t nattempts, nblocks;
+  size_t off_flags, off_rank, off_scan, off_consumed, total;
+};
+static MtWs mt_ws(int64_t n, int per) {
+  MtWs w;
+  w.nattempts = mt_attempt_budget(n * per);
+  w.nblocks = (2 * w.nattempts + MT_N) / MT_N + 2;   // from anywhere inside block 0
+  size_t o = (size_t)w.nblocks * MT_N * 4;
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+  o = (o + 255) / 256 * 256;
+  w.off_flags = take((size_t)w.nattempts * 4);
+  w.off_rank = take((size_t)w.nattempts * 4);
+  w.off_scan = take(mt_scan_bytes(w.nattempts));
+  w.off_consumed = take(256);
+  w.total = o;
+  return w;
+}
+extern "C" size_t tdr_rng_dev_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return mt_ws(n, 3).total;
+}
+// z4_out [hi - lo][4] = the standard normals {theta, dx, dy, scale} of particles [lo, hi) of n, exactly what
+// tdr_propagate_normals_host draws for them; `state` (device, TDR_RNG_STATE_WORDS words) moves on by the words the WHOLE
+// call of n particles consumes (every rank of a sharded filter keeps the same state).
+extern "C" int tdr_k_rng_propagate_normals(uint32_t* state, int64_t n, int64_t lo, int64_t hi, int scale_freeze, float* z4_out,
+                                           void* workspace, void* stream) {
+  if (!state || !z4_out || !workspace) return fail(TDR_ERR_ARG, "rng_propagate_normals: null pointer");
+  if (n < 1 || lo < 0 || hi > n || lo > hi) return fail(TDR_ERR_ARG, "rng_propagate_normals: bad range");
+  hipStream_t s = (hipStream_t)stream;
+  const int per = scale_freeze ? 2 : 3;
+  const MtWs W = mt_ws(n, per);
+  char* base = reinterpret_cast<char*>(workspace);
+  uint32_t* raw = reinterpret_cast<uint32_t*>(base);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(base + W.off_flags);
+  uint32_t* rank = reinterpret_cast<uint32_t*>(base + W.off_rank);
+  uint32_t* consumed = reinterpret_cast<uint32_t*>(base + W.off_consumed);
+  HIP_TRY(hipMemsetAsync(consumed, 0xFF, 4, s));
+  hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)state, (int)W.nblocks, raw);
+  LAUNCH_CHECK("mt_fill");
+  const unsigned blocks = (unsigned)cdiv(W.nattempts, 256);
+  hipLaunchKernelGGL(mt_attempt_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)raw, (const uint32_t*)state,
+                     W.nattempts, flags);
+  LAUNCH_CHECK("mt_attempt");
+  size_t scan_bytes = mt_scan_bytes(W.nattempts);
+  HIP_TRY(rocprim::exclusive_scan(base + W.off_scan, scan_bytes, flags, rank, 0u, (size_t)W.nattempts,
+                                  rocprim::plus<uint32_t>(), s, false));
+  hipLaunchKernelGGL(mt_normal_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)raw, (const uint32_t*)state,
+                     (const uint32_t*)flags, (const uint32_t*)rank, W.nattempts, n, per, lo, hi, z4_out, consumed);
+  LAUNCH_CHECK("mt_normal");
+  hipLaunchKernelGGL(mt_advance_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)raw, (int)W.nblocks,
+                     (const uint32_t*)consumed, state);
+  LAUNCH_CHECK("mt_advance");
+  return TDR_OK;
+}
+extern "C" int tdr_k_rng_uniform(uint32_t* state, float* out, void* stream) {
+  if (!state || !out) return fail(TDR_ERR_ARG, "rng_uniform: null pointer");
+  hipLaunchKernelGGL(mt_uniform_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, out);
+  LAUNCH_CHECK("mt_uniform");
+  return TDR_OK;
+}
+
+// A host std::mt19937 <-> the device representation: words[0 .. 623] the engine's state array, words[624] the index of the
+// next word (624: a twist comes first), words[625] the error flag of the device kernels (0).  Through the engine's own
+// stream operators — the textual form libstdc++ defines: the 624 words, then the index.
+extern "C" int tdr_rng_get_state_host(void* rng, uint32_t* words) {
+  if (!rng || !words) return fail(TDR_ERR_ARG, "rng_get_state: null pointer");
+  std::ostringstream os;
+  os << *(std::mt19937*)rng;
+  std::istringstream is(os.str());
+  for (int k = 0; k <= MT_N; k++) {
+    unsigned long long v = 0;
+    if (!(is >> v)) return fail(TDR_ERR_ARG, "rng_get_state: unexpected engine format");
+    words[k] = (uint32_t)v;
+  }
+  for (int k = MT_N + 1; k < TDR_RNG_STATE_WORDS; k++) words[k] = 0;
+  return TDR_OK;
+}
+extern "C" int tdr_rng_set_state_host(void* rng, const uint32_t* words) {
+  if (!rng || !words) return fail(TDR_ERR_ARG, "rng_set_state: null pointer");
+  if (words[MT_N] > MT_N) return fail(TDR_ERR_ARG, "rng_set_state: index %u", words[MT_N]);
+  if (words[MT_N + 1] != 0) return fail(TDR_ERR_ARG, "rng_set_state: the device generator ran out of its attempt budget");
+  std::ostringstream os;
+  for (int k = 0; k <= MT_N; k++) os << words[k] << (k < MT_N ? " " : "");
+  std::istringstream is(os.str());
+  is >> *(std::mt19937*)rng;
+  if (!is) return fail(TDR_ERR_ARG, "rng_set_state: the engine refused the state");
+  return TDR_OK;
+}
+
+// self tests of the logf restatement (tests/test_libm.py): on the host, and on the device
+extern "C" int tdr_logf_host(const float* x, int64_t n, float* out) {
+  if (!x || !out || n < 0) return fail(TDR_ERR_ARG, "logf_host: bad arguments");
+  for (int64_t i = 0; i < n; i++) out[i] = tdr_libm::logf_t<true>(x[i]);
+  return TDR_OK;
+}
+__global__ void selftest_logf_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = tdr_libm::logf_t<true>(x[i]);
+}
+extern "C" int tdr_k_selftest_logf(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n < 0) return fail(TDR_ERR_ARG, "selftest_logf: bad arguments");
+  if (n == 0) return TDR_OK;
+  hipLaunchKernelGGL(selftest_logf_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  LAUNCH_CHECK("selftest_logf");
+  return TDR_OK;
+}

@@ -397,6 +397,31 @@ class HipKernels:
     def rng_create(self, seed):
         return C.c_void_p(self.lib.tdr_rng_create(C.c_uint32(seed & 0xFFFFFFFF)))
 
+    # the same generator continued on the device (csrc/tdr_rng.hip): state = 640 uint32 words (include/tdr.h)
+    device_rng = True
+
+    def rng_state_to_device(self, rng):
+        words = np.zeros(640, np.uint32)
+        check(self.lib.tdr_rng_get_state_host(rng, words.ctypes.data_as(C.c_void_p)))
+        return self.to_device(words.view(np.int32))
+
+    def rng_state_to_host(self, rng, state_dev):
+        words = np.ascontiguousarray(state_dev.cpu().numpy()).view(np.uint32)
+        check(self.lib.tdr_rng_set_state_host(rng, words.ctypes.data_as(C.c_void_p)))
+
+    def rng_propagate_normals_dev(self, state_dev, n, lo, hi, scale_freeze, z4_out, n_max):
+        need = int(self.lib.tdr_rng_dev_workspace_bytes(max(n, n_max)))
+        if getattr(self, "_rws", None) is None or self._rws.numel() < need:
+            self._rws = self.empty((need,), torch.uint8)
+        check(self.lib.tdr_k_rng_propagate_normals(_ptr(state_dev), n, lo, hi, int(scale_freeze), _ptr(z4_out),
+                                                   _ptr(self._rws), self.stream()))
+
+    def rng_uniform_dev(self, state_dev, out_dev):
+        check(self.lib.tdr_k_rng_uniform(_ptr(state_dev), _ptr(out_dev), self.stream()))
+
+    def resample_dev(self, runmax, n, n_new, shift_dev, i_begin, i_end, idx):
+        check(self.lib.tdr_k_resample_dev(_ptr(runmax), n, n_new, _ptr(shift_dev), i_begin, i_end, _ptr(idx), self.stream()))
+
     def rng_uniform(self, rng):
         return float(self.lib.tdr_rng_uniform_host(rng))
 

@@ -126,6 +126,12 @@ class ParticleFilter:
         self.seed = int(seed)
         self.score_ctx = self.k.score_ctx_create()   # this filter's side stream + span tuner (include/tdr.h)
         self.gen_ = self.k.rng_create(seed)
+        # parity mode: the generator's stream continues on the device (csrc/tdr_rng.hip) between the host's own draws
+        self._rng_dev = None          # 640 words: the engine's state in libstdc++'s representation
+        self._rng_on_device = False
+        self._shift_dev = None
+        self._z4_dev = None
+        self._last_shift = None
         self.step_ = 0
         self.prop_calls_ = 0      # device RNG counter: every propagate call draws fresh noise
         self._maybe_uninit = True
@@ -209,11 +215,31 @@ class ParticleFilter:
             if not good:
                 return  # "No road in map at init location" :49-52
         self.fp_c = p.to_c(m.numClasses())
+        self._rng_to_host()
         states = self.k.init_particles(self.gen_, m.maps_cm_host, m.numClasses(), m.rows, m.cols, m.resolution(),
                                        self.fp_c, self.max_num_particles_, STATE_DTYPE)
         n = (len(states) // self.comm.world) * self.comm.world
         n = min(n, self.max_num_particles_)
         self.set_states(states[:n])
+
+    @property
+    def last_shift_(self):
+        """The uniform draw of the last update's resample (src/particle_filter.cpp:172-173); read back from the device when it
+        was drawn there."""
+        if self._last_shift is None and self._shift_dev is not None:
+            return float(self._shift_dev[0].item())
+        return self._last_shift
+
+    def _rng_to_device(self):
+        if not self._rng_on_device:
+            self._rng_dev = self.k.rng_state_to_device(self.gen_)
+            self._rng_on_device = True
+
+    def _rng_to_host(self):
+        """The host engine takes the stream back (synchronises)."""
+        if self._rng_on_device:
+            self.k.rng_state_to_host(self.gen_, self._rng_dev)
+            self._rng_on_device = False
 
     # ---- particle_filter.cpp:86-92 ------------------------------------------------------------------------------------
     def propagate(self, trans, omega):
@@ -222,8 +248,16 @@ class ParticleFilter:
             return
         p = self.params_
         z_dev = None
-        if self.parity_rng:
-            # the reference draws serially in global particle order from one shared generator
+        if self.parity_rng and getattr(self.k, "device_rng", False):
+            # the reference draws serially in global particle order from one shared generator: every rank continues that
+            # stream on its device and keeps the normals of its own particles
+            self._rng_to_device()
+            if self._z4_dev is None or self._z4_dev.shape[0] < nl:
+                self._z4_dev = self.k.empty((max(nl, self.cap_local), 4))
+            z_dev = self._z4_dev
+            self.k.rng_propagate_normals_dev(self._rng_dev, n, self.comm.rank * nl, (self.comm.rank + 1) * nl,
+                                             self.scale_frozen_, z_dev, self.max_num_particles_)
+        elif self.parity_rng:
             z = self.k.propagate_normals(self.gen_, n, self.scale_frozen_)
             z_dev = self.k.to_device(z[self.comm.rank * nl:(self.comm.rank + 1) * nl])
         self.k.propagate(self.st, nl, self.last_dist, float(trans[0]), float(trans[1]), float(omega),
@@ -310,12 +344,19 @@ class ParticleFilter:
             n_new = min(int(n_target), self.max_num_particles_)
         n_new = max(comm.world, (n_new // comm.world) * comm.world)
 
-        if shift is None:
-            shift = k.rng_uniform(self.gen_)  # :172-173 (every rank owns an identically seeded generator)
         k.prefix(self.weights_, n, self.runmax)
         nl_new = n_new // comm.world
         i0 = comm.rank * nl_new
-        k.resample(self.runmax, n, n_new, float(shift), i0, i0 + nl_new, self.idx)
+        if shift is None and self._rng_on_device:
+            # :172-173 (every rank owns an identically seeded generator): the stream is on the device, so is the draw
+            if self._shift_dev is None:
+                self._shift_dev = k.zeros((64,))
+            k.rng_uniform_dev(self._rng_dev, self._shift_dev)
+            k.resample_dev(self.runmax, n, n_new, self._shift_dev, i0, i0 + nl_new, self.idx)
+        else:
+            if shift is None:
+                shift = k.rng_uniform(self.gen_)
+            k.resample(self.runmax, n, n_new, float(shift), i0, i0 + nl_new, self.idx)
         if comm.active:
             if st_work is not None:
                 st_work.wait()
@@ -328,7 +369,7 @@ class ParticleFilter:
         self.num_particles_ = n_new
         self.perm = None if n_new != n else self.perm
         self.step_ += 1
-        self.last_shift_ = float(shift)
+        self._last_shift = None if shift is None else float(shift)
 
     def _save_ml_state(self, st_all, nl):
         """max_likelihood_particle_ (:145-147) points at the PRE-resample particle: copy its 7 fields into a small
