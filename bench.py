@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--locality-every", type=int, default=1, help="recompute the cache-locality order every k steps (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="particles in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--device-rng", action="store_true",
+                    help="time the steps with the counter-based device noise instead of the reference's std::mt19937 stream "
+                         "(default: the reference's stream, reproduced on the device; the other figure is reported beside it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
@@ -245,8 +248,10 @@ def main():
         m.setWindow(cfg.nb, cfg.nr)
         r = pkg.ScanRenderer(sc.lut, kernels=k)
     r.set_output_shape(cfg.ncls, cfg.nb, cfg.nr)
+    # propagate draws the reference's own noise: std::mt19937 + libstdc++'s normal_distribution in the reference's order,
+    # reproduced on the device (csrc/tdr_rng.hip) — the identical-results path is the one that is timed
     f = pkg.ParticleFilter(n_global, m, pkg.FilterParams(fixed_scale=1.0), seed=1, group=group, kernels=k,
-                           parity_rng=False, locality_every=a.locality_every, init_particles=False)
+                           parity_rng=not a.device_rng, locality_every=a.locality_every, init_particles=False)
     f.set_states(sc.states)
     nl = f.n_local
     pts_host = torch.from_numpy(sc.pts).pin_memory()
@@ -312,6 +317,18 @@ def main():
     tot_ms, launches = C.c_double(0), C.c_int64(0)
     k.lib.tdr_profile_score_ms(C.byref(tot_ms), C.byref(launches))
     k.lib.tdr_profile_enable(0)
+    # the same steps with the other noise source, beside the headline (a fifth of the steps, at least 5)
+    other_steps = max(5, a.steps // 5)
+    f.parity_rng = not f.parity_rng
+    for _ in range(2):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(other_steps):
+        step()
+    barrier()
+    dt_other = (time.perf_counter() - t1) / other_steps
+    f.parity_rng = not f.parity_rng
     if world > 1:
         t = torch.tensor([dt], device=k.device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -377,6 +394,11 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rng": {"timed": ("device counter-based noise (Philox)" if a.device_rng else
+                              "the reference's std::mt19937 + std::normal_distribution stream, reproduced on the device "
+                              "(bit-identical propagate; csrc/tdr_rng.hip)"),
+                    "other": "std::mt19937 stream" if a.device_rng else "device counter-based noise (Philox)",
+                    "other_ms_per_step": dt_other * 1e3, "other_steps": other_steps},
             "config": {"workload": f"{cfg.name}: {cfg.n_pts}-pt scan, {cfg.ncls} classes, {cfg.nb}x{cfg.nr} "
                                    f"{'polar' if cfg.polar else 'Cartesian'} render, {cfg.map_size}x{cfg.map_size} map",
                        "particles_per_gpu": per_gpu, "particles_total": n_global,

@@ -48,36 +48,45 @@ __device__ __forceinline__ float mt_canonical(uint32_t u) {
   return c >= 1.f ? 0x1.fffffep-1f : c;
 }
 // One twist of the state in LDS (mersenne_twister_engine::_M_gen_rand), by ONE wave: elements in ascending order, 192 at
-// a time — element k needs the OLD x[k], x[k + 1] and, from 227 on, the NEW x[k - 227], written at least one batch earlier.
-__device__ __forceinline__ void mt_twist(uint32_t* x, int lane) {
-  for (int base = 0; base < MT_N; base += 192) {
-    uint32_t nv[3];
+// a time — element k needs the OLD x[k], x[k + 1] and, from 227 on, the NEW x[k - 227], written at least one batch earlier;
+// element 623 reads the NEW x[0] (it is the last of the engine's loop), long written when its batch comes.  So a batch is
+// nine LDS reads in flight together, then three writes.  One wave, and the LDS serves a wave's instructions in order: no
+// hardware barrier is needed — only the compiler must keep a batch's loads in front of its stores and the stores in front
+// of the next batch's loads (with workgroup barriers a block took 0.9 us).  x holds MT_X words: the lanes behind element
+// 623 work on padding instead of being predicated off.
+#define MT_X 1040
+template <int S0, int NS>
+__device__ __forceinline__ void mt_twist_batch(uint32_t* x, int lane, uint32_t* __restrict__ out) {
+  uint32_t nv[NS];
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-      const int k = base + 64 * s + lane;
-      if (k < MT_N) {
-        const int k1 = k + 1 == MT_N ? 0 : k + 1;
-        const uint32_t y = (x[k] & 0x80000000u) | (x[k1] & 0x7fffffffu);
-        const uint32_t src = k < MT_N - MT_M ? x[k + MT_M] : x[k - (MT_N - MT_M)];
-        nv[s] = src ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
-      }
-    }
-    // element 623 reads the NEW x[0] (it is the last of the loop in the engine): its batch is the last one, x[0] is long
-    // written; every other read above is of values no store of this batch touches.  (One wave: the barriers are there for
-    // the compiler — loads of a batch before its stores, stores before the next batch's loads.)
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      const int k = base + 64 * s + lane;
-      if (k < MT_N) x[k] = nv[s];
-    }
-    __syncthreads();
+  for (int s = 0; s < NS; s++) {
+    const int k = 64 * (S0 + s) + lane;
+    const int k1 = k == MT_N - 1 ? 0 : k + 1;
+    const int si = k < MT_N - MT_M ? k + MT_M : k - (MT_N - MT_M);
+    const uint32_t y = (x[k] & 0x80000000u) | (x[k1] & 0x7fffffffu);
+    nv[s] = x[si] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int k = 64 * (S0 + s) + lane;
+    x[k] = nv[s];
+    if (out && k < MT_N) out[k] = nv[s];   // the new block to global memory, from the registers
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void mt_twist(uint32_t* x, int lane, uint32_t* __restrict__ out) {
+  mt_twist_batch<0, 3>(x, lane, out);
+  mt_twist_batch<3, 3>(x, lane, out);
+  mt_twist_batch<6, 3>(x, lane, out);
+  mt_twist_batch<9, 1>(x, lane, out);   // elements 576 .. 623 (and 16 lanes of padding)
 }
 
 // raw [nblocks][624]: block 0 = the state as it is, block b = the state b twists later (untempered words)
 __global__ __launch_bounds__(64) void mt_fill_kernel(const uint32_t* __restrict__ state, int nblocks, uint32_t* __restrict__ raw) {
-  __shared__ uint32_t x[MT_N];
+  __shared__ uint32_t x[MT_X];
   const int lane = threadIdx.x;
   for (int k = lane; k < MT_N; k += 64) {
     const uint32_t v = state[k];
@@ -85,10 +94,7 @@ __global__ __launch_bounds__(64) void mt_fill_kernel(const uint32_t* __restrict_
     raw[k] = v;
   }
   __syncthreads();
-  for (int b = 1; b < nblocks; b++) {
-    mt_twist(x, lane);
-    for (int k = lane; k < MT_N; k += 64) raw[(int64_t)b * MT_N + k] = x[k];
-  }
+  for (int b = 1; b < nblocks; b++) mt_twist(x, lane, raw + (int64_t)b * MT_N);
 }
 
 struct MtAttempt {
@@ -156,15 +162,14 @@ __global__ __launch_bounds__(64) void mt_advance_kernel(const uint32_t* __restri
 }
 // std::uniform_real_distribution<float>(0, 1)(gen): one word
 __global__ __launch_bounds__(64) void mt_uniform_kernel(uint32_t* __restrict__ state, float* __restrict__ out) {
-  __shared__ uint32_t x[MT_N];
+  __shared__ uint32_t x[MT_X];
   const int lane = threadIdx.x;
   uint32_t p = state[MT_N];
   uint32_t word;
   if (p >= MT_N) {   // (uniform) the block is used up: twist first
     for (int k = lane; k < MT_N; k += 64) x[k] = state[k];
     __syncthreads();
-    mt_twist(x, lane);
-    for (int k = lane; k < MT_N; k += 64) state[k] = x[k];
+    mt_twist(x, lane, state);
     p = 0;
     word = x[0];
   } else {
