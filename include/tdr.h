@@ -297,6 +297,24 @@ int tdr_k_rng_propagate_normals(uint32_t* state, int64_t n, int64_t lo, int64_t 
 int tdr_k_rng_uniform(uint32_t* state, float* out_dev, void* stream);
 int tdr_rng_get_state_host(void* rng, uint32_t* words);
 int tdr_rng_set_state_host(void* rng, const uint32_t* words);
+/* tdr_rng_pipe: the generator of ONE filter on the device, drawing ahead (csrc/tdr_rng.hip).  A filter's step draws in a
+ * fixed order — propagate's normals, the resample's uniform, the next step's normals — and none of it depends on the
+ * particles: when a propagate call has been served, the pipe draws what the step after it will most likely ask for on a
+ * stream of its own, beside the scoring launch.  A call that asks for something else (another particle count, another
+ * order, the host engine taking the stream back) makes it drop what it drew ahead and continue from the state the stream
+ * really is in: the values handed out are the stream's own in every case.  One pipe per filter, one caller thread; n_max:
+ * the largest particle count of a call.  from_host / to_host move the stream between a host std::mt19937 and the device
+ * (they synchronise `stream`); normals / uniform are ordered on `stream` and wait for nothing on the host; the device
+ * pointers they return stay valid until the next call of the same function. */
+typedef struct tdr_rng_pipe tdr_rng_pipe;
+int tdr_rng_pipe_create(int64_t n_max, tdr_rng_pipe** out);
+void tdr_rng_pipe_destroy(tdr_rng_pipe* p);
+int tdr_rng_pipe_on_device(const tdr_rng_pipe* p);
+int tdr_rng_pipe_from_host(tdr_rng_pipe* p, void* host_rng, void* stream);
+int tdr_rng_pipe_to_host(tdr_rng_pipe* p, void* host_rng, void* stream);
+int tdr_rng_pipe_normals(tdr_rng_pipe* p, int64_t n, int64_t lo, int64_t hi, int scale_freeze, const float** z4_out,
+                         void* stream);
+int tdr_rng_pipe_uniform(tdr_rng_pipe* p, const float** shift_out, void* stream);
 /* ParticleFilter::initializeParticles particle loop (src/particle_filter.cpp:57-71) with the StateParticle
  * constructor (src/state_particle.cpp:3-49): host-side, serial mt19937 draws with on-road rejection.
  * class_maps: HOST copy of class_maps_ (column-major [ncls][rows*cols]); out must hold max_num+16 states. */

@@ -122,3 +122,46 @@ def test_many_uniform_draws_cross_the_blocks(k):
         else:
             L.tdr_rng_uniform_host(host)
     L.tdr_rng_destroy(host)
+
+
+@pytest.mark.gpu
+def test_the_pipe_draws_ahead_and_never_changes_the_stream(k):
+    """Call sequences through a tdr_rng_pipe against the host engine drawing the same things in the same order: the step's
+    own pattern (normals, uniform, normals, ... — everything after the first call is served from what was drawn ahead),
+    and every way of breaking it: two propagates in a row, two uniforms, a change of the particle count and of the freeze
+    flag, a sharded range, the host taking the stream back in the middle and handing it over again."""
+    L = k.lib
+    host = C.c_void_p(L.tdr_rng_create(C.c_uint32(99)))
+    for _ in range(17):
+        L.tdr_rng_uniform_host(host)
+    mirror = C.c_void_p(L.tdr_rng_create(C.c_uint32(99)))
+    for _ in range(17):
+        L.tdr_rng_uniform_host(mirror)
+    pipe = k.rng_pipe_create(6000)
+    pipe.from_host(host)
+    seq = [("n", 5000, 0, 5000, 0), ("u",), ("n", 5000, 0, 5000, 0), ("u",), ("n", 5000, 0, 5000, 0),   # the step's pattern
+           ("n", 5000, 0, 5000, 0),                      # two propagates in a row
+           ("u",), ("u",),                               # two uniforms
+           ("n", 3000, 0, 3000, 0), ("u",),              # another count
+           ("n", 3000, 0, 3000, 1), ("u",),              # the freeze flag
+           ("n", 3000, 0, 3000, 1), ("host",),           # the host takes the stream (after a draw-ahead started) ...
+           ("u",), ("n", 6000, 1500, 3000, 0), ("u",),   # ... and gives it back; a rank's slice of a sharded call
+           ("n", 6000, 1500, 3000, 0), ("u",), ("n", 6000, 1500, 3000, 0), ("host",)]
+    for step in seq:
+        if step[0] == "n":
+            _, n, lo, hi, fr = step
+            z = pipe.normals(n, lo, hi, fr)
+            got = k.read_device_floats(z, 4 * (hi - lo)).reshape(-1, 4)
+            ref = _host_normals(L, mirror, n, fr)[lo:hi]
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), step
+        elif step[0] == "u":
+            if not pipe.on_device():
+                pipe.from_host(host)
+            got = float(k.read_device_floats(pipe.uniform(), 1)[0])
+            assert got == float(L.tdr_rng_uniform_host(mirror)), step
+        else:
+            pipe.to_host(host)
+            a, b = _host_normals(L, host, 20, False), _host_normals(L, mirror, 20, False)   # the host engine continues
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for h in (host, mirror):
+        L.tdr_rng_destroy(h)

@@ -90,6 +90,13 @@ SIGNATURES = {
     "tdr_active_candidates_host": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "tdr_logf_host": (_i, [_vp, _i64, _vp]),
     "tdr_k_selftest_logf": (_i, [_vp, _i64, _vp, _vp]),
+    "tdr_rng_pipe_create": (_i, [_i64, C.POINTER(_vp)]),
+    "tdr_rng_pipe_destroy": (None, [_vp]),
+    "tdr_rng_pipe_on_device": (_i, [_vp]),
+    "tdr_rng_pipe_from_host": (_i, [_vp, _vp, _vp]),
+    "tdr_rng_pipe_to_host": (_i, [_vp, _vp, _vp]),
+    "tdr_rng_pipe_normals": (_i, [_vp, _i64, _i64, _i64, _i, C.POINTER(_vp), _vp]),
+    "tdr_rng_pipe_uniform": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tdr_rng_dev_workspace_bytes": (C.c_size_t, [_i64]),
     "tdr_k_rng_propagate_normals": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp]),
     "tdr_k_rng_uniform": (_i, [_vp, _vp, _vp]),

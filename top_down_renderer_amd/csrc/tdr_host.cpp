@@ -127,14 +127,11 @@ struct tdr_filter {
   bool have_ml = false;
   hipStream_t stream = nullptr;
   tdr_score_ctx* score_ctx = nullptr;   // this filter's own side stream and span tuner for its scoring launches (tdr.h)
-  // The reference's generator in parity mode: the host std::mt19937 `rng` and its copy on the device (csrc/tdr_rng.hip).
-  // Exactly one of them is current: propagate and the resample's uniform draw continue the stream on the device, the
-  // host engine takes it back when host code draws (particle initialisation).  A generator shared with the caller
-  // (tdr_filter_share_rng) stays on the host.
-  DevBuf<uint32_t> rng_dev;
-  DevBuf<uint8_t> rng_ws;
-  DevBuf<float> shift_dev;
-  bool rng_on_device = false;
+  // The reference's generator in parity mode: the host std::mt19937 `rng` and its continuation on the device, a
+  // tdr_rng_pipe (csrc/tdr_rng.hip).  Exactly one of them is current: propagate and the resample's uniform draw continue
+  // the stream on the device (drawn ahead, beside the scoring launch), the host engine takes it back when host code
+  // draws (particle initialisation).  A generator shared with the caller (tdr_filter_share_rng) stays on the host.
+  tdr_rng_pipe* pipe = nullptr;
   // Sharded over the ranks of `comm` (one process per GPU; NULL = the whole filter lives here).  n / n_max stay the
   // GLOBAL counts; this rank holds particles [rank * nl, (rank + 1) * nl), nl = n / world, in st[7][cap] with
   // cap = n_max / world.  raw_glob / ld_glob / w / runmax are global arrays, identical on every rank.
@@ -747,13 +744,14 @@ void tdr_filter_destroy(tdr_filter* f) {
   if (!f) return;
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
   tdr_score_ctx_destroy(f->score_ctx);   // (waits for its side stream)
+  tdr_rng_pipe_destroy(f->pipe);
   delete f;
 }
 
 static int rng_to_host(tdr_filter* f);   // (below, with the propagate step)
 int tdr_filter_configure(tdr_filter* f, int parity_rng, int locality_every) {
   if (!f) return failh(TDR_ERR_ARG, "filter_configure: null filter");
-  if (!parity_rng && f->rng_on_device) TTRY(rng_to_host(f));
+  if (!parity_rng) TTRY(rng_to_host(f));
   f->parity_rng = parity_rng != 0;
   f->locality_every = locality_every;
   return TDR_OK;
@@ -827,25 +825,15 @@ int tdr_filter_initialize_particles(tdr_filter* f) {
 }
 
 // the generator's stream continues on the device / on the host (see tdr_filter::rng_dev)
+static bool rng_on_device(const tdr_filter* f) { return f->pipe && tdr_rng_pipe_on_device(f->pipe); }
 static int rng_to_device(tdr_filter* f) {
-  if (f->rng_on_device) return TDR_OK;
-  uint32_t words[TDR_RNG_STATE_WORDS];
-  TTRY(tdr_rng_get_state_host(f->rng, words));
-  TTRY(f->rng_dev.resize(TDR_RNG_STATE_WORDS));
-  TTRY(f->shift_dev.resize(64));
-  HTRY(hipMemcpyAsync(f->rng_dev.p, words, sizeof(words), hipMemcpyHostToDevice, f->stream));
-  HTRY(hipStreamSynchronize(f->stream));   // `words` lives on this frame
-  f->rng_on_device = true;
-  return TDR_OK;
+  if (rng_on_device(f)) return TDR_OK;
+  if (!f->pipe) TTRY(tdr_rng_pipe_create(f->n_max, &f->pipe));
+  return tdr_rng_pipe_from_host(f->pipe, f->rng, f->stream);
 }
 static int rng_to_host(tdr_filter* f) {
-  if (!f->rng_on_device) return TDR_OK;
-  uint32_t words[TDR_RNG_STATE_WORDS];
-  HTRY(hipMemcpyAsync(words, f->rng_dev.p, sizeof(words), hipMemcpyDeviceToHost, f->stream));
-  HTRY(hipStreamSynchronize(f->stream));
-  TTRY(tdr_rng_set_state_host(f->rng, words));
-  f->rng_on_device = false;
-  return TDR_OK;
+  if (!rng_on_device(f)) return TDR_OK;
+  return tdr_rng_pipe_to_host(f->pipe, f->rng, f->stream);
 }
 static bool rng_device_capable(const tdr_filter* f) { return f->rng_owned && f->parity_rng; }
 
@@ -858,10 +846,8 @@ static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool
     // the reference draws serially in GLOBAL particle order from one generator: every rank continues the same stream on
     // its device (same state everywhere) and keeps the normals of its own particles — nothing is drawn on the host
     TTRY(rng_to_device(f));
-    TTRY(f->rng_ws.resize(tdr_rng_dev_workspace_bytes(f->n_max)));
-    TTRY(tdr_k_rng_propagate_normals(f->rng_dev.p, f->n, (int64_t)f->rank * nl, (int64_t)(f->rank + 1) * nl, scale_freeze ? 1 : 0,
-                                     f->z4.p, f->rng_ws.p, f->stream));
-    z = f->z4.p;
+    TTRY(tdr_rng_pipe_normals(f->pipe, f->n, (int64_t)f->rank * nl, (int64_t)(f->rank + 1) * nl, scale_freeze ? 1 : 0, &z,
+                              f->stream));
   } else if (f->parity_rng) {
     // a generator shared with the caller (StateParticle's surface): the host draws, serially
     std::vector<float> zh((size_t)4 * f->n);
@@ -888,7 +874,7 @@ int tdr_filter_propagate_freeze(tdr_filter* f, float tx, float ty, float omega, 
 // built with; it is not owned.
 int tdr_filter_share_rng(tdr_filter* f, void* mt19937) {
   if (!f || !mt19937) return failh(TDR_ERR_ARG, "filter_share_rng: bad arguments");
-  f->rng_on_device = false;   // (the filter's own stream ends here)
+  if (f->pipe) { tdr_rng_pipe_destroy(f->pipe); f->pipe = nullptr; }   // (the filter's own stream ends here)
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
   f->rng = mt19937;
   f->rng_owned = false;
@@ -1048,9 +1034,10 @@ static int filter_resample(tdr_filter* f, int64_t n_target) {
   TTRY(tdr_k_prefix(f->w.p, n, f->runmax.p, f->pfx_ws.p, f->stream));
   // :172-173 (every rank owns an identically seeded generator); each rank draws its own slice [i0, i0 + nl_new) of the new
   // set, idx holds GLOBAL source indices
-  if (f->rng_on_device) {   // the stream is on the device: so is the draw
-    TTRY(tdr_k_rng_uniform(f->rng_dev.p, f->shift_dev.p, f->stream));
-    TTRY(tdr_k_resample_dev(f->runmax.p, n, n_new, f->shift_dev.p, i0, i0 + nl_new, f->idx.p, f->stream));
+  if (rng_on_device(f)) {   // the stream is on the device: so is the draw
+    const float* shift_dev = nullptr;
+    TTRY(tdr_rng_pipe_uniform(f->pipe, &shift_dev, f->stream));
+    TTRY(tdr_k_resample_dev(f->runmax.p, n, n_new, shift_dev, i0, i0 + nl_new, f->idx.p, f->stream));
   } else {
     const float shift = tdr_rng_uniform_host(f->rng);
     TTRY(tdr_k_resample(f->runmax.p, n, n_new, shift, i0, i0 + nl_new, f->idx.p, f->stream));

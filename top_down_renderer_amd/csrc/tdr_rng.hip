@@ -301,3 +301,167 @@ extern "C" int tdr_k_selftest_logf(const float* x, int64_t n, float* out, void* 
   LAUNCH_CHECK("selftest_logf");
   return TDR_OK;
 }
+
+// ---- tdr_rng_pipe: the generator of ONE filter on the device, drawing AHEAD ----------------------------------------------
+// A filter's step draws in a fixed order — the normals of propagate, then the uniform of the resample, then the next
+// step's normals — and none of it depends on the particles.  So when a propagate call has been served, the pipe at once
+// draws, on a stream of its own and from a COPY of the state, what the step after it will most likely ask for: the uniform,
+// then the normals of a propagate call with the same particle count and freeze flag.  It runs beside the scoring launch;
+// the next calls find their values ready.  Nothing is assumed: a call that asks for something else (another count, another
+// order, the host taking the stream back) makes the pipe drop what it drew ahead and continue from the state the stream
+// really is in — the states behind each speculative step are kept for exactly that.  Results are the stream's own either
+// way (tests/test_rng.py replays call sequences against the host engine).
+// (device-to-device moves of a state are kernels, not runtime copies: a runtime copy between event waits of two streams
+// cost the caller's stream ~0.3 ms per step whenever it also did host-to-device copies of its own)
+__global__ void mt_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+static int mt_copy(const void* src, void* dst, int words, hipStream_t s) {
+  hipLaunchKernelGGL(mt_copy_kernel, dim3((unsigned)cdiv(words, 256)), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, words);
+  LAUNCH_CHECK("mt_copy");
+  return TDR_OK;
+}
+struct tdr_rng_pipe {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_uniform = nullptr, ev_all = nullptr;
+  uint32_t* state = nullptr;        // the stream's real state (device, TDR_RNG_STATE_WORDS)
+  uint32_t* spec_state = nullptr;   // working state of the draw-ahead; behind it: [1] snapshot after the uniform
+  float* shift = nullptr;           // [0] served value, [16] drawn ahead
+  float* z[2] = {nullptr, nullptr};
+  void* ws[2] = {nullptr, nullptr};
+  int64_t n_max = 0;
+  int cur = 0;                      // z[cur] / ws[cur]: what a call on the caller's stream uses; the other: draw-ahead
+  bool on_device = false;
+  // the draw-ahead in flight: 0 none, 1 uniform not yet taken, 2 uniform taken
+  int spec = 0;
+  int64_t spec_n = 0, spec_lo = 0, spec_hi = 0;
+  int spec_freeze = 0;
+  int misses = 0;                   // consecutive calls the draw-ahead did not fit: it pauses after two
+};
+extern "C" int tdr_rng_pipe_create(int64_t n_max, tdr_rng_pipe** out) {
+  if (!out || n_max < 1) return fail(TDR_ERR_ARG, "rng_pipe_create: bad arguments");
+  *out = nullptr;
+  tdr_rng_pipe* p = new (std::nothrow) tdr_rng_pipe;
+  if (!p) return fail(TDR_ERR_NOMEM, "rng_pipe_create: out of memory");
+  p->n_max = n_max;
+  const size_t wsb = tdr_rng_dev_workspace_bytes(n_max);
+  hipError_t e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_uniform, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_all, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->state, sizeof(uint32_t) * TDR_RNG_STATE_WORDS);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->spec_state, sizeof(uint32_t) * TDR_RNG_STATE_WORDS * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->shift, sizeof(float) * 32);
+  for (int k = 0; k < 2 && e == hipSuccess; k++) {
+    e = hipMalloc((void**)&p->z[k], sizeof(float) * 4 * (size_t)n_max);
+    if (e == hipSuccess) e = hipMalloc(&p->ws[k], wsb);
+  }
+  if (e != hipSuccess) {
+    tdr_rng_pipe_destroy(p);
+    return fail(TDR_ERR_HIP, "rng_pipe_create: %s", hipGetErrorString(e));
+  }
+  *out = p;
+  return TDR_OK;
+}
+extern "C" void tdr_rng_pipe_destroy(tdr_rng_pipe* p) {
+  if (!p) return;
+  if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+  for (hipEvent_t ev : {p->ev_fork, p->ev_uniform, p->ev_all})
+    if (ev) (void)hipEventDestroy(ev);
+  (void)hipFree(p->state); (void)hipFree(p->spec_state); (void)hipFree(p->shift);
+  for (int k = 0; k < 2; k++) { (void)hipFree(p->z[k]); (void)hipFree(p->ws[k]); }
+  delete p;
+}
+extern "C" int tdr_rng_pipe_on_device(const tdr_rng_pipe* p) { return p && p->on_device ? 1 : 0; }
+// what was drawn ahead is dropped; `s` continues from the state the stream really is in
+static int pipe_drop(tdr_rng_pipe* p, hipStream_t s) {
+  if (!p->spec) return TDR_OK;
+  HIP_TRY(hipStreamWaitEvent(s, p->ev_all, 0));   // (its kernels still use the other workspace and the snapshot)
+  if (p->spec == 2)   // the uniform was handed out: the stream stands behind it
+    if (int rc = mt_copy(p->spec_state + TDR_RNG_STATE_WORDS, p->state, TDR_RNG_STATE_WORDS, s)) return rc;
+  p->spec = 0;
+  return TDR_OK;
+}
+static int pipe_draw_ahead(tdr_rng_pipe* p, int64_t n, int64_t lo, int64_t hi, int freeze, hipStream_t s) {
+  if (p->misses >= 2) return TDR_OK;   // the caller's pattern is not the step's: wait until it is again
+  HIP_TRY(hipEventRecord(p->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  if (int rc = mt_copy(p->state, p->spec_state, TDR_RNG_STATE_WORDS, p->side)) return rc;
+  if (int rc = tdr_k_rng_uniform(p->spec_state, p->shift + 16, p->side)) return rc;
+  if (int rc = mt_copy(p->spec_state, p->spec_state + TDR_RNG_STATE_WORDS, TDR_RNG_STATE_WORDS, p->side)) return rc;
+  HIP_TRY(hipEventRecord(p->ev_uniform, p->side));
+  if (int rc = tdr_k_rng_propagate_normals(p->spec_state, n, lo, hi, freeze, p->z[1 - p->cur], p->ws[1 - p->cur], p->side)) return rc;
+  HIP_TRY(hipEventRecord(p->ev_all, p->side));
+  p->spec = 1;
+  p->spec_n = n; p->spec_lo = lo; p->spec_hi = hi; p->spec_freeze = freeze;
+  return TDR_OK;
+}
+// the stream continues on the device from where the host engine stands (synchronises: the state travels through the host)
+extern "C" int tdr_rng_pipe_from_host(tdr_rng_pipe* p, void* host_rng, void* stream) {
+  if (!p || !host_rng) return fail(TDR_ERR_ARG, "rng_pipe_from_host: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = pipe_drop(p, s)) return rc;
+  uint32_t words[TDR_RNG_STATE_WORDS];
+  if (int rc = tdr_rng_get_state_host(host_rng, words)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->state, words, sizeof(words), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  p->on_device = true;
+  p->misses = 0;
+  return TDR_OK;
+}
+// ... and back on the host engine (synchronises)
+extern "C" int tdr_rng_pipe_to_host(tdr_rng_pipe* p, void* host_rng, void* stream) {
+  if (!p || !host_rng) return fail(TDR_ERR_ARG, "rng_pipe_to_host: null pointer");
+  if (!p->on_device) return TDR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = pipe_drop(p, s)) return rc;
+  uint32_t words[TDR_RNG_STATE_WORDS];
+  HIP_TRY(hipMemcpyAsync(words, p->state, sizeof(words), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (int rc = tdr_rng_set_state_host(host_rng, words)) return rc;
+  p->on_device = false;
+  return TDR_OK;
+}
+// The normals of a propagate call (tdr_k_rng_propagate_normals): *z4_out = device array [hi - lo][4], valid until the next
+// call of this function.  Ordered on `stream`.
+extern "C" int tdr_rng_pipe_normals(tdr_rng_pipe* p, int64_t n, int64_t lo, int64_t hi, int scale_freeze, const float** z4_out,
+                                    void* stream) {
+  if (!p || !z4_out) return fail(TDR_ERR_ARG, "rng_pipe_normals: null pointer");
+  if (!p->on_device) return fail(TDR_ERR_ARG, "rng_pipe_normals: the stream is on the host (tdr_rng_pipe_from_host)");
+  if (n < 1 || n > p->n_max || lo < 0 || hi > n || lo > hi) return fail(TDR_ERR_ARG, "rng_pipe_normals: bad range");
+  hipStream_t s = (hipStream_t)stream;
+  const int fr = scale_freeze ? 1 : 0;
+  if (p->spec == 2 && p->spec_n == n && p->spec_lo == lo && p->spec_hi == hi && p->spec_freeze == fr) {
+    // drawn ahead: adopt its values and the state behind them
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_all, 0));
+    if (int rc = mt_copy(p->spec_state, p->state, TDR_RNG_STATE_WORDS, s)) return rc;
+    p->cur = 1 - p->cur;
+    p->spec = 0;
+    p->misses = 0;
+  } else {
+    if (p->spec) p->misses++;
+    else if (p->misses) p->misses--;   // (a call that had nothing to compare with: the pattern gets another chance)
+    if (int rc = pipe_drop(p, s)) return rc;
+    if (int rc = tdr_k_rng_propagate_normals(p->state, n, lo, hi, fr, p->z[p->cur], p->ws[p->cur], s)) return rc;
+  }
+  *z4_out = p->z[p->cur];
+  return pipe_draw_ahead(p, n, lo, hi, fr, s);
+}
+// The uniform draw of the resample: *shift_out = device float, valid until the next call of this function.
+extern "C" int tdr_rng_pipe_uniform(tdr_rng_pipe* p, const float** shift_out, void* stream) {
+  if (!p || !shift_out) return fail(TDR_ERR_ARG, "rng_pipe_uniform: null pointer");
+  if (!p->on_device) return fail(TDR_ERR_ARG, "rng_pipe_uniform: the stream is on the host (tdr_rng_pipe_from_host)");
+  hipStream_t s = (hipStream_t)stream;
+  if (p->spec == 1) {   // drawn ahead
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_uniform, 0));
+    if (int rc = mt_copy(p->shift + 16, p->shift, 1, s)) return rc;
+    p->spec = 2;
+  } else {
+    if (p->spec) p->misses++;
+    if (int rc = pipe_drop(p, s)) return rc;
+    if (int rc = tdr_k_rng_uniform(p->state, p->shift, s)) return rc;
+  }
+  *shift_out = p->shift;
+  return TDR_OK;
+}

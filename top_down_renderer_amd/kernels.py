@@ -36,6 +36,50 @@ class ScoreCtx:
             pass
 
 
+class DevPtr:
+    """A raw device pointer the library handed out, passed on like a tensor."""
+
+    def __init__(self, addr):
+        self.addr = addr
+
+    def data_ptr(self):
+        return self.addr
+
+
+class RngPipe:
+    """Owner of a tdr_rng_pipe (include/tdr.h)."""
+
+    def __init__(self, kernels, handle):
+        self.k, self.lib, self.handle = kernels, kernels.lib, handle
+
+    def on_device(self):
+        return bool(self.lib.tdr_rng_pipe_on_device(self.handle))
+
+    def from_host(self, rng):
+        check(self.lib.tdr_rng_pipe_from_host(self.handle, rng, self.k.stream()))
+
+    def to_host(self, rng):
+        check(self.lib.tdr_rng_pipe_to_host(self.handle, rng, self.k.stream()))
+
+    def normals(self, n, lo, hi, scale_freeze):
+        z = C.c_void_p(0)
+        check(self.lib.tdr_rng_pipe_normals(self.handle, n, lo, hi, int(scale_freeze), C.byref(z), self.k.stream()))
+        return DevPtr(z.value)
+
+    def uniform(self):
+        u = C.c_void_p(0)
+        check(self.lib.tdr_rng_pipe_uniform(self.handle, C.byref(u), self.k.stream()))
+        return DevPtr(u.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.tdr_rng_pipe_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class DeviceMap:
     """Device-resident interleaved map (tdr_map_desc) + the polar sampling table."""
 
@@ -129,6 +173,17 @@ class HipKernels:
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
+
+    def read_device_floats(self, dev, n):
+        """n floats behind a device pointer the library handed out (synchronises)."""
+        if getattr(self, "_hip", None) is None:
+            self._hip = C.CDLL("libamdhip64.so")
+        self.synchronize()
+        out = np.zeros(n, np.float32)
+        rc = self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(dev.data_ptr()), C.c_size_t(4 * n), 2)
+        if rc != 0:
+            raise _lib.TdrError(f"hipMemcpy device -> host failed ({rc})")
+        return out
 
     # ---- map ------------------------------------------------------------------------------------------------
     def make_map(self, class_maps, class_mask, resolution):
@@ -421,6 +476,12 @@ class HipKernels:
 
     def resample_dev(self, runmax, n, n_new, shift_dev, i_begin, i_end, idx):
         check(self.lib.tdr_k_resample_dev(_ptr(runmax), n, n_new, _ptr(shift_dev), i_begin, i_end, _ptr(idx), self.stream()))
+
+    def rng_pipe_create(self, n_max):
+        """A tdr_rng_pipe (include/tdr.h): one filter's generator on the device, drawing ahead of the step."""
+        h = C.c_void_p(0)
+        check(self.lib.tdr_rng_pipe_create(n_max, C.byref(h)))
+        return RngPipe(self, h)
 
     def rng_uniform(self, rng):
         return float(self.lib.tdr_rng_uniform_host(rng))

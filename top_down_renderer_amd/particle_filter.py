@@ -126,11 +126,10 @@ class ParticleFilter:
         self.seed = int(seed)
         self.score_ctx = self.k.score_ctx_create()   # this filter's side stream + span tuner (include/tdr.h)
         self.gen_ = self.k.rng_create(seed)
-        # parity mode: the generator's stream continues on the device (csrc/tdr_rng.hip) between the host's own draws
-        self._rng_dev = None          # 640 words: the engine's state in libstdc++'s representation
-        self._rng_on_device = False
+        # parity mode: the generator's stream continues on the device between the host's own draws, drawn ahead of the
+        # step (a tdr_rng_pipe, csrc/tdr_rng.hip)
+        self._pipe = None
         self._shift_dev = None
-        self._z4_dev = None
         self._last_shift = None
         self.step_ = 0
         self.prop_calls_ = 0      # device RNG counter: every propagate call draws fresh noise
@@ -227,19 +226,23 @@ class ParticleFilter:
         """The uniform draw of the last update's resample (src/particle_filter.cpp:172-173); read back from the device when it
         was drawn there."""
         if self._last_shift is None and self._shift_dev is not None:
-            return float(self._shift_dev[0].item())
+            return float(self.k.read_device_floats(self._shift_dev, 1)[0])
         return self._last_shift
 
+    @property
+    def _rng_on_device(self):
+        return self._pipe is not None and self._pipe.on_device()
+
     def _rng_to_device(self):
-        if not self._rng_on_device:
-            self._rng_dev = self.k.rng_state_to_device(self.gen_)
-            self._rng_on_device = True
+        if self._pipe is None:
+            self._pipe = self.k.rng_pipe_create(self.max_num_particles_)
+        if not self._pipe.on_device():
+            self._pipe.from_host(self.gen_)
 
     def _rng_to_host(self):
         """The host engine takes the stream back (synchronises)."""
         if self._rng_on_device:
-            self.k.rng_state_to_host(self.gen_, self._rng_dev)
-            self._rng_on_device = False
+            self._pipe.to_host(self.gen_)
 
     # ---- particle_filter.cpp:86-92 ------------------------------------------------------------------------------------
     def propagate(self, trans, omega):
@@ -252,12 +255,9 @@ class ParticleFilter:
             # the reference draws serially in global particle order from one shared generator: every rank continues that
             # stream on its device and keeps the normals of its own particles
             self._rng_to_device()
-            if self._z4_dev is None or self._z4_dev.shape[0] < nl:
-                self._z4_dev = self.k.empty((max(nl, self.cap_local), 4))
-            z_dev = self._z4_dev
-            self.k.rng_propagate_normals_dev(self._rng_dev, n, self.comm.rank * nl, (self.comm.rank + 1) * nl,
-                                             self.scale_frozen_, z_dev, self.max_num_particles_)
+            z_dev = self._pipe.normals(n, self.comm.rank * nl, (self.comm.rank + 1) * nl, self.scale_frozen_)
         elif self.parity_rng:
+            self._rng_to_host()
             z = self.k.propagate_normals(self.gen_, n, self.scale_frozen_)
             z_dev = self.k.to_device(z[self.comm.rank * nl:(self.comm.rank + 1) * nl])
         self.k.propagate(self.st, nl, self.last_dist, float(trans[0]), float(trans[1]), float(omega),
@@ -349,9 +349,7 @@ class ParticleFilter:
         i0 = comm.rank * nl_new
         if shift is None and self._rng_on_device:
             # :172-173 (every rank owns an identically seeded generator): the stream is on the device, so is the draw
-            if self._shift_dev is None:
-                self._shift_dev = k.zeros((64,))
-            k.rng_uniform_dev(self._rng_dev, self._shift_dev)
+            self._shift_dev = self._pipe.uniform()
             k.resample_dev(self.runmax, n, n_new, self._shift_dev, i0, i0 + nl_new, self.idx)
         else:
             if shift is None:
