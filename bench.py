@@ -396,6 +396,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "toolchain": __import__("top_down_renderer_amd.build", fromlist=["toolchain"]).toolchain(),
             "rng": {"timed": ("device counter-based noise (Philox)" if a.device_rng else
                               "the reference's std::mt19937 + std::normal_distribution stream, reproduced on the device "
                               "(bit-identical propagate; csrc/tdr_rng.hip)"),

@@ -202,6 +202,17 @@ def test_png_codec_of_the_raster_cache(tmp_path):
     rc, w, h, _ = read(p, cap=10)
     assert rc == -1 and (w, h) == (6, 6)                      # buffer too small: the size is still reported
     assert read(tmp_path / "missing.png")[0] == -1
+    # a header that announces 2^24 x 2^24 pixels over a few bytes of image data (valid CRCs): refused before anything of
+    # that size is allocated — an error code, not std::bad_alloc through the C ABI
+    import struct
+    import zlib
+    good = _png_bytes(img, [0])
+    ihdr_at = good.index(b"IHDR")
+    hdr = struct.pack(">II", 1 << 24, 1 << 24) + good[ihdr_at + 12: ihdr_at + 17]
+    bomb = good[: ihdr_at + 4] + hdr + struct.pack(">I", zlib.crc32(b"IHDR" + hdr)) + good[ihdr_at + 21:]
+    p.write_bytes(bomb)
+    rc, w, h, _ = read(p)
+    assert rc == -1 and b"announces" in L.tdr_last_error()
 
 
 @pytest.mark.gpu

@@ -17,6 +17,7 @@ HDR = [os.path.join(ROOT, "include", "tdr.h")] + \
       [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h", "tdr_score_su_asm.h", "tdr_score_cart.h", "tdr_logf.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 OBJ_DIR = os.path.join(PKG, "_obj")
+STAMP = os.path.join(PKG, "libtdr_hip.toolchain.txt")
 
 # -ffp-contract=off: index arithmetic must round like the reference's non-FMA x86-64 build (see csrc/tdr_common.h)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(ROOT, "include")]
@@ -72,7 +73,23 @@ def build(force=False, verbose=False, extra_flags=()):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    # build stamp: the toolchain the objects came from.  Two kernels issue loads through inline assembly with hand-counted
+    # waits (tdr_score_su_asm.h, tdr_score_cart.hip): their correctness leans on this compiler's register allocation, the
+    # bit-parity tests are the guard, and the stamp says which compiler the guard last passed with (bench.py reports it).
+    try:
+        ver = subprocess.run([cc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+        open(STAMP, "w").write("\n".join(ver[:3]) + "\n")
+    except OSError:
+        pass
     return OUT
+
+
+def toolchain():
+    """First line of the build stamp (hipcc --version at build time), or None."""
+    try:
+        return open(STAMP).read().splitlines()[0]
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":

@@ -553,7 +553,15 @@ int tdr_map_save_rasters(tdr_map* m, const char* dir) {
 }
 // TopDownMap::loadRasterizedMaps (:213-224) followed by what the constructor does with the rasters (:48-58): the geometric
 // layers derived from them and computeDists on both — on the device (tdr_k_map_from_rasters).
+static int map_load_rasters(tdr_map* m, const char* dir, int num_classes, float resolution, int center_x, int center_y);
 int tdr_map_load_rasters(tdr_map* m, const char* dir, int num_classes, float resolution, int center_x, int center_y) {
+  try {   // (no exception crosses the C ABI: a file that makes an allocation fail is an error code)
+    return map_load_rasters(m, dir, num_classes, resolution, center_x, center_y);
+  } catch (const std::exception& e) {
+    return failh(TDR_ERR_NOMEM, "map_load_rasters: %s", e.what());
+  }
+}
+static int map_load_rasters(tdr_map* m, const char* dir, int num_classes, float resolution, int center_x, int center_y) {
   if (!m || !dir) return failh(TDR_ERR_ARG, "map_load_rasters: null pointer");
   if (num_classes < 1 || num_classes > TDR_MAX_CLASSES || !(resolution > 0.f))
     return failh(TDR_ERR_ARG, "map_load_rasters: bad class count / resolution");

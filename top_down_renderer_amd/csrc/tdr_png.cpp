@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <exception>
 #include <vector>
 
 #include "tdr_common.h"
@@ -59,6 +60,10 @@ int tdr_png_read_gray8(const char* path, std::vector<uint8_t>& px, int& w, int& 
   }
   if (!have_hdr || idat.empty()) return fail(TDR_ERR_ARG, "png: %s has no image data", path);
   const size_t stride = (size_t)w + 1;
+  // deflate expands at most ~1032 : 1: a header that announces more pixels than the image data can hold is refused before
+  // anything of that size is allocated (a damaged or hostile file must not be able to ask for 2^48 bytes)
+  if ((uint64_t)stride * (uint64_t)h > (uint64_t)idat.size() * 1032u + 64u)
+    return fail(TDR_ERR_ARG, "png: %s announces %d x %d pixels but holds %zu bytes of image data", path, w, h, idat.size());
   std::vector<uint8_t> raw(stride * (size_t)h);
   uLongf out_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size())
@@ -120,13 +125,21 @@ int tdr_png_write_gray8(const char* path, const uint8_t* px, int w, int h) {
 // C-ABI face of the codec (host only, no device): px_out holds capacity bytes; *w / *h are set even when the image does not fit
 extern "C" int tdr_png_read_gray8_host(const char* path, uint8_t* px_out, int64_t capacity, int* w, int* h) {
   if (!path || !w || !h) return fail(TDR_ERR_ARG, "png: null pointer");
-  std::vector<uint8_t> px;
-  if (int rc = tdr_png_read_gray8(path, px, *w, *h)) return rc;
-  if (!px_out || capacity < (int64_t)px.size()) return fail(TDR_ERR_ARG, "png: %s needs %zu bytes", path, px.size());
-  memcpy(px_out, px.data(), px.size());
-  return TDR_OK;
+  try {   // (no exception crosses the C ABI: an allocation failure is an error code)
+    std::vector<uint8_t> px;
+    if (int rc = tdr_png_read_gray8(path, px, *w, *h)) return rc;
+    if (!px_out || capacity < (int64_t)px.size()) return fail(TDR_ERR_ARG, "png: %s needs %zu bytes", path, px.size());
+    memcpy(px_out, px.data(), px.size());
+    return TDR_OK;
+  } catch (const std::exception& e) {
+    return fail(TDR_ERR_NOMEM, "png: %s: %s", path, e.what());
+  }
 }
 extern "C" int tdr_png_write_gray8_host(const char* path, const uint8_t* px, int w, int h) {
   if (!path) return fail(TDR_ERR_ARG, "png: null pointer");
-  return tdr_png_write_gray8(path, px, w, h);
+  try {
+    return tdr_png_write_gray8(path, px, w, h);
+  } catch (const std::exception& e) {
+    return fail(TDR_ERR_NOMEM, "png: %s: %s", path, e.what());
+  }
 }
