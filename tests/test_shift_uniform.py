@@ -85,6 +85,9 @@ CASES = [  # ncls, nb, nr, n, fixed scale, locality
     (7, 32, 16, 1000, True, 1),
     (9, 40, 24, 1200, False, 1),
     (11, 24, 12, 600, True, 1),
+    (6, 100, 25, 2500, True, 1),      # the reference node's own image (src/top_down_render.cpp:115): 25 rings, a ragged last group
+    (6, 100, 50, 2500, False, 1),     # the map's default table (src/top_down_map_polar.cpp:4)
+    (3, 40, 13, 900, True, 0),
 ]
 
 

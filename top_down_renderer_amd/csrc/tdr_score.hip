@@ -1712,6 +1712,11 @@ static ScoreWs score_ws(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   const int rf = tdr_rec_floats(ncls);
   if (n_total <= 0) n_total = n;
   w.group = score_group_rings(nb, nr, rf, n_total);
+  // the shift-uniform kernel steps through a ray four rings at a time: where it can take the launch the groups are whole
+  // fours (a small filter's single-ring groups — the reference's 20 000 particles on 100 x 25 bins — become groups of 4; the
+  // last group of an image whose ring count is no multiple of 4 is ragged)
+  if (w.group % 4 != 0 && tdr_cmap_words(ncls) != 0 && tdr_su_shape_ok(nb, nr, 4, n_total))
+    w.group = std::max(4, w.group - w.group % 4);
   w.nchunks = (int)cdiv(nr, w.group);
   w.npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   w.su = tdr_su_shape_ok(nb, nr, w.group, n_total) && tdr_cmap_words(ncls) != 0;

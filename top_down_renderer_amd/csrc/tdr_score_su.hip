@@ -43,6 +43,7 @@
 
 #define SU_CODE_FULL 0xFFu       // several classes present: packed scan record, classes with a zero count skipped
 #define SU_CODE_FULL_ALL 0xFEu   // a non-finite value is in play: every class multiplied like score_polar_kernel does
+#define SU_CODE_PAD 0xFDu        // no such ring: the last group of an image whose ring count is no multiple of the group
 #define SU_NSECT 8               // sectors of directions per known-mask staging (16: 2 % slower on config 2)
 #define SU_BOX_WORDS 3072        // LDS words of the staged known mask (12 KB; 18 KB measured 4 % slower on config 2)
 
@@ -94,8 +95,14 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
   const int i = (int)(q % nb), chunk = (int)(q / nb);
   const int j = chunk * group + jj;
   float tx = 0.f, ty = 0.f, val = 0.f;
-  uint32_t code = 0, ckc = (uint32_t)ckconst, sh = 0;
+  uint32_t code = SU_CODE_PAD, ckc = (uint32_t)ckconst, sh = 0;
+  if (live && j >= nr) {   // no such ring: the offset of the direction's last real one (inside every box the real ones span)
+    const int64_t k = (int64_t)(nr - 1) * nb + i;
+    tx = tab[2 * k];
+    ty = tab[2 * k + 1];
+  }
   if (live && j < nr) {
+    code = 0;
     const int64_t k = (int64_t)j * nb + i;
     tx = tab[2 * k];
     ty = tab[2 * k + 1];
@@ -355,13 +362,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const tdr_const_f T = tbase + ((int64_t)i * G + jj) * 2;
     const tdr_const_u D = dbase + ((int64_t)r * G + jj) * 4;
     uint32_t val[4];
-    uint32_t code[4];
+    uint32_t code[4], pad[4];
     uint32_t w[4], bits[4];
     int cis[4];
     unsigned offs[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       code[u] = D[4 * u];
+      // A ring the image does not have (SU_CODE_PAD) goes through the step like an EMPTY bin — su_prep gives it the offset of
+      // the direction's last real ring, so its mask lookup stays inside the staged box — and is masked out of the known
+      // count below.  (Not by branching around the loads: another definition of their destination registers makes the
+      // compiler merge them with copies, and a copy between an inline-assembly load and its wait reads a stale register.)
+      pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;
+      code[u] = code[u] == SU_CODE_PAD ? 0u : code[u];
       val[u] = D[4 * u + 1];
       const uint32_t ckc = D[4 * u + 2];
       int ri, ci;
@@ -388,10 +401,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                  : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
 #pragma unroll
     for (int u = 0; u < 4; u++) {
+      const uint32_t cd = code[u];
       int kmsk;   // 0 / -1: the cell's known bit
       asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(bits[u]), "v"(cis[u]));
-      known -= (uint32_t)kmsk;
-      const uint32_t cd = code[u];
+      known -= (uint32_t)kmsk & pad[u];
       if (cd != 0) {   // wave-uniform
         if (cd < SU_CODE_FULL_ALL) {
           // the bin's count x known (state_particle.cpp:141-142)
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         cell(T[2 * u], T[2 * u + 1], ri, ci);
         unsigned off;
         const int sidx = 4 * d + u;   // (d, u are unrolled: constants after unrolling)
-        if (D[4 * u] == 0) {   // wave-uniform: an empty bin reads the cell's mask word
+        if (D[4 * u] == 0 || D[4 * u] == SU_CODE_PAD) {   // wave-uniform: an empty bin (or no ring at all) reads the cell's mask word
           off = kmask_offset(ri, ci, mtrb, mconst);
           cbits[sidx / 6] |= (uint32_t)(ci & 31) << (5 * (sidx % 6));
         } else {               // a single class: the dword it lives in; several classes: dword 0
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         asm volatile("global_load_dword %0, %1, %2" : "=v"(w[4 * d + u]) : "v"(off), "s"(crec));
       }
       jx += 4;
-      if (jx >= gn) { jx = 0; ii++; }
+      if (jx >= ((gn + 3) & ~3)) { jx = 0; ii++; }
     }
     ii = i; jx = jj;
 #pragma unroll
@@ -461,10 +474,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // (the requests return in order: sample 4 d + u is there once all but the 4 NS - 1 - (4 d + u) behind it are)
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[4 * d + u]) : "n"(4 * NS - 1 - (4 * d + u)));
         const uint32_t ww = w[4 * d + u];
-        const uint32_t cd = D[4 * u];
+        const uint32_t cdr = D[4 * u];
+        const uint32_t cd = cdr == SU_CODE_PAD ? 0u : cdr;   // a ring the image does not have: an empty bin that counts nothing
         const int sidx = 4 * d + u;
         const uint32_t kb = cd == 0 ? (ww >> ((cbits[sidx / 6] >> (5 * (sidx % 6))) & 31u)) & 1u : (ww & 1u);
-        known += kb;
+        known += cdr == SU_CODE_PAD ? 0u : kb;
         if (cd != 0) {   // wave-uniform
           const uint32_t v = D[4 * u + 1];
           if (cd < SU_CODE_FULL_ALL) {
@@ -490,16 +504,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
       }
       jx += 4;
-      if (jx >= gn) { jx = 0; ii++; }
+      if (jx >= ((gn + 3) & ~3)) { jx = 0; ii++; }
     }
   };
   constexpr int FAR_DEPTH = 4;   // steps (of 4 samples) a wave of the memory-bound path keeps in flight
   auto far_sector = [&](int i0, int i1) {
-    const int spd = gn >> 2, total = (i1 - i0) * spd;
+    const int gn4 = (gn + 3) & ~3;   // steps cover whole fours of rings; what lies behind the last ring is SU_CODE_PAD
+    const int spd = gn4 >> 2, total = (i1 - i0) * spd;
     int i = i0, jj = 0, k = 0;
     auto advance = [&](int steps) {
       jj += 4 * steps;
-      while (jj >= gn) { jj -= gn; i++; }
+      while (jj >= gn4) { jj -= gn4; i++; }
     };
     for (; k + FAR_DEPTH <= total; k += FAR_DEPTH) {
       far_steps(std::integral_constant<int, FAR_DEPTH>{}, i, jj);
@@ -715,8 +730,12 @@ extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches.load(
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total) {
   if (g_su_mode == 0) return false;
-  if (group % 4 != 0 || nr % 4 != 0 || nb > 4095) return false;
-  if (g_su_mode == 2) return true;   // tests: small filters too
+  if (group % 4 != 0 || nb > 4095) return false;
+  if (g_su_mode == 2) return true;   // tests: small filters and small windows too
+  // A small window does not pay for the per-sector set-up of the shift-uniform kernel (bounding box, mask staging, three
+  // barriers) nor for a wave per particle: at the reference node's own 100 x 25 bins and 20 000 particles the integer form
+  // takes 0.23 ms (0.18 + 0.10, side by side) where the float kernel takes 0.11 (profiles/r04_bench_ref_integer_form_v1.json).
+  if ((int64_t)nb * nr < 8192) return false;
   return n_total >= (int64_t)64 * nb;
 }
 static size_t su_sort_tmp_bytes(int64_t n) {
