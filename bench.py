@@ -31,8 +31,9 @@ events on its launch stream; a polar launch runs two kernels, the events span bo
     what a gather moves);
   * `issue` = {valu_busy, lds_busy, insts_per_sample} from a second counter pass; `bound` = the busiest of
     {hbm: `frac`, valu, lds};
-  * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, without the side
-    stream): shift-uniform kernel over the dense particles, ray-mapped kernel over the scattered ones, particles in each;
+  * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, on the particle set
+    every timed step starts from, before propagate): shift-uniform kernel over the dense particles, ray-mapped kernel over the
+    scattered ones, particles in each;
   * `dense_work_rate` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the
     same duration.  The launch does not move those bytes (compact records, empty bins skipped, shared lines): a WORK rate,
     not a roofline figure — `x_hbm_peak` above 1 says exactly that.
@@ -338,7 +339,7 @@ def main():
 
     shares = None
     if rank == 0 and cfg.polar:
-        # the launch's two kernels on their own: one more scoring call, without the filter's context (no side stream)
+        # the launch's two kernels on their own: one more scoring call on the particle set every timed step starts from
         try:
             f.st[:, :nl].copy_(st0)   # the particle set every timed step starts from
             if f.locality_every and f.perm is not None:
@@ -360,7 +361,7 @@ def main():
         b_pu = P * (4 * cfg.ncls + 1) + 64
         kname = "score_cart"   # score_cart_skip_kernel (tdr_score_cart.hip) or the general score_cart_kernel
         if cfg.polar:
-            kname = "score_polar"   # score_polar_kernel, or score_polar_su_kernel + score_polar_kernel side by side
+            kname = "score_polar"   # score_polar_su_kernel + score_polar_ray_kernel (the integer form), or score_polar_kernel (the float form)
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -418,10 +419,9 @@ def main():
                          "issue": issue,
                          "note": "`achieved`, `peak`, `frac` price the launch against the HBM roofline whatever `bound` says; "
                                  "`bound` names the unit the launch keeps busiest (hbm = `frac`, valu / lds = `issue`).  "
-                                 "Clustered particles are bound by vector-instruction issue, scattered ones by the memory "
-                                 "system (DESIGN.md 5.1); a polar launch may run two kernels side by side — "
-                                 "score_polar_su_kernel for the dense particles, score_polar_kernel for the scattered ones — "
-                                 "and `avg_launch_ms` spans both",
+                                 "A polar launch runs two kernels one after the other — score_polar_su_kernel for the dense "
+                                 "particles (vector-issue bound), score_polar_ray_kernel for the scattered ones (L1 address "
+                                 "path) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          # polar configs: the dense / scattered split of the mixed launch this filter's tuner settled on
                          "shift_uniform_span_cells": f.score_ctx.span() if cfg.polar else None,

@@ -11,8 +11,8 @@
  *  - plain C, no torch / Eigen / PCL types; every function returns an int status (TDR_OK == 0), never throws;
  *  - "tdr_k_*" entry points are stateless launchers: every pointer is a DEVICE pointer unless the name says
  *    `_host`, `stream` is a hipStream_t (NULL = default stream), nothing is allocated, nothing synchronises, and no
- *    state is kept between calls.  The one thing a launcher may be GIVEN is a caller-owned tdr_score_ctx (below):
- *    a side stream and a tuner that then belong to that caller alone.  Load-time entry points (tdr_k_compact_map,
+ *    state is kept between calls.  What a launcher may be GIVEN is an object the caller owns (tdr_score_ctx: the tuner of
+ *    the polar launch; tdr_rng_pipe: the generator's state and what it drew ahead, with a stream of its own).  Load-time entry points (tdr_k_compact_map,
  *    tdr_k_map_from_*) say so where they synchronise.  The tdr_config_* calls and the TDR_* environment variables they
  *    mirror are PROCESS-WIDE switches for A/B measurements and tests (set them before the first launch, not while
  *    another thread launches); results never depend on them unless a comment says so;
@@ -224,12 +224,10 @@ int tdr_k_score_polar(const tdr_map_desc* map, const float* tab, const float* sc
                       const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
                       const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,
                       void* stream);
-/* The same with a caller-owned context.  A large launch runs two kernels — dense particles through the shift-uniform
- * kernel, scattered ones through the ray-mapped kernel (tdr_config_shift_uniform below) — and chooses the split between
- * them by timing; the context gives the call a stream of its own to run the two side by side (forked from and joined back
- * into `stream` through events inside the call: the caller sees plain stream order) and keeps the tuner's state from call to
- * call.  One context per filter (or per caller thread); it is bound to the device current at creation; calls that share a
- * context must not overlap.  ctx == NULL: tdr_k_score_polar — the kernels one after the other on `stream`, the configured
+/* The same with a caller-owned context.  A large launch runs two kernels one after the other on `stream` — dense particles
+ * through the shift-uniform kernel, scattered ones through the ray-mapped kernel (tdr_config_shift_uniform below) — and
+ * chooses the split between them by timing; the context keeps the tuner's state from call to call.  One context per filter
+ * (or per caller thread); calls that share a context must not overlap.  ctx == NULL: tdr_k_score_polar — the configured
  * span, no state.  Results never depend on the context.  Nothing waits on the host either way (the tuner polls its events).
  * tdr_score_ctx_span: the split the context's tuner has settled on so far (map cells). */
 typedef struct tdr_score_ctx tdr_score_ctx;
@@ -337,7 +335,7 @@ int tdr_k_update_weights(const float* raw_w, const float* last_dist, int64_t n, 
 
 /* ---- systematic resample (src/particle_filter.cpp:171-185) -------------------------------------------------- */
 /* Serial-order float32 running sum of w (the additions of :179 in the same order) and its running maximum.
- * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  From 1024 to 32 768 weights — the
+ * workspace: device scratch of tdr_prefix_workspace_bytes(n) bytes, or NULL.  From 256 to 32 768 weights — the
  * reference's operating point — everything is one launch of one workgroup with the weights in LDS; above, with a
  * workspace, the chain is evaluated by many workgroups (per-chunk parity summaries, see csrc/tdr_prefix.hip); without
  * one, by one workgroup.  The bits written are the serial chain's either way.  tdr_config_prefix_small(0) takes the
@@ -428,8 +426,8 @@ int tdr_config_compact(int on);
  * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
  * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow
  * compact records and class planes); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
- * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — 8, 12, 16, 24 and 40 cells are timed over one
- * scoring call each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
+ * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — 8, 16, 24 and 40 cells are timed over two
+ * scoring calls each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
  * repeated every 4000 calls.  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env TDR_SU_SPAN fix
  * it for every caller; -1 only returns the configured span (16 by default: what a launch without a context uses); -2 goes
  * back to tuning. */
@@ -461,8 +459,7 @@ int64_t tdr_shift_uniform_launches(void);
  * tdr_profile_score_ms synchronises on them, returns the summed duration and the launch count, and resets. */
 int tdr_profile_enable(int on);
 int tdr_profile_score_ms(double* total_ms, int64_t* launches);
-/* While enabled, a polar launch of the integer form made WITHOUT a context (its two kernels then run one after the other)
- * also brackets each of the two: the last such launch's durations — shift-uniform kernel over the dense particles,
+/* While enabled, a polar launch of the integer form also brackets each of its two kernels: the last such launch's durations — shift-uniform kernel over the dense particles,
  * ray-mapped kernel over the scattered ones — and the number of scattered particles (synchronises).  Measurement state is
  * process-wide like the switch itself: one measuring thread. */
 int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles);

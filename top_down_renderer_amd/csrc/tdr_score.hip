@@ -1772,9 +1772,8 @@ struct ScoreProfScope {
     if (stop) (void)hipEventRecord(stop, s);
   }
 };
-// ... and, for a launch WITHOUT a context (its two kernels run one after the other on the caller's stream), of each of the two
-// kernels on its own: the last such launch's {dense, scattered} durations and the device words that say how many particles
-// each share held (tdr_profile_shares).
+// ... and of each of the two kernels of an integer-form launch on its own: the last launch's {dense, scattered} durations
+// and the device words that say how many particles each share held (tdr_profile_shares).
 static hipEvent_t g_share_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 static bool g_share_valid = false;
 static const int32_t* g_share_counts = nullptr;
@@ -1800,7 +1799,7 @@ extern "C" int tdr_profile_enable(int on) {
 }
 extern "C" int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles) {
   if (!dense_ms || !scattered_ms || !scattered_particles) return fail(TDR_ERR_ARG, "profile_shares: null pointer");
-  if (!g_share_valid || !g_share_counts) return fail(TDR_ERR_ARG, "profile_shares: no launch without a context was profiled");
+  if (!g_share_valid || !g_share_counts) return fail(TDR_ERR_ARG, "profile_shares: no integer-form launch was profiled");
   float ms[2] = {0.f, 0.f};
   for (int k = 0; k < 2; k++) {
     HIP_TRY(hipEventSynchronize(g_share_ev[k][1]));
@@ -1921,15 +1920,14 @@ static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, 
   return launch_score_form<true>(a, rf, ncls, s);
 }
 
-// tdr_score_ctx (tdr.h): what a scoring call keeps BETWEEN calls and BESIDE the caller's stream — a stream of its own for
-// the second kernel of a mixed launch (joined again through events before the call's last kernel, so the caller sees
-// plain stream order) and the span tuner of tdr_score_su.h.  It belongs to one caller (a filter handle): nothing of it is
-// shared between filters, threads or devices.  Without a context a call runs its kernels one after the other on the
-// caller's stream with the configured span.
+// tdr_score_ctx (tdr.h): what a scoring call keeps BETWEEN calls — the span tuner of tdr_score_su.h.  It belongs to one
+// caller (a filter handle): nothing of it is shared between filters, threads or devices.  Without a context a call uses
+// the configured span.  (Rounds 3 and 4 also gave a call a stream of its own to run its two kernels side by side: measured
+// on every configuration, the two never overlapped usefully — config 2: 5.22 ms on one stream, 5.32 on two; config 5: 16.4
+// against 17.0 — because the dense kernel waits for its gathers right after issuing them and becomes latency-bound as soon
+// as another kernel fills the L1's queues.  The kernels of a call now run one after the other on the caller's stream.)
 struct tdr_score_ctx {
   int device = 0;
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
   SpanTuner tuner;
 };
 extern "C" int tdr_score_ctx_create(tdr_score_ctx** out) {
@@ -1937,12 +1935,9 @@ extern "C" int tdr_score_ctx_create(tdr_score_ctx** out) {
   *out = nullptr;
   tdr_score_ctx* c = new (std::nothrow) tdr_score_ctx;
   if (!c) return fail(TDR_ERR_NOMEM, "score_ctx_create: out of memory");
-  hipError_t e = hipGetDevice(&c->device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+  const hipError_t e = hipGetDevice(&c->device);
   if (e != hipSuccess) {
-    tdr_score_ctx_destroy(c);
+    delete c;
     return fail(TDR_ERR_HIP, "score_ctx_create: %s", hipGetErrorString(e));
   }
   *out = c;
@@ -1950,9 +1945,6 @@ extern "C" int tdr_score_ctx_create(tdr_score_ctx** out) {
 }
 extern "C" void tdr_score_ctx_destroy(tdr_score_ctx* c) {
   if (!c) return;
-  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-  if (c->fork) (void)hipEventDestroy(c->fork);
-  if (c->join) (void)hipEventDestroy(c->join);
   if (c->tuner.e0) (void)hipEventDestroy(c->tuner.e0);
   if (c->tuner.e1) (void)hipEventDestroy(c->tuner.e1);
   delete c;
@@ -1960,27 +1952,12 @@ extern "C" void tdr_score_ctx_destroy(tdr_score_ctx* c) {
 extern "C" float tdr_score_ctx_span(const tdr_score_ctx* c) {   // the span the context's tuner has settled on so far
   return c ? c->tuner.best : tdr_config_shift_uniform_span(-1.f);
 }
-// Fork onto the context's stream and join again — on EVERY way out of the scope, so that a failed launch never leaves the
-// side stream running against buffers the caller may free, nor the tuner's measurement open.
-struct SideScope {
+// closes the tuner's measurement on EVERY way out of a call
+struct TunerScope {
   tdr_score_ctx* c;
   hipStream_t s;
-  bool forked = false;
-  SideScope(tdr_score_ctx* c_, hipStream_t s_) : c(c_), s(s_) {}
-  hipStream_t fork() {   // the stream the second kernel goes to: the context's, ordered behind what `s` holds so far
-    if (!c) return s;
-    if (hipEventRecord(c->fork, s) != hipSuccess || hipStreamWaitEvent(c->side, c->fork, 0) != hipSuccess) return s;
-    forked = true;
-    return c->side;
-  }
-  void join() {
-    if (!forked) return;
-    forked = false;
-    if (hipEventRecord(c->join, c->side) == hipSuccess) (void)hipStreamWaitEvent(s, c->join, 0);
-    else (void)hipStreamSynchronize(c->side);
-  }
-  ~SideScope() {
-    join();
+  TunerScope(tdr_score_ctx* c_, hipStream_t s_) : c(c_), s(s_) {}
+  ~TunerScope() {
     if (c) tdr_su_span_end(&c->tuner, s);
   }
 };
@@ -2139,8 +2116,7 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
   if (W.su && map_has_compact(map, rf) && !map_is_wide(map, rf) && tdr_ray_map_ok(map)) {
     // The INTEGER form of the launch (tdr_score_su.h): dense particles by heading bin through the shift-uniform kernel,
     // scattered ones — behind the bins in the same slot list — one wave each through the ray-mapped kernel; both form exact
-    // integer sums, so a particle's weight does not depend on which of the two scored it.  The two run side by side when the
-    // caller brought a context (one is bound by vector issue, the other by the memory system).  A scan or a map without
+    // integer sums, so a particle's weight does not depend on which of the two scored it.  A scan or a map without
     // an integer form (fractional or non-finite counts; a dictionary finer than 2^-q) raises the device word `inexact`:
     // the integer kernels then return at once and the float kernel below does the launch — nothing is decided on the host.
     const int32_t* slots = nullptr;
@@ -2151,7 +2127,7 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
     L.ray_split = tdr_ray_splits(nb, nr, n);
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
-    SideScope side(ctx, s);   // (closes the tuner's measurement and joins the side stream on every way out)
+    TunerScope tuner_scope(ctx, s);   // (closes the tuner's measurement on every way out)
     L.span = tdr_su_span_begin(ctx ? &ctx->tuner : nullptr,
                                ((int64_t)n << 24) ^ ((int64_t)nb << 12) ^ nr ^ ((int64_t)map->rows << 40), s);
     if ((rc = tdr_su_prepare(L, W.suw, s, &slots, &counts))) return rc;
@@ -2159,17 +2135,15 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     const int32_t* inexact = counts + 4;
     {
       ScoreProfScope prof(s);
-      hipStream_t s2 = side.fork();
       {
-        ShareProfScope sp(0, s2, ctx == nullptr);
-        if ((rc = tdr_ray_score(L, W.suw, s2))) return rc;
+        ShareProfScope sp(0, s, true);
+        if ((rc = tdr_ray_score(L, W.suw, s))) return rc;
       }
       {
-        ShareProfScope sp(1, s, ctx == nullptr);
+        ShareProfScope sp(1, s, true);
         if ((rc = tdr_su_score(L, W.suw, s))) return rc;
       }
-      if (g_prof_on && !ctx) { g_share_valid = true; g_share_counts = counts; }
-      side.join();
+      if (g_prof_on) { g_share_valid = true; g_share_counts = counts; }
       // the float form, for the launches the integer form does not cover
       ScoreArgs r = a;
       r.run_if = inexact;

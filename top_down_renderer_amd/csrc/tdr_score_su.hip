@@ -691,7 +691,7 @@ extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it 
 namespace {
 // (measured on MI355X with the ray-mapped kernel taking the scattered share, ms per scoring call at 8 / 16 / 24 / 40 cells:
 // config 2's mix 5.88 / 5.55 / 5.51 / 5.67, uniform particles 10.7 / 11.0 / - / 11.7, a converged filter 3.1 / 3.05 / - / 3.0)
-constexpr float kSpanCand[] = {8.f, 12.f, 16.f, 24.f, 40.f};
+constexpr float kSpanCand[] = {8.f, 16.f, 24.f, 40.f};
 constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
 constexpr int kSpanTrials = 2;        // timed calls per candidate: the faster one counts (a single call is noisy)
 constexpr int kSpanRetune = 4000;     // launches between two trials
