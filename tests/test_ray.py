@@ -215,3 +215,61 @@ def test_large_counts_and_many_points_in_one_bin(tdr, oracle):
     finally:
         k.lib.tdr_config_shift_uniform(before)
         k.lib.tdr_config_shift_uniform_span(-2.0)
+
+
+@pytest.mark.parametrize("ncls,rows,cols,kind", [(6, 50, 64, "scan"), (3, 33, 21, "scan"), (9, 18, 140, "scan"),
+                                                 (6, 37, 300, "dense"), (6, 24, 24, "empty"), (6, 20, 36, "fractional")])
+def test_cartesian_integer_form(tdr, oracle, ncls, rows, cols, kind):
+    """The Cartesian score's integer form (csrc/tdr_score_cart.hip): the skipping kernel with integer accumulators for
+    dense particles, score_cart_ray_kernel (one wave per particle, lanes = consecutive window columns) for scattered ones.
+    All dense, all scattered and a mixed launch give the same bits; the float kernels agree to rounding, the oracle to 1e-5.
+    Window widths of 1, 2 and 4 steps per block and more than one block; a scan with several classes in every bin (the
+    list); an empty scan; a scan with fractional counts (no integer form: the float kernel scores it in every mode)."""
+    from top_down_renderer_amd import synth
+    pkg, k = tdr
+    cfg = synth.Config("cartint", 6000, ncls, rows, cols, 500, 900, polar=False, seed=177 + ncls + rows, res=0.75)
+    sc = synth.make_scene(cfg)
+    st = sc.states.copy()
+    rng = np.random.default_rng(15)
+    st["scale"] = rng.uniform(0.8, 1.25, len(st)).astype(np.float32)
+    st["init_x_px"][:6] = np.asarray([-50, 5, 500, 495, 250, 0.5], np.float32)          # off / at the border
+    st["init_y_px"][:6] = np.asarray([250, 250, 250, 250, -40, 0.5], np.float32)
+    scan = oracle.raster_cart(sc.pts, cfg.res, sc.lut, ncls, rows, cols)
+    if kind == "dense":
+        scan = rng.integers(0, 3, scan.shape).astype(np.float32)
+    elif kind == "empty":
+        scan = np.zeros_like(scan)
+    elif kind == "fractional":
+        scan = (scan * np.float32(0.5)).astype(np.float32)
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0)
+    with np.errstate(all="ignore"):
+        ref = oracle.compute_weights_cart(om, rows, cols, scan, cfg.res, oracle.make_params(ncls), st.copy())
+    m = pkg.TopDownMap(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.setWindow(rows, cols)
+    before = k.lib.tdr_config_shift_uniform(-1)
+    got = {}
+    try:
+        for name, mode, span in (("float", 0, 16.0), ("dense", 2, 0.0), ("ray", 2, ALL_RAY), ("mixed", 2, 6.0)):
+            k.lib.tdr_config_shift_uniform(mode)
+            k.lib.tdr_config_shift_uniform_span(span)
+            f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
+                                   locality_every=1)
+            f.set_states(st)
+            f.update(np.ascontiguousarray(scan, np.float32), None, cfg.res)
+            got[name] = f.raw_weights()
+    finally:
+        k.lib.tdr_config_shift_uniform(before)
+        k.lib.tdr_config_shift_uniform_span(-2.0)
+    assert np.array_equal(got["dense"], got["ray"], equal_nan=True)
+    assert np.array_equal(got["dense"], got["mixed"], equal_nan=True)
+    if kind == "fractional":
+        assert np.array_equal(got["float"], got["dense"], equal_nan=True)   # the float kernel ran in every mode
+    else:
+        assert np.array_equal(np.isnan(got["float"]), np.isnan(got["dense"]))
+        ok = ~np.isnan(got["dense"])
+        err = np.abs(got["float"][ok] - got["dense"][ok]) / np.maximum(np.abs(got["dense"][ok]), 1e-30)
+        assert err.max(initial=0.0) <= 3e-6
+    assert np.array_equal(np.isnan(got["dense"]), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    err = np.abs(got["dense"][ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)
+    assert err.max(initial=0.0) <= 1e-5, err.max()

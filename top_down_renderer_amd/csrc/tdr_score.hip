@@ -2287,11 +2287,16 @@ extern "C" int tdr_k_score_polar_geo(const tdr_map_desc* map, const tdr_map_desc
 static int64_t cart_part_floats(int ncls, int cols, int64_t n, int64_t n_total) {   // partial sums, 256-byte aligned
   int cpc, nchunks;
   choose_chunks(n_total > 0 ? n_total : n, cols, cpc, nchunks, TDR_CART_WAVE_MUL);
-  const int64_t npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
-  return cdiv((int64_t)nchunks * (tdr_rec_floats(ncls) + 1) * npad + 64, 64) * 64;
+  // (the integer form's slot list pads the dense share to whole waves, its rows are words: 2 per class + 2, and a scattered
+  // particle's window may be split over up to TDR_RAY_MAX_SPLIT chunk rows)
+  const int64_t npad = su_npad(std::max<int64_t>(n, 1), 1);
+  const int rowsmax = std::max(tdr_rec_floats(ncls) + 1, 2 * ncls + 2);
+  return cdiv((int64_t)std::max(nchunks, TDR_RAY_MAX_SPLIT) * rowsmax * npad + 64, 64) * 64;
 }
 extern "C" size_t tdr_score_cart_workspace_floats(int ncls, int rows, int cols, int64_t n, int64_t n_total) {
-  return (size_t)(cart_part_floats(ncls, cols, n, n_total) + tdr_cart_desc_words(rows, cols));   // + scan descriptors
+  // partial sums + the float form's scan descriptors + the integer form's tables and ordering workspace
+  return (size_t)(cart_part_floats(ncls, cols, n, n_total) + tdr_cart_desc_words(rows, cols) +
+                  tdr_cart_int_words(rows, cols, std::max<int64_t>(n, 1)));
 }
 
 extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, int rows, int cols, float res,
@@ -2326,10 +2331,18 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
     const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
     a.crec = map->crec; a.dict = map->dict; a.dict_n = map->dict_n; a.ctiles_r = (map->rows >> lc) + 2;
   }
+  CartIntOut io{};
+  bool int_form = false;
   if (cm && !wide && tdr_cart_skip_ok(map, rf)) {
     ScoreProfScope prof(s);
     uint32_t* desc_ws = reinterpret_cast<uint32_t*>(workspace + cart_part_floats(map->ncls, cols, n, n_total));
-    if (int rc = tdr_cart_skip_launch(a, map, rf, desc_ws, s)) return rc;
+    if (tdr_cart_int_ok(map, rf, rows, cols, n_total)) {
+      // the integer form: dense particles through the skipping kernel with integer accumulators, scattered ones one wave
+      // each through score_cart_ray_kernel; the float skipping kernel behind them for what has no integer form
+      int32_t* iws = reinterpret_cast<int32_t*>(desc_ws + tdr_cart_desc_words(rows, cols));
+      if (int rc = tdr_cart_int_launch(a, map, rf, desc_ws, iws, tdr_config_shift_uniform_span(-1.f), s, &io)) return rc;
+      int_form = true;
+    } else if (int rc = tdr_cart_skip_launch(a, map, rf, desc_ws, s)) return rc;
   } else {
     ScoreProfScope prof(s);
 #define TDR_LAUNCH_CART2(NV4, CM)                                                                       \
@@ -2362,6 +2375,15 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
   f.P = (int64_t)rows * cols; f.ncls = map->ncls; f.mode = 0; f.first = 0; f.theta_override = 0.f;
   f.raw_w = raw_w; f.best_cost = nullptr; f.best_theta = nullptr;
   f.gpart = nullptr; f.gnchunks = 0; f.gsum0 = f.gsum1 = 0.f; f.only_uninit = 0;
+  if (int_form) {
+    FinalizeArgs fx = f;
+    fx.npad = io.npad; fx.order = io.slots; fx.counts = io.counts; fx.inexact = io.flags;
+    fx.ipart = reinterpret_cast<const uint32_t*>(a.part);
+    fx.dict_tail = reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT;
+    fx.nchunks = a.nchunks; fx.ray_split = io.ray_split;
+    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(io.npad, 256)), dim3(256), 0, s, fx);
+    f.run_if = io.flags;
+  }
   launch_finalize(f, n, s);
   LAUNCH_CHECK("score_finalize(cart)");
   return TDR_OK;

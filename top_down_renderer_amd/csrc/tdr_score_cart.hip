@@ -19,6 +19,7 @@
 
 #include "tdr_score_cart.h"
 #include "tdr_score_dev.h"
+#include "tdr_score_su.h"   // the ordering passes (tdr_su_order) and the ray order's helpers
 #include "tdr_sincosf.h"
 
 #define CART_CODE_FULL 0xFFu       // several classes present
@@ -30,9 +31,10 @@
 //   [1] the bin's sum over the classes (slot rf - 1 of the packed record) — for a single class: its value
 //   [2] cmap_offset's constant advanced to the dword the class lives in: ckconst + 4 * (c / 3)
 //   [3] bit offset of the class's field in that dword minus 2 (10 * (c % 3))
+// as_int: descriptor word [1] holds the count as an integer (the integer form's kernels) instead of float bits
 __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict__ scan_pk, int rows, int cols, int rf, int ncls,
                                                         int ckconst, const float* __restrict__ dict, int dict_n,
-                                                        uint32_t* __restrict__ desc) {
+                                                        uint32_t* __restrict__ desc, int as_int) {
   bool bad = false;   // the dictionary is small: every workgroup checks it for itself
   for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
   const bool dict_bad = __syncthreads_or(bad);
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict_
   uint32_t ckc, sh;
   const uint32_t code = classify(t, val, ckc, sh);
   desc[4 * t] = code;
-  desc[4 * t + 1] = __float_as_uint(val);
+  desc[4 * t + 1] = as_int ? (uint32_t)val : __float_as_uint(val);
   desc[4 * t + 2] = ckc;
   desc[4 * t + 3] = sh;
 }
@@ -71,18 +73,24 @@ __device__ __forceinline__ float cart_linspaced(int i, int size1, float low, flo
 
 // lane = particle; grid.y = chunk of a.cpc window columns; the sample order and the partition into partial sums are
 // score_cart_kernel's.
-template <int NV4, bool KSLOT>
+// INT: the integer form — scan counts times the dictionary's integers (tdr_cmap.hip), accumulated in 64 bits: exact, so the
+// sums equal score_cart_ray_kernel's whatever the order (see tdr_score_su.hip); the slot list may hold padding (-1).
+template <int NV4, bool KSLOT, bool INT = false>
 __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
   constexpr int RF = 4 * NV4;
   constexpr int ND = CmapShape<RF, KSLOT>::ND, CW = CmapShape<RF, KSLOT>::CW, LC = CmapShape<RF, KSLOT>::LC;
-  __shared__ float ldict[TDR_CMAP_MAX_DICT];
-  for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict[t];
+  __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];   // the dictionary: float bits, or (INT) the integers
+  if (a.flags && int_form_off(a.flags) == (a.run_if_int != 0)) return;   // (uniform) the other form does this launch
+  for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = INT ? a.dict_int[t] : __float_as_uint(a.dict[t]);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
-  if ((int64_t)blockIdx.x * 256 >= a.n) return;
-  const bool valid = slot < a.n;
-  const int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const int64_t nact = a.count ? (int64_t)*a.count : a.n;
+  if ((int64_t)blockIdx.x * 256 >= nact) return;
+  const bool valid = slot < nact;
+  int64_t p = a.order ? (int64_t)a.order[valid ? slot : 0] : (valid ? slot : 0);
+  const bool real = valid && p >= 0;
+  if (p < 0) p = a.order[((int64_t)blockIdx.x * 4 + wave) * 64];   // padding of the slot list: a wave's first slot never is
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
   const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
@@ -111,29 +119,33 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
   const tdr_const_u descc = (tdr_const_u)a.desc;
 
-  auto field = [&](const uint32_t (&w)[CW], int k) -> float {   // distance k of a compact record (cmap_decode, one field)
+  auto field = [&](const uint32_t (&w)[CW], int k) -> uint32_t {   // distance k of a compact record (cmap_decode, one field)
     const uint32_t ww = w[k / 3];
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + boff);
   };
-  auto field1 = [&](uint32_t ww, int k) -> float {   // ... when the sample loaded only the dword class k lives in
+  auto field1 = [&](uint32_t ww, int k) -> uint32_t {   // ... when the sample loaded only the dword class k lives in
     const int sh = 10 * (k % 3);
     const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldict) + boff);
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + boff);
   };
-  float acc[ND];
+  typedef typename std::conditional<INT, unsigned long long, float>::type acc_t;
+  acc_t acc[ND];
 #pragma unroll
-  for (int k = 0; k < ND; k++) acc[k] = 0.f;
-  float norm = 0.f;
+  for (int k = 0; k < ND; k++) acc[k] = 0;
+  float norm = 0.f;       // float form
+  uint32_t inorm = 0;     // integer form
   uint32_t known = 0;
-  auto single_class = [&](uint32_t cd, float v, uint32_t ww) {   // a switch over a wave-uniform value
+  // v: the bin's value as the descriptor carries it — float bits, or (INT) the count as an integer
+  auto single_class = [&](uint32_t cd, uint32_t v, uint32_t ww) {   // a switch over a wave-uniform value
     switch (cd) {
 #define CART_CASE(K)                                                                                \
   case K + 1:                                                                                       \
     if constexpr (K < ND) {                                                                         \
-      const float m = field1(ww, K < ND ? K : 0);                                                   \
-      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m));           \
+      const uint32_t m = field1(ww, K < ND ? K : 0);                                                \
+      if constexpr (INT) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m) : "vcc"); \
+      else asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m));      \
     }                                                                                               \
     break;
       CART_CASE(0) CART_CASE(1) CART_CASE(2) CART_CASE(3) CART_CASE(4) CART_CASE(5)
@@ -191,11 +203,12 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
       } else {
         const uint32_t kb = w[u] & 1u;   // bit 0 of every dword of a compact record (tdr_cmap.hip)
         known += kb;
-        const float v = __uint_as_float(D[4 * u + 1]);
+        const uint32_t vb = D[4 * u + 1];   // float bits (INT: the count as an integer — cart_prep_kernel writes both forms)
         if (cd < CART_CODE_FULL_ALL) {
-          // the bin's sum x known (state_particle.cpp:141-142): fma(val, 1 or 0, norm) for a finite val
-          norm = norm + __uint_as_float((0u - kb) & __float_as_uint(v));
-          single_class(cd, v, w[u]);
+          // the bin's sum x known (state_particle.cpp:141-142)
+          if constexpr (INT) inorm += (0u - kb) & vb;
+          else norm = norm + __uint_as_float((0u - kb) & vb);   // fma(val, 1 or 0, norm) for a finite val
+          single_class(cd, vb, w[u]);
         } else {   // several classes (or a non-finite value in play): the whole record, the packed scan record
           uint32_t wr[CW];
           wr[0] = w[u];
@@ -203,11 +216,16 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
           for (int d = 1; d < CW; d++)
             wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
           const tdr_const_f S = scanc + (bin0 + u) * RF;
-          norm = __builtin_fmaf(v, (float)kb, norm);
+          if constexpr (INT) inorm += (0u - kb) & vb;
+          else norm = __builtin_fmaf(__uint_as_float(vb), (float)kb, norm);
 #pragma unroll
           for (int k = 0; k < ND; k++) {
             const float sk = S[k];
-            if (cd == CART_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, field(wr, k), acc[k]);
+            if constexpr (INT) {
+              if (sk != 0.f) acc[k] += (unsigned long long)(uint32_t)sk * field(wr, k);
+            } else {
+              if (cd == CART_CODE_FULL_ALL || sk != 0.f) acc[k] = __builtin_fmaf(sk, __uint_as_float(field(wr, k)), acc[k]);
+            }
           }
         }
       }
@@ -231,10 +249,23 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
       samples(std::integral_constant<int, 1>{}, &cyi, column_terms(j), descc + bin0 * 4, bin0);
     }
   }
-  if (slot < a.npad) {
+  if constexpr (INT) {
+    if (real) {   // [chunk][2 ncls + 2][npad] words, like score_polar_su_kernel
+      const int ncls = a.ncls;
+      uint32_t* o = reinterpret_cast<uint32_t*>(a.part) + (int64_t)blockIdx.y * (2 * ncls + 2) * a.npad + slot;
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        if (k < ncls) {
+          o[(int64_t)(2 * k) * a.npad] = (uint32_t)acc[k];
+          o[(int64_t)(2 * k + 1) * a.npad] = (uint32_t)((unsigned long long)acc[k] >> 32);
+        }
+      o[(int64_t)(2 * ncls) * a.npad] = inorm;
+      o[(int64_t)(2 * ncls + 1) * a.npad] = known;
+    }
+  } else if (slot < a.npad) {
     float* o = a.part + (int64_t)blockIdx.y * (RF + 1) * a.npad + slot;
 #pragma unroll
-    for (int k = 0; k < ND; k++) o[(int64_t)k * a.npad] = acc[k];
+    for (int k = 0; k < ND; k++) o[(int64_t)k * a.npad] = (float)acc[k];
     o[(int64_t)(RF - 1) * a.npad] = norm;
     o[(int64_t)RF * a.npad] = (float)known;
   }
@@ -262,7 +293,7 @@ int tdr_cart_skip_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* 
   const int ckconst = ((map->rows >> lc) + 2) * 128 + 128;   // cmap_offset (tdr_score_dev.h)
   const int64_t nbins = (int64_t)a.rows * a.cols;
   hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
-                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws);
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0);
   LAUNCH_CHECK("cart_prep");
   a.desc = desc_ws;
   a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
@@ -280,5 +311,367 @@ int tdr_cart_skip_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* 
   }
 #undef TDR_LAUNCH_CART_SKIP
   LAUNCH_CHECK("score_cart_skip");
+  return TDR_OK;
+}
+
+// =========================================================================================================================
+// The integer form of a Cartesian launch: score_cart_skip_kernel<.., INT> for the dense particles, score_cart_ray_kernel for
+// the scattered ones — one WAVE per particle, lanes = 64 consecutive window columns of one window row, i.e. 64 cells along a
+// line of the map (the rotation lives in the sampling, src/top_down_map.cpp:367-389): the mapping, the data (class planes,
+// coarse mask plane, integer dictionary) and the loop of score_polar_ray_kernel (tdr_score_ray.hip).  The sample offsets are
+// not a table here but three float operations per coordinate from the particle's rotation, computed per lane exactly like
+// the lane = particle kernels compute them; the scan descriptors are not rotated (shift 0).
+static inline int cart_ray_gq(int cols) { return cols <= 64 ? 1 : (cols <= 128 ? 2 : 4); }
+static inline int cart_ray_blocks(int cols) { return (int)cdiv(cols, 64 * cart_ray_gq(cols)); }
+
+// One thread per (window row i, padded column j): the 16-bit descriptor code << 12 | count of bin (i, j) in ray order
+// [((i * blocks + b) * 64 + lane) * GQ + g], the list of bins with several classes or a count >= 4096 (as i << 16 | j), and
+// the two words of int_form_off (see ray_prep_kernel, tdr_score_ray.hip).
+__global__ __launch_bounds__(256) void cart_ray_prep_kernel(const float* __restrict__ scan_pk, int rows, int cols, int rf, int ncls,
+                                                            int gq, int blocks, const uint32_t* __restrict__ dict_tail,
+                                                            uint16_t* __restrict__ desc_ray, uint32_t* __restrict__ list,
+                                                            int32_t* __restrict__ n_list, int32_t* __restrict__ flags) {
+  const int cpad = blocks * gq * 64;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && dict_tail[1] != 1u) atomicOr(flags, 1);
+  const bool live = t < (int64_t)rows * cpad;
+  const int i = live ? (int)(t / cpad) : 0, j = live ? (int)(t - (int64_t)i * cpad) : 0;
+  const bool real = live && j < cols;
+  const int64_t bin = (int64_t)j * rows + i;   // scan_pk is [cols][rows][rf]
+  uint32_t mass = 0;
+  if (real) {
+    const float sum = scan_pk[bin * rf + rf - 1];
+    if (sum >= 1.f && sum < 16777216.f) mass = ((uint32_t)sum >> 8) + 1u;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mass += __shfl_xor(mass, d, 64);
+  if ((threadIdx.x & 63) == 0 && mass) atomicAdd(reinterpret_cast<unsigned*>(flags) + 1, mass);
+  if (!live) return;
+  uint32_t d = 0;
+  if (real) {
+    const float* r = scan_pk + bin * rf;
+    int nz = 0, first = 0;
+    bool ok = true;
+    for (int c = 0; c < ncls; c++) {
+      const float v = r[c];
+      ok &= v >= 0.f && v < 16777216.f && v == floorf(v);
+      if (v != 0.f) {
+        if (!nz) first = c;
+        nz++;
+      }
+    }
+    const float sum = r[rf - 1];
+    ok &= sum >= 0.f && sum < 16777216.f && sum == floorf(sum);
+    if (!ok) atomicOr(flags, 1);
+    else if (nz == 1 && r[first] < 4096.f) d = (uint32_t)r[first] | ((uint32_t)(first + 1) << 12);
+    else if (nz >= 1) list[atomicAdd(n_list, 1)] = ((uint32_t)i << 16) | (uint32_t)j;
+  }
+  const int g = j >> 6, l = j & 63, b = g / gq;
+  desc_ray[(((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq)] = (uint16_t)d;
+}
+
+struct CartRayArgs {
+  const uint32_t* crec;
+  unsigned planes_off, plane_bytes, cmask_off;
+  int pkcol;
+  const uint32_t* dict_int;
+  int dict_n;
+  int map_rows, map_cols;
+  float resolution;
+  const uint16_t* desc_ray;
+  const uint32_t* list;
+  const int32_t* n_list;
+  const float* scan_pk;
+  int rf, ncls, rows, cols, blocks;
+  float res;
+  const float* st;
+  int64_t cap;
+  const int32_t* slots;
+  const int32_t* counts;
+  const int32_t* flags;
+  int nsplit, libm_fma;
+  int64_t npad;
+  uint32_t* part;
+};
+
+template <int GQ>
+__global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
+  extern __shared__ unsigned long long lacc[];   // [4 waves][ncls + 1][64 lanes]
+  __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
+  __shared__ uint4 lut[16];
+  if (int_form_off(a.flags)) return;
+  const int nsparse = a.counts[1];
+  if ((int64_t)blockIdx.x * 4 >= (int64_t)nsparse * a.nsplit) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict_int[t];
+  const unsigned pconst = (unsigned)(a.pkcol + 16) + 128u;
+  if (threadIdx.x < 16) {
+    const int code = threadIdx.x;
+    uint4 e;
+    if (code >= 1 && code <= a.ncls) {
+      e.x = a.planes_off + (unsigned)(code - 1) * a.plane_bytes + pconst;
+      e.y = 0; e.z = 15; e.w = (unsigned)code * 512u;
+    } else {
+      e.x = a.cmask_off + pconst;
+      e.y = 4; e.z = 0; e.w = 0;
+    }
+    lut[code] = e;
+  }
+  unsigned long long* const my = lacc + (size_t)wave * (a.ncls + 1) * 64 + lane;
+  for (int c = 0; c <= a.ncls; c++) my[c * 64] = 0;
+  __syncthreads();
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t q = gw / a.nsplit;
+  const int part_id = (int)(gw - q * a.nsplit);
+  if (q >= nsparse) return;
+  const int64_t slot = (int64_t)a.counts[0] + q;
+  const int64_t p = a.slots[slot];
+  // the window of getLocalMap(center, rot = theta, res * scale) (src/top_down_map.cpp:429-459 via samplePts :367-389): the
+  // float operations of score_cart_skip_kernel
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const float theta = a.st[TDR_ST_THETA * a.cap + p];
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const float resq = (a.res * scale) / a.resolution;
+  const float c = tdr_libm::cosf_v(theta, a.libm_fma), s = tdr_libm::sinf_v(theta, a.libm_fma);
+  const float ns = -s;
+  typedef float tdr_v2f __attribute__((ext_vector_type(2)));
+  const tdr_v2f cs = {c, s}, offv = {off0, off1};
+  const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
+  const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
+  const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
+  const float step_c = a.cols == 1 ? 0.f : (hi_c - lo_c) / (float)(a.cols - 1);
+  const int r1 = a.rows == 1 ? 1 : a.rows - 1, c1 = a.cols == 1 ? 1 : a.cols - 1;
+  const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  auto cell = [&](tdr_v2f cyi, int j, int& ri, int& ci) {
+    const float xj = cart_linspaced(j, c1, lo_c, hi_c, step_c);
+    const tdr_v2f AB = {ns * xj, c * xj};
+    tdr_v2f pv = cyi + AB;
+    pv = pv + offv;
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+  };
+  auto row_term = [&](int i) -> tdr_v2f { return cs * cart_linspaced(i, r1, lo_r, hi_r, step_r); };
+
+  // rows of steps: m = window row * blocks + block; this wave's share
+  const int rows_all = a.rows * a.blocks, per = (rows_all + a.nsplit - 1) / a.nsplit;
+  const int m0 = part_id * per, m1 = min(rows_all, m0 + per);
+  uint32_t known = 0, norm = 0;
+  constexpr int U = 8 / GQ;
+  typedef uint16_t desc_t __attribute__((ext_vector_type(GQ)));
+  const desc_t* __restrict__ descv = reinterpret_cast<const desc_t*>(a.desc_ray);
+  auto rows_step = [&](auto cnt_c, int m) {
+    constexpr int N = decltype(cnt_c)::value;
+    desc_t dd[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) dd[u] = descv[(int64_t)(m + u) * 64 + lane];
+    uint32_t v[N * GQ], shb[N * GQ], cnt[N * GQ], acc_at[N * GQ], ok[N * GQ];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+      const int i = (m + u) / a.blocks, b = (m + u) - i * a.blocks;   // (wave-uniform)
+      const tdr_v2f cyi = row_term(i);
+#pragma unroll
+      for (int g = 0; g < GQ; g++) {
+        const int sidx = u * GQ + g;
+        const int j = (b * GQ + g) * 64 + lane;
+        int ri, ci;
+        cell(cyi, j, ri, ci);
+        ok[sidx] = j < a.cols ? 1u : 0u;   // a column the window does not have counts nothing
+        const uint32_t d = dd[u][g];
+        cnt[sidx] = d & 0xFFFu;
+        const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
+        const int cc = ci >> (int)e.y;
+        const unsigned off = plane_offset(ri, cc, a.pkcol, (int)e.x);
+        shb[sidx] = ((uint32_t)ci & 15u) | e.z;
+        acc_at[sidx] = e.w;
+        v[sidx] = *reinterpret_cast<const uint16_t*>(crecb + off);
+      }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < N * GQ; sidx++) {
+      uint32_t kbit;
+      asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(v[sidx]), "v"(shb[sidx]));
+      kbit &= ok[sidx];
+      known += kbit;
+      norm = __umul24(cnt[sidx], kbit) + norm;
+      const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + (v[sidx] & 0xFFCu));
+      const unsigned long long prod = (unsigned long long)cnt[sidx] * D;
+      unsigned long long* const acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(my) + acc_at[sidx]);
+      __hip_atomic_fetch_add(acc, prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  int m = m0;
+  for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, m);
+  for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, m);
+  {   // the list: bins with several classes (or one large count)
+    const int nm = *a.n_list, mper = (nm + a.nsplit - 1) / a.nsplit;
+    const int e1 = min(nm, (part_id + 1) * mper);
+    for (int e = part_id * mper + lane; e < e1; e += 64) {
+      const uint32_t w = a.list[e];
+      const int i = (int)(w >> 16), j = (int)(w & 0xFFFFu);
+      const int64_t bin = (int64_t)j * a.rows + i;
+      int ri, ci;
+      cell(row_term(i), j, ri, ci);
+      const unsigned cell_off = plane_offset(ri, ci, a.pkcol, (int)(a.planes_off + pconst));
+      uint32_t kbit = 0;
+      for (int cl = 0; cl < a.ncls; cl++) {
+        const float sv = a.scan_pk[bin * a.rf + cl];
+        if (sv != 0.f) {
+          const uint32_t vv = *reinterpret_cast<const uint16_t*>(crecb + cell_off + (unsigned)cl * a.plane_bytes);
+          kbit = vv >> 15;
+          __hip_atomic_fetch_add(&my[(cl + 1) * 64], (unsigned long long)(uint32_t)sv * ldict[(vv & 0xFFCu) >> 2],
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      norm += (uint32_t)a.scan_pk[bin * a.rf + a.rf - 1] & (0u - kbit);
+    }
+  }
+  uint32_t* o = a.part + (int64_t)part_id * (2 * a.ncls + 2) * a.npad + slot;
+  for (int cl = 0; cl < a.ncls; cl++) {
+    unsigned long long sum = __hip_atomic_load(&my[(cl + 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) sum += __shfl_xor(sum, dlt, 64);
+    if (lane == 0) {
+      o[(int64_t)(2 * cl) * a.npad] = (uint32_t)sum;
+      o[(int64_t)(2 * cl + 1) * a.npad] = (uint32_t)(sum >> 32);
+    }
+  }
+#pragma unroll
+  for (int dlt = 32; dlt > 0; dlt >>= 1) {
+    known += __shfl_xor(known, dlt, 64);
+    norm += __shfl_xor(norm, dlt, 64);
+  }
+  if (lane == 0) {
+    o[(int64_t)(2 * a.ncls) * a.npad] = norm;
+    o[(int64_t)(2 * a.ncls + 1) * a.npad] = known;
+  }
+}
+
+// ---- host side of the integer form ---------------------------------------------------------------------------------------
+extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
+extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
+extern "C" int tdr_config_shift_uniform(int mode);
+
+bool tdr_cart_int_ok(const tdr_map_desc* map, int rf, int rows, int cols, int64_t n_total) {
+  // (mode 0 of tdr_config_shift_uniform switches the integer forms off altogether: A/B measurements, tests)
+  return tdr_config_shift_uniform(-1) != 0 && tdr_cart_skip_ok(map, rf) && tdr_ray_map_ok(map) && rows < 65536 && cols < 65536 &&
+         (tdr_config_shift_uniform(-1) == 2 || n_total >= 4096);
+}
+static inline int64_t cart_ray_desc_words(int rows, int cols) {
+  return ((int64_t)rows * cart_ray_blocks(cols) * cart_ray_gq(cols) * 64 + 1) / 2 + 64;
+}
+static SuWs cart_order_ws(int64_t n) { return tdr_su_ws(1, 4, 4, std::max<int64_t>(n, 1)); }
+int64_t tdr_cart_int_words(int rows, int cols, int64_t n) {
+  // [integer descriptors rows * cols * 4][ray descriptors][list rows * cols][ordering workspace]
+  return tdr_cart_desc_words(rows, cols) + cart_ray_desc_words(rows, cols) + (int64_t)rows * cols + 64 + cart_order_ws(n).total;
+}
+
+int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* desc_ws, int32_t* ws, float span, hipStream_t s,
+                        CartIntOut* out) {
+  const int64_t n = a.n;
+  // workspace
+  uint32_t* desc_int = reinterpret_cast<uint32_t*>(ws);
+  uint16_t* desc_ray = reinterpret_cast<uint16_t*>(ws + tdr_cart_desc_words(a.rows, a.cols));
+  uint32_t* list = reinterpret_cast<uint32_t*>(ws + tdr_cart_desc_words(a.rows, a.cols) + cart_ray_desc_words(a.rows, a.cols));
+  int32_t* ows = ws + tdr_cart_desc_words(a.rows, a.cols) + cart_ray_desc_words(a.rows, a.cols) + (int64_t)a.rows * a.cols + 64;
+  const SuWs W = cart_order_ws(n);
+  // ordering: dense particles (their 64 neighbours in the caller's pose order lie within the span) first, padded to whole
+  // waves, then the scattered ones
+  SuLaunch L{};
+  L.map = map; L.st = a.st; L.cap = a.cap; L.n = n; L.perm = a.order; L.nb = 1; L.span = span; L.ws = ows;
+  L.npad = su_npad(std::max<int64_t>(n, 1), 1);
+  const int32_t* slots = nullptr;
+  const int32_t* counts = nullptr;
+  if (int rc = tdr_su_order(L, W, s, &slots, &counts)) return rc;
+  int32_t* ints = const_cast<int32_t*>(counts);   // [counts 3][n_list][inexact][mass bound]
+  // descriptors: the float form's (desc_ws, for the fallback), the integer form's, the ray order's + the flags
+  const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
+  const int ckconst = ((map->rows >> lc) + 2) * 128 + 128;
+  const int64_t nbins = (int64_t)a.rows * a.cols;
+  hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0);
+  hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_int, 1);
+  LAUNCH_CHECK("cart_prep");
+  const int gq = cart_ray_gq(a.cols), blocks = cart_ray_blocks(a.cols);
+  const int64_t T = (int64_t)a.rows * blocks * gq * 64;
+  hipLaunchKernelGGL(cart_ray_prep_kernel, dim3((unsigned)cdiv(T, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf, map->ncls,
+                     gq, blocks, reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT, desc_ray, list, ints + 3,
+                     ints + 4);
+  LAUNCH_CHECK("cart_ray_prep");
+  const int32_t* flags = ints + 4;
+  a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
+  a.kmask_row = kmask_trows(map->rows) * 128;
+  a.ncls = map->ncls;
+  const bool ks = tdr_has_kslot(map->ncls, rf);
+  const int64_t npad_int = L.npad;
+  // scattered particles: one wave each
+  {
+    CartRayArgs r;
+    r.crec = map->crec;
+    const size_t pw = tdr_cmap_plane_words(map->ncls, map->rows, map->cols);
+    r.planes_off = (unsigned)(tdr_cmap_plane_offset_words(map->ncls, map->rows, map->cols) * 4);
+    r.plane_bytes = (unsigned)(pw * 4);
+    r.cmask_off = r.planes_off + (unsigned)map->ncls * r.plane_bytes;
+    r.pkcol = plane_trows(map->rows) * 128 - 16;
+    r.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
+    r.dict_n = map->dict_n;
+    r.map_rows = map->rows; r.map_cols = map->cols; r.resolution = map->resolution;
+    r.desc_ray = desc_ray; r.list = list; r.n_list = ints + 3; r.scan_pk = a.scan_pk;
+    r.rf = rf; r.ncls = map->ncls; r.rows = a.rows; r.cols = a.cols; r.blocks = blocks; r.res = a.res;
+    r.st = a.st; r.cap = a.cap; r.slots = slots; r.counts = counts; r.flags = flags;
+    r.nsplit = tdr_ray_splits(a.rows, a.cols, n);
+    r.libm_fma = a.libm_fma;
+    r.npad = npad_int; r.part = reinterpret_cast<uint32_t*>(a.part);
+    const dim3 grid((unsigned)cdiv(n * r.nsplit, 4)), block(256);
+    const size_t lds = (size_t)4 * (map->ncls + 1) * 64 * sizeof(unsigned long long);
+    if (gq == 1) hipLaunchKernelGGL((score_cart_ray_kernel<1>), grid, block, lds, s, r);
+    else if (gq == 2) hipLaunchKernelGGL((score_cart_ray_kernel<2>), grid, block, lds, s, r);
+    else hipLaunchKernelGGL((score_cart_ray_kernel<4>), grid, block, lds, s, r);
+    LAUNCH_CHECK("score_cart_ray");
+    out->ray_split = r.nsplit;
+  }
+  // dense particles: the skipping kernel with integer accumulators over the dense slots
+  {
+    CartArgs d = a;
+    d.desc = desc_int;
+    d.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
+    d.flags = flags; d.run_if_int = 1;
+    d.order = slots; d.count = counts; d.npad = npad_int;
+    const dim3 grid((unsigned)cdiv(npad_int, 256), (unsigned)a.nchunks), block(256);
+#define TDR_LAUNCH_CART_INT(NV4)                                                                 \
+  if (ks) hipLaunchKernelGGL((score_cart_skip_kernel<NV4, true, true>), grid, block, 0, s, d);    \
+  else hipLaunchKernelGGL((score_cart_skip_kernel<NV4, false, true>), grid, block, 0, s, d);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_CART_INT(1) break;
+      case 2: TDR_LAUNCH_CART_INT(2) break;
+      case 3: TDR_LAUNCH_CART_INT(3) break;
+      default: return fail(TDR_ERR_ARG, "score_cart: no skipping kernel for record size %d", rf);
+    }
+#undef TDR_LAUNCH_CART_INT
+    LAUNCH_CHECK("score_cart_skip(int)");
+  }
+  // the float form, for a scan / map without an integer form (returns at once otherwise)
+  {
+    CartArgs f = a;
+    f.desc = desc_ws;
+    f.flags = flags; f.run_if_int = 0;
+    const dim3 grid((unsigned)cdiv(a.n, 256), (unsigned)a.nchunks), block(256);
+#define TDR_LAUNCH_CART_FLT(NV4)                                                           \
+  if (ks) hipLaunchKernelGGL((score_cart_skip_kernel<NV4, true>), grid, block, 0, s, f);    \
+  else hipLaunchKernelGGL((score_cart_skip_kernel<NV4, false>), grid, block, 0, s, f);
+    switch (rf / 4) {
+      case 1: TDR_LAUNCH_CART_FLT(1) break;
+      case 2: TDR_LAUNCH_CART_FLT(2) break;
+      default: TDR_LAUNCH_CART_FLT(3) break;
+    }
+#undef TDR_LAUNCH_CART_FLT
+    LAUNCH_CHECK("score_cart_skip(float form)");
+  }
+  out->slots = slots; out->counts = counts; out->flags = flags; out->npad = npad_int;
   return TDR_OK;
 }

@@ -38,6 +38,8 @@ struct SuLaunch {
 // by heading bin, every bin padded to whole waves (-1), then the sparse particles in the caller's order (su_key_kernel);
 // counts_out: device words {slots of the heading bins, sparse particles behind them, both together (what finalize walks)}
 int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out);
+// the ordering passes alone (L.st, cap, n, perm, nb, span, ws; nb == 1: no heading bins — the Cartesian score)
+int tdr_su_order(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out);
 // The span for this launch.  With a fixed span (tdr_config_shift_uniform_span, TDR_SU_SPAN) that one; otherwise it is tuned
 // while the filter runs: a few candidates are timed over one launch each (events on `s` around the whole scoring call,
 // tdr_su_span_end closes the measurement), the fastest is kept, and the trial is repeated every few thousand launches

@@ -770,10 +770,10 @@ SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   return w;
 }
 
-int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out) {
+// The ordering passes alone: the slot list — dense particles by heading bin (one bin when L.nb == 1: the Cartesian score has
+// no heading bins), every bin padded to whole waves (-1), then the sparse particles in the caller's order — and the counts.
+int tdr_su_order(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out) {
   int32_t* base = L.ws;
-  float* tab_su = reinterpret_cast<float*>(base + W.tab_su);
-  uint32_t* desc = reinterpret_cast<uint32_t*>(base + W.desc);
   uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + W.keys_in);
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + W.keys_out);
   int32_t* vals_in = base + W.vals_in;
@@ -800,6 +800,15 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   hipLaunchKernelGGL(su_scatter_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const uint32_t*)keys_out,
                      (const int32_t*)vals_out, n, (const int*)start, (const int*)slot_start, slots);
   LAUNCH_CHECK("su_scatter");
+  *slots_out = slots;
+  *counts_out = counts;
+  return TDR_OK;
+}
+int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t** slots_out, const int32_t** counts_out) {
+  if (int rc = tdr_su_order(L, W, s, slots_out, counts_out)) return rc;
+  int32_t* base = L.ws;
+  float* tab_su = reinterpret_cast<float*>(base + W.tab_su);
+  uint32_t* desc = reinterpret_cast<uint32_t*>(base + W.desc);
   const int64_t ndesc = (int64_t)L.nchunks * L.nb * L.group;
   const int lc = L.map->cwords == 1 ? 3 : (L.map->cwords == 2 ? 2 : 1);
   const int ckconst = ((L.map->rows >> lc) + 2) * 128 + 128;   // cmap_offset (tdr_score_dev.h)
@@ -809,8 +818,6 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   hipLaunchKernelGGL(su_bbox_kernel, dim3((unsigned)L.nchunks, SU_NSECT), dim3(256), 0, s, (const float*)tab_su, L.nb, L.nr,
                      L.group, reinterpret_cast<float*>(base + W.bbox));
   LAUNCH_CHECK("su_bbox");
-  *slots_out = slots;
-  *counts_out = counts;
   return TDR_OK;
 }
 
