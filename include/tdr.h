@@ -436,7 +436,12 @@ float tdr_config_shift_uniform_span(float cells);
 /* Waves a scattered particle's window is split over in the ray-mapped kernel (1 .. 8; 0 = chosen per launch from its size,
  * the default; < 0 only queries).  The sums are exact integers: results never depend on it (tests). */
 int tdr_config_ray_split(int k);
-/* The Cartesian scoring has a second kernel that reads the scan side of a sample as a scalar descriptor and gives an empty
+/* Large Cartesian launches (a filter of >= 4096 particles on a map with narrow compact records and class planes) take the
+ * INTEGER form too, with the same guarantee as the polar one (tdr_config_shift_uniform above, whose mode 0 switches both
+ * off): dense particles through the skipping kernel below with 64-bit integer accumulators, scattered ones one wave each,
+ * lanes = consecutive window columns (csrc/tdr_score_cart.hip: score_cart_ray_kernel); the span is four times the polar
+ * launch's.  The float kernels score what has no integer form and agree to rounding.
+ * The Cartesian scoring has a second kernel that reads the scan side of a sample as a scalar descriptor and gives an empty
  * scan bin one 4-byte gather from the map's known mask instead of the record gather, decode and FMAs
  * (csrc/tdr_score_cart.hip); same partial sums, bit for bit.  It is used whenever the map has narrow compact records;
  * 0 forces the general kernel (A/B measurements, tests), 1 restores the default, < 0 only queries.  Env TDR_CART_SKIP. */
