@@ -1,5 +1,5 @@
 // ActiveLocalizer — reference surface: include/top_down_render/active_localizer.h:6-17, src/active_localizer.cpp.
-// Same constructor and methods as the reference (its two private helpers are public here, for tests).  The reference keeps
+// Same constructor and public method as the reference.  The reference keeps
 // the class alive but never calls it (src/particle_filter.cpp:77-78, 316 are commented out); it is rebuilt for
 // completeness of the surface ParticleFilter's header pulls in.  Every candidate displacement of getBestRelPos is one
 // workgroup of ONE launch on the MI355X (csrc/tdr_active.hip); the local maps are gathered in place, never materialised.
@@ -35,38 +35,8 @@ class ActiveLocalizer {
   }
   float lastBestDiff() const { return last_best_diff_; }   // the "Max diff" the reference logs (:79)
 
-  // :7-20 on host images (the device path never builds them)
-  float computeTotalDifference(std::vector<std::vector<Eigen::ArrayXXf>>& local_maps) {
-    float total_difference = 0;
-    int cnt = 0;
-    for (size_t i = 0; i < local_maps.size(); i++)
-      for (size_t j = 0; j < i; j++)
-        for (size_t cls = 0; cls < local_maps[0].size(); cls++) {
-          const Eigen::ArrayXXf& a = local_maps[i][cls];
-          const Eigen::ArrayXXf& b = local_maps[j][cls];
-          double s = 0;
-          for (Eigen::Index k = 0; k < a.size(); k++) s += std::fabs(a.data()[k] - b.data()[k]);
-          total_difference += (float)s;
-          cnt += 1;
-        }
-    return total_difference / (float)cnt;
-  }
-  // :22-42: the window at state.head<2>() (res 2, scale 1) with its rows rotated by the heading
-  void getLocalMap(Eigen::Vector3f& state, std::vector<Eigen::ArrayXXf>& local_map) {
-    const Eigen::Vector2i shape = map_->polarShape();
-    std::vector<Eigen::ArrayXXf> orig;
-    for (int n = 0; n < map_->numClasses(); n++) orig.push_back(Eigen::ArrayXXf(shape[0], shape[1]));
-    Eigen::ArrayXXc mask(shape[0], shape[1]);
-    map_->getLocalMap(Eigen::Vector2f(state[0], state[1]), 2.f, orig, mask);                    // :30
-    const int num_bins = (int)local_map[0].rows();
-    int rot_shift = (int)std::round((double)(state[2] * (float)num_bins / 2) / 3.14159265358979323846);   // :33
-    while (rot_shift >= num_bins) rot_shift -= num_bins;
-    while (rot_shift < 0) rot_shift += num_bins;
-    for (int n = 0; n < map_->numClasses(); n++)
-      for (Eigen::Index j = 0; j < local_map[n].cols(); j++)
-        for (int a = 0; a < num_bins; a++)
-          local_map[n](a, j) = orig[n](a < rot_shift ? num_bins - rot_shift + a : a - rot_shift, j);   // :38-41
-  }
+  // (computeTotalDifference and getLocalMap, :7-42, are private helpers of the reference's CPU loop; the launch above gathers
+  // the hypotheses' cells in place and has no host images to hand them)
 
  private:
   TopDownMapPolar* map_;

