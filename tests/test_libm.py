@@ -102,7 +102,7 @@ def _host_logf(x):
 def test_logf_restatement_matches_the_host_libm():
     """csrc/tdr_logf.h against this machine's logf on 300 000 arguments spread over every bit pattern (zeros, subnormals,
     negatives, infinities, NaN included) and densely over (0, 1], where the polar method's r2 lives.  The sweep of all 2^32
-    arguments (tools/libm_sweep.cpp) finds 0 mismatches, and glibc's plain and FMA builds agree everywhere."""
+    arguments (tools/logf_sweep.cpp) finds 0 mismatches, and glibc's plain and FMA builds agree everywhere."""
     from top_down_renderer_amd import _lib
     L = _lib.load()
     x = np.concatenate([_args(step=(1 << 32) // 200_000 + 1, offset=4321),

@@ -7,7 +7,7 @@
 // of {1/c, log c}, a cubic in r = z/c - 1 — and rounds once to float.  Restated here operation for operation (a third-party
 // libm algorithm, like tdr_sincosf.h; the table is the library's own data).  As for sinf / cosf, x86-64 glibc picks at load
 // time between the plain build and one compiled with -mfma, in which the five `a * b + c` of the evaluation are fused:
-// FMA = true / false, chosen by tdr_libm_variant().  tools/libm_sweep.cpp sweeps all 2^32 arguments against the host's
+// FMA = true / false, chosen by tdr_libm_variant().  tools/logf_sweep.cpp sweeps all 2^32 arguments against the host's
 // logf; tests/test_libm.py checks strided sweeps on the CPU and the device against the host on the GPU.
 #ifndef TDR_LOGF_H_
 #define TDR_LOGF_H_
