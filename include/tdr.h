@@ -125,8 +125,8 @@ int tdr_cmap_words(int ncls);
  *  - from dword tdr_cmap_plane_offset_words on, the CLASS PLANES (tdr_cmap_plane_words dwords each, 0 = none: the map is
  *    too large for 32-bit offsets): per class one 16-bit value per cell — dictionary index * 4 in bits 2-11, known in bit
  *    15 — in tiles of 8 x 8 cells, tile column by tile column, a guard band of 8 cells (csrc/tdr_score_dev.h:
- *    plane_offset); behind them the COARSE MASK PLANE (tdr_cmap_cmask_words dwords), the same shape with a 16-bit cell
- *    holding the known bits of columns 16 cc .. 16 cc + 15 of one row at cell (r, cc).
+ *    plane_offset); behind them the COARSE MASK PLANE (tdr_cmap_cmask_words dwords), the same shape and tile-column stride
+ *    with a 16-bit cell holding the known bits of a 4 x 4 block of map cells: cell (r >> 2, c >> 2), bit (r & 3) * 4 + (c & 3).
  * Behind the float dictionary, `dict` also carries the dictionary as integers (narrow form): entries [1024, 2048) =
  * value * 2^q as uint32, [2048] = q, [2049] = 1 when every value has that form (csrc/tdr_cmap.hip). */
 size_t tdr_cmap_words_total(int ncls, int rows, int cols);

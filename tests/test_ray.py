@@ -65,12 +65,13 @@ def test_class_planes_and_integer_dictionary_decode_to_the_map(tdr, ncls, rows, 
     gr = np.array([-1, -1, rows, rows, 5]); gc = np.array([-1, cols, -1, cols, -1])
     el = (((gc + 8) >> 3) * trows + ((gr + 8) >> 3)) * 64 + ((gr + 8) & 7) * 8 + ((gc + 8) & 7)
     assert (planes[el] == 0).all()
-    # the coarse mask plane behind the class planes: cell (r, c >> 4), bit c & 15
+    # the coarse mask plane behind the class planes: cell (r >> 2, c >> 2), bit (r & 3) * 4 + (c & 3), the planes' stride
     cm = crec[off + pw * ncls: off + pw * ncls + cmw].view(np.uint16)
-    ccp = (c >> 4) + 8
-    el = ((ccp >> 3) * trows + (rp >> 3)) * 64 + (rp & 7) * 8 + (ccp & 7)
-    assert np.array_equal((cm[el] >> (c & 15)) & 1, 1 - mask)
-    assert (cm[(((gc >> 4) + 8) >> 3) * trows * 64 + ((gr + 8) >> 3) * 64 + ((gr + 8) & 7) * 8 + (((gc >> 4) + 8) & 7)] >> (gc & 15) & 1 == 0).all()
+    Rp, Cp = (r >> 2) + 8, (c >> 2) + 8
+    el = ((Cp >> 3) * trows + (Rp >> 3)) * 64 + (Rp & 7) * 8 + (Cp & 7)
+    assert np.array_equal((cm[el] >> ((r & 3) * 4 + (c & 3))) & 1, 1 - mask)
+    gR, gC = (gr >> 2) + 8, (gc >> 2) + 8
+    assert ((cm[((gC >> 3) * trows + (gR >> 3)) * 64 + (gR & 7) * 8 + (gC & 7)] >> ((gr & 3) * 4 + (gc & 3))) & 1 == 0).all()
 
 
 def test_a_map_without_an_integer_form_says_so(tdr, oracle):

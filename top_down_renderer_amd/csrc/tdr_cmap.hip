@@ -117,11 +117,14 @@ extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols) {
   return per;
 }
 // ... and behind the class planes the COARSE MASK PLANE: the known mask once more in the planes' own shape — a 16-bit cell
-// holds the known bits of 16 neighbouring columns of one row (cell (r, c >> 4), bit c & 15), tiles of 8 rows x 8 such cells —
-// so that the ray-mapped kernel addresses "the cell's known bit" and "the cell's class value" with one formula.
+// holds the known bits of a 4 x 4 block of map cells (cell (r >> 2, c >> 2), bit (r & 3) * 4 + (c & 3)), tiles of 8 x 8 such
+// cells: a 128-byte line covers 32 x 32 map cells, like the known mask's, and a ray of 64 cells crosses 2-3 of them (16
+// columns of one row per cell, the first layout, made that 1-8) — so that the ray-mapped kernel addresses "the cell's known
+// bit" and "the cell's class value" with one formula.  A tile column has the class planes' stride (plane_trows tile rows, of
+// which the first quarter is used): the formula's column constant is then the same for every plane.
 extern "C" size_t tdr_cmap_cmask_words(int ncls, int rows, int cols) {
   if (!tdr_cmap_plane_words(ncls, rows, cols)) return 0;
-  return (size_t)plane_trows(rows) * plane_tcols(cols >> 4) * 32;
+  return (size_t)plane_trows(rows) * plane_tcols(cols >> 2) * 32;
 }
 extern "C" size_t tdr_cmap_words_total(int ncls, int rows, int cols) {
   const size_t off = tdr_cmap_plane_offset_words(ncls, rows, cols);
@@ -172,12 +175,12 @@ __global__ __launch_bounds__(256) void cmap_cmask_kernel(const float* __restrict
   const int64_t tile = t >> 6;
   const int within = (int)(t & 63);
   const int tc = (int)(tile / tr_n), tr = (int)(tile - (int64_t)tc * tr_n);
-  const int r = ((tr - 1) << 3) + (within >> 3), cc = ((tc - 1) << 3) + (within & 7);
+  const int R = ((tr - 1) << 3) + (within >> 3), C = ((tc - 1) << 3) + (within & 7);   // the 4 x 4 block (R, C)
   uint16_t v = 0;
-  if (r >= 0 && r < rows && cc >= 0)
+  if (R >= 0 && C >= 0)
     for (int b = 0; b < 16; b++) {
-      const int c = cc * 16 + b;
-      if (c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) v |= (uint16_t)(1u << b);
+      const int r = R * 4 + (b >> 2), c = C * 4 + (b & 3);
+      if (r < rows && c < cols && rec[((int64_t)(r + 1) * (cols + 2) + (c + 1)) * rf + rf - 1] != 0.f) v |= (uint16_t)(1u << b);
     }
   cmask[t] = v;
 }

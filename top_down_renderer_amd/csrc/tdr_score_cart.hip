@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
       e.y = 0; e.z = 15; e.w = (unsigned)code * 512u;
     } else {
       e.x = a.cmask_off + pconst;
-      e.y = 4; e.z = 0; e.w = 0;
+      e.y = 2; e.z = 0; e.w = 0;
     }
     lut[code] = e;
   }
@@ -484,9 +484,9 @@ __global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
         const uint32_t d = dd[u][g];
         cnt[sidx] = d & 0xFFFu;
         const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
-        const int cc = ci >> (int)e.y;
-        const unsigned off = plane_offset(ri, cc, a.pkcol, (int)e.x);
-        shb[sidx] = ((uint32_t)ci & 15u) | e.z;
+        const int rr = ri >> (int)e.y, cc = ci >> (int)e.y;
+        const unsigned off = plane_offset(rr, cc, a.pkcol, (int)e.x);
+        shb[sidx] = ((((uint32_t)ri & 3u) << 2) | ((uint32_t)ci & 3u)) | e.z;
         acc_at[sidx] = e.w;
         v[sidx] = *reinterpret_cast<const uint16_t*>(crecb + off);
       }

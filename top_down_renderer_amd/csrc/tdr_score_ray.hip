@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
     if (code >= 1 && code <= a.ncls) {   // class code - 1 alone: its plane, cells as they are, `known` in bit 15
       e.x = a.planes_off + (unsigned)(code - 1) * a.plane_bytes + pconst;
       e.y = 0; e.z = 15; e.w = (unsigned)code * 512u;
-    } else {                             // nothing to multiply: the coarse mask plane (16 columns per cell), bit = column & 15
+    } else {                             // nothing to multiply: the coarse mask plane (4 x 4 map cells per cell)
       e.x = a.cmask_off + pconst;
-      e.y = 4; e.z = 0; e.w = 0;
+      e.y = 2; e.z = 0; e.w = 0;
     }
     lut[code] = e;
   }
@@ -213,9 +213,10 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
         cnt[s] = d & 0xFFFu;
         // one 16-byte LDS read: everything that depends on the bin's class
         const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
-        const int cc = ci >> (int)e.y;                       // a mask cell spans 16 columns
-        const unsigned off = plane_offset(ri, cc, a.pkcol, (int)e.x);
-        shb[s] = ((uint32_t)ci & 15u) | e.z;                 // bit of `known`: 15 in a class cell, the column's in a mask cell
+        const int rr = ri >> (int)e.y, cc = ci >> (int)e.y;  // a mask cell spans 4 x 4 map cells
+        const unsigned off = plane_offset(rr, cc, a.pkcol, (int)e.x);
+        // bit of `known`: 15 in a class cell, (row & 3) * 4 + (column & 3) in a mask cell
+        shb[s] = ((((uint32_t)ri & 3u) << 2) | ((uint32_t)ci & 3u)) | e.z;
         acc_at[s] = e.w;
         v[s] = *reinterpret_cast<const uint16_t*>(crecb + off);
       }
