@@ -167,6 +167,12 @@ int tdr_k_unpack_map(const float* rec, int ncls, int rows, int cols, float* clas
 /* TopDownMapPolar::samplePtsPolar (src/top_down_map_polar.cpp:7-19, via TopDownMap::samplePts
  * src/top_down_map.cpp:367-389): fills the HOST table tab[nb*nr][2] = {cos(theta_i)*r_j, sin(theta_i)*r_j}. */
 int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float* tab_out);
+/* The same table as its two factors, fac_out[2 nb + nr] (HOST): {cos, sin}(theta_i) at [2 i], [2 i + 1], r_j at
+ * [2 nb + j] — every table entry is one float product of the two (top_down_map_polar.cpp:17-18).  A DEVICE copy handed
+ * to a tdr_score_ctx (tdr_score_ctx_set_polar_factors) lets the ray-mapped kernel multiply the offsets itself instead of
+ * reading the table; it checks on the device, every call, that the table it was given is those products, and reads the
+ * table when it is not. */
+int tdr_polar_factors_host(int nb, int nr, float ang_res, float resolution, float* fac_out);
 
 /* ---- scan raster -------------------------------------------------------------------------------------------- */
 /* ScanRendererPolar::renderSemanticTopDown (src/scan_renderer_polar.cpp:83-109).
@@ -234,6 +240,9 @@ typedef struct tdr_score_ctx tdr_score_ctx;
 int tdr_score_ctx_create(tdr_score_ctx** out);
 void tdr_score_ctx_destroy(tdr_score_ctx* ctx);
 float tdr_score_ctx_span(const tdr_score_ctx* ctx);
+/* fac_dev: device copy of tdr_polar_factors_host's output for the (nb, nr) table the context's calls score with; the
+ * caller's memory, alive until replaced (NULL: none).  Calls with another shape ignore it. */
+int tdr_score_ctx_set_polar_factors(tdr_score_ctx* ctx, const float* fac_dev, int nb, int nr);
 int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, const float* scan_pk, int nb, int nr, float res,
                           const tdr_filter_params* fp, float* st, int64_t cap, int64_t n, int64_t n_total,
                           const int32_t* perm, float uniform_scale, int init_search, float* raw_w, float* workspace,

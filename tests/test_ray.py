@@ -2,6 +2,8 @@
 the class planes and the integer dictionary decode to the map's own values (from the layout include/tdr.h documents), and a
 particle's weight is the same bits whatever order its products were added in — any split of a window over waves, any
 particle order, either kernel, one caller context or none.  Run with `pytest -m gpu`."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -164,6 +166,71 @@ def test_weights_do_not_depend_on_the_order_of_the_additions(tdr, oracle, ncls, 
         k.lib.tdr_config_shift_uniform(before)
         k.lib.tdr_config_shift_uniform_span(-2.0)
         k.lib.tdr_config_ray_split(0)
+    assert np.array_equal(np.isnan(a), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    err = np.abs(a[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)
+    assert err.max(initial=0.0) <= 1e-5, err.max()
+
+
+@pytest.mark.parametrize("nb,nr,scale_fixed", [(64, 32, True), (100, 100, True), (40, 200, False), (12, 300, True),
+                                               (9, 530, False)])
+def test_offsets_multiplied_out_of_the_tables_factors(tdr, oracle, nb, nr, scale_fixed):
+    """A context that holds the table's factors (tdr_polar_factors_host): the ray-mapped kernel multiplies a direction's
+    pair with a ring's radius itself instead of reading the product — the same float products (checked here on the host,
+    and by the kernel's preparation on the device), so the same bits as the kernel that reads the table; one, two and four
+    rings per lane, one block and several.  With factors that are NOT the table's (another angular resolution) the
+    preparation notices and the table is read: the same bits again."""
+    import torch
+    pkg, k = tdr
+    sc = _scene(ncls=5, nb=nb, nr=nr, size=400, n=1200, seed=5300 + nr, pts=9000)
+    cfg = sc.cfg
+    st = sc.states.copy()
+    n = len(st)
+    rng = np.random.default_rng(nr)
+    if not scale_fixed:
+        st["scale"] = rng.uniform(0.4, 1.2, n).astype(np.float32)
+    st["init_x_px"][::7] = rng.uniform(-100, 500, len(st[::7])).astype(np.float32)
+    params = dict(fixed_scale=1.0 if scale_fixed else -1.0)
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
+    m.samplePtsPolar((nb, nr), cfg.ang_res)
+    fac = m.dev.fac.cpu().numpy()
+    prod = np.stack([np.outer(fac[2 * nb:], fac[0:2 * nb:2]), np.outer(fac[2 * nb:], fac[1:2 * nb:2])], axis=-1)
+    assert np.array_equal(prod.reshape(-1, 2).view(np.uint32), m.dev.tab_host.view(np.uint32))
+    scan = oracle.raster_polar(sc.pts, cfg.res, cfg.ang_res, sc.lut, cfg.ncls, nb, nr)
+    f = pkg.ParticleFilter(n, m, pkg.FilterParams(**params), kernels=k, init_particles=False, locality_every=1)
+    f.set_states(st)
+    pk = m.scan_handle(scan)
+    ctx = k.score_ctx_create()
+
+    def run(span, split, ctx):
+        k.lib.tdr_config_shift_uniform_span(span)
+        k.lib.tdr_config_ray_split(split)
+        f.raw_w.fill_(-7.0)
+        k.score(m.dev, pk, float(cfg.res), f.fp_c, f.st, n, f.raw_w, uniform_scale=f._uniform_scale, n_total=N_TOTAL, ctx=ctx)
+        k.synchronize()
+        return f.raw_w[:n].cpu().numpy()
+
+    before = k.lib.tdr_config_shift_uniform(-1)
+    good = m.dev.fac
+    try:
+        k.lib.tdr_config_shift_uniform(2)
+        a = run(ALL_RAY, 1, None)
+        assert not (a == -7.0).any()
+        for split in (1, 2, 8):
+            assert np.array_equal(a, run(ALL_RAY, split, ctx), equal_nan=True), f"factors, {split} waves per particle"
+        assert np.array_equal(a, run(3.0, 0, ctx), equal_nan=True)
+        other = np.empty(2 * nb + nr, np.float32)
+        rc = k.lib.tdr_polar_factors_host(nb, nr, C.c_float(cfg.ang_res * 1.01), C.c_float(1.0), other.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        m.dev.fac = k.to_device(other)
+        assert np.array_equal(a, run(ALL_RAY, 2, ctx), equal_nan=True), "factors of another table"
+    finally:
+        m.dev.fac = good
+        k.lib.tdr_config_shift_uniform(before)
+        k.lib.tdr_config_shift_uniform_span(-2.0)
+        k.lib.tdr_config_ray_split(0)
+    ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0), oracle.polar_table(nb, nr, cfg.ang_res),
+                                 nb, nr, scan, cfg.res, oracle.make_params(cfg.ncls, **params), st.copy())
     assert np.array_equal(np.isnan(a), np.isnan(ref))
     ok = ~np.isnan(ref)
     err = np.abs(a[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)

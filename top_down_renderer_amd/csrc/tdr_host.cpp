@@ -75,6 +75,7 @@ struct DevBuf {
 struct tdr_map {
   DevBuf<float> rec;
   DevBuf<float> tab;
+  DevBuf<float> fac;   // the table's factors (tdr_polar_factors_host), handed to the filter's tdr_score_ctx
   DevBuf<uint32_t> crec;   // compact form of `rec` (tdr_k_compact_map), when the map has one
   DevBuf<float> cdict;
   DevBuf<uint8_t> cws;
@@ -335,6 +336,10 @@ int tdr_map_sample_pts_polar(tdr_map* m, int nb, int nr, float ang_res) {
   TTRY(tdr_polar_table_host(nb, nr, ang_res, m->desc.resolution, tab.data()));
   TTRY(m->tab.resize(tab.size()));
   HTRY(hipMemcpy(m->tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<float> fac((size_t)2 * nb + nr);
+  TTRY(tdr_polar_factors_host(nb, nr, ang_res, m->desc.resolution, fac.data()));
+  TTRY(m->fac.resize(fac.size()));
+  HTRY(hipMemcpy(m->fac.p, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice));
   return TDR_OK;
 }
 
@@ -1025,6 +1030,7 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
       m->desc.rec16 = m->rec16.p;
     }
   }
+  TTRY(tdr_score_ctx_set_polar_factors(f->score_ctx, m->fac.p, nb, nr));
   TTRY(tdr_k_score_polar_ctx(&m->desc, m->tab.p, pk, nb, nr, res, &f->fp, f->st.p, f->cap, n, f->n, perm, f->uniform_scale,
                              f->maybe_uninit ? 1 : 0, f->raw_w.p, f->ws.p, f->score_ctx, f->stream));
   // the search initialises every un-gated particle; only gated ones (state_particle.cpp:163-176) can stay un-initialised

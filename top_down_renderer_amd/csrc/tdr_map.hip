@@ -312,27 +312,49 @@ static inline float linspaced_f(int i, int n, float low, float high) {
   if (fabsf(high) < fabsf(low)) return (i == 0) ? low : (high - (float)(size1 - i) * step);
   return (i == size1) ? high : (low + (float)i * step);
 }
+// the angle and the radius of sample (direction i, ring j), as samplePtsPolar has them before the product (:10-14)
+static void polar_angle_radius(int i, int j, int nb, int nr, float ang_res, float resolution, float& a, float& r) {
+  // samplePts(0, 0, pts, cols=nr, rows=nb, res=1): row0 = L_nb[i], row1 = L_nr[j]; identity rotation
+  const float lo_r = (float)((double)(-1.f * (float)(nb - 1)) / 2.), hi_r = (float)((double)(1.f * (float)(nb - 1)) / 2.);
+  const float lo_c = (float)((double)(-1.f * (float)(nr - 1)) / 2.), hi_c = (float)((double)(1.f * (float)(nr - 1)) / 2.);
+  const float c = cosf(0.f), s = sinf(0.f);
+  const float inv_res = (float)(1. / (double)resolution);
+  const float first = s * linspaced_f(0, nb, lo_r, hi_r) + c * linspaced_f(0, nr, lo_c, hi_c) + 0.f;
+  const float p0 = linspaced_f(i, nb, lo_r, hi_r), p1 = linspaced_f(j, nr, lo_c, hi_c);
+  a = c * p0 + (-s) * p1 + 0.f;
+  r = s * p0 + c * p1 + 0.f;
+  r = r + (-first);
+  a = a * ang_res;
+  r = r * inv_res;
+}
 extern "C" int tdr_polar_table_host(int nb, int nr, float ang_res, float resolution, float* tab) {
   if (nb < 1 || nr < 1 || !tab) return fail(TDR_ERR_ARG, "polar_table: bad arguments");
-  // samplePts(0, 0, pts, cols=nr, rows=nb, res=1): row0 = L_nb[i], row1 = L_nr[j]; identity rotation
-  float lo_r = (float)((double)(-1.f * (float)(nb - 1)) / 2.), hi_r = (float)((double)(1.f * (float)(nb - 1)) / 2.);
-  float lo_c = (float)((double)(-1.f * (float)(nr - 1)) / 2.), hi_c = (float)((double)(1.f * (float)(nr - 1)) / 2.);
-  float c = cosf(0.f), s = sinf(0.f);
-  float inv_res = (float)(1. / (double)resolution);
-  float first = 0.f;
   for (int j = 0; j < nr; j++) {
     for (int i = 0; i < nb; i++) {
-      float p0 = linspaced_f(i, nb, lo_r, hi_r), p1 = linspaced_f(j, nr, lo_c, hi_c);
-      float a = c * p0 + (-s) * p1 + 0.f;
-      float r = s * p0 + c * p1 + 0.f;
-      if (i == 0 && j == 0) first = r;
-      r = r + (-first);
-      a = a * ang_res;
-      r = r * inv_res;
+      float a, r;
+      polar_angle_radius(i, j, nb, nr, ang_res, resolution, a, r);
       size_t k = (size_t)i + (size_t)nb * j;
       tab[2 * k] = cosf(a) * r;
       tab[2 * k + 1] = sinf(a) * r;
     }
+  }
+  return TDR_OK;
+}
+// The table's two factors: fac[2 i], fac[2 i + 1] = cos, sin of direction i; fac[2 nb + j] = radius of ring j — every table
+// entry is ONE float product of a direction's and a ring's (the identity rotation leaves the angle to i and the radius to j).
+// A scoring kernel given them (tdr_score_ctx_set_polar_factors) checks that on the device against the table it is given.
+extern "C" int tdr_polar_factors_host(int nb, int nr, float ang_res, float resolution, float* fac) {
+  if (nb < 1 || nr < 1 || !fac) return fail(TDR_ERR_ARG, "polar_factors: bad arguments");
+  for (int i = 0; i < nb; i++) {
+    float a, r;
+    polar_angle_radius(i, 0, nb, nr, ang_res, resolution, a, r);
+    fac[2 * i] = cosf(a);
+    fac[2 * i + 1] = sinf(a);
+  }
+  for (int j = 0; j < nr; j++) {
+    float a, r;
+    polar_angle_radius(0, j, nb, nr, ang_res, resolution, a, r);
+    fac[2 * nb + j] = r;
   }
   return TDR_OK;
 }

@@ -1929,7 +1929,16 @@ static int launch_score(ScoreArgs a, const tdr_map_desc* map, int rf, int ncls, 
 struct tdr_score_ctx {
   int device = 0;
   SpanTuner tuner;
+  const float* fac = nullptr;   // the table's factors on the device (tdr_polar_factors_host), the caller's memory
+  int fac_nb = 0, fac_nr = 0;
 };
+extern "C" int tdr_score_ctx_set_polar_factors(tdr_score_ctx* c, const float* fac_dev, int nb, int nr) {
+  if (!c || (fac_dev && (nb < 1 || nr < 1))) return fail(TDR_ERR_ARG, "score_ctx_set_polar_factors: bad arguments");
+  c->fac = fac_dev;
+  c->fac_nb = fac_dev ? nb : 0;
+  c->fac_nr = fac_dev ? nr : 0;
+  return TDR_OK;
+}
 extern "C" int tdr_score_ctx_create(tdr_score_ctx** out) {
   if (!out) return fail(TDR_ERR_ARG, "score_ctx_create: null pointer");
   *out = nullptr;
@@ -2126,6 +2135,8 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
     L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
     L.ray_split = tdr_ray_splits(nb, nr, n);
+    L.fac = ctx && ctx->fac && ctx->fac_nb == nb && ctx->fac_nr == nr ? ctx->fac : nullptr;
+    L.uscale = uniform_scale;
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
     TunerScope tuner_scope(ctx, s);   // (closes the tuner's measurement on every way out)
     L.span = tdr_su_span_begin(ctx ? &ctx->tuner : nullptr,

@@ -49,11 +49,17 @@ int64_t tdr_ray_padded_samples(int nb, int nr) { return (int64_t)nb * ray_blocks
 // `list`: bins holding several classes or a count >= 4096, as row << 16 | ring.
 // inexact[0] is raised when the scan has no integer form: a count that is negative, fractional, not finite or >= 2^24, or
 // a dictionary without one (tdr_cmap.hip); inexact[1] collects the bound on the total count (int_form_off).
+// fac (optional): the table's factors (tdr_polar_factors_host).  rad_ray[(b * 64 + l) * GQ + g] = ring j's radius (rings
+// beyond nr: 1e30 — one of a direction's two products then leaves the map whatever the direction); inexact[2] is raised
+// when an entry of `tab` is not the float product its factors give (with a uniform scale: that product, scaled like
+// utab_kernel scales the table) — the kernel that multiplies the factors itself then stands back for the one that reads tab_ray.
 __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk, int nb,
                                                        int nr, int rf, int ncls, int gq, int blocks,
                                                        const uint32_t* __restrict__ dict_tail, float* __restrict__ tab_ray,
                                                        uint16_t* __restrict__ desc_ray, uint32_t* __restrict__ list,
-                                                       int32_t* __restrict__ n_list, int32_t* __restrict__ inexact) {
+                                                       int32_t* __restrict__ n_list, int32_t* __restrict__ inexact,
+                                                       const float* __restrict__ fac, float uscale, float res,
+                                                       float* __restrict__ rad_ray) {
   const int rpad = blocks * gq * 64;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0 && dict_tail[1] != 1u) atomicOr(inexact, 1);
@@ -74,9 +80,18 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
   const int64_t at = (((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq);
   float tx = -1.0e30f, ty = -1.0e30f;
   uint32_t d = 0;
+  if (fac && i == 0) rad_ray[((int64_t)b * 64 + l) * gq + (g - b * gq)] = real ? fac[2 * nb + j] : 1.0e30f;
   if (real) {
     tx = tab[2 * k];
     ty = tab[2 * k + 1];
+    if (fac) {
+      float fx = fac[2 * i] * fac[2 * nb + j], fy = fac[2 * i + 1] * fac[2 * nb + j];
+      if (uscale > 0.f) {
+        fx = (fx * uscale) * res;
+        fy = (fy * uscale) * res;
+      }
+      if (__float_as_uint(fx) != __float_as_uint(tx) || __float_as_uint(fy) != __float_as_uint(ty)) atomicOr(inexact + 2, 1);
+    }
     const float* r = scan_pk + k * rf;
     int nz = 0, first = 0;
     bool ok = true;
@@ -111,6 +126,9 @@ struct RayArgs {
   float resolution;
   const float* tab;         // [P][2] in the table's own order (the list pass)
   const float* tab_ray;
+  const float* fac;         // the table's factors, or NULL; rad_ray: the radii in ray order
+  const float* rad_ray;
+  float uscale;
   const uint16_t* desc_ray;
   const uint32_t* list;
   const int32_t* n_list;
@@ -127,12 +145,16 @@ struct RayArgs {
   uint32_t* part;           // [>= nsplit][2 ncls + 2][npad], like score_polar_su_kernel
 };
 
-template <int GQ, bool USCALE>
+// FAC: the sample offsets are multiplied out of the table's factors — a direction's pair (uniform over the wave: two scalar
+// loads) times the lane's own radii (registers) — instead of read from tab_ray: the same float products the table holds
+// (ray_prep_kernel checked that), and 16 bytes per lane and row less through the texture path.
+template <int GQ, bool USCALE, bool FAC>
 __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   extern __shared__ unsigned long long lacc[];   // [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class)
   __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
   __shared__ uint4 lut[16];                      // per class code: {plane constant, column shift, known-bit index, accumulator}
   if (int_form_off(a.inexact)) return;
+  if (a.fac && (a.inexact[2] == 0) != FAC) return;   // (launched as a pair when factors were given)
   const int nsparse = a.counts[1];
   if ((int64_t)blockIdx.x * 4 >= (int64_t)nsparse * a.nsplit) return;   // whole workgroup idle (uniform)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -160,6 +182,7 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   const int64_t slot = (int64_t)a.counts[0] + q;
   const int64_t p = a.slots[slot];
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float fscale = USCALE ? a.uscale : scale;   // (the caller's promise: the same number)
   const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];  // state_particle.cpp:161
   const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];  // :162
   const float off0 = cy / a.resolution;  // top_down_map_polar.cpp:29
@@ -178,6 +201,15 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
   };
+  auto cell_fac = [&](tdr_v2f dir, float rad, int& ri, int& ci) {
+    tdr_v2f pv = dir * rad;                             // top_down_map_polar.cpp:17-18
+    pv = (pv * fscale) * a.res;                         // :28
+    pv = pv + offv;
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+  };
 
   // this wave's share of the window: rows m = direction * blocks + block; a window row meets scan row (m + shift * blocks)
   // mod (nb * blocks)
@@ -188,18 +220,32 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   constexpr int U = 8 / GQ;   // rows whose gathers are in flight together: 8 steps
   typedef uint16_t desc_t __attribute__((ext_vector_type(GQ)));
   typedef float tab_t __attribute__((ext_vector_type(2 * GQ)));
+  typedef float rad_t __attribute__((ext_vector_type(GQ)));
   const desc_t* __restrict__ descv = reinterpret_cast<const desc_t*>(a.desc_ray);
   const tab_t* __restrict__ tabv = reinterpret_cast<const tab_t*>(a.tab_ray);
+  const rad_t* __restrict__ radv = reinterpret_cast<const rad_t*>(a.rad_ray);
+  const tdr_v2f* __restrict__ dirv = reinterpret_cast<const tdr_v2f*>(a.fac);
+  const bool one_block = a.blocks == 1;
+  rad_t rad0 = {};
+  if constexpr (FAC) rad0 = radv[lane];   // (block 0's; the only block of a window of up to 256 rings)
   auto rows_step = [&](auto cnt_c, int m) {
     constexpr int N = decltype(cnt_c)::value;
     desc_t dd[N];
     tab_t tt[N];
+    rad_t rr_[N];
+    tdr_v2f dir[N];
 #pragma unroll
     for (int u = 0; u < N; u++) {
       int mr = m + u + rot;
       mr -= mr >= rows_all ? rows_all : 0;
       dd[u] = descv[(int64_t)mr * 64 + lane];
-      tt[u] = tabv[(int64_t)(m + u) * 64 + lane];
+      if constexpr (FAC) {
+        const int i = one_block ? m + u : (m + u) / a.blocks;
+        dir[u] = dirv[i];
+        rr_[u] = one_block ? rad0 : radv[(int64_t)(m + u - i * a.blocks) * 64 + lane];
+      } else {
+        tt[u] = tabv[(int64_t)(m + u) * 64 + lane];
+      }
     }
     uint32_t v[N * GQ], shb[N * GQ], cnt[N * GQ], acc_at[N * GQ];
 #pragma unroll
@@ -208,7 +254,8 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
       for (int g = 0; g < GQ; g++) {
         const int s = u * GQ + g;
         int ri, ci;
-        cell(tt[u][2 * g], tt[u][2 * g + 1], ri, ci);
+        if constexpr (FAC) cell_fac(dir[u], rr_[u][g], ri, ci);
+        else cell(tt[u][2 * g], tt[u][2 * g + 1], ri, ci);
         const uint32_t d = dd[u][g];
         cnt[s] = d & 0xFFFu;
         // one 16-byte LDS read: everything that depends on the bin's class
@@ -317,7 +364,8 @@ int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   hipLaunchKernelGGL(ray_prep_kernel, dim3((unsigned)cdiv(T, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
                      L.map->ncls, gq, blocks, reinterpret_cast<const uint32_t*>(L.map->dict) + 2 * TDR_CMAP_MAX_DICT,
                      reinterpret_cast<float*>(base + W.ray_tab), reinterpret_cast<uint16_t*>(base + W.ray_desc),
-                     reinterpret_cast<uint32_t*>(base + W.ray_multi), ints + 3, ints + 4);
+                     reinterpret_cast<uint32_t*>(base + W.ray_multi), ints + 3, ints + 4, L.fac,
+                     L.uniform_scale ? L.uscale : 0.f, L.res, reinterpret_cast<float*>(base + W.ray_rad));
   LAUNCH_CHECK("ray_prep");
   return TDR_OK;
 }
@@ -338,6 +386,9 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   r.rows = map->rows; r.cols = map->cols; r.resolution = map->resolution;
   r.tab = L.tab;
   r.tab_ray = reinterpret_cast<const float*>(base + W.ray_tab);
+  r.fac = L.fac;
+  r.rad_ray = reinterpret_cast<const float*>(base + W.ray_rad);
+  r.uscale = L.uscale;
   r.desc_ray = reinterpret_cast<const uint16_t*>(base + W.ray_desc);
   r.list = reinterpret_cast<const uint32_t*>(base + W.ray_multi);
   r.n_list = ints + 3;
@@ -352,9 +403,15 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   r.part = reinterpret_cast<uint32_t*>(L.part);
   const dim3 grid((unsigned)cdiv(L.n * r.nsplit, 4)), block(256);
   const size_t lds = (size_t)4 * (map->ncls + 1) * 64 * sizeof(unsigned long long);
-#define TDR_LAUNCH_RAY(GQ)                                                                              \
-  if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true>), grid, block, lds, s, r);  \
-  else hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false>), grid, block, lds, s, r);
+  // (with factors: both kernels, of which the one the check in ray_prep_kernel did not choose returns at once)
+#define TDR_LAUNCH_RAY(GQ)                                                                                       \
+  if (L.uniform_scale) {                                                                                         \
+    if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true, true>), grid, block, lds, s, r);             \
+    hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true, false>), grid, block, lds, s, r);                       \
+  } else {                                                                                                       \
+    if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, true>), grid, block, lds, s, r);            \
+    hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, false>), grid, block, lds, s, r);                      \
+  }
   switch (ray_gq(L.nr)) {
     case 1: TDR_LAUNCH_RAY(1) break;
     case 2: TDR_LAUNCH_RAY(2) break;

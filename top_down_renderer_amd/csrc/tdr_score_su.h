@@ -10,10 +10,10 @@ static inline int64_t su_npad(int64_t n, int nb) { return cdiv(n + 63 * std::min
 bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
 // The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
 struct SuWs {
-  int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, ray_tab, ray_desc, ray_multi, total;
+  int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, ray_tab, ray_desc, ray_multi, ray_rad, total;
   // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3][n_multi][inexact][mass bound]  (int_form_off)
 };
-#define TDR_SU_TAIL_INTS 6        // the words of `ints` behind the three per-key tables
+#define TDR_SU_TAIL_INTS 7        // the words of `ints` behind the three per-key tables
 #define TDR_RAY_MAX_SPLIT 8       // waves a particle's window may be split over (tdr_ray_splits): chunk rows of `part`
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
 
@@ -31,6 +31,8 @@ struct SuLaunch {
   int64_t npad;              // slot capacity = stride of part (su_npad)
   float* part;               // integer partial sums, [chunks][2 ncls + 2][npad] words (tdr_score_su.hip)
   int ray_split;             // waves per scattered particle (tdr_ray_splits)
+  const float* fac;          // the table's factors (tdr_polar_factors_host) or NULL
+  float uscale;              // the caller's uniform scale (<= 0: none)
   int32_t* ws;               // tdr_su_ws(...).total words
   float span;                // map cells the 64 locality neighbours of a dense particle may span (tdr_su_span_begin)
 };

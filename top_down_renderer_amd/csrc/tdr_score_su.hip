@@ -761,13 +761,14 @@ SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   w.keys_out = take(n);
   w.vals_in = take(n);
   w.vals_out = take(n);
-  w.ints = take(3 * ((int64_t)nb + 1) + TDR_SU_TAIL_INTS);   // [cnt][start][slot_start] nb + 1 each, [counts 3][n_multi][inexact][mass bound]
+  w.ints = take(3 * ((int64_t)nb + 1) + TDR_SU_TAIL_INTS);   // [cnt][start][slot_start] nb + 1 each, [counts 3][n_multi][inexact][mass bound][table is not its factors]
   w.slots = take(su_npad(n, nb));
   w.sort_tmp = take((int64_t)((su_sort_tmp_bytes(n) + 3) / 4));
   const int64_t T = tdr_ray_padded_samples(nb, nr);
   w.ray_tab = take(2 * T);                     // tdr_score_ray.hip: sample offsets and 16-bit scan descriptors in ray order,
   w.ray_desc = take((T + 1) / 2);              // the list of bins that hold several classes
   w.ray_multi = take((int64_t)nb * nr);
+  w.ray_rad = take(T / nb);                    // the rings' radii in ray order (a table given as factors)
   w.total = o;
   return w;
 }

@@ -89,6 +89,7 @@ class DeviceMap:
         self.desc = MapDescC(rec.data_ptr(), ncls, rows, cols, self.rec_floats, self.resolution)
         self.tab = None       # device (P,2) f32
         self.tab_host = None  # numpy (P,2) f32
+        self.fac = None       # device (2 nb + nr,) f32: the table's factors (tdr_polar_factors_host)
         self.nb = self.nr = 0
         self.ang_res = 0.0
         self.crec = self.dict = None   # compact form of the records (tdr_k_compact_map), when the map has one
@@ -259,6 +260,10 @@ class HipKernels:
         check(self.lib.tdr_polar_table_host(nb, nr, C.c_float(ang_res), C.c_float(m.resolution),
                                             tab.ctypes.data_as(C.c_void_p)))
         m.tab_host, m.tab, m.nb, m.nr, m.ang_res = tab, self.to_device(tab), nb, nr, float(ang_res)
+        fac = np.empty(2 * nb + nr, np.float32)
+        check(self.lib.tdr_polar_factors_host(nb, nr, C.c_float(ang_res), C.c_float(m.resolution),
+                                              fac.ctypes.data_as(C.c_void_p)))
+        m.fac = self.to_device(fac)
 
     # ---- raster ---------------------------------------------------------------------------------------------
     def _raster_workspace(self, n):
@@ -335,6 +340,8 @@ class HipKernels:
         cap = st.shape[1]
         if init_search and max(n, n_total) >= int(self.lib.tdr_config_rec16_min_particles(-1)):
             m.init_scratch(self)
+        if ctx is not None:   # the table as its factors (include/tdr.h): the call checks them against m.tab itself
+            check(self.lib.tdr_score_ctx_set_polar_factors(ctx.handle, _ptr(getattr(m, "fac", None)), m.nb, m.nr))
         check(self.lib.tdr_k_score_polar_ctx(C.byref(m.desc), _ptr(m.tab), _ptr(scan_pk), m.nb, m.nr, C.c_float(res),
                                              C.byref(fp), _ptr(st), cap, n, n_total, _ptr(perm), C.c_float(uniform_scale),
                                              int(bool(init_search)), _ptr(raw_w), _ptr(ws),
