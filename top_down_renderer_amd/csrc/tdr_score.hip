@@ -709,10 +709,45 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(FinalizeArgs a) {
 // integers.  Integer sums are exact: whatever kernel, split or order produced the rows, their total is the same number, and
 // so is the weight.  dot_c = total 2^-q rounded to float once (the reference: a float sum of float products in Eigen's
 // order, state_particle.cpp:136-138), then the reference's own arithmetic (:136-139, 154, 212).
+// A workgroup = 64 slots x 4 shares of a slot's chunk rows (a large filter has 25 rows of 18 words per slot: one lane per
+// slot walked them one after the other with a quarter of the waves); the shares meet in LDS — integers: any grouping.
 __global__ __launch_bounds__(256) void score_finalize_exact_kernel(FinalizeArgs a) {
+  __shared__ unsigned long long red[3][TDR_MAX_CLASSES + 2][64];
   if (int_form_off(a.inexact)) return;
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= (int64_t)a.counts[2]) return;
+  const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+  const int64_t nslots = (int64_t)a.counts[2];
+  if ((int64_t)blockIdx.x * 64 >= nslots) return;   // (uniform)
+  const int64_t slot = min((int64_t)blockIdx.x * 64 + lane, nslots - 1);
+  const int rows = 2 * a.ncls + 2;
+  const int nch = slot < (int64_t)a.counts[0] ? a.nchunks : a.ray_split;
+  unsigned long long tot[TDR_MAX_CLASSES], norm = 0, known = 0;
+#pragma unroll
+  for (int k = 0; k < TDR_MAX_CLASSES; k++) tot[k] = 0;
+  for (int c = t; c < nch; c += 4) {
+    const uint32_t* o = a.ipart + (int64_t)c * rows * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls)
+        tot[k] += (unsigned long long)o[(int64_t)(2 * k) * a.npad] | ((unsigned long long)o[(int64_t)(2 * k + 1) * a.npad] << 32);
+    norm += o[(int64_t)(2 * a.ncls) * a.npad];
+    known += o[(int64_t)(2 * a.ncls + 1) * a.npad];
+  }
+  if (t > 0) {
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls) red[t - 1][k][lane] = tot[k];
+    red[t - 1][TDR_MAX_CLASSES][lane] = norm;
+    red[t - 1][TDR_MAX_CLASSES + 1][lane] = known;
+  }
+  __syncthreads();
+  if (t > 0 || (int64_t)blockIdx.x * 64 + lane >= nslots) return;
+  for (int u = 0; u < 3; u++) {
+#pragma unroll
+    for (int k = 0; k < TDR_MAX_CLASSES; k++)
+      if (k < a.ncls) tot[k] += red[u][k][lane];
+    norm += red[u][TDR_MAX_CLASSES][lane];
+    known += red[u][TDR_MAX_CLASSES + 1][lane];
+  }
   const int64_t p = a.order[slot];
   if (p < 0) return;   // a padding slot of the shift-uniform order
   const float scale = a.st[TDR_ST_SCALE * a.cap + p];
@@ -721,20 +756,6 @@ __global__ __launch_bounds__(256) void score_finalize_exact_kernel(FinalizeArgs 
   if (particle_gated(a.gate, cx, cy, scale)) {
     a.raw_w[p] = 0.f;
     return;
-  }
-  const int rows = 2 * a.ncls + 2;
-  const int nch = slot < (int64_t)a.counts[0] ? a.nchunks : a.ray_split;
-  unsigned long long tot[TDR_MAX_CLASSES], norm = 0, known = 0;
-#pragma unroll
-  for (int k = 0; k < TDR_MAX_CLASSES; k++) tot[k] = 0;
-  for (int c = 0; c < nch; c++) {
-    const uint32_t* o = a.ipart + (int64_t)c * rows * a.npad + slot;
-#pragma unroll
-    for (int k = 0; k < TDR_MAX_CLASSES; k++)
-      if (k < a.ncls)
-        tot[k] += (unsigned long long)o[(int64_t)(2 * k) * a.npad] | ((unsigned long long)o[(int64_t)(2 * k + 1) * a.npad] << 32);
-    norm += o[(int64_t)(2 * a.ncls) * a.npad];
-    known += o[(int64_t)(2 * a.ncls + 1) * a.npad];
   }
   float cost;
   if ((float)known / (float)a.P < 0.5) {   // state_particle.cpp:117-120
@@ -1703,6 +1724,7 @@ static int init_half_image_rows(int nb, int R) {
 extern "C" int tdr_cmap_words(int ncls);   // tdr_cmap.hip
 struct ScoreWs {
   int group, nchunks;
+  int su_group, su_nchunks;   // the ring groups of the shift-uniform kernel (integer sums: any partition gives the same bits)
   int64_t npad, npad_part, off_aux, off_utab, off_su, total;
   bool su;
   SuWs suw;
@@ -1720,16 +1742,28 @@ static ScoreWs score_ws(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   w.nchunks = (int)cdiv(nr, w.group);
   w.npad = cdiv(std::max<int64_t>(n, 1), 64) * 64;
   w.su = tdr_su_shape_ok(nb, nr, w.group, n_total) && tdr_cmap_words(ncls) != 0;
+  w.su_group = w.group;
+  {
+    static const int forced = [] {
+      const char* e = getenv("TDR_SU_GROUP");
+      return e ? atoi(e) : 0;
+    }();
+    // eight rings per group where that divides the image and still leaves thousands of workgroups: a sector's mask is
+    // staged half as often (config 2: 3.50 against 3.56 ms; 16 rings: 3.69, the staged boxes grow)
+    if (w.su && w.group == 4 && nr % 8 == 0 && cdiv(n_total, 256) * (nr / 8) >= 4096) w.su_group = 8;
+    if (w.su && forced >= 4 && forced % 4 == 0) w.su_group = forced;
+  }
+  w.su_nchunks = (int)cdiv(nr, w.su_group);
   w.npad_part = w.su ? su_npad(std::max<int64_t>(n, 1), nb) : w.npad;
   // partial sums: [chunks][rows][slots] — float form rf + 1 rows; integer form (tdr_score_su.hip) 2 ncls + 2 rows of
   // words and room for the chunk rows of a scattered particle's window (tdr_score_ray.hip)
-  w.off_aux = w.su ? (int64_t)std::max(w.nchunks, TDR_RAY_MAX_SPLIT) * std::max(rf + 1, 2 * ncls + 2) * w.npad_part
+  w.off_aux = w.su ? (int64_t)std::max(std::max(w.nchunks, w.su_nchunks), TDR_RAY_MAX_SPLIT) * std::max(rf + 1, 2 * ncls + 2) * w.npad_part
                    : (int64_t)w.nchunks * (rf + 1) * w.npad_part;
   w.off_utab = w.off_aux + 3 * w.npad + 64;
   w.off_su = (w.off_utab + 2 * (int64_t)nb * nr + 63) / 64 * 64;
   w.total = w.off_su;
   if (w.su) {
-    w.suw = tdr_su_ws(nb, nr, w.group, std::max<int64_t>(n, 1));
+    w.suw = tdr_su_ws(nb, nr, w.su_group, std::max<int64_t>(n, 1));
     w.total += w.suw.total;
   }
   return w;
@@ -2133,7 +2167,7 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     SuLaunch L;
     L.map = map; L.tab = a.utab ? a.utab : a.tab; L.uniform_scale = a.utab != nullptr; L.scan_pk = scan_pk;
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
-    L.group = W.group; L.nchunks = W.nchunks; L.npad = W.npad_part; L.part = a.part;
+    L.group = W.su_group; L.nchunks = W.su_nchunks; L.npad = W.npad_part; L.part = a.part;
     L.ray_split = tdr_ray_splits(nb, nr, n);
     L.fac = ctx && ctx->fac && ctx->fac_nb == nb && ctx->fac_nr == nr ? ctx->fac : nullptr;
     L.uscale = uniform_scale;
@@ -2164,8 +2198,8 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     fx.npad = W.npad_part; fx.order = slots; fx.counts = counts; fx.inexact = inexact;
     fx.ipart = reinterpret_cast<const uint32_t*>(a.part);
     fx.dict_tail = reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT;
-    fx.nchunks = W.nchunks; fx.ray_split = L.ray_split;
-    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(W.npad_part, 256)), dim3(256), 0, s, fx);
+    fx.nchunks = W.su_nchunks; fx.ray_split = L.ray_split;
+    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(W.npad_part, 64)), dim3(256), 0, s, fx);
     LAUNCH_CHECK("score_finalize_exact");
     f.run_if = inexact;
     launch_finalize(f, n, s);
@@ -2395,7 +2429,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
     fx.ipart = reinterpret_cast<const uint32_t*>(a.part);
     fx.dict_tail = reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT;
     fx.nchunks = a.nchunks; fx.ray_split = io.ray_split;
-    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(io.npad, 256)), dim3(256), 0, s, fx);
+    hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(io.npad, 64)), dim3(256), 0, s, fx);
     f.run_if = io.flags;
   }
   launch_finalize(f, n, s);
