@@ -2168,9 +2168,9 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     L.map = map; L.tab = a.utab ? a.utab : a.tab; L.uniform_scale = a.utab != nullptr; L.scan_pk = scan_pk;
     L.nb = nb; L.nr = nr; L.rf = rf; L.res = res; L.st = st; L.cap = cap; L.n = n; L.perm = perm;
     L.group = W.su_group; L.nchunks = W.su_nchunks; L.npad = W.npad_part; L.part = a.part;
-    L.ray_split = tdr_ray_splits(nb, nr, n);
     L.fac = ctx && ctx->fac && ctx->fac_nb == nb && ctx->fac_nr == nr ? ctx->fac : nullptr;
     L.uscale = uniform_scale;
+    L.ray_split = tdr_ray_splits(nb, nr, n, tdr_ray_block_major(L));
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
     TunerScope tuner_scope(ctx, s);   // (closes the tuner's measurement on every way out)
     L.span = tdr_su_span_begin(ctx ? &ctx->tuner : nullptr,

@@ -38,9 +38,20 @@
 
 // ray order: a direction's rings in BLOCKS of GQ steps of 64 rings (GQ = 1, 2 or 4: ray_gq); "row" m = direction * blocks
 // + block.  Lane l of step g of block b is ring (b * GQ + g) * 64 + l.
-static inline int ray_gq(int nr) { return nr <= 64 ? 1 : (nr <= 128 ? 2 : 4); }
-static inline int ray_blocks(int nr) { return (int)cdiv(nr, 64 * ray_gq(nr)); }
-int64_t tdr_ray_padded_samples(int nb, int nr) { return (int64_t)nb * ray_blocks(nr) * ray_gq(nr) * 64; }
+// BLOCK-MAJOR order (bm; launches whose table comes with its factors): one step per row, GQ = 1, and the rows of ring
+// segment 0 (rings 0..63, every direction) first, then segment 1's, ...: row m = segment * nb + direction.  The eight
+// gathers a wave has in flight are then neighbouring directions of ONE segment (config 2, uniform particles: 9.5 -> 8.4 ms;
+// with the offsets read from tab_ray the narrow rows cost more than that gains, so those launches keep the first order).
+// TDR_RAY_BM=0 keeps the first order everywhere (A/B).
+static const bool g_ray_bm = [] {
+  const char* e = getenv("TDR_RAY_BM");
+  return !e || atoi(e) != 0;
+}();
+static inline bool ray_bm(const SuLaunch& L) { return g_ray_bm && L.fac != nullptr; }
+static inline int ray_gq(int nr, bool bm) { return bm ? 1 : (nr <= 64 ? 1 : (nr <= 128 ? 2 : 4)); }
+static inline int ray_blocks(int nr, bool bm) { return (int)cdiv(nr, 64 * ray_gq(nr, bm)); }
+// (the first order pads to whole blocks of GQ steps: never less than the block-major order needs)
+int64_t tdr_ray_padded_samples(int nb, int nr) { return (int64_t)nb * ray_blocks(nr, false) * ray_gq(nr, false) * 64; }
 
 // One thread per (scan row, padded ring).  tab_ray[((i * blocks + b) * 64 + l) * GQ + g] = sample offset of (direction i,
 // ring j); desc_ray (16-bit) at the same index for scan row i, ring j: code << 12 | count — code 0: nothing for the loop
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
                                                        uint16_t* __restrict__ desc_ray, uint32_t* __restrict__ list,
                                                        int32_t* __restrict__ n_list, int32_t* __restrict__ inexact,
                                                        const float* __restrict__ fac, float uscale, float res,
-                                                       float* __restrict__ rad_ray) {
+                                                       float* __restrict__ rad_ray, int bm) {
   const int rpad = blocks * gq * 64;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0 && dict_tail[1] != 1u) atomicOr(inexact, 1);
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0 && mass) atomicAdd(reinterpret_cast<unsigned*>(inexact) + 1, mass);
   if (!live) return;
   const int g = j >> 6, l = j & 63, b = g / gq;
-  const int64_t at = (((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq);
+  const int64_t at = bm ? ((int64_t)b * nb + i) * 64 + l : (((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq);
   float tx = -1.0e30f, ty = -1.0e30f;
   uint32_t d = 0;
   if (fac && i == 0) rad_ray[((int64_t)b * 64 + l) * gq + (g - b * gq)] = real ? fac[2 * nb + j] : 1.0e30f;
@@ -148,8 +159,9 @@ struct RayArgs {
 // FAC: the sample offsets are multiplied out of the table's factors — a direction's pair (uniform over the wave: two scalar
 // loads) times the lane's own radii (registers) — instead of read from tab_ray: the same float products the table holds
 // (ray_prep_kernel checked that), and 16 bytes per lane and row less through the texture path.
-template <int GQ, bool USCALE, bool FAC>
+template <int GQ, bool USCALE, bool FAC, bool BM = false>
 __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
+  static_assert(!BM || GQ == 1, "block-major: one step per row");
   extern __shared__ unsigned long long lacc[];   // [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class)
   __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
   __shared__ uint4 lut[16];                      // per class code: {plane constant, column shift, known-bit index, accumulator}
@@ -216,6 +228,7 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   const int rows_all = a.nb * a.blocks, per = (rows_all + a.nsplit - 1) / a.nsplit;
   const int m0 = part_id * per, m1 = min(rows_all, m0 + per);
   const int rot = shift * a.blocks;
+  int bm_b = m0 / a.nb, bm_i = m0 - bm_b * a.nb;   // BM: the row's block and direction, kept by counting
   uint32_t known = 0, norm = 0;
   constexpr int U = 8 / GQ;   // rows whose gathers are in flight together: 8 steps
   typedef uint16_t desc_t __attribute__((ext_vector_type(GQ)));
@@ -238,13 +251,25 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
     for (int u = 0; u < N; u++) {
       int mr = m + u + rot;
       mr -= mr >= rows_all ? rows_all : 0;
+      if constexpr (BM) {
+        int r = bm_i + shift;
+        r -= r >= a.nb ? a.nb : 0;
+        mr = bm_b * a.nb + r;
+      }
       dd[u] = descv[(int64_t)mr * 64 + lane];
-      if constexpr (FAC) {
+      if constexpr (FAC && BM) {
+        dir[u] = dirv[bm_i];
+        rr_[u] = radv[(int64_t)bm_b * 64 + lane];
+      } else if constexpr (FAC) {
         const int i = one_block ? m + u : (m + u) / a.blocks;
         dir[u] = dirv[i];
         rr_[u] = one_block ? rad0 : radv[(int64_t)(m + u - i * a.blocks) * 64 + lane];
       } else {
         tt[u] = tabv[(int64_t)(m + u) * 64 + lane];
+      }
+      if constexpr (BM) {
+        bm_i++;
+        if (bm_i == a.nb) { bm_i = 0; bm_b++; }
       }
     }
     uint32_t v[N * GQ], shb[N * GQ], cnt[N * GQ], acc_at[N * GQ];
@@ -345,27 +370,30 @@ extern "C" int tdr_config_ray_split(int k) {   // >= 1: force; 0: per launch (de
   if (k >= 0) g_ray_split = k > TDR_RAY_MAX_SPLIT ? TDR_RAY_MAX_SPLIT : k;
   return g_ray_split;
 }
-int tdr_ray_splits(int nb, int nr, int64_t n) {
+bool tdr_ray_block_major(const SuLaunch& L) { return ray_bm(L); }
+int tdr_ray_splits(int nb, int nr, int64_t n, bool bm) {
   if (g_ray_split > 0) return g_ray_split;
   // waves per particle: a window is nb * blocks rows of up to four steps; small launches split it to fill the chip (the
   // sums are exact: any split gives the same bits)
-  const int64_t rows = (int64_t)nb * ray_blocks(nr);
+  const int64_t rows = (int64_t)nb * ray_blocks(nr, bm);
   int s = 1;
   while (s < TDR_RAY_MAX_SPLIT && n * s < 32768 && rows / (2 * s) >= 8) s *= 2;
   if (s == 1 && rows >= 128) s = 2;
+  if (s == 2 && bm && rows >= 512) s = 4;   // (config 2, uniform particles, block-major: 8.99 / 8.43 / 8.58 ms at 2 / 4 / 8)
   return s;
 }
 
 int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   int32_t* base = L.ws;
   int* ints = base + W.ints + 3 * (L.nb + 1);   // [counts 3][n_list][inexact][mass bound]
-  const int gq = ray_gq(L.nr), blocks = ray_blocks(L.nr);
+  const bool bm = ray_bm(L);
+  const int gq = ray_gq(L.nr, bm), blocks = ray_blocks(L.nr, bm);
   const int64_t T = tdr_ray_padded_samples(L.nb, L.nr);
   hipLaunchKernelGGL(ray_prep_kernel, dim3((unsigned)cdiv(T, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
                      L.map->ncls, gq, blocks, reinterpret_cast<const uint32_t*>(L.map->dict) + 2 * TDR_CMAP_MAX_DICT,
                      reinterpret_cast<float*>(base + W.ray_tab), reinterpret_cast<uint16_t*>(base + W.ray_desc),
                      reinterpret_cast<uint32_t*>(base + W.ray_multi), ints + 3, ints + 4, L.fac,
-                     L.uniform_scale ? L.uscale : 0.f, L.res, reinterpret_cast<float*>(base + W.ray_rad));
+                     L.uniform_scale ? L.uscale : 0.f, L.res, reinterpret_cast<float*>(base + W.ray_rad), bm ? 1 : 0);
   LAUNCH_CHECK("ray_prep");
   return TDR_OK;
 }
@@ -393,7 +421,7 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   r.list = reinterpret_cast<const uint32_t*>(base + W.ray_multi);
   r.n_list = ints + 3;
   r.scan_pk = L.scan_pk;
-  r.rf = L.rf; r.ncls = map->ncls; r.nb = L.nb; r.nr = L.nr; r.blocks = ray_blocks(L.nr); r.res = L.res;
+  r.rf = L.rf; r.ncls = map->ncls; r.nb = L.nb; r.nr = L.nr; r.blocks = ray_blocks(L.nr, ray_bm(L)); r.res = L.res;
   r.st = L.st; r.cap = L.cap;
   r.slots = base + W.slots;
   r.counts = ints;
@@ -412,7 +440,15 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
     if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, true>), grid, block, lds, s, r);            \
     hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, false>), grid, block, lds, s, r);                      \
   }
-  switch (ray_gq(L.nr)) {
+  if (ray_bm(L)) {
+    if (L.uniform_scale) {
+      if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<1, true, true, true>), grid, block, lds, s, r);
+      hipLaunchKernelGGL((score_polar_ray_kernel<1, true, false, true>), grid, block, lds, s, r);
+    } else {
+      if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<1, false, true, true>), grid, block, lds, s, r);
+      hipLaunchKernelGGL((score_polar_ray_kernel<1, false, false, true>), grid, block, lds, s, r);
+    }
+  } else switch (ray_gq(L.nr, false)) {
     case 1: TDR_LAUNCH_RAY(1) break;
     case 2: TDR_LAUNCH_RAY(2) break;
     default: TDR_LAUNCH_RAY(4) break;

@@ -66,7 +66,8 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 // space), the split of a window over waves, its tables / the `inexact` flag (before either scoring kernel), the launch
 bool tdr_ray_map_ok(const tdr_map_desc* map);
 int64_t tdr_ray_padded_samples(int nb, int nr);   // window samples with every direction padded to whole blocks of steps
-int tdr_ray_splits(int nb, int nr, int64_t n);
+int tdr_ray_splits(int nb, int nr, int64_t n, bool block_major = false);
+bool tdr_ray_block_major(const SuLaunch& L);   // (L.fac set)
 int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s);
 int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 #endif  // TDR_SCORE_SU_H_
