@@ -63,7 +63,7 @@ int64_t tdr_ray_padded_samples(int nb, int nr) { return (int64_t)nb * ray_blocks
 // fac (optional): the table's factors (tdr_polar_factors_host).  rad_ray[(b * 64 + l) * GQ + g] = ring j's radius (rings
 // beyond nr: 1e30 — one of a direction's two products then leaves the map whatever the direction); inexact[2] is raised
 // when an entry of `tab` is not the float product its factors give (with a uniform scale: that product, scaled like
-// utab_kernel scales the table) — the kernel that multiplies the factors itself then stands back for the one that reads tab_ray.
+// utab_kernel scales the table) — the scoring kernel then reads tab_ray instead of multiplying the factors itself.
 __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk, int nb,
                                                        int nr, int rf, int ncls, int gq, int blocks,
                                                        const uint32_t* __restrict__ dict_tail, float* __restrict__ tab_ray,
@@ -159,14 +159,11 @@ struct RayArgs {
 // FAC: the sample offsets are multiplied out of the table's factors — a direction's pair (uniform over the wave: two scalar
 // loads) times the lane's own radii (registers) — instead of read from tab_ray: the same float products the table holds
 // (ray_prep_kernel checked that), and 16 bytes per lane and row less through the texture path.
-template <int GQ, bool USCALE, bool FAC, bool BM = false>
-__global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
+// lacc [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class); lut, per class code: {plane constant,
+// column shift, known-bit index, accumulator}
+template <int GQ, bool USCALE, bool FAC, bool BM>
+__device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* lacc, uint32_t* ldict, uint4* lut) {
   static_assert(!BM || GQ == 1, "block-major: one step per row");
-  extern __shared__ unsigned long long lacc[];   // [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class)
-  __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
-  __shared__ uint4 lut[16];                      // per class code: {plane constant, column shift, known-bit index, accumulator}
-  if (int_form_off(a.inexact)) return;
-  if (a.fac && (a.inexact[2] == 0) != FAC) return;   // (launched as a pair when factors were given)
   const int nsparse = a.counts[1];
   if ((int64_t)blockIdx.x * 4 >= (int64_t)nsparse * a.nsplit) return;   // whole workgroup idle (uniform)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -356,6 +353,17 @@ __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
     o[(int64_t)(2 * a.ncls + 1) * a.npad] = known;
   }
 }
+template <int GQ, bool USCALE, bool BM = false>
+__global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
+  extern __shared__ unsigned long long lacc[];
+  __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
+  __shared__ uint4 lut[16];
+  if (int_form_off(a.inexact)) return;
+  // with factors that ARE the table's (ray_prep_kernel's check; uniform over the launch) the offsets are multiplied out
+  if (a.fac && a.inexact[2] == 0) ray_body<GQ, USCALE, true, BM>(a, lacc, ldict, lut);
+  else ray_body<GQ, USCALE, false, BM>(a, lacc, ldict, lut);
+}
+
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
@@ -431,23 +439,12 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   r.part = reinterpret_cast<uint32_t*>(L.part);
   const dim3 grid((unsigned)cdiv(L.n * r.nsplit, 4)), block(256);
   const size_t lds = (size_t)4 * (map->ncls + 1) * 64 * sizeof(unsigned long long);
-  // (with factors: both kernels, of which the one the check in ray_prep_kernel did not choose returns at once)
-#define TDR_LAUNCH_RAY(GQ)                                                                                       \
-  if (L.uniform_scale) {                                                                                         \
-    if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true, true>), grid, block, lds, s, r);             \
-    hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true, false>), grid, block, lds, s, r);                       \
-  } else {                                                                                                       \
-    if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, true>), grid, block, lds, s, r);            \
-    hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false, false>), grid, block, lds, s, r);                      \
-  }
+#define TDR_LAUNCH_RAY(GQ)                                                                            \
+  if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true>), grid, block, lds, s, r); \
+  else hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false>), grid, block, lds, s, r);
   if (ray_bm(L)) {
-    if (L.uniform_scale) {
-      if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<1, true, true, true>), grid, block, lds, s, r);
-      hipLaunchKernelGGL((score_polar_ray_kernel<1, true, false, true>), grid, block, lds, s, r);
-    } else {
-      if (L.fac) hipLaunchKernelGGL((score_polar_ray_kernel<1, false, true, true>), grid, block, lds, s, r);
-      hipLaunchKernelGGL((score_polar_ray_kernel<1, false, false, true>), grid, block, lds, s, r);
-    }
+    if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<1, true, true>), grid, block, lds, s, r);
+    else hipLaunchKernelGGL((score_polar_ray_kernel<1, false, true>), grid, block, lds, s, r);
   } else switch (ray_gq(L.nr, false)) {
     case 1: TDR_LAUNCH_RAY(1) break;
     case 2: TDR_LAUNCH_RAY(2) break;
