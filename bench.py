@@ -24,11 +24,11 @@ events on its launch stream; a polar launch runs two kernels, the events span bo
     profiles/score_traffic.json) and REPLAYED here — `traffic_source` says so and carries the record's source hash; when
     the kernel sources or the launch shape differ from the record's, `traffic` and `issue` are null.  Hits in the Infinity
     Cache are among the requests: an upper bound on what HBM delivers.
-  * `achieved` / `frac` = traffic / launch duration (/ peak) when traffic is known;
-  * `sparse_algorithmic` = the bytes the launch cannot do without, from THIS run's scan: per particle one mask byte per
-    window sample (the known-fraction gate reads every sample) + 4 bytes per non-empty scan bin (one dictionary value),
-    with `frac` against the peak and `traffic_over_sparse` = how much more the counters saw (cache lines, not bytes, are
-    what a gather moves);
+  * `achieved` / `frac` = ALGORITHMIC bytes per launch / launch duration (/ peak), the algorithmic bytes being
+    `sparse_algorithmic` = the bytes the launch cannot do without, from THIS run's scan: per particle one mask byte per
+    window sample (the known-fraction gate reads every sample) + 4 bytes per non-empty scan bin (one dictionary value);
+    `traffic_over_sparse` = what the counters saw of it (below 1: particles that share window cells share the lines);
+  * `traffic_GBps` / `traffic_frac` = the counters' bytes over the same duration (/ peak);
   * `issue` = {valu_busy, lds_busy, insts_per_sample} from a second counter pass; `bound` = the busiest of
     {hbm: `frac`, valu, lds};
   * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, on the particle set
@@ -367,12 +367,9 @@ def main():
         achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         alg_gbps = achieved
         traffic, issue, traffic_note = measured_traffic(cfg.name, kname, n_local)
-        if traffic is not None and avg_ms > 0:
-            achieved, basis = traffic / (avg_ms * 1e-3) / 1e9, "pmc_traffic"
-        else:
-            basis = "algorithmic (no measured traffic for this build / shape: " + traffic_note + ")"
+        traffic_gbps = traffic / (avg_ms * 1e-3) / 1e9 if traffic is not None and avg_ms > 0 else None
         # the unit the launch keeps busiest: memory system (fraction of the HBM peak), vector issue or the LDS arrays
-        util = {"hbm": achieved / 8000.0 if traffic is not None else 0.0}
+        util = {"hbm": traffic_gbps / 8000.0 if traffic_gbps is not None else 0.0}
         if issue:
             issue = {"valu_busy": issue.get("valu_busy"), "lds_busy": issue.get("lds_busy"),
                      "insts_per_sample": issue.get("insts_per_sample"),
@@ -385,6 +382,9 @@ def main():
         # bytes the launch cannot do without, from this run's scan
         nnz = int((r.last_images().sum(dim=0) > 0).sum().item())
         sparse_bytes = n_local * (P + 4 * nnz)
+        achieved = sparse_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        basis = ("algorithmic: per particle one mask byte per window sample + 4 bytes per non-empty scan bin "
+                 "(`sparse_algorithmic`), over the launch duration measured in this run")
         sparse = {"bytes_per_launch": sparse_bytes, "nonempty_bins": nnz, "bins": P,
                   "GBps": sparse_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
                   "frac": sparse_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0 if avg_ms > 0 else None,
@@ -411,14 +411,16 @@ def main():
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
+                         "traffic_GBps": traffic_gbps, "traffic_frac": traffic_gbps / 8000.0 if traffic_gbps is not None else None,
                          "traffic_source": (f"replayed from profiles/score_traffic.json (kernel sources {kernel_source_hash()}): "
-                                            + traffic_note) if traffic is not None else None,
+                                            + traffic_note) if traffic is not None else "none (" + traffic_note + ")",
                          "sparse_algorithmic": sparse, "shares": shares,
                          "traffic_is": "read requests the L2s send to the fabric (TCC_EA0_RDREQ), Infinity-Cache hits "
                                        "included: an upper bound on the bytes HBM itself delivers",
                          "issue": issue,
-                         "note": "`achieved`, `peak`, `frac` price the launch against the HBM roofline whatever `bound` says; "
-                                 "`bound` names the unit the launch keeps busiest (hbm = `frac`, valu / lds = `issue`).  "
+                         "note": "`achieved`, `peak`, `frac` price the launch's algorithmic bytes against the HBM roofline "
+                                 "whatever `bound` says; `bound` names the unit the launch keeps busiest (hbm = "
+                                 "`traffic_frac`, valu / lds = `issue`).  "
                                  "A polar launch runs two kernels one after the other — score_polar_su_kernel for the dense "
                                  "particles (vector-issue bound), score_polar_ray_kernel for the scattered ones (L1 address "
                                  "path) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",

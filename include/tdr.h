@@ -435,8 +435,8 @@ int tdr_config_compact(int on);
  * mode 0 = never, 1 = when the filter holds enough particles per heading bin for the padding to pay (default: 64 x the
  * polar image's rows), 2 = whenever the shapes allow (ring groups and ring count multiples of 4, a map with narrow
  * compact records and class planes); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
- * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — from the 31st call of a shape on, 8, 16, 24 and
- * 40 cells are timed over two scoring calls each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
+ * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — from the 31st call of a shape on, 2, 8, 16, 24
+ * and 40 cells are timed over two scoring calls each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
  * repeated every 4000 calls.  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env TDR_SU_SPAN fix
  * it for every caller; -1 only returns the configured span (16 by default: what a launch without a context uses); -2 goes
  * back to tuning. */

@@ -2,8 +2,9 @@
 """Times one polar scoring call of a config (default c2) in its integer form under several particle distributions and
 splits between the two kernels (GPU box only):
     span 0       every particle through the shift-uniform kernel
-    span 8 / 16  the mixed launch (dense particles shift-uniform, scattered ones ray-mapped), with a context (two streams)
-    all ray      every particle through the ray-mapped kernel
+    span 8 / 16  the mixed launch (dense particles shift-uniform, scattered ones ray-mapped); "+ctx": with a caller context
+                 that holds the table's factors (the ray-mapped kernel multiplies the offsets out, block-major rows)
+    all ray      every particle through the ray-mapped kernel (with and without the factors)
     float        the float kernel (tdr_config_shift_uniform(0))
 Usage: python3 tools/time_int_form.py [config] [quick] [only=<distribution>] [ray|su]
    ray / su: only the all-ray / all-shift-uniform launch, three times (counter passes: tools/pmc_ray_bound.sh)"""
@@ -85,14 +86,15 @@ def main():
             lib.tdr_config_shift_uniform_span(-2.0)
             continue
         for label, span, c in (("span 0", 0.0, None), ("span 8 +ctx", 8.0, ctx), ("span 16 +ctx", 16.0, ctx),
-                               ("span 16 one stream", 16.0, None), ("span 40 +ctx", 40.0, ctx), ("all ray", 1e-6, None)):
+                               ("span 16 no ctx", 16.0, None), ("span 40 +ctx", 40.0, ctx), ("all ray +ctx", 1e-6, ctx),
+                               ("all ray no ctx", 1e-6, None)):
             lib.tdr_config_shift_uniform_span(span)
             row.append((label, timed(4, ctx=c)))
         if not quick:
             for split in (1, 2, 4):
                 lib.tdr_config_ray_split(split)
                 lib.tdr_config_shift_uniform_span(1e-6)
-                row.append((f"all ray, split {split}", timed(3)))
+                row.append((f"all ray +ctx, split {split}", timed(3, ctx=ctx)))
             lib.tdr_config_ray_split(0)
         ref = raw[:n].clone()
         lib.tdr_config_shift_uniform(0)

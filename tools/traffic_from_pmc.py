@@ -10,8 +10,8 @@ Read bytes per launch = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64 (MI355X_MIC
 memory-side request counters; FETCH_SIZE tallies the 128-byte requests at 64 bytes on gfx950, so it is not used).  These
 are the requests the L2s send to the fabric: what the Infinity Cache serves is among them.  A second pass
 (SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE) gives the issue figures bench.py reports beside
-the traffic.  Counters are summed over the XCDs per dispatch, averaged over the dispatches of each kernel, and the
-kernels of one scoring launch added up.  The record stores a hash of the kernel sources: bench.py ignores it once they change.
+the traffic.  Counters are summed over the XCDs per dispatch and over all dispatches of the scoring kernels, and divided by the number
+of scoring launches.  The record stores a hash of the kernel sources: bench.py ignores it once they change.
 """
 import csv
 import glob
@@ -44,10 +44,13 @@ def main():
         for c, v in ctr.items():
             by_kernel[kern][c].append(v)
     names = sorted(by_kernel)
+    # launches = the dispatches of the kernel every launch runs; a kernel that ran in only a few of them (the first call of
+    # a run, before the caller's context knows the table's factors, takes another instantiation) counts with that share
+    n_launches = max(max(len(v) for v in by_kernel[kern].values()) for kern in names)
     launch = defaultdict(float)
     for kern in names:
         for c, v in by_kernel[kern].items():
-            launch[c] += sum(v) / len(v)
+            launch[c] += sum(v) / n_launches
     m128, mrd = launch.get("TCC_EA0_RDREQ_128B_sum", 0.0), launch.get("TCC_EA0_RDREQ_sum", 0.0)
     bytes_per_launch = m128 * 128 + max(0.0, mrd - m128) * 64
     from bench import kernel_source_hash
@@ -74,8 +77,8 @@ def main():
         "kernel": " + ".join(names), "particles_per_launch": n_launch, "hbm_bytes_per_launch": bytes_per_launch,
         "dispatches": len(per), "TCC_EA0_RDREQ_128B_sum": m128, "TCC_EA0_RDREQ_sum": mrd, "issue": issue,
         "kernel_source_hash": kernel_source_hash(), "source": os.path.relpath(summary, ROOT),
-        "how": "rocprofv3 --pmc, passes of their own over bench.py (counters only); mean over the dispatches of each scoring "
-               "kernel, the kernels of one launch added up; bytes = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64: requests "
+        "how": "rocprofv3 --pmc, passes of their own over bench.py (counters only); all dispatches of the scoring kernels "
+               "added up and divided by the number of scoring launches; bytes = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64: requests "
                "the L2s send to the fabric — hits in the 256 MB Infinity Cache are among them, so this is an upper bound on "
                "what HBM itself delivers",
     }

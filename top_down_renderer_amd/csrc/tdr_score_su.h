@@ -54,7 +54,8 @@ struct SpanTuner {
   int phase = -2;                     // < 0: skipping; < number of candidates: timing that candidate; else settled
   int settled_launches = 0;
   int trial = 0;                      // timed calls of the current candidate so far
-  float best = 16.f, best_ms = 3.0e38f;
+  float best = 16.f;                  // the span in use: what the last COMPLETED round of trials found fastest
+  float round_best = 16.f, best_ms = 3.0e38f;   // the fastest candidate of the round in progress, and its time
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool open = false, pending = false;
 };

@@ -691,33 +691,40 @@ extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it 
 namespace {
 // (measured on MI355X with the ray-mapped kernel taking the scattered share, ms per scoring call at 8 / 16 / 24 / 40 cells:
 // config 2's mix 5.88 / 5.55 / 5.51 / 5.67, uniform particles 10.7 / 11.0 / - / 11.7, a converged filter 3.1 / 3.05 / - / 3.0)
-constexpr float kSpanCand[] = {8.f, 16.f, 24.f, 40.f};
+// (round 4, later: with the table's factors the ray-mapped kernel scores 100 000 uniform particles in 7.6 ms, the mixed
+// launch at 8 cells in 8.4 — hence a candidate that sends all but the densest cores to it;
+// profiles/r04_time_int_form_c2_v2.txt)
+constexpr float kSpanCand[] = {2.f, 8.f, 16.f, 24.f, 40.f};
 constexpr int kSpanCands = (int)(sizeof(kSpanCand) / sizeof(kSpanCand[0]));
 constexpr int kSpanTrials = 2;        // timed calls per candidate: the faster one counts (a single call is noisy)
 constexpr int kSpanSkip = 30;         // calls of a new shape before the first trial (first-use allocations, cold caches, and
-                                      // a short run — a benchmark of a few dozen steps — is not worth eight trial calls)
+                                      // a short run — a benchmark of a few dozen steps — is not worth ten trial calls)
 constexpr int kSpanRetune = 4000;     // launches between two trials
 }  // namespace
 float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
   if (g_su_span_fixed || !t) return g_su_span;
   if (!t->e0 && (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess)) return g_su_span;
-  if (shape != t->shape) { t->shape = shape; t->phase = -kSpanSkip; t->trial = 0; t->best_ms = 3.0e38f; t->pending = false; t->best = g_su_span; }
+  if (shape != t->shape) { t->shape = shape; t->phase = -kSpanSkip; t->trial = 0; t->best_ms = 3.0e38f; t->pending = false; t->best = t->round_best = g_su_span; }
   if (t->pending) {   // the candidate timed by an earlier launch — if its events are not through yet, ask again next time
     if (hipEventQuery(t->e1) != hipSuccess) return t->best;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, t->e0, t->e1) == hipSuccess && ms > 0.f && ms < t->best_ms) {
       t->best_ms = ms;
-      t->best = kSpanCand[t->phase];
+      t->round_best = kSpanCand[t->phase];
     }
     t->pending = false;
     if (++t->trial >= kSpanTrials) { t->trial = 0; t->phase++; }
-    if (t->phase >= kSpanCands) t->settled_launches = 0;
+    // Only a finished round changes the span in use.  (A caller that runs ahead of the device — a benchmark loop — makes
+    // hundreds of calls while one trial's events are pending: they must not run at the first candidate's span just because
+    // it is the only one timed so far.  Seen with the candidate of 2 cells in front: 5.3 -> 5.95 ms per config-2 step.)
+    if (t->phase >= kSpanCands) { t->settled_launches = 0; t->best = t->round_best; }
   }
   if (t->phase < 0) { t->phase++; return t->best; }
   if (t->phase >= kSpanCands) {
     if (++t->settled_launches < kSpanRetune) return t->best;
     t->phase = 0;   // try them again: the particle set changes as the filter converges
     t->best_ms = 3.0e38f;
+    t->round_best = t->best;
   }
   t->open = hipEventRecord(t->e0, s) == hipSuccess;
   return kSpanCand[t->phase];
