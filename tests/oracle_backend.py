@@ -114,7 +114,7 @@ class OracleKernels:
         return oracle.propagate_normals(n, bool(scale_freeze), rng)
 
     def score_ctx_create(self):
-        return None   # (the device kernels' side stream and tuner: nothing to keep here)
+        return None   # (the device kernels' span tuner: nothing to keep here)
 
     def score(self, m, scan, res, fp, st, n, raw_w, perm=None, init_search=False, uniform_scale=0.0, n_total=0, ctx=None):
         self.calls.append(("score", n))

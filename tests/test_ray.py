@@ -115,8 +115,8 @@ def test_a_map_without_an_integer_form_says_so(tdr, oracle):
 @pytest.mark.parametrize("ncls,nb,nr,scale_fixed", [(6, 64, 32, True), (4, 48, 20, False), (2, 100, 24, True), (11, 24, 12, True)])
 def test_weights_do_not_depend_on_the_order_of_the_additions(tdr, oracle, ncls, nb, nr, scale_fixed):
     """One set of particles scored (a) by the shift-uniform kernel, (b)-(e) by the ray-mapped kernel with a window split
-    over 1, 2, 4 and 8 waves, (f) in a mixed launch, (g) in another particle order, (h) in a mixed launch with the second
-    kernel on a context's own stream: eight different orders of the same products, one set of bits — and the oracle's
+    over 1, 2, 4 and 8 waves, (f) in a mixed launch, (g) in another particle order, (h) in a mixed launch with a caller's
+    context (sample offsets multiplied out of the table's factors, block-major rows): eight different orders of the same products, one set of bits — and the oracle's
     weights to 1e-5."""
     import torch
     pkg, k = tdr

@@ -127,7 +127,7 @@ struct tdr_filter {
   DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
   bool have_ml = false;
   hipStream_t stream = nullptr;
-  tdr_score_ctx* score_ctx = nullptr;   // this filter's own side stream and span tuner for its scoring launches (tdr.h)
+  tdr_score_ctx* score_ctx = nullptr;   // this filter's own span tuner (and the table's factors) for its scoring launches (tdr.h)
   // The reference's generator in parity mode: the host std::mt19937 `rng` and its continuation on the device, a
   // tdr_rng_pipe (csrc/tdr_rng.hip).  Exactly one of them is current: propagate and the resample's uniform draw continue
   // the stream on the device (drawn ahead, beside the scoring launch), the host engine takes it back when host code
@@ -756,7 +756,7 @@ int64_t tdr_filter_num_local(const tdr_filter* f) { return f ? f->nl() : 0; }
 void tdr_filter_destroy(tdr_filter* f) {
   if (!f) return;
   if (f->rng && f->rng_owned) tdr_rng_destroy(f->rng);
-  tdr_score_ctx_destroy(f->score_ctx);   // (waits for its side stream)
+  tdr_score_ctx_destroy(f->score_ctx);
   tdr_rng_pipe_destroy(f->pipe);
   delete f;
 }

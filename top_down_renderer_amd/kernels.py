@@ -328,7 +328,7 @@ class HipKernels:
         return self._ws
 
     def score_ctx_create(self):
-        """A tdr_score_ctx: the side stream and the span tuner of ONE caller's scoring launches (include/tdr.h)."""
+        """A tdr_score_ctx: the span tuner of ONE caller's scoring launches and the table's factors (include/tdr.h)."""
         h = C.c_void_p(0)
         check(self.lib.tdr_score_ctx_create(C.byref(h)))
         return ScoreCtx(self.lib, h)

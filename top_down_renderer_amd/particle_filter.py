@@ -124,7 +124,7 @@ class ParticleFilter:
         self.parity_rng = parity_rng
         self.locality_every = int(locality_every)
         self.seed = int(seed)
-        self.score_ctx = self.k.score_ctx_create()   # this filter's side stream + span tuner (include/tdr.h)
+        self.score_ctx = self.k.score_ctx_create()   # this filter's span tuner and table factors (include/tdr.h)
         self.gen_ = self.k.rng_create(seed)
         # parity mode: the generator's stream continues on the device between the host's own draws, drawn ahead of the
         # step (a tdr_rng_pipe, csrc/tdr_rng.hip)
