@@ -177,7 +177,7 @@ def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_score_su.h", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
+    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_cmap.hip", "tdr_score_su.h", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
         h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -489,7 +489,10 @@ int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattere
  *   TDR_SCORE_WAVES    waves the float scoring kernel aims for        TDR_SCORE_GROUP rings per workgroup of the float /
  *                      shift-uniform kernels (changes the partition of the FLOAT kernel's sums: its results move in the
  *                      last bits)
- *   TDR_SU_GROUP       rings per workgroup of the shift-uniform kernel alone (a multiple of 4; integer sums: same bits) */
+ *   TDR_SU_GROUP       rings per workgroup of the shift-uniform kernel alone (a multiple of 4; integer sums: same bits)
+ *   TDR_RAY_BM         0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
+ *                      holds the table's factors (same bits)
+ *   TDR_RAY_SPLIT      initial tdr_config_ray_split */
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
 /* sinf / cosf on the device are the HOST libm's, bit for bit (csrc/tdr_sincosf.h: glibc >= 2.28's double-precision

@@ -428,9 +428,10 @@ def test_cart_skip_kernel_equals_general_kernel(tdr, oracle, ncls, rows, cols, k
         ref = oracle.compute_weights_cart(om, rows, cols, scan, cfg.res, oracle.make_params(ncls), st.copy())
     m = pkg.TopDownMap(pkg.Params(resolution=1.0), sc.class_maps, sc.class_mask, kernels=k)
     m.setWindow(rows, cols)
-    before = k.lib.tdr_config_cart_skip(-1)
+    before, before_form = k.lib.tdr_config_cart_skip(-1), k.lib.tdr_config_shift_uniform(-1)
     got = []
     try:
+        k.lib.tdr_config_shift_uniform(0)   # the two FLOAT kernels (the integer form: tests/test_ray.py)
         for on in (0, 1):
             k.lib.tdr_config_cart_skip(on)
             f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(fixed_scale=1.0), kernels=k, init_particles=False,
@@ -440,6 +441,7 @@ def test_cart_skip_kernel_equals_general_kernel(tdr, oracle, ncls, rows, cols, k
             got.append(f.raw_weights())
     finally:
         k.lib.tdr_config_cart_skip(before)
+        k.lib.tdr_config_shift_uniform(before_form)
     assert np.array_equal(got[0], got[1], equal_nan=True)
     _assert_weights(got[1], ref)
 
@@ -600,9 +602,10 @@ def test_compact_and_dense_records_score_identically(tdr, oracle, ncls, nb, scal
     ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0),
                                  oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res), cfg.nb, cfg.nr, scan, cfg.res,
                                  oracle.make_params(cfg.ncls, **params), st.copy())
-    before = k.lib.tdr_config_compact(-1)
+    before, before_form = k.lib.tdr_config_compact(-1), k.lib.tdr_config_shift_uniform(-1)
     out = []
     try:
+        k.lib.tdr_config_shift_uniform(0)   # the float kernel on either record form (the integer form: tests/test_ray.py)
         for on in (0, 1):
             k.lib.tdr_config_compact(on)
             f = pkg.ParticleFilter(len(st), m, pkg.FilterParams(**params), kernels=k, init_particles=False,
@@ -612,6 +615,7 @@ def test_compact_and_dense_records_score_identically(tdr, oracle, ncls, nb, scal
             out.append(f.raw_weights())
     finally:
         k.lib.tdr_config_compact(before)
+        k.lib.tdr_config_shift_uniform(before_form)
     _assert_weights(out[0], ref)
     for o in out[1:]:
         assert np.array_equal(out[0], o, equal_nan=True)

@@ -74,7 +74,7 @@ def main():
                     lib.tdr_config_shift_uniform_span(span)
                     for split in (1, 2, 4, 8):
                         lib.tdr_config_ray_split(split)
-                        print(f"{sname:14s} span {span:g} split {split}: one stream {timed(5):6.2f}", flush=True)
+                        print(f"{sname:14s} span {span:g} split {split}: no ctx {timed(5):6.2f}   +ctx {timed(5, ctx=ctx):6.2f}", flush=True)
                 lib.tdr_config_ray_split(0)
                 continue
             print(f"{sname:14s} span 16 +ctx: {timed(6, ctx=ctx):6.2f}   one stream: {timed(6):6.2f}", flush=True)

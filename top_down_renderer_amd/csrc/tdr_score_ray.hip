@@ -40,7 +40,7 @@
 // + block.  Lane l of step g of block b is ring (b * GQ + g) * 64 + l.
 // BLOCK-MAJOR order (bm; launches whose table comes with its factors): one step per row, GQ = 1, and the rows of ring
 // segment 0 (rings 0..63, every direction) first, then segment 1's, ...: row m = segment * nb + direction.  The eight
-// gathers a wave has in flight are then neighbouring directions of ONE segment (config 2, uniform particles: 9.5 -> 8.4 ms;
+// gathers a wave has in flight are then neighbouring directions of ONE segment (config 2, uniform particles: 9.1 -> 8.4 ms;
 // with the offsets read from tab_ray the narrow rows cost more than that gains, so those launches keep the first order).
 // TDR_RAY_BM=0 keeps the first order everywhere (A/B).
 static const bool g_ray_bm = [] {
@@ -387,7 +387,10 @@ int tdr_ray_splits(int nb, int nr, int64_t n, bool bm) {
   int s = 1;
   while (s < TDR_RAY_MAX_SPLIT && n * s < 32768 && rows / (2 * s) >= 8) s *= 2;
   if (s == 1 && rows >= 128) s = 2;
-  if (s == 2 && bm && rows >= 512) s = 4;   // (config 2, uniform particles, block-major: 8.99 / 8.43 / 8.58 ms at 2 / 4 / 8)
+  // (config 2, 100 000 uniform particles at a span of 8, ms per call at 1 / 2 / 4 / 8 waves per particle — block-major:
+  // 8.42 / 8.36 / 8.33 / 8.69; the first order: 10.35 / 10.42 / 10.35 / 9.66; the bench mix moves by 1 % at most)
+  if (s == 2 && bm && rows >= 512) s = 4;
+  if (s == 2 && !bm && rows >= 256) s = 8;
   return s;
 }
 
