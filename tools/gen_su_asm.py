@@ -10,11 +10,11 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v8..v15   sample u: v(8+2u) row -> ri, v(9+2u) column -> ci
   v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
   v20..v23  scratch
-  v24..v27  sample u: the record dword
+  v24..v27  sample u: the 2-byte cell of the bin's class plane
   (the accumulators of classes 0..5 — 64-bit integers, see below — , the normalisation and the known count are operands
    of the statement: the register allocator places them)
   s40..s47 / s72..s79   the step's sample offsets {tx, ty} x 4           (even / odd steps: the loop body exists twice and
-  s48..s63 / s80..s95   the step's descriptors {code, value, ckc, shift | flag} x 4 (su_prep_kernel)   requests the next
+  s48..s63 / s80..s95   the step's descriptors {code, value, plane constant, flag} x 4 (su_prep_kernel)   requests the next
                         step's scalars into the other set before it works on its own)
   s65 / s66 byte offsets of the step in the offset / descriptor streams, s67 steps left - 1,
             s68 steps until the scan rows wrap - 1;  s69..s71 the same offsets / count for the step behind it
@@ -122,23 +122,26 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a("s_nop 0")
         for u in range(4):
             a(f"ds_read_b32 v{28 + u}, v{16 + u}")
-    # the record dword of every non-empty bin (cmap_offset with the dword folded into its constant)
+    # the cell of the class's plane for every non-empty bin (plane_offset, tdr_score_dev.h: (c >> 3) * pkcol + 2 c + 16 r +
+    # the plane's constant): 2 bytes — the dictionary index * 4 in bits 2..11.  (Until round 4 this was the dword of the
+    # compact record the class lives in: 4 x 4-cell tiles, three times the lines per gather of a wave whose particles lie a
+    # few cells apart — and the lines a gather touches are what bounds the kernel.)
     for u in range(4):
         code, ckc = D + 4 * u, D + 2 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
         a(f"s_cbranch_scc1 .Lsu_a{u}{tag}%=")
         if not mask:
             coords([u])
-        a(f"v_ashrrev_i32 v{20 + u}, 2, v{9 + 2 * u}")
+        a(f"v_ashrrev_i32 v{20 + u}, 3, v{9 + 2 * u}")
         a("s_nop 0")
-        a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[ckcol], s{ckc}")
+        a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[pkcol], s{ckc}")
         a("s_nop 0")
-        a(f"v_lshl_add_u32 v{20 + u}, v{9 + 2 * u}, 3, v{20 + u}")
+        a(f"v_lshl_add_u32 v{20 + u}, v{9 + 2 * u}, 1, v{20 + u}")
         a("s_nop 0")
-        a(f"v_lshl_add_u32 v{20 + u}, v{8 + 2 * u}, 5, v{20 + u}")
+        a(f"v_lshl_add_u32 v{20 + u}, v{8 + 2 * u}, 4, v{20 + u}")
         a("s_nop 0")
         # (never into its own address register: a load that is replayed reads its address again)
-        a(f"global_load_dword v{24 + u}, v{20 + u}, %[crec]")
+        a(f"global_load_ushort v{24 + u}, v{20 + u}, %[crec]")
         a(f".Lsu_a{u}{tag}%=:")
     # ---- phase B
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -154,17 +157,16 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
     else:   # every cell the sector can reach is known: four more known samples, nothing to look up
         a("v_add_u32 %[known], 4, %[known]")
     for u in range(4):
-        code, val, sh = D + 4 * u, D + 1 + 4 * u, D + 3 + 4 * u
+        code, val = D + 4 * u, D + 1 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
         a(f"s_cbranch_scc1 .Lsu_b{u}{tag}%=")
         if mask:
             a(f"v_and_b32 v20, s{val}, v{16 + u}")                               # the bin's count x known (:141-142)
-        a(f"v_lshrrev_b32 v21, s{sh}, v{24 + u}")                                # the class's dictionary index * 4
+        a(f"v_and_b32 v21, 0xffc, v{24 + u}")                                    # the class's dictionary index * 4
         if mask:
             a("v_add_u32 %[norm], %[norm], v20")
         else:
             a(f"v_add_u32 %[norm], s{val}, %[norm]")
-        a("v_and_b32 v21, 0xffc, v21")
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                # the dictionary sits at LDS address 0
         a("s_waitcnt lgkmcnt(0)")

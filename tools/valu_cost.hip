@@ -45,6 +45,10 @@ KERNEL(k_pk_mul_f32, I8P("v_pk_mul_f32", ", %9"))
 KERNEL(k_med3_f32, I8("v_med3_f32", ", %12, %13"))
 KERNEL(k_cvt_flr, "v_cvt_flr_i32_f32 %0, %0\nv_cvt_flr_i32_f32 %1, %1\nv_cvt_flr_i32_f32 %2, %2\nv_cvt_flr_i32_f32 %3, %3\n"
                   "v_cvt_flr_i32_f32 %4, %4\nv_cvt_flr_i32_f32 %5, %5\nv_cvt_flr_i32_f32 %6, %6\nv_cvt_flr_i32_f32 %7, %7\n")
+KERNEL(k_cvt_rpi, "v_cvt_rpi_i32_f32 %0, %0\nv_cvt_rpi_i32_f32 %1, %1\nv_cvt_rpi_i32_f32 %2, %2\nv_cvt_rpi_i32_f32 %3, %3\n"
+                  "v_cvt_rpi_i32_f32 %4, %4\nv_cvt_rpi_i32_f32 %5, %5\nv_cvt_rpi_i32_f32 %6, %6\nv_cvt_rpi_i32_f32 %7, %7\n")
+KERNEL(k_sub_u32, I8("v_sub_u32", ", %12"))
+KERNEL(k_bfe_i32_v, I8("v_bfe_i32", ", %12, 1"))
 KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %0\nv_cvt_f32_u32 %1, %1\nv_cvt_f32_u32 %2, %2\nv_cvt_f32_u32 %3, %3\n"
                       "v_cvt_f32_u32 %4, %4\nv_cvt_f32_u32 %5, %5\nv_cvt_f32_u32 %6, %6\nv_cvt_f32_u32 %7, %7\n")
 KERNEL(k_cvt_f32_ubyte0, "v_cvt_f32_ubyte0 %0, %0\nv_cvt_f32_ubyte0 %1, %1\nv_cvt_f32_ubyte0 %2, %2\nv_cvt_f32_ubyte0 %3, %3\n"
@@ -89,7 +93,7 @@ typedef void (*kern_t)(unsigned*, unsigned long long*, float);
 struct Entry { const char* name; kern_t k; };
 #define E(n) {#n, n}
 static Entry entries[] = {E(k_add_f32), E(k_add_f32_s), E(k_fma_f32), E(k_fma_f32_s), E(k_pk_add_f32), E(k_pk_fma_f32),
-                          E(k_pk_mul_f32), E(k_med3_f32), E(k_cvt_flr), E(k_cvt_f32_u32), E(k_cvt_f32_ubyte0),
+                          E(k_pk_mul_f32), E(k_med3_f32), E(k_cvt_flr), E(k_cvt_rpi), E(k_sub_u32), E(k_bfe_i32_v), E(k_cvt_f32_u32), E(k_cvt_f32_ubyte0),
                           E(k_mad_i32_i24), E(k_mad_u32_u24), E(k_mul_u32_u24), E(k_mul_lo_u32), E(k_lshl_add_u32),
                           E(k_add_lshl_u32), E(k_lshl_or_b32), E(k_and_or_b32), E(k_and_b32), E(k_and_b32_lit),
                           E(k_ashrrev_i32), E(k_bfe_u32), E(k_bfi_b32), E(k_add_u32), E(k_add3_u32), E(k_perm_b32),

@@ -54,6 +54,7 @@ struct SuArgs {
   unsigned kmask_off;      // its byte offset from crec
   const uint32_t* dict_int;   // the dictionary as integers: value * 2^q (tdr_cmap.hip)
   int dict_n, ctiles_r;
+  int pkcol;               // class planes (tdr_cmap.hip): bytes of a tile column - 16 (plane_offset); their constants come with the descriptors
   const int32_t* inexact;  // device words (int_form_off): this scan / map has no exact integer form, the launch does nothing
   int rows, cols;          // map
   float resolution;
@@ -76,11 +77,16 @@ struct SuArgs {
 //   [0] code: 0 = every class zero; c + 1 = class c alone is non-zero; SU_CODE_FULL = several classes;
 //       SU_CODE_FULL_ALL = a non-finite dictionary / scan value: no skipping in this bin
 //   [1] the bin's count summed over the classes, as an integer — for a single class: its count
-//   [2] the constant of the record offset (cmap_offset) advanced to the dword the class lives in: ckconst + 4 * (c / 3)
-//   [3] bits 0-4: the bit offset of the class's field in that dword minus 2 (10 * (c % 3)); bit 31, on the first bin of a
-//       step (4 consecutive rings) only: one of the step's bins is SU_CODE_FULL / SU_CODE_FULL_ALL
+//   [2] a single class: the constant of plane_offset for the class's PLANE (byte offset from crec: pbase + c * plane_bytes) —
+//       the 2-byte cell of the one class is what such a bin fetches: tiles of 8 x 8 cells, a third of the lines the 4 x 4-cell
+//       record tiles cost a wave whose particles lie a few cells apart (the gathers' lines bound this kernel: DESIGN.md
+//       5.1); several classes: the constant of the record offset (cmap_offset)
+//   [3] bit 31, on the first bin of a step (4 consecutive rings) only: one of the step's bins is SU_CODE_FULL / SU_CODE_FULL_ALL
+//   (the steps that read RECORDS — the C++ steps, for bins with several classes and their neighbours, and the far path —
+//    work the record constants of a single class out of its code: su_rec_const / single_class)
 __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ tab, const float* __restrict__ scan_pk,
-                                                      int nb, int nr, int rf, int ncls, int ckconst, int group, int nchunks,
+                                                      int nb, int nr, int rf, int ncls, int ckconst, unsigned pbase,
+                                                      unsigned plane_bytes, int group, int nchunks,
                                                       const float* __restrict__ dict, int dict_n, float* __restrict__ tab_su,
                                                       uint32_t* __restrict__ desc) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void su_prep_kernel(const float* __restrict__ 
     }
     // (a non-finite or fractional count: the launch runs in its float form instead — ray_prep_kernel raises `inexact`)
     if (dict_bad || !finite) { code = SU_CODE_FULL_ALL; val = r[rf - 1]; }
-    else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc += 4u * (uint32_t)(first / 3); sh = 10u * (uint32_t)(first % 3); }
+    else if (nz == 1) { code = (uint32_t)first + 1u; val = r[first]; ckc = pbase + (uint32_t)first * plane_bytes; }
     else if (nz > 1) { code = SU_CODE_FULL; val = r[rf - 1]; }
   }
   // steps are 4 consecutive bins (group is a multiple of 4, so they are 4 consecutive threads of a wave)
@@ -285,7 +291,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const int nb = a.nb, G = a.group;
   const int j0 = blockIdx.y * G, gn = min(a.nr - j0, G);
   const float rmaxf = (float)a.rows, cmaxf = (float)a.cols;
-  const int ckcol = a.ctiles_r * 128 - 16 * CW;   // cmap_offset; its constant comes with the descriptor
+  const int ckcol = a.ctiles_r * 128 - 16 * CW;   // cmap_offset
+  const int pkcol = a.pkcol;                      // plane_offset; its constant comes with the descriptor
+  // the record constant of a bin for the steps that read records: dword (c / 3) of class c = code - 1 alone (c < 11: c / 3
+  // == c * 11 >> 5), dword 0 otherwise (wave-uniform: scalar arithmetic)
+  const uint32_t ckconst = (uint32_t)(a.ctiles_r * 128 + 128);
+  auto su_rec_const = [&](uint32_t cd) -> uint32_t {
+    return cd != 0 && cd < SU_CODE_PAD ? ckconst + 4u * (((cd - 1u) * 11u) >> 5) : ckconst;
+  };
   typedef const float __attribute__((address_space(4))) * tdr_const_f;
   typedef const uint32_t __attribute__((address_space(4))) * tdr_const_u;
   const tdr_const_f tbase = (tdr_const_f)a.tab_su + (int64_t)blockIdx.y * nb * G * 2;
@@ -326,6 +339,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   case K + 1:                                                                                      \
     if constexpr (K < ND) {                                                                        \
       const uint32_t m = field1(ww, K < ND ? K : 0);                                               \
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m) : "vcc"); \
+    }                                                                                              \
+    break;
+      SU_CASE(0) SU_CASE(1) SU_CASE(2) SU_CASE(3) SU_CASE(4) SU_CASE(5)
+      SU_CASE(6) SU_CASE(7) SU_CASE(8) SU_CASE(9) SU_CASE(10)
+#undef SU_CASE
+      default: break;
+    }
+  };
+  // ... when the sample loaded the 2-byte cell of the class's plane (dictionary index * 4 in bits 2..11)
+  auto single_class_plane = [&](uint32_t cd, uint32_t v, uint32_t cell) {
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds.dict) + (cell & 0xFFCu));
+    switch (cd) {
+#define SU_CASE(K)                                                                                 \
+  case K + 1:                                                                                      \
+    if constexpr (K < ND) {                                                                        \
       asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m) : "vcc"); \
     }                                                                                              \
     break;
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;
       code[u] = code[u] == SU_CODE_PAD ? 0u : code[u];
       val[u] = D[4 * u + 1];
-      const uint32_t ckc = D[4 * u + 2];
+      const uint32_t ckc = su_rec_const(code[u]);
       int ri, ci;
       cell(T[2 * u], T[2 * u + 1], ri, ci);
       cis[u] = ci;
@@ -421,6 +450,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
     }
   };
+  // The same step when none of its bins holds several classes (the descriptor's flag, wave-uniform): a bin with a class
+  // fetches the 2-byte cell of that class's PLANE (8 x 8-cell tiles) instead of a record dword (4 x 4-cell tiles) — a third
+  // of the lines for a wave whose particles lie a few cells apart.  The assembly loop does the same.
+  auto cpp_step_plane = [&](int i, int r, int jj, int krow4, int kconst) {
+    const tdr_const_f T = tbase + ((int64_t)i * G + jj) * 2;
+    const tdr_const_u D = dbase + ((int64_t)r * G + jj) * 4;
+    uint32_t val[4];
+    uint32_t code[4], pad[4];
+    uint32_t w[4], bits[4];
+    int cis[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      code[u] = D[4 * u];
+      pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;   // (see cpp_step: masked, never branched around)
+      code[u] = code[u] == SU_CODE_PAD ? 0u : code[u];
+      val[u] = D[4 * u + 1];
+      const uint32_t pkc = D[4 * u + 2];
+      int ri, ci;
+      cell(T[2 * u], T[2 * u + 1], ri, ci);
+      cis[u] = ci;
+      int wa;
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(wa) : "v"(ri), "v"(krow4), "s"(kconst));
+      const int cw5 = ci >> 5;
+      unsigned la;
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
+      if (code[u] != 0) {   // wave-uniform
+        int t1, t2;
+        unsigned off;
+        const int cq = ci >> 3;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(pkcol), "s"(pkc));
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t2) : "v"(ci), "v"(t1));
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ri), "v"(t2));
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(w[u]) : "v"(off), "s"(crec));
+      } else {
+        asm volatile("" : "=v"(w[u]));   // not read
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int kmsk;   // 0 / -1: the cell's known bit
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(bits[u]), "v"(cis[u]));
+      known -= (uint32_t)kmsk & pad[u];
+      if (code[u] != 0) {   // wave-uniform
+        norm += (uint32_t)kmsk & val[u];   // the bin's count x known (state_particle.cpp:141-142)
+        single_class_plane(code[u], val[u], w[u]);
+      }
+    }
+  };
   // NS consecutive steps of a sector (step k = direction i0 + k / spd, rings (k % spd) * 4 ..) WITHOUT the staged mask:
   // the windows of the workgroup's particles are too far apart to stage (scattered particles: su_key_kernel gives them
   // waves of their own).  Every gather of such a wave misses the caches, so the wave is bound by how many it keeps in
@@ -451,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           off = kmask_offset(ri, ci, mtrb, mconst);
           cbits[sidx / 6] |= (uint32_t)(ci & 31) << (5 * (sidx % 6));
         } else {               // a single class: the dword it lives in; several classes: dword 0
-          const uint32_t ckc = D[4 * u + 2];
+          const uint32_t ckc = su_rec_const(D[4 * u]);
           int t1, t2;
           const int cq = ci >> 2;
           asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
@@ -556,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),   /* 64-bit */ \
             [a5] "+v"(acc[ND > 5 ? 5 : 0]), [norm] "+v"(norm), [known] "+v"(known), [toff] "+v"(toff), [doff] "+v"(doff), \
             [nleft] "+v"(nleft), [wleft] "+v"(wleft)                                                                   \
-          : [offv] "v"(offv), [krow4] "v"(krow4), [ckcol] "v"(ckcol), [tb] "s"(tbase), [db] "s"(dbase),              \
+          : [offv] "v"(offv), [krow4] "v"(krow4), [pkcol] "v"(pkcol), [tb] "s"(tbase), [db] "s"(dbase),              \
             [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
             [wrapm1] "s"(wrapm1), [scale2] "v"(scale2), [res2] "s"(res2)                                               \
           : SU_ASM_CLOBBERS
@@ -595,7 +675,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     for (int i = i0; i < i1; i++) {
       int r = i + shift;
       r -= r >= nb ? nb : 0;
-      for (int jj = 0; jj < gn; jj += 4) cpp_step(i, r, jj, krow4, kconst);
+      for (int jj = 0; jj < gn; jj += 4) {
+        // (the flag sits on the step's first bin: su_prep_kernel)
+        if (dbase[((int64_t)r * G + jj) * 4 + 3] >> 31) cpp_step(i, r, jj, krow4, kconst);
+        else cpp_step_plane(i, r, jj, krow4, kconst);
+      }
     }
   };
 
@@ -672,6 +756,8 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
   return g_su_mode;
 }
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
+extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
+extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
 // map cells the 64 locality neighbours of a "dense" particle may span: fixed (env TDR_SU_SPAN / the config call), or — the
 // default — tuned while running, starting from SU_SPAN_START
 #define SU_SPAN_START 16.f
@@ -822,8 +908,12 @@ int tdr_su_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_
   const int64_t ndesc = (int64_t)L.nchunks * L.nb * L.group;
   const int lc = L.map->cwords == 1 ? 3 : (L.map->cwords == 2 ? 2 : 1);
   const int ckconst = ((L.map->rows >> lc) + 2) * 128 + 128;   // cmap_offset (tdr_score_dev.h)
+  // plane_offset's constant for class 0's plane, as a byte offset from crec (tdr_score_ray.hip uses the same)
+  const unsigned plane_bytes = (unsigned)(tdr_cmap_plane_words(L.map->ncls, L.map->rows, L.map->cols) * 4);
+  const unsigned pbase = (unsigned)(tdr_cmap_plane_offset_words(L.map->ncls, L.map->rows, L.map->cols) * 4) +
+                         (unsigned)(plane_trows(L.map->rows) * 128) + 128u;
   hipLaunchKernelGGL(su_prep_kernel, dim3((unsigned)cdiv(ndesc, 256)), dim3(256), 0, s, L.tab, L.scan_pk, L.nb, L.nr, L.rf,
-                     L.map->ncls, ckconst, L.group, L.nchunks, L.map->dict, L.map->dict_n, tab_su, desc);
+                     L.map->ncls, ckconst, pbase, plane_bytes, L.group, L.nchunks, L.map->dict, L.map->dict_n, tab_su, desc);
   LAUNCH_CHECK("su_prep");
   hipLaunchKernelGGL(su_bbox_kernel, dim3((unsigned)L.nchunks, SU_NSECT), dim3(256), 0, s, (const float*)tab_su, L.nb, L.nr,
                      L.group, reinterpret_cast<float*>(base + W.bbox));
@@ -839,6 +929,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   u.crec = map->crec; u.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
   u.dict_n = map->dict_n; u.ctiles_r = (map->rows >> lc) + 2;
+  u.pkcol = plane_trows(map->rows) * 128 - 16;
   u.inexact = nslots + 4;
   u.rows = map->rows; u.cols = map->cols; u.resolution = map->resolution;
   u.tab_su = reinterpret_cast<const float*>(base + W.tab_su);
