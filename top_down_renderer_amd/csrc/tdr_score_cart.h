@@ -32,6 +32,8 @@ struct CartArgs {
   int run_if_int = 0;                   // with flags: 1 = run only while the integer form is on, 0 = only while it is off
   const int32_t* count = nullptr;       // device word: slots of `order` this launch covers (the dense share); NULL: n
   int ncls = 0;
+  int pkcol = 0;                        // != 0: a bin with one class fetches the cell of the class's PLANE (tdr_cmap.hip; plane_offset:
+                                        // bytes of a tile column - 16), its constant in descriptor word [2] — the integer form's dense kernel
 };
 
 // dwords of workspace the descriptors take (behind the partial sums of tdr_score_cart_workspace_floats)

@@ -32,9 +32,13 @@
 //   [2] cmap_offset's constant advanced to the dword the class lives in: ckconst + 4 * (c / 3)
 //   [3] bit offset of the class's field in that dword minus 2 (10 * (c % 3))
 // as_int: descriptor word [1] holds the count as an integer (the integer form's kernels) instead of float bits
+// pbase != 0 (the integer form's dense kernel): word [2] of a bin with ONE class is plane_offset's constant for the class's
+// plane instead (pbase + c * plane_bytes, a byte offset from crec) — 8 x 8-cell tiles of 2-byte cells: a wave whose
+// particles lie a few cells apart touches a third of the lines the 4 x 4-cell record tiles cost it (tdr_score_su.hip)
 __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict__ scan_pk, int rows, int cols, int rf, int ncls,
                                                         int ckconst, const float* __restrict__ dict, int dict_n,
-                                                        uint32_t* __restrict__ desc, int as_int) {
+                                                        uint32_t* __restrict__ desc, int as_int, unsigned pbase,
+                                                        unsigned plane_bytes) {
   bool bad = false;   // the dictionary is small: every workgroup checks it for itself
   for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
   const bool dict_bad = __syncthreads_or(bad);
@@ -53,7 +57,12 @@ __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict_
     }
     val = 0.f; ckc = (uint32_t)ckconst; sh = 0;
     if (dict_bad || !finite) { val = r[rf - 1]; return CART_CODE_FULL_ALL; }
-    if (nz == 1) { val = r[first]; ckc += 4u * (uint32_t)(first / 3); sh = 10u * (uint32_t)(first % 3); return (uint32_t)first + 1u; }
+    if (nz == 1) {
+      val = r[first];
+      if (pbase) ckc = pbase + (uint32_t)first * plane_bytes;
+      else { ckc += 4u * (uint32_t)(first / 3); sh = 10u * (uint32_t)(first % 3); }
+      return (uint32_t)first + 1u;
+    }
     if (nz > 1) { val = r[rf - 1]; return CART_CODE_FULL; }
     return 0u;
   };
@@ -138,12 +147,15 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
   uint32_t inorm = 0;     // integer form
   uint32_t known = 0;
   // v: the bin's value as the descriptor carries it — float bits, or (INT) the count as an integer
+  const bool planes = INT && a.pkcol != 0;   // (uniform) a bin with one class reads the class's plane
+  const int pkcol = a.pkcol;
   auto single_class = [&](uint32_t cd, uint32_t v, uint32_t ww) {   // a switch over a wave-uniform value
     switch (cd) {
 #define CART_CASE(K)                                                                                \
   case K + 1:                                                                                       \
     if constexpr (K < ND) {                                                                         \
-      const uint32_t m = field1(ww, K < ND ? K : 0);                                                \
+      /* (a plane's cell: the dictionary index * 4 in bits 2..11, whatever the class) */            \
+      const uint32_t m = field1(ww, planes ? 0 : (K < ND ? K : 0));                                 \
       if constexpr (INT) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m) : "vcc"); \
       else asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[K < ND ? K : 0]) : "s"(v), "v"(m));      \
     }                                                                                               \
@@ -182,6 +194,12 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
       cis[u] = ci;
       if (D[4 * u] == 0) {   // wave-uniform
         offs[u] = kmask_offset(ri, ci, mrow, mconst);
+      } else if (planes && D[4 * u] < CART_CODE_FULL_ALL) {   // one class: the 2-byte cell of its plane (plane_offset), read
+        int t1, t2;                                           // as the low half of a dword at a 2-byte aligned address
+        const int cq = ci >> 3;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(pkcol), "s"(D[4 * u + 2]));
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t2) : "v"(ci), "v"(t1));
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(offs[u]) : "v"(ri), "v"(t2));
       } else {
         int t1, t2;
         const int cq = ci >> 2;
@@ -201,7 +219,8 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kmsk) : "v"(w[u]), "v"(cis[u]));
         known -= (uint32_t)kmsk;
       } else {
-        const uint32_t kb = w[u] & 1u;   // bit 0 of every dword of a compact record (tdr_cmap.hip)
+        // bit 0 of every dword of a compact record, bit 15 of a plane's cell (tdr_cmap.hip)
+        const uint32_t kb = (planes && cd < CART_CODE_FULL_ALL) ? (w[u] >> 15) & 1u : w[u] & 1u;
         known += kb;
         const uint32_t vb = D[4 * u + 1];   // float bits (INT: the count as an integer — cart_prep_kernel writes both forms)
         if (cd < CART_CODE_FULL_ALL) {
@@ -293,7 +312,7 @@ int tdr_cart_skip_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* 
   const int ckconst = ((map->rows >> lc) + 2) * 128 + 128;   // cmap_offset (tdr_score_dev.h)
   const int64_t nbins = (int64_t)a.rows * a.cols;
   hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
-                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0);
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0, 0u, 0u);
   LAUNCH_CHECK("cart_prep");
   a.desc = desc_ws;
   a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);   // the mask lies behind the tiles
@@ -592,10 +611,13 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
   const int lc = map->cwords == 1 ? 3 : (map->cwords == 2 ? 2 : 1);
   const int ckconst = ((map->rows >> lc) + 2) * 128 + 128;
   const int64_t nbins = (int64_t)a.rows * a.cols;
+  const unsigned plane_bytes = (unsigned)(tdr_cmap_plane_words(map->ncls, map->rows, map->cols) * 4);
+  const unsigned pbase = (unsigned)(tdr_cmap_plane_offset_words(map->ncls, map->rows, map->cols) * 4) +
+                         (unsigned)(plane_trows(map->rows) * 128) + 128u;   // plane_offset's constant for class 0's plane
   hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
-                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0);
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_ws, 0, 0u, 0u);
   hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
-                     map->ncls, ckconst, map->dict, map->dict_n, desc_int, 1);
+                     map->ncls, ckconst, map->dict, map->dict_n, desc_int, 1, pbase, plane_bytes);
   LAUNCH_CHECK("cart_prep");
   const int gq = cart_ray_gq(a.cols), blocks = cart_ray_blocks(a.cols);
   const int64_t T = (int64_t)a.rows * blocks * gq * 64;
@@ -642,6 +664,7 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
     d.dict_int = reinterpret_cast<const uint32_t*>(map->dict) + TDR_CMAP_MAX_DICT;
     d.flags = flags; d.run_if_int = 1;
     d.order = slots; d.count = counts; d.npad = npad_int;
+    d.pkcol = plane_trows(map->rows) * 128 - 16;
     const dim3 grid((unsigned)cdiv(npad_int, 256), (unsigned)a.nchunks), block(256);
 #define TDR_LAUNCH_CART_INT(NV4)                                                                 \
   if (ks) hipLaunchKernelGGL((score_cart_skip_kernel<NV4, true, true>), grid, block, 0, s, d);    \
