@@ -29,8 +29,10 @@ events on its launch stream; a polar launch runs two kernels, the events span bo
     window sample (the known-fraction gate reads every sample) + 4 bytes per non-empty scan bin (one dictionary value);
     `traffic_over_sparse` = what the counters saw of it (below 1: particles that share window cells share the lines);
   * `traffic_GBps` / `traffic_frac` = the counters' bytes over the same duration (/ peak);
-  * `issue` = {valu_busy, lds_busy, insts_per_sample} from a second counter pass; `bound` = the busiest of
-    {hbm: `frac`, valu, lds};
+  * `issue` = {valu_busy, lds_busy, l1_addr_busy, insts_per_sample} from two more counter passes (valu_busy counts four
+    cycles per vector instruction — an upper bound, see tools/valu_cost.hip —, l1_addr_busy = TA_BUSY_avr over the kernels'
+    cycles: the texture addressers, what a gather's cache lines cost); `bound` = the busiest of {hbm: `traffic_frac`, valu,
+    lds, l1_addr};
   * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, on the particle set
     every timed step starts from, before propagate): shift-uniform kernel over the dense particles, ray-mapped kernel over the
     scattered ones, particles in each;
@@ -372,12 +374,18 @@ def main():
         util = {"hbm": traffic_gbps / 8000.0 if traffic_gbps is not None else 0.0}
         if issue:
             issue = {"valu_busy": issue.get("valu_busy"), "lds_busy": issue.get("lds_busy"),
+                     "l1_addr_busy": issue.get("l1_addr_busy"),
                      "insts_per_sample": issue.get("insts_per_sample"),
-                     "how": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE over this "
-                            "command (tools/traffic_from_pmc.py): issue cycles of the vector units / cycles of the LDS arrays "
-                            "over the kernels' cycles, vector instructions per wave per window sample"}
+                     "how": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE, and "
+                            "--pmc TA_BUSY_avr, over this command (tools/traffic_from_pmc.py): issue cycles of the vector "
+                            "units at four per instruction (an upper bound: tools/valu_cost.hip measures 2.4 - 4.2) / cycles "
+                            "of the LDS arrays / busy cycles of the texture addressers (the L1 address path) over the "
+                            "kernels' cycles, vector instructions per wave per window sample"}
+            # (valu_busy counts four cycles per vector instruction; tools/valu_cost.hip measures 2.4 for plain VOP2 and 4.2 for
+            # VOP3 / packed / conversions on this device — the figure is an upper bound on what the vector units are busy)
             util["valu"] = issue["valu_busy"] or 0.0
             util["lds"] = issue["lds_busy"] or 0.0
+            util["l1_addr"] = issue["l1_addr_busy"] or 0.0
         bound = max(util, key=util.get)
         # bytes the launch cannot do without, from this run's scan
         nnz = int((r.last_images().sum(dim=0) > 0).sum().item())
@@ -420,10 +428,10 @@ def main():
                          "issue": issue,
                          "note": "`achieved`, `peak`, `frac` price the launch's algorithmic bytes against the HBM roofline "
                                  "whatever `bound` says; `bound` names the unit the launch keeps busiest (hbm = "
-                                 "`traffic_frac`, valu / lds = `issue`).  "
+                                 "`traffic_frac`, valu / lds / l1_addr = `issue`).  "
                                  "A polar launch runs two kernels one after the other — score_polar_su_kernel for the dense "
-                                 "particles (vector-issue bound), score_polar_ray_kernel for the scattered ones (L1 address "
-                                 "path) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",
+                                 "particles, score_polar_ray_kernel for the scattered ones, both bound by the L1 address path "
+                                 "(cache lines per gather) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          # polar configs: the dense / scattered split of the mixed launch this filter's tuner settled on
                          "shift_uniform_span_cells": f.score_ctx.span() if cfg.polar else None,

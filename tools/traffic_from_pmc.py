@@ -10,7 +10,7 @@ Read bytes per launch = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64 (MI355X_MIC
 memory-side request counters; FETCH_SIZE tallies the 128-byte requests at 64 bytes on gfx950, so it is not used).  These
 are the requests the L2s send to the fabric: what the Infinity Cache serves is among them.  A second pass
 (SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE) gives the issue figures bench.py reports beside
-the traffic.  Counters are summed over the XCDs per dispatch and over all dispatches of the scoring kernels, and divided by the number
+the traffic, a third (TA_BUSY_avr alone) how busy the L1 address path is.  Counters are summed over the XCDs per dispatch and over all dispatches of the scoring kernels, and divided by the number
 of scoring launches.  The record stores a hash of the kernel sources: bench.py ignores it once they change.
 """
 import csv
@@ -66,6 +66,9 @@ def main():
         issue = {"valu_busy": launch["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
                  "lds_busy": (launch["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles)) if "SQ_LDS_IDX_ACTIVE" in launch else None,
                  "insts_per_sample": (launch["SQ_INSTS_VALU"] / wave_samples) if "SQ_INSTS_VALU" in launch else None,
+                 # TA_BUSY_avr (a pass of its own): busy cycles of the texture addressers — the L1 address path — averaged
+                 # over the CUs, against the kernels' cycles
+                 "l1_addr_busy": (launch["TA_BUSY_avr"] / cycles) if "TA_BUSY_avr" in launch else None,
                  "cycles": cycles, "wave_samples": wave_samples}
     path = os.path.join(ROOT, "profiles", "score_traffic.json")
     try:
@@ -92,8 +95,8 @@ def main():
         fh.write(f"L2 -> fabric read bytes per launch {bytes_per_launch:.6g}  ({bytes_per_launch / n_launch:.6g} per particle; "
                  f"Infinity-Cache hits included)\n")
         if issue:
-            fh.write(f"issue: vector units busy {issue['valu_busy']:.3f}, LDS busy {issue['lds_busy']}, vector instructions per "
-                     f"wave-sample {issue['insts_per_sample']}\n")
+            fh.write(f"issue: vector units busy {issue['valu_busy']:.3f} (four cycles per instruction), LDS busy {issue['lds_busy']}, "
+                     f"L1 address path busy {issue['l1_addr_busy']}, vector instructions per wave-sample {issue['insts_per_sample']}\n")
     print(open(summary).read())
 
 
