@@ -727,7 +727,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (active) {
       const bool inside = rlo >= 0 && rhi < a.rows && __builtin_amdgcn_readfirstlane(lds.box[2]) >= 0 &&
                           __builtin_amdgcn_readfirstlane(lds.box[3]) < a.cols;
-      if (fits) run_sector(i0, i1, Wb * 4, (int)lbits_lds + (1 - wlo - rlo * Wb) * 4, inside, allknown);
+      // one call of the sector's loop (two would double the assembly text in the kernel), its box chosen here
+      int box_krow4 = Wb * 4, box_kconst = (int)lbits_lds + (1 - wlo - rlo * Wb) * 4;
+      int box_ok = fits ? 1 : 0, box_inside = inside ? 1 : 0, box_allknown = allknown ? 1 : 0;
+      if (!fits) {
+        // The workgroup's windows do not fit one box — its waves belong to different clusters or heading bins (config 5:
+        // 8 clusters x 40 headings, more than half of the sectors).  A wave's own 64 particles still lie together: a box
+        // per wave in a quarter of the staging area each (rl .. ch: the wave's own bounds after the shuffles above;
+        // nothing here crosses waves, so no workgroup barrier: a wave's LDS operations execute in order).
+        const int wrl = __builtin_amdgcn_readfirstlane(rl), wrh = __builtin_amdgcn_readfirstlane(rh);
+        const int wcl = __builtin_amdgcn_readfirstlane(cl), wch = __builtin_amdgcn_readfirstlane(ch);
+        const int wl = (wcl >> 5) + 1, wh = (wch >> 5) + 1;
+        const int Hw = wrh - wrl + 1, Wbw = wh - wl + 1;
+        if ((int64_t)Hw * Wbw <= SU_BOX_WORDS / 4) {
+          uint32_t* const mine = lds.bits + wave * (SU_BOX_WORDS / 4);
+          uint32_t ev = 0xFFFFFFFFu;
+          const int total = Hw * Wbw;
+          for (int idx = lane; idx < total; idx += 64) {
+            const int wc = idx / Hw, row = idx - wc * Hw;
+            const uint32_t wv = kmask[(int64_t)(wl + wc) * a.kcolw + (wrl + row + 32)];
+            mine[row * Wbw + wc] = wv;
+            ev &= wv;
+          }
+          box_ok = 1;
+          box_krow4 = Wbw * 4;
+          box_kconst = (int)lbits_lds + wave * (SU_BOX_WORDS / 4) * 4 + (1 - wl - wrl * Wbw) * 4;
+          box_inside = (wrl >= 0 && wrh < a.rows && wcl >= 0 && wch < a.cols) ? 1 : 0;
+          box_allknown = __all(ev == 0xFFFFFFFFu) ? 1 : 0;
+        }
+      }
+      // (readfirstlane: the loop's variants are chosen by these, and the compiler must see them wave-uniform)
+      box_ok = __builtin_amdgcn_readfirstlane(box_ok);
+      box_inside = __builtin_amdgcn_readfirstlane(box_inside);
+      box_allknown = __builtin_amdgcn_readfirstlane(box_allknown);
+      box_krow4 = __builtin_amdgcn_readfirstlane(box_krow4);
+      box_kconst = __builtin_amdgcn_readfirstlane(box_kconst);
+      if (box_ok) run_sector(i0, i1, box_krow4, box_kconst, box_inside != 0, box_allknown != 0);
       else far_sector(i0, i1);
     }
   }
