@@ -45,7 +45,9 @@
 #define SU_CODE_FULL_ALL 0xFEu   // a non-finite value is in play: every class multiplied like score_polar_kernel does
 #define SU_CODE_PAD 0xFDu        // no such ring: the last group of an image whose ring count is no multiple of the group
 #define SU_NSECT 8               // sectors of directions per known-mask staging (16: 2 % slower on config 2)
-#define SU_BOX_WORDS 3072        // LDS words of the staged known mask (12 KB; 18 KB measured 4 % slower on config 2)
+#define SU_BOX_WORDS 4096        // LDS words of the staged known mask: 16 KB (config 2's dense share 2.97 ms at 12 KB, 2.81 at 16
+                                 // and at 20 KB, 4.18 at 24 KB, where a sixth wave per SIMD no longer fits; a wave that
+                                 // stages a box of its own — the far-apart waves of config 5 — has a quarter of it)
 
 struct SuArgs {
   const uint32_t* crec;    // compact records (narrow form)
