@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400, help="default: a timed region of >= 2 s at configs[1]")
+    ap.add_argument("--steps", type=int, default=500, help="default: a timed region of >= 2 s at configs[1]")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="", help="default: c2 on one GPU, c3 (125 000 particles per GPU) on several")
     ap.add_argument("--particles-per-gpu", type=int, default=0, help="default: the config's particle count (c3, c5: / 8)")
