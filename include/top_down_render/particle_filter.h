@@ -70,16 +70,20 @@ class ParticleFilter {
     }
     if (top_down_scan.empty() || numParticles() == 0) return;
     const int ncls = map_->numClasses();
-    if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("update: fewer scan images than map classes");
+    // Wrong-sized input: the reference's library never throws — its per-scan calls return silently on a size they cannot
+    // use (scan_renderer_polar.cpp:85, top_down_map_polar.cpp:25, particle_filter.cpp:96-99) — and the node's only handler
+    // is main()'s catch-and-exit (top_down_render_node.cpp:8-14).  Same here: nothing is scored, the particle set stays as
+    // it is, and the reason is left in tdr_last_error().
+    if ((int)top_down_scan.size() < ncls) return soft_fail("update: fewer scan images than map classes");
     // tdr_filter_update reads ncls * nb * nr floats, (nb, nr) = the shape given to samplePtsPolar: every image must
     // have exactly that shape (the reference indexes the images with the table's size too, state_particle.cpp:178-188)
     const Eigen::Vector2i shape = map_->polarShape();
     const size_t P = (size_t)shape[0] * shape[1];
     for (int c = 0; c < ncls; c++)
       if (top_down_scan[c].rows() != shape[0] || top_down_scan[c].cols() != shape[1])
-        throw std::invalid_argument("update: scan image " + std::to_string(c) + " is " + std::to_string(top_down_scan[c].rows()) +
-                                    "x" + std::to_string(top_down_scan[c].cols()) + ", samplePtsPolar was given " +
-                                    std::to_string(shape[0]) + "x" + std::to_string(shape[1]));
+        return soft_fail("update: scan image " + std::to_string(c) + " is " + std::to_string(top_down_scan[c].rows()) +
+                         "x" + std::to_string(top_down_scan[c].cols()) + ", samplePtsPolar was given " +
+                         std::to_string(shape[0]) + "x" + std::to_string(shape[1]));
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
     if (geometric_cost_ && top_down_geo.size() >= 2 && (size_t)top_down_geo[0].size() == P && (size_t)top_down_geo[1].size() == P) {
@@ -192,6 +196,11 @@ class ParticleFilter {
     if (n > 0) check(tdr_filter_get_weights(f_, w.data(), n), "weights");
     return w;
   }
+  std::vector<float> rawWeights(int n) {   // StateParticle::weight() of every particle, as scored by the last update
+    std::vector<float> w((size_t)n);
+    if (n > 0) check(tdr_filter_get_raw_weights(f_, w.data(), n), "rawWeights");
+    return w;
+  }
   std::vector<int32_t> resampleIndices() {
     std::vector<int32_t> idx((size_t)tdr_filter_num_local(f_));
     if (!idx.empty()) check(tdr_filter_get_resample_indices(f_, idx.data(), (int64_t)idx.size()), "resampleIndices");
@@ -210,6 +219,8 @@ class ParticleFilter {
     return adaptive_ ? tdr_filter_adaptive_count(f_) : -1;
   }
   void check(int rc, const char* what) { if (rc != TDR_OK) fail(what); }
+  // a per-scan call given something it cannot use: no exception (see update()), the message goes to tdr_last_error()
+  static void soft_fail(const std::string& msg) { tdr_set_error(TDR_ERR_ARG, msg.c_str()); }
   [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + tdr_last_error()); }
 
   int max_num_particles_ = 0;

@@ -44,6 +44,12 @@ class ScanRenderer {
     if (imgs.size() < 1) return;
     const int rows = (int)imgs[0].rows(), cols = (int)imgs[0].cols(), ncls = (int)imgs.size();
     const size_t P = (size_t)rows * cols;
+    // images of different sizes: the reference would write past the smaller ones; a silent return, the reason in tdr_last_error()
+    for (int c = 1; c < ncls; c++)
+      if (imgs[c].rows() != imgs[0].rows() || imgs[c].cols() != imgs[0].cols()) {
+        tdr_set_error(TDR_ERR_ARG, "renderSemanticTopDown: images of different sizes");
+        return;
+      }
     std::vector<float> buf(P * ncls);
     const float* pts = cloud && !cloud->points.empty() ? reinterpret_cast<const float*>(cloud->points.data()) : nullptr;
     const int64_t n = cloud ? (int64_t)cloud->points.size() : 0;

@@ -101,12 +101,13 @@ class StateParticle {
   // :157-219.  top_down_geo is accepted and ignored like in the reference's score (:145-152).
   void computeWeight(std::vector<Eigen::ArrayXXf>& top_down_scan, std::vector<Eigen::ArrayXXf>& /*top_down_geo*/, float res) {
     const int ncls = map_->numClasses();
-    if ((int)top_down_scan.size() < ncls) throw std::invalid_argument("computeWeight: fewer scan images than map classes");
+    // (sizes it cannot use: a silent return like the reference's per-scan calls, the reason in tdr_last_error())
+    if ((int)top_down_scan.size() < ncls) { tdr_set_error(TDR_ERR_ARG, "computeWeight: fewer scan images than map classes"); return; }
     const Eigen::Vector2i shape = map_->polarShape();
     const size_t P = (size_t)shape[0] * shape[1];
     for (int c = 0; c < ncls; c++)
       if (top_down_scan[c].rows() != shape[0] || top_down_scan[c].cols() != shape[1])
-        throw std::invalid_argument("computeWeight: scan image shape differs from the shape given to samplePtsPolar");
+        { tdr_set_error(TDR_ERR_ARG, "computeWeight: scan image shape differs from the shape given to samplePtsPolar"); return; }
     std::vector<float> buf(P * ncls);
     for (int c = 0; c < ncls; c++) std::memcpy(buf.data() + P * c, top_down_scan[c].data(), P * sizeof(float));
     check(tdr_filter_compute_weights(f_, buf.data(), nullptr, res), "computeWeight");

@@ -146,8 +146,13 @@ class TopDownMap {
   void local_map(int polar, const Eigen::Vector2f& center, float scale_or_rot, float res, int rows, int cols,
                  std::vector<Eigen::ArrayXXf>& dists, Eigen::ArrayXXc& mask) {
     const int ncls = params_.num_classes;
-    if ((int)dists.size() < ncls) throw std::invalid_argument("getLocalMap: fewer output arrays than map classes");
+    // sizes the call cannot use: a silent return like the reference's (top_down_map.cpp:431, top_down_map_polar.cpp:25),
+    // the reason in tdr_last_error()
+    if ((int)dists.size() < ncls) { tdr_set_error(TDR_ERR_ARG, "getLocalMap: fewer output arrays than map classes"); return; }
     const size_t P = (size_t)rows * cols;
+    for (int c = 0; c < ncls; c++)
+      if ((size_t)dists[c].rows() * dists[c].cols() != P) { tdr_set_error(TDR_ERR_ARG, "getLocalMap: output arrays of different sizes"); return; }
+    if ((size_t)mask.rows() * mask.cols() != P) { tdr_set_error(TDR_ERR_ARG, "getLocalMap: mask size differs from the windows'"); return; }
     std::vector<float> d(P * ncls);
     std::vector<uint8_t> k(P);
     if (tdr_map_local_map(m_, polar, center[0], center[1], scale_or_rot, res, rows, cols, d.data(), k.data()) != TDR_OK)
@@ -158,6 +163,8 @@ class TopDownMap {
   void local_geo_map(int polar, const Eigen::Vector2f& center, float scale_or_rot, float res, int rows, int cols,
                      std::vector<Eigen::ArrayXXf>& dists) {
     const size_t P = (size_t)rows * cols;
+    for (size_t c = 0; c < dists.size() && c < 2; c++)
+      if ((size_t)dists[c].rows() * dists[c].cols() != P) { tdr_set_error(TDR_ERR_ARG, "getLocalGeoMap: output arrays of different sizes"); return; }
     std::vector<float> d(P * 2);
     if (tdr_map_local_geo_map(m_, polar, center[0], center[1], scale_or_rot, res, rows, cols, d.data()) != TDR_OK)
       throw std::runtime_error(std::string("getLocalGeoMap: ") + tdr_last_error());

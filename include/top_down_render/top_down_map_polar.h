@@ -22,8 +22,11 @@ class TopDownMapPolar : public TopDownMap {
   void getLocalMap(Eigen::Vector2f center, float scale, float res, std::vector<Eigen::ArrayXXf>& dists,
                    Eigen::ArrayXXc& mask) {
     if (dists.size() < 1) return;   // :25
-    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1] || mask.rows() * mask.cols() != dists[0].rows() * dists[0].cols())
-      throw std::invalid_argument("getLocalMap: output arrays do not have the shape given to samplePtsPolar");
+    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1] || mask.rows() * mask.cols() != dists[0].rows() * dists[0].cols()) {
+      // (the reference would index past the arrays here; a silent return, the reason in tdr_last_error())
+      tdr_set_error(TDR_ERR_ARG, "getLocalMap: output arrays do not have the shape given to samplePtsPolar");
+      return;
+    }
     local_map(1, center, scale, res, shape_[0], shape_[1], dists, mask);
   }
   void getLocalMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists, Eigen::ArrayXXc& mask) {
@@ -32,8 +35,10 @@ class TopDownMapPolar : public TopDownMap {
   // :55-76: the polar window gathered from the two geometric layers geo_maps_ (see TopDownMap::getLocalGeoMap)
   void getLocalGeoMap(Eigen::Vector2f center, float scale, float res, std::vector<Eigen::ArrayXXf>& dists) {
     if (dists.size() < 1) return;   // :58
-    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1])
-      throw std::invalid_argument("getLocalGeoMap: output arrays do not have the shape given to samplePtsPolar");
+    if (dists[0].rows() * dists[0].cols() != (Eigen::Index)shape_[0] * shape_[1]) {
+      tdr_set_error(TDR_ERR_ARG, "getLocalGeoMap: output arrays do not have the shape given to samplePtsPolar");
+      return;
+    }
     local_geo_map(1, center, scale, res, shape_[0], shape_[1], dists);
   }
   void getLocalGeoMap(Eigen::Vector2f center, float res, std::vector<Eigen::ArrayXXf>& dists) {

@@ -353,3 +353,75 @@ def adaptive_count(covs2x2, last_num, max_num):
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+# ---- the unpinned overload choices as switches (oracle.cpp, "orc_set_overload_mode"); CPU sensitivity study only ----
+def set_overload_mode(mode):
+    """bit 0: polar raster through the double atan2 / sqrt; bit 1: meanLikelihood through the double cos / sin / atan2."""
+    lib().orc_set_overload_mode(C.c_int(int(mode)))
+
+
+def get_overload_mode():
+    return int(lib().orc_get_overload_mode())
+
+
+# ---- N2: TopDownRender::publishPoseEst (src/top_down_render.cpp:331-365) + the takeStep loop around it --------------
+class NodeState(C.Structure):
+    _fields_ = [("current_range_scale", C.c_float), ("range_scale_min", C.c_float), ("range_scale_max", C.c_float),
+                ("target_uncertainty_m", C.c_float), ("is_converged", C.c_int32)]
+
+
+def filter_scale(fp, scale_frozen, states):
+    lib().orc_filter_scale.restype = C.c_float
+    return float(lib().orc_filter_scale(C.byref(fp), C.c_int(int(scale_frozen)), _p(states), C.c_long(len(states))))
+
+
+class TakeStepLoop:
+    """The node's per-scan sequence on the CPU: takeStep (src/top_down_render.cpp:505-560) = render at
+    current_range_scale_, propagate, update (weights, statistics, resample), then publishPoseEst (:331-365) = range-scale
+    stepping, freeze trigger, convergence gate.  Holds what the node holds; one `step()` per scan."""
+
+    def __init__(self, om, tab_fn, cfg_nb, cfg_nr, ang_res, lut, ncls, fp, states, seed, range_scale_min=0.5,
+                 range_scale_max=4.0, target_uncertainty_m=2.5):
+        self.om, self.nb, self.nr, self.ang_res, self.lut, self.ncls, self.fp = om, cfg_nb, cfg_nr, ang_res, lut, ncls, fp
+        self.tab = tab_fn
+        self.states = states.copy()
+        self.rng = Rng(seed)
+        self.node = NodeState(range_scale_max, range_scale_min, range_scale_max, target_uncertainty_m, 0)   # :47
+        self.scale_frozen = False
+
+    def step(self, pts, tx, ty, omega, force_idx=None):
+        """Returns a dict of the step's intermediate results (raw weights before the resample, ...).  force_idx: resample
+        with these indices instead of the loop's own (a test that keeps two implementations on one particle set; the
+        loop's own indices are still reported)."""
+        res = float(self.node.current_range_scale)
+        scan = raster_polar(pts, res, self.ang_res, self.lut, self.ncls, self.nb, self.nr)              # :539
+        last = propagate(self.states, tx, ty, omega, self.scale_frozen, self.fp, self.rng)              # :423
+        pre = self.states.copy()
+        raw = compute_weights(self.om, self.tab, self.nb, self.nr, scan, res, self.fp, self.states)     # :425
+        w, best, stats = update_weights(raw, last)
+        shift = self.rng.uniform()
+        idx = resample_prefix(w, len(self.states), shift)
+        scored = self.states.copy()    # after computeWeight: theta / have_init of un-initialised particles are set
+        self.states = gather_states(self.states, idx if force_idx is None else np.ascontiguousarray(force_idx, np.int32))
+        out = dict(res=res, scan=scan, pre=pre, last=last, scored=scored, raw=raw, w=w, best=best, shift=shift, idx=idx)
+        out.update(self.publish_pose_est())
+        return out
+
+    def publish_pose_est(self):
+        mean, cov = mean_cov(self.states)                                                               # :333
+        sc = filter_scale(self.fp, self.scale_frozen, self.states)                                      # :335
+        covf = np.ascontiguousarray(cov.reshape(16), np.float32)
+        froze = False
+        freeze = lib().orc_publish_pose_est(C.byref(self.node), _p(covf), C.c_float(sc), C.c_int(len(self.states)),
+                                            C.c_float(float(mean[3])), C.c_int(int(self.scale_frozen)))
+        if len(self.states) >= 1:
+            if freeze:
+                freeze_scale(self.states)                                                               # :359
+                self.scale_frozen = True
+                froze = True
+            sc_now = filter_scale(self.fp, self.scale_frozen, self.states)
+            lib().orc_publish_pose_est_gate(C.byref(self.node), _p(covf), C.c_float(np.float32(sc) * np.float32(sc)),
+                                            C.c_float(sc_now))
+        return dict(mean=mean, cov=cov, range_scale=float(self.node.current_range_scale), froze=froze,
+                    scale_frozen=self.scale_frozen, converged=bool(self.node.is_converged))

@@ -59,6 +59,23 @@ struct orc_map {
   float resolution;
 };
 
+// ---- the unpinned overload choices, as switches (CPU sensitivity study only: tools/overload_sensitivity.py) ----------
+// The reference calls UNQUALIFIED atan2 / sqrt on floats (src/scan_renderer_polar.cpp:32-33, 97-98) and unqualified
+// cos / sin / atan2 in meanLikelihood (src/particle_filter.cpp:198-202).  Which function that is depends on the include
+// graph of its translation units, which is not in this image: with only <cmath> in scope the global names are the C
+// library's double functions — (float)atan2((double)x, (double)y) — while libstdc++'s <math.h> wrapper pulls the float
+// overloads into the global namespace.  Default here (and what the HIP path implements): the float overloads.
+// bit 0: A1 / A3 polar raster through the double functions; bit 1: meanLikelihood through the double functions.
+static int g_overload_mode = 0;
+void orc_set_overload_mode(int mode) { g_overload_mode = mode; }
+int orc_get_overload_mode() { return g_overload_mode; }
+static inline float orc_atan2_raster(float x, float y) {
+  return (g_overload_mode & 1) ? (float)atan2((double)x, (double)y) : atan2f(x, y);
+}
+static inline float orc_hypot_raster(float x, float y) {   // sqrt(pt.x*pt.x + pt.y*pt.y): the argument is a float either way
+  return (g_overload_mode & 1) ? (float)sqrt((double)(x * x + y * y)) : sqrtf(x * x + y * y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // A1  ScanRendererPolar::renderSemanticTopDown   (src/scan_renderer_polar.cpp:83-109)
 // pts: n points, `stride` floats apart, x,y,z at [0..2], class id ("intensity") at [ioff].
@@ -72,8 +89,8 @@ void orc_raster_polar(const float* pts, int stride, int ioff, long n, float res,
     const float* p = pts + (size_t)k * stride;
     float x = p[0], y = p[1];
     if (x == 0 && y == 0) continue;                                // :95
-    float theta = atan2f(x, y);                                    // :97 (argument order x,y)
-    float r = sqrtf(x * x + y * y);                                // :98
+    float theta = orc_atan2_raster(x, y);                          // :97 (argument order x,y)
+    float r = orc_hypot_raster(x, y);                              // :98
     // :100  std::round(float) + int -> float sum, truncated to int
     int theta_ind = (int)(roundf(theta / ang_res) + (float)(nb / 2));
     int r_ind = (int)roundf(r / res);                              // :101
@@ -127,8 +144,8 @@ void orc_raster_geo_polar(const float* pts, int stride, long width, long height,
       const float x = p[0], y = p[1], z = p[2];
       if (x == 0 && y == 0) continue;                              // :30
       if (!std::isfinite(x) || !std::isfinite(y)) continue;
-      const float theta = atan2f(x, y);                            // :32
-      const float r = sqrtf(x * x + y * y);                        // :33
+      const float theta = orc_atan2_raster(x, y);                  // :32
+      const float r = orc_hypot_raster(x, y);                      // :33
       float t = roundf(theta / ang_res) + (float)(nb / 2);         // :36-37 std::clamp<float>(.., 0, rows-1)
       t = t < 0.f ? 0.f : (t > (float)(nb - 1) ? (float)(nb - 1) : t);
       bins[(size_t)(int)t].push_back(P{x, y, z, r});               // :39
@@ -672,11 +689,17 @@ void orc_mean_likelihood(const orc_state* st, long n, float mean[4]) {
     float s[4];
     ml_state(st[p], s);
     for (int k = 0; k < 4; k++) acc[k] += s[k];
-    cos_sum += cosf(s[2]);
-    sin_sum += sinf(s[2]);
+    if (g_overload_mode & 2) {   // float += double: (float)((double)sum + cos((double)theta))
+      cos_sum = (float)((double)cos_sum + cos((double)s[2]));
+      sin_sum = (float)((double)sin_sum + sin((double)s[2]));
+    } else {
+      cos_sum += cosf(s[2]);
+      sin_sum += sinf(s[2]);
+    }
   }
   for (int k = 0; k < 4; k++) mean[k] = acc[k] / (float)n;
-  mean[2] = atan2f(sin_sum / (float)n, cos_sum / (float)n);
+  mean[2] = (g_overload_mode & 2) ? (float)atan2((double)(sin_sum / (float)n), (double)(cos_sum / (float)n))
+                                  : atan2f(sin_sum / (float)n, cos_sum / (float)n);
 }
 
 // A16  ParticleFilter::computeMeanCov / computeCov   (src/particle_filter.cpp:205-236); cov row-major 4x4.
@@ -839,6 +862,44 @@ void orc_active_best_rel_pos(const orc_map* m, const float* tab, int nb, int nr,
   out[0] = best[0];
   out[1] = best[1];
   if (best_diff_out) *best_diff_out = best_diff;
+}
+
+// N2  TopDownRender::publishPoseEst — the per-step control logic   (src/top_down_render.cpp:331-365)
+// The node's own members travel in `orc_node_state`; the filter's answers (computeMeanCov, scale(), numParticles(),
+// meanLikelihood()[3], isScaleFrozen()) are arguments.  Returns bit 0: freezeScale() is to be called now (:356-359).
+// Arithmetic as written there: `current_range_scale_ += 0.05` is float += double; `std::pow(float, int)` and
+// `0.003 * ml_state[3]` are double, the comparisons against them promote the float side.
+struct orc_node_state {
+  float current_range_scale, range_scale_min, range_scale_max, target_uncertainty_m;   // top_down_render.h:78-82
+  int32_t is_converged;                                                                 // :83
+};
+int orc_publish_pose_est(orc_node_state* ns, const float cov[16], float filter_scale, int num_particles, float ml_scale,
+                         int scale_frozen) {
+  const float scale = filter_scale;                                                     // :335
+  const float scale_2 = scale * scale;                                                  // :336
+  const float big = std::max(cov[0], cov[5]) / scale_2;                                 // :337 max(cov(0,0), cov(1,1))/scale_2
+  if ((double)big > std::pow((double)ns->target_uncertainty_m, 2) && ns->current_range_scale < ns->range_scale_max) {
+    ns->current_range_scale = (float)((double)ns->current_range_scale + 0.05);          // :341
+  } else if (ns->current_range_scale > ns->range_scale_min) {
+    ns->current_range_scale = (float)((double)ns->current_range_scale - 0.02);          // :344
+  }
+  if (num_particles < 1) return 0;                                                      // :347-350
+  int freeze = 0;
+  if ((double)cov[15] < 0.003 * (double)ml_scale && !scale_frozen) freeze = 1;          // :356-359 cov(3,3)
+  // :362 reads filter_->scale() AFTER the freeze: frozen -> particles_[0]->state().scale, which the caller passes back in
+  // through orc_publish_pose_est_gate once it has frozen; kept in one function for the common case of a fixed scale
+  return freeze;
+}
+// :362-364, evaluated with the scale the filter reports after a possible freezeScale()
+void orc_publish_pose_est_gate(orc_node_state* ns, const float cov[16], float scale_2_before, float filter_scale_now) {
+  if (cov[0] / scale_2_before < 40 && cov[5] / scale_2_before < 40 && cov[10] < 0.5 && filter_scale_now > 0)
+    ns->is_converged = 1;
+}
+// ParticleFilter::scale()   (src/particle_filter.cpp:359-367)
+float orc_filter_scale(const orc_filter_params* fp, int scale_frozen, const orc_state* st, long n) {
+  if (fp->fixed_scale > 0) return fp->fixed_scale;
+  if (scale_frozen && n > 0) return st[0].scale;
+  return -1;
 }
 
 int orc_max_threads() {

@@ -290,14 +290,41 @@ int main(int argc, char** argv) {
       filter_->visualize(canvas);
       extra[7] -= (float)filter_->numParticles();                // 0.5 left: every particle + a best state arrived
     }
-    {   // update() refuses images that do not have the shape given to samplePtsPolar instead of reading past them
+    {   // Wrong-sized images: the reference's per-scan calls return silently (scan_renderer_polar.cpp:85,
+        // top_down_map_polar.cpp:25, particle_filter.cpp:96-99) and so do these — no exception reaches the node's single
+        // catch-and-exit (top_down_render_node.cpp:8-14), the particle set is untouched, tdr_last_error() says why
       std::vector<Eigen::ArrayXXf> wrong, geo2;
       for (int c = 0; c < ncls; c++) wrong.push_back(Eigen::ArrayXXf(nb, nr + 1));
+      const std::vector<State> st0 = filter_->states();
+      bool threw = false;
       try {
-        filter_->update(wrong, geo2, res);
-      } catch (const std::invalid_argument&) {
-        extra[2] = 1.f;
+        filter_->update(wrong, geo2, res);                               // every image the wrong shape
+        std::string why = tdr_last_error();
+        bool said = why.find("update: scan image") != std::string::npos;
+        std::vector<Eigen::ArrayXXf> few(1, Eigen::ArrayXXf(nb, nr));
+        if (ncls > 1) {
+          filter_->update(few, geo2, res);                               // fewer images than classes
+          why = tdr_last_error();
+          said = said && why.find("fewer scan images") != std::string::npos;
+        }
+        std::vector<Eigen::ArrayXXf> ragged;
+        for (int c = 0; c < ncls; c++) ragged.push_back(Eigen::ArrayXXf(nb, c == ncls - 1 ? nr - 1 : nr));
+        renderer_->renderSemanticTopDown(cloud_ptr, res, ang_res, ragged);   // images of different sizes
+        why = tdr_last_error();
+        said = said && (ncls < 2 || why.find("different sizes") != std::string::npos);
+        std::vector<Eigen::ArrayXXf> win;
+        for (int c = 0; c < ncls; c++) win.push_back(Eigen::ArrayXXf(nb, nr + 2));
+        Eigen::ArrayXXc wmask(nb, nr + 2);
+        map_->getLocalMap(Eigen::Vector2f(60.f, 70.f), 1.f, res, win, wmask);   // not the shape given to samplePtsPolar
+        why = tdr_last_error();
+        said = said && why.find("getLocalMap") != std::string::npos;
+        const std::vector<State> st1 = filter_->states();
+        const bool same = st0.size() == st1.size() && std::memcmp(st0.data(), st1.data(), st0.size() * sizeof(State)) == 0;
+        extra[2] = (said && same) ? 1.f : 0.f;
+      } catch (const std::exception&) {
+        threw = true;
       }
+      if (threw) extra[2] = -1.f;
     }
     {   // renderGeometricTopDown + getLocalGeoMap (dead at the node's call site, part of the surface)
       std::vector<Eigen::ArrayXXf> geo_imgs;

@@ -1,0 +1,234 @@
+"""N2, second half: the node's per-scan control loop — TopDownRender::takeStep + publishPoseEst
+(src/top_down_render.cpp:505-560, 331-365) — through the drop-in classes (include/top_down_render/top_down_render_core.h,
+tests/cpp/facade_loop.cpp) against the oracle's restatement of the same loop (oracle.cpp: orc_publish_pose_est,
+c_oracle.TakeStepLoop).
+
+The point of the test: the node moves `current_range_scale_` on EVERY step (+0.05 while the position covariance is large,
+-0.02 otherwise, :337-345), so one filter is rendered and scored with a different `res` scan after scan — every cached
+product keyed on `res` (sample offsets, ray tables, the span tuner's state) must follow.  16 steps; the scenario passes
+through the oscillation around range_scale_max, the freezeScale trigger (:356-359), the convergence gate (:362-364) and the
+shrinking phase.  PARITY UNPINNED like the rest of the oracle (the reference holds no test of this logic).
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "top_down_renderer_amd")
+STEPS = 16
+MOTION = (0.3, 0.1, 0.005)
+RS_MIN, RS_MAX, TARGET = 0.5, 4.0, 6.5
+SEED = 7
+
+
+def _scenario(n=3072):
+    """A cloud of sigma 9 px about the true pose whose scale is unknown (fixed_scale < 0): most particles near scale 1, 4 %
+    at scale 2.5 scattered around it — while those survive the scale variance keeps freezeScale away; they die out within a
+    few resamples."""
+    from top_down_renderer_amd import synth
+    sc = synth.make_scene("ref", n_particles=16)
+    cfg = sc.cfg
+    rng = np.random.default_rng(3)
+    st = synth.make_particles(cfg, sc.lab, sc.pose, rng, n=n, sigma_px=9.0, sigma_deg=4.0, uniform_frac=0.0)
+    st["scale"] = rng.normal(1.0, 0.015, n).astype(np.float32)
+    no = int(0.04 * n)
+    sel = rng.permutation(n)[:no]
+    st["scale"][sel] = 2.5
+    st["init_x_px"][sel] += rng.normal(0, 60, no).astype(np.float32)
+    st["init_y_px"][sel] += rng.normal(0, 60, no).astype(np.float32)
+    return sc, cfg, st
+
+
+def _oracle_loop(oracle, sc, cfg, st):
+    om = oracle.OracleMap(sc.class_maps, sc.class_mask, cfg.map_resolution)
+    tab = oracle.polar_table(cfg.nb, cfg.nr, cfg.ang_res, cfg.map_resolution)
+    fp = oracle.make_params(cfg.ncls, fixed_scale=-1.0)
+    return oracle.TakeStepLoop(om, tab, cfg.nb, cfg.nr, cfg.ang_res, sc.lut, cfg.ncls, fp, st, seed=SEED,
+                               range_scale_min=RS_MIN, range_scale_max=RS_MAX, target_uncertainty_m=TARGET)
+
+
+def test_publish_pose_est_logic_by_hand(oracle):
+    """orc_publish_pose_est against values worked out from the text of src/top_down_render.cpp:331-365."""
+    L = oracle.lib()
+    f32 = np.float32
+
+    def call(ns, cov, scale, n, ml_scale, frozen):
+        c = np.ascontiguousarray(cov, np.float32).reshape(16)
+        return L.orc_publish_pose_est(C.byref(ns), oracle._p(c), C.c_float(scale), C.c_int(n), C.c_float(ml_scale),
+                                      C.c_int(frozen))
+
+    big = np.zeros((4, 4), np.float32)
+    big[0, 0], big[1, 1], big[3, 3] = 100, 50, 1.0
+    ns = oracle.NodeState(4.0, 0.5, 4.0, 2.5, 0)
+    # cov large but the range scale is AT its maximum: the first condition fails on `< range_scale_max_`, the else-if
+    # shrinks (:342-345) — float member stepped by a double constant
+    assert call(ns, big, 1.0, 10, 1.0, 0) == 0
+    assert f32(ns.current_range_scale) == f32(np.float64(f32(4.0)) - 0.02)
+    prev = f32(ns.current_range_scale)
+    call(ns, big, 1.0, 10, 1.0, 0)              # now below the maximum and the covariance is large: widen (:341)
+    assert f32(ns.current_range_scale) == f32(np.float64(prev) + 0.05)
+    # an unknown scale (-1): scale_2 = 1 (:336); 6.2 < 2.5^2 = 6.25 -> shrink
+    small = np.zeros((4, 4), np.float32)
+    small[0, 0], small[1, 1], small[3, 3] = 6.2, 3.0, 1.0
+    prev = f32(ns.current_range_scale)
+    call(ns, small, -1.0, 10, 1.0, 0)
+    assert f32(ns.current_range_scale) == f32(np.float64(prev) - 0.02)
+    # the same covariance over scale^2 = 0.25 is 24.8 > 6.25 -> widen (below the maximum again after the shrink)
+    ns.current_range_scale = 3.0
+    call(ns, small, 0.5, 10, 1.0, 0)
+    assert f32(ns.current_range_scale) == f32(np.float64(f32(3.0)) + 0.05)
+    # at the minimum and converged: nothing moves
+    ns.current_range_scale = 0.5
+    call(ns, small * 0, 1.0, 10, 1.0, 0)
+    assert f32(ns.current_range_scale) == f32(0.5)
+    # freeze trigger (:356): cov(3,3) < 0.003 * ml_state[3], only while not frozen, only with particles (:347)
+    tight = np.zeros((4, 4), np.float32)
+    tight[3, 3] = 0.0029
+    assert call(ns, tight, -1.0, 10, 1.0, 0) == 1
+    assert call(ns, tight, -1.0, 10, 1.0, 1) == 0
+    assert call(ns, tight, -1.0, 0, 1.0, 0) == 0
+    tight[3, 3] = 0.0031
+    assert call(ns, tight, -1.0, 10, 1.0, 0) == 0
+    assert call(ns, tight, -1.0, 10, 1.1, 0) == 1          # 0.0031 < 0.0033
+    # convergence gate (:363): all four conditions, the scale read after a possible freeze
+    gate = np.zeros((4, 4), np.float32)
+    gate[0, 0], gate[1, 1], gate[2, 2] = 39.0, 39.0, 0.4
+
+    def gate_call(cov, s2, scale_now):
+        n2 = oracle.NodeState(4.0, 0.5, 4.0, 2.5, 0)
+        c = np.ascontiguousarray(cov, np.float32).reshape(16)
+        L.orc_publish_pose_est_gate(C.byref(n2), oracle._p(c), C.c_float(s2), C.c_float(scale_now))
+        return n2.is_converged
+
+    assert gate_call(gate, 1.0, 1.0) == 1
+    assert gate_call(gate, 1.0, -1.0) == 0                 # scale unknown and not frozen
+    g2 = gate.copy(); g2[2, 2] = 0.5
+    assert gate_call(g2, 1.0, 1.0) == 0                    # cov(2,2) < 0.5 is strict
+    g3 = gate.copy(); g3[1, 1] = 41.0
+    assert gate_call(g3, 1.0, 1.0) == 0
+    assert gate_call(g3, 4.0, 2.0) == 1                    # 41 / 4 < 40
+
+
+def test_oracle_loop_passes_through_every_phase(oracle):
+    """The scenario the GPU test replays, on the oracle alone: `res` differs on every step, the scale freezes after the
+    first steps, the convergence gate opens later, the range scale then shrinks."""
+    sc, cfg, st = _scenario()
+    loop = _oracle_loop(oracle, sc, cfg, st)
+    res, froze, conv = [], [], []
+    for k in range(STEPS):
+        r = loop.step(sc.pts, *MOTION)
+        res.append(r["res"])
+        froze.append(r["froze"])
+        conv.append(r["converged"])
+    assert all(a != b for a, b in zip(res, res[1:]))
+    assert sum(froze) == 1 and 2 <= froze.index(True) < STEPS - 4
+    assert conv[-1] and not conv[froze.index(True)]        # converges later than it freezes
+    assert res[-1] < res[-2] < res[-3] < res[-4]           # the shrinking phase
+    assert max(res) > RS_MAX                               # ... after the oscillation around the maximum (4.03, 4.04)
+
+
+@pytest.fixture(scope="module")
+def loop_exe():
+    from top_down_renderer_amd import build
+    build.build()
+    exe = os.path.join(tempfile.mkdtemp(prefix="tdr_facade_"), "facade_loop")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "facade_loop.cpp"), "-o", exe, "-L", PKG, "-ltdr_hip",
+                    f"-Wl,-rpath,{PKG}"], check=True)
+    return exe
+
+
+def write_inputs(d, sc, cfg, st, steps, device_scan, fixed_scale=-1.0, clouds=None):
+    clouds = [sc.pts] if clouds is None else clouds
+    open(os.path.join(d, "meta.txt"), "w").write(
+        f"{cfg.ncls} {cfg.map_size} {cfg.map_size} {cfg.nb} {cfg.nr} {len(clouds[0])} {len(clouds)} {len(st)} {SEED} {steps} "
+        f"{RS_MIN} {RS_MAX} {TARGET} {fixed_scale} {cfg.map_resolution} {device_scan}\n")
+    np.ascontiguousarray(np.transpose(sc.class_maps, (0, 2, 1)), np.float32).tofile(os.path.join(d, "maps.bin"))
+    np.ascontiguousarray(sc.class_mask.T, np.uint8).tofile(os.path.join(d, "mask.bin"))
+    pcl = np.zeros((len(clouds), len(clouds[0]), 8), np.float32)
+    for k, p in enumerate(clouds):
+        pcl[k, :, :3] = p[:, :3]
+        pcl[k, :, 4] = p[:, 3]
+    pcl.tofile(os.path.join(d, "pts.bin"))
+    st.tofile(os.path.join(d, "states.bin"))
+    np.tile(np.asarray(MOTION, np.float32), (steps, 1)).tofile(os.path.join(d, "motion.bin"))
+
+
+def test_loop_program_compiles_and_fails_loudly_without_gpu(loop_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from top_down_renderer_amd import synth
+    sc = synth.make_scene("micro")
+    d = tempfile.mkdtemp()
+    write_inputs(d, sc, sc.cfg, sc.states, 2, 0)
+    r = subprocess.run([loop_exe, d], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_scan", [0, 1])
+def test_take_step_loop_with_a_moving_range_scale_matches_oracle(loop_exe, oracle, device_scan):
+    sc, cfg, st = _scenario()
+    n = len(st)
+    d = tempfile.mkdtemp(prefix="tdr_loop_")
+    write_inputs(d, sc, cfg, st, STEPS, device_scan)
+    r = subprocess.run([loop_exe, d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(os.path.join(d, "out_raw.bin"), np.float32).reshape(STEPS, n)
+    idx = np.fromfile(os.path.join(d, "out_idx.bin"), np.int32).reshape(STEPS, n)
+    states = np.fromfile(os.path.join(d, "out_states.bin"), oracle.STATE_DTYPE).reshape(STEPS, n)
+    est = np.fromfile(os.path.join(d, "out_est.bin"), np.float32).reshape(STEPS, 26)
+
+    loop = _oracle_loop(oracle, sc, cfg, st)
+    fields = ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale")
+    res_seen, froze_at, conv_at, mism_total = [], None, None, 0
+    for k in range(STEPS):
+        # the oracle steps from the SAME particle set (its resample follows the device's indices), with its own generator,
+        # its own range scale and its own flags: nothing of the device's control state is handed over
+        o = loop.step(sc.pts, *MOTION, force_idx=idx[k])
+        assert np.float32(o["res"]) == est[k, 0], f"step {k}: rendered at res {est[k, 0]}, the oracle at {o['res']}"
+        res_seen.append(float(est[k, 0]))
+        # per-step raw weights (the scoring at THIS step's res), NaN pattern, 1e-5
+        assert np.array_equal(np.isnan(raw[k]), np.isnan(o["raw"])), f"step {k}: NaN pattern"
+        ok = ~np.isnan(o["raw"])
+        err = float(np.max(np.abs(raw[k][ok] - o["raw"][ok]) / np.abs(o["raw"][ok])))
+        assert err < 1e-5, f"step {k}: raw weights off by {err:.2e} at res {o['res']}"
+        # resample: the oracle's statistics + prefix on the DEVICE's raw weights give the device's indices
+        w_o, _, _ = oracle.update_weights(raw[k], o["last"])
+        idx_o = oracle.resample_prefix(w_o, n, o["shift"])
+        mism = int((idx_o != idx[k]).sum())
+        mism_total += mism
+        assert mism <= 2 + n // 200, f"step {k}: {mism} resample indices differ"
+        # the particle set after the step: the propagated, scored states gathered by the device's indices, bit for bit
+        # (a freeze replaces the scale by the geometric mean: 1e-6)
+        want = loop.states
+        for name in fields:
+            if name == "scale" and o["froze"]:
+                assert np.allclose(states[k][name], want[name], rtol=2e-6), f"step {k}: frozen scale"
+            else:
+                assert np.array_equal(states[k][name], want[name]), f"step {k}: {name}"
+        # publishPoseEst: range-scale trajectory, freeze step, convergence step — identical
+        assert np.float32(o["range_scale"]) == est[k, 1], f"step {k}: range scale {est[k, 1]} vs {o['range_scale']}"
+        assert bool(est[k, 2]) == o["froze"], f"step {k}: freeze trigger (cov33 {o['cov'][3, 3]:.6f}, scale {o['mean'][3]:.4f})"
+        assert bool(est[k, 3]) == o["converged"], f"step {k}: convergence gate"
+        assert bool(est[k, 5]) == o["scale_frozen"]
+        assert np.allclose(est[k, 6:22].reshape(4, 4), o["cov"], rtol=2e-4, atol=2e-4), f"step {k}: covariance"
+        assert np.allclose(est[k, 22:26], o["mean"], rtol=2e-5, atol=2e-5), f"step {k}: mean state"
+        if o["froze"]:
+            froze_at = k
+            # after the freeze every particle carries the geometric mean (:343-357): copy it over so that both sides keep
+            # stepping from identical bits (the device's pow / product order differs in the last ulp)
+            loop.states["scale"] = states[k]["scale"]
+        if o["converged"] and conv_at is None:
+            conv_at = k
+    assert all(a != b for a, b in zip(res_seen, res_seen[1:])), "res must differ on every step"
+    assert froze_at is not None and froze_at >= 2 and conv_at is not None and conv_at > froze_at
+    assert res_seen[-1] < res_seen[-2] < res_seen[-3]
+    print(f"loop ok: res {res_seen[0]:.2f} .. {min(res_seen):.2f}/{max(res_seen):.2f}, froze at {froze_at}, converged at {conv_at}, "
+          f"{mism_total} resample indices differed over {STEPS} steps")
+
