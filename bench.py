@@ -22,23 +22,28 @@ events on its launch stream; a polar launch runs two kernels, the events span bo
   * `traffic` = read bytes per launch the L2s request from the fabric, measured with rocprofv3 --pmc
     TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum in a pass of its own over this same command (tools/traffic_from_pmc.py ->
     profiles/score_traffic.json) and REPLAYED here — `traffic_source` says so and carries the record's source hash; when
-    the kernel sources or the launch shape differ from the record's, `traffic` and `issue` are null.  Hits in the Infinity
-    Cache are among the requests: an upper bound on what HBM delivers.
-  * `achieved` / `frac` = ALGORITHMIC bytes per launch / launch duration (/ peak), the algorithmic bytes being
-    `sparse_algorithmic` = the bytes the launch cannot do without, from THIS run's scan: per particle one mask byte per
-    window sample (the known-fraction gate reads every sample) + 4 bytes per non-empty scan bin (one dictionary value);
-    `traffic_over_sparse` = what the counters saw of it (below 1: particles that share window cells share the lines);
-  * `traffic_GBps` / `traffic_frac` = the counters' bytes over the same duration (/ peak);
+    the kernel sources or the launch shape differ from the record's, `traffic`, `achieved`, `frac` and `issue` are null.
+    Hits in the Infinity Cache are among the requests: an upper bound on what HBM delivers.
+  * `achieved` / `frac` = those COUNTER bytes per launch / the launch duration measured in this run (/ peak): the fraction of
+    the HBM roofline the launch really uses.  (The scoring launches are not HBM-bound: `bound` names the unit that is.)
+  * `bound_unit_frac` = how far the binding unit is from ITS floor, for launches bound by the L1 address path: vector-memory
+    wave-instructions of the launch (SQ_INSTS_VMEM_RD, a fourth counter pass) x 16 cycles — what a 64-lane gather costs the
+    address path at best (tools/ta_cost.hip) — over the CU-cycles of the launch (256 CUs x its cycles).  1.0 = every
+    address-path cycle of every CU spent on gathers that touch four lines or fewer.
   * `issue` = {valu_busy, lds_busy, l1_addr_busy, insts_per_sample} from two more counter passes (valu_busy counts four
     cycles per vector instruction — an upper bound, see tools/valu_cost.hip —, l1_addr_busy = TA_BUSY_avr over the kernels'
-    cycles: the texture addressers, what a gather's cache lines cost); `bound` = the busiest of {hbm: `traffic_frac`, valu,
+    cycles: the texture addressers, what a gather's cache lines cost); `bound` = the busiest of {hbm: `frac`, valu,
     lds, l1_addr};
   * `shares` = the launch's two kernels timed on their own (one extra launch behind the timed region, on the particle set
     every timed step starts from, before propagate): shift-uniform kernel over the dense particles, ray-mapped kernel over the
     scattered ones, particles in each;
   * `dense_work_rate` = the dense byte model of SURVEY.md §8(d) (B_pu = P*(4*ncls+1) + 64 per particle-update) over the
     same duration.  The launch does not move those bytes (compact records, empty bins skipped, shared lines): a WORK rate,
-    not a roofline figure — `x_hbm_peak` above 1 says exactly that.
+    not a roofline figure — `x_hbm_peak` above 1 says exactly that;
+  * `sparse_algorithmic` = a second work rate: the bytes a launch that shares nothing between particles could not do without,
+    from THIS run's scan — per particle one mask BIT per window sample (the known-fraction gate reads every sample) + 2 bytes
+    per non-empty scan bin (the class plane's cell); `traffic_over_sparse` = what the counters saw of it;
+  * `tuner` = the span tuner's state: the span in use and how many of the timed launches ran at a trial span.
 `cpu_baseline` times the CPU oracle (oracle/oracle.cpp, OpenMP over particles like the reference's parallel for_each)
 on a bounded sample of the same workload on this host's cores.
 """
@@ -66,6 +71,7 @@ def parse():
     ap.add_argument("--device-rng", action="store_true",
                     help="time the steps with the counter-based device noise instead of the reference's std::mt19937 stream "
                          "(default: the reference's stream, reproduced on the device; the other figure is reported beside it)")
+    ap.add_argument("--tuning", default="", help="name=value[,name=value...] for tdr_config_tuning (A/B measurements)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
@@ -237,6 +243,10 @@ def main():
     from top_down_renderer_amd.kernels import HipKernels
 
     k = HipKernels()
+    for kv in filter(None, a.tuning.split(",")):
+        name, _, val = kv.partition("=")
+        if k.lib.tdr_config_tuning(name.encode(), int(val)) < 0:
+            raise SystemExit(f"--tuning: unknown knob {name!r}")
     cfg = synth.CONFIGS[a.config or ("c2" if world == 1 else "c3")]
     # configs 3 and 5 name a total over 8 GPUs: every GPU holds an eighth of it, whatever N is (weak scaling)
     per_gpu = a.particles_per_gpu or (cfg.n_particles // 8 if cfg.name in ("c3", "c5") else cfg.n_particles)
@@ -314,11 +324,13 @@ def main():
     barrier()
     import ctypes as C
     k.lib.tdr_profile_enable(1)
+    trials0 = f.score_ctx.trial_calls() if cfg.polar else 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    trials_timed = (f.score_ctx.trial_calls() - trials0) if cfg.polar else 0
     tot_ms, launches = C.c_double(0), C.c_int64(0)
     k.lib.tdr_profile_score_ms(C.byref(tot_ms), C.byref(launches))
     k.lib.tdr_profile_enable(0)
@@ -366,37 +378,39 @@ def main():
             kname = "score_polar"   # score_polar_su_kernel + score_polar_ray_kernel (the integer form), or score_polar_kernel (the float form)
         n_local = per_gpu
         avg_ms = tot_ms.value / max(1, launches.value)
-        achieved = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        alg_gbps = achieved
-        traffic, issue, traffic_note = measured_traffic(cfg.name, kname, n_local)
-        traffic_gbps = traffic / (avg_ms * 1e-3) / 1e9 if traffic is not None and avg_ms > 0 else None
-        # the unit the launch keeps busiest: memory system (fraction of the HBM peak), vector issue or the LDS arrays
-        util = {"hbm": traffic_gbps / 8000.0 if traffic_gbps is not None else 0.0}
-        if issue:
-            issue = {"valu_busy": issue.get("valu_busy"), "lds_busy": issue.get("lds_busy"),
-                     "l1_addr_busy": issue.get("l1_addr_busy"),
-                     "insts_per_sample": issue.get("insts_per_sample"),
-                     "how": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE, and "
-                            "--pmc TA_BUSY_avr, over this command (tools/traffic_from_pmc.py): issue cycles of the vector "
+        alg_gbps = (b_pu * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, issue_rec, traffic_note = measured_traffic(cfg.name, kname, n_local)
+        # ONE roofline fraction: what the counters saw the launch request from the fabric, over the duration measured here
+        achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic is not None and avg_ms > 0 else None
+        frac = achieved / 8000.0 if achieved is not None else None
+        # the unit the launch keeps busiest: memory system (fraction of the HBM peak), vector issue, the LDS arrays, the L1 address path
+        util = {"hbm": frac or 0.0}
+        issue, bound_unit_frac = None, None
+        if issue_rec:
+            issue = {"valu_busy": issue_rec.get("valu_busy"), "lds_busy": issue_rec.get("lds_busy"),
+                     "l1_addr_busy": issue_rec.get("l1_addr_busy"),
+                     "insts_per_sample": issue_rec.get("insts_per_sample"),
+                     "vmem_rd_insts_per_launch": issue_rec.get("vmem_rd_insts"), "cycles_per_launch": issue_rec.get("cycles"),
+                     "how": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE, --pmc "
+                            "TA_BUSY_avr and --pmc SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE over this command "
+                            "(tools/traffic_from_pmc.py): issue cycles of the vector "
                             "units at four per instruction (an upper bound: tools/valu_cost.hip measures 2.4 - 4.2) / cycles "
                             "of the LDS arrays / busy cycles of the texture addressers (the L1 address path) over the "
                             "kernels' cycles, vector instructions per wave per window sample"}
-            # (valu_busy counts four cycles per vector instruction; tools/valu_cost.hip measures 2.4 for plain VOP2 and 4.2 for
-            # VOP3 / packed / conversions on this device — the figure is an upper bound on what the vector units are busy)
             util["valu"] = issue["valu_busy"] or 0.0
             util["lds"] = issue["lds_busy"] or 0.0
             util["l1_addr"] = issue["l1_addr_busy"] or 0.0
+            bound_unit_frac = issue_rec.get("bound_unit_frac")
         bound = max(util, key=util.get)
-        # bytes the launch cannot do without, from this run's scan
+        # a work rate beside the dense one: bytes a launch that shares nothing between particles could not do without
         nnz = int((r.last_images().sum(dim=0) > 0).sum().item())
-        sparse_bytes = n_local * (P + 4 * nnz)
-        achieved = sparse_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        basis = ("algorithmic: per particle one mask byte per window sample + 4 bytes per non-empty scan bin "
-                 "(`sparse_algorithmic`), over the launch duration measured in this run")
+        sparse_bytes = n_local * (P // 8 + 2 * nnz)
         sparse = {"bytes_per_launch": sparse_bytes, "nonempty_bins": nnz, "bins": P,
                   "GBps": sparse_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
-                  "frac": sparse_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0 if avg_ms > 0 else None,
-                  "traffic_over_sparse": traffic / sparse_bytes if traffic is not None else None}
+                  "x_hbm_peak": sparse_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0 if avg_ms > 0 else None,
+                  "traffic_over_sparse": traffic / sparse_bytes if traffic is not None else None,
+                  "what": "per particle one mask bit per window sample + 2 bytes (a class-plane cell) per non-empty scan "
+                          "bin, nothing shared between particles: a work rate, not bytes moved"}
         out = {
             "metric": "particle-updates/sec (render+score+resample)",
             "value": n_global * a.steps / dt,
@@ -418,23 +432,28 @@ def main():
                                                  if cfg.have_init else "8 Gaussian clusters (40 px) on road cells"),
                        "locality_every": a.locality_every, "parallelism": f"particles sharded over {world} GPU(s)"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "basis": basis,
-                         "traffic_GBps": traffic_gbps, "traffic_frac": traffic_gbps / 8000.0 if traffic_gbps is not None else None,
+                         "unit": "GB/s", "frac": frac, "traffic": traffic,
+                         "basis": "counter traffic: bytes the L2s request from the fabric per launch (TCC_EA0_RDREQ, a counter "
+                                  "pass of its own over this command) over the launch duration measured in this run",
+                         "bound_unit_frac": bound_unit_frac,
+                         "bound_unit_frac_is": "vector-memory wave-instructions per launch x 16 address-path cycles (the floor "
+                                               "of a 64-lane gather) / (256 CUs x the launch's cycles)",
                          "traffic_source": (f"replayed from profiles/score_traffic.json (kernel sources {kernel_source_hash()}): "
                                             + traffic_note) if traffic is not None else "none (" + traffic_note + ")",
                          "sparse_algorithmic": sparse, "shares": shares,
                          "traffic_is": "read requests the L2s send to the fabric (TCC_EA0_RDREQ), Infinity-Cache hits "
                                        "included: an upper bound on the bytes HBM itself delivers",
                          "issue": issue,
-                         "note": "`achieved`, `peak`, `frac` price the launch's algorithmic bytes against the HBM roofline "
-                                 "whatever `bound` says; `bound` names the unit the launch keeps busiest (hbm = "
-                                 "`traffic_frac`, valu / lds / l1_addr = `issue`).  "
+                         "note": "`achieved`, `peak`, `frac` price the launch's counter traffic against the HBM roofline "
+                                 "whatever `bound` says; `bound` names the unit the launch keeps busiest (hbm = `frac`, "
+                                 "valu / lds / l1_addr = `issue`).  "
                                  "A polar launch runs two kernels one after the other — score_polar_su_kernel for the dense "
                                  "particles, score_polar_ray_kernel for the scattered ones, both bound by the L1 address path "
                                  "(cache lines per gather) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          # polar configs: the dense / scattered split of the mixed launch this filter's tuner settled on
-                         "shift_uniform_span_cells": f.score_ctx.span() if cfg.polar else None,
+                         "tuner": ({"span_cells": f.score_ctx.span(), "trials_in_timed_region": trials_timed,
+                                    "timed_launches": launches.value} if cfg.polar else None),
                          "dense_work_rate": {"bytes_per_launch": b_pu * n_local, "GBps": alg_gbps,
                                              "x_hbm_peak": alg_gbps / 8000.0,
                                              "what": "SURVEY 8(d) dense byte model over the launch duration: a work rate, "

@@ -240,6 +240,8 @@ typedef struct tdr_score_ctx tdr_score_ctx;
 int tdr_score_ctx_create(tdr_score_ctx** out);
 void tdr_score_ctx_destroy(tdr_score_ctx* ctx);
 float tdr_score_ctx_span(const tdr_score_ctx* ctx);
+/* launches of this context that ran at a TRIAL span so far (a benchmark reports how many fell into its timed region) */
+int64_t tdr_score_ctx_trial_calls(const tdr_score_ctx* ctx);
 /* fac_dev: device copy of tdr_polar_factors_host's output for the (nb, nr) table the context's calls score with; the
  * caller's memory, alive until replaced (NULL: none).  Calls with another shape ignore it. */
 int tdr_score_ctx_set_polar_factors(tdr_score_ctx* ctx, const float* fac_dev, int nb, int nr);
@@ -418,7 +420,7 @@ int tdr_k_shift_init(float* st, int64_t cap, int64_t n, float dx, float dy, void
 
 /* The scoring kernels read the compact records whenever the map has them (tdr_k_compact_map); tdr_config_compact(0)
  * forces the dense records (A/B measurements, tests), 1 restores the default, < 0 only queries.  Results never depend on
- * it: both forms decode to the same operands.  Returns the value in force.  (Environment: TDR_COMPACT=0.) */
+ * it: both forms decode to the same operands.  Returns the value in force. */
 int tdr_config_compact(int on);
 /* Large polar launches take the INTEGER form of the score.  A scan count is an integer and a distance value of the map
  * an integer multiple of 2^-q (tdr_cmap_words_total above), so a class's product sum is accumulated as a 64-bit integer:
@@ -478,21 +480,18 @@ int tdr_profile_score_ms(double* total_ms, int64_t* launches);
  * process-wide like the switch itself: one measuring thread. */
 int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles);
 
-/* Environment variables (read once, when the library first needs them; each mirrors a tdr_config_* call where one exists;
- * A/B measurements and debugging only — results never depend on them unless stated):
- *   TDR_SHIFT_UNIFORM  initial tdr_config_shift_uniform mode          TDR_SU_SPAN     fixes tdr_config_shift_uniform_span
- *   TDR_COMPACT        initial tdr_config_compact                     TDR_CART_SKIP   initial tdr_config_cart_skip
- *   TDR_INIT_MFMA      initial tdr_config_init_mfma                   TDR_INIT_HALF   0: never use tdr_map_desc.rec16
- *   TDR_INIT_AHEAD     record loads in flight in the init search (1-3)
- *   TDR_PFX_SMALL      initial tdr_config_prefix_small                TDR_UW_WAVES    initial tdr_config_uw_waves
- *   TDR_PFX_HEAD       0: the long chains walk from the first addend (no one-workgroup head)
- *   TDR_SCORE_WAVES    waves the float scoring kernel aims for        TDR_SCORE_GROUP rings per workgroup of the float /
- *                      shift-uniform kernels (changes the partition of the FLOAT kernel's sums: its results move in the
- *                      last bits)
- *   TDR_SU_GROUP       rings per workgroup of the shift-uniform kernel alone (a multiple of 4; integer sums: same bits)
- *   TDR_RAY_BM         0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
- *                      holds the table's factors (same bits)
- *   TDR_RAY_SPLIT      initial tdr_config_ray_split */
+/* The library reads NOTHING from the process environment: behaviour switches are these calls (and the tdr_config_* calls
+ * above), process-wide, meant for A/B measurements, tests and debugging — results never depend on them unless stated.
+ * tdr_config_tuning(name, value): value < 0 queries; returns the value in force, -1 for an unknown name.
+ *   "score_waves"      waves the float / Cartesian scoring kernels aim for (default 131072)
+ *   "score_group"      rings per workgroup of the float and shift-uniform kernels, 0 = from the shapes (changes the
+ *                      partition of the FLOAT kernel's sums: its results move in the last bits)
+ *   "su_group"         rings per workgroup of the shift-uniform kernel alone (a multiple of 4; integer sums: same bits)
+ *   "init_ahead"       record loads in flight in the init search (1-3)
+ *   "prefix_head"      leading addends the long running sum's walk adds one by one
+ *   "ray_block_major"  0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
+ *                      holds the table's factors (same bits) */
+int64_t tdr_config_tuning(const char* name, int64_t value);
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
 /* sinf / cosf on the device are the HOST libm's, bit for bit (csrc/tdr_sincosf.h: glibc >= 2.28's double-precision

@@ -87,8 +87,9 @@ def _worker(rank, world, port, tmp, six_classes):
     import torch.distributed as dist
     if six_classes == "cart":
         # few window chunks, so that their number depends on the particle count: a shard must still split the window
-        # like the whole filter does (tdr_k_score_cart's n_total).  Read once per process by the library.
-        os.environ["TDR_SCORE_WAVES"] = "256"
+        # like the whole filter does (tdr_k_score_cart's n_total).
+        from top_down_renderer_amd import _lib
+        _lib.load().tdr_config_tuning(b"score_waves", 256)
     if world == 1:
         _run(None, os.path.join(tmp, "single.npz"), six_classes)
         return

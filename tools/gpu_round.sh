@@ -22,6 +22,7 @@ for C in $CONFIGS; do
   rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc_$C/traffic -o pmc --output-format csv -- python3 bench.py --config $C --steps $PSTEPS --warmup 1 --no-cpu > $OUT/pmc_$C.log 2>&1 || { echo "pmc $C failed"; tail -5 $OUT/pmc_$C.log; }
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_$C/issue -o pmc --output-format csv -- python3 bench.py --config $C --steps $PSTEPS --warmup 1 --no-cpu > $OUT/pmc_issue_$C.log 2>&1 || { echo "pmc issue $C failed"; tail -5 $OUT/pmc_issue_$C.log; }
   rocprofv3 --pmc TA_BUSY_avr -d $OUT/pmc_$C/ta -o pmc --output-format csv -- python3 bench.py --config $C --steps $PSTEPS --warmup 1 --no-cpu > $OUT/pmc_ta_$C.log 2>&1 || { echo "pmc ta $C failed"; tail -5 $OUT/pmc_ta_$C.log; }
+  rocprofv3 --pmc SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $OUT/pmc_$C/vmem -o pmc --output-format csv -- python3 bench.py --config $C --steps $PSTEPS --warmup 1 --no-cpu > $OUT/pmc_vmem_$C.log 2>&1 || { echo "pmc vmem $C failed"; tail -5 $OUT/pmc_vmem_$C.log; }
   python3 tools/traffic_from_pmc.py $C $K $N $OUT/pmc_$C $OUT/pmc_${C}_summary.txt || echo "no traffic record for $C"
   cp profiles/score_traffic.json $OUT/score_traffic.json
   CPU=""

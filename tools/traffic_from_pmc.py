@@ -10,7 +10,9 @@ Read bytes per launch = RDREQ_128B x 128 + (RDREQ - RDREQ_128B) x 64 (MI355X_MIC
 memory-side request counters; FETCH_SIZE tallies the 128-byte requests at 64 bytes on gfx950, so it is not used).  These
 are the requests the L2s send to the fabric: what the Infinity Cache serves is among them.  A second pass
 (SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE) gives the issue figures bench.py reports beside
-the traffic, a third (TA_BUSY_avr alone) how busy the L1 address path is.  Counters are summed over the XCDs per dispatch and over all dispatches of the scoring kernels, and divided by the number
+the traffic, a third (TA_BUSY_avr alone) how busy the L1 address path is, a fourth (SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE) the
+vector-memory wave-instructions: x 16 address-path cycles each (the floor of a 64-lane gather, tools/ta_cost.hip) over the
+CU-cycles of the launch = `bound_unit_frac`, how far the L1 address path is from its own floor.  Counters are summed over the XCDs per dispatch and over all dispatches of the scoring kernels, and divided by the number
 of scoring launches.  The record stores a hash of the kernel sources: bench.py ignores it once they change.
 """
 import csv
@@ -32,10 +34,15 @@ def main():
     # (pass, kernel, dispatch) -> counter -> value summed over the XCDs / shader engines
     per = defaultdict(lambda: defaultdict(float))
     for f in files:
+        # (GRBM_GUI_ACTIVE is collected by two passes: the fourth pass's copy gets a name of its own)
+        vm_pass = os.sep + "vmem" + os.sep in f
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if pat in row["Kernel_Name"]:
-                    per[(f, row["Kernel_Name"].split("(")[0], row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
+                    cn = row["Counter_Name"]
+                    if vm_pass and cn == "GRBM_GUI_ACTIVE":
+                        cn = "GRBM_GUI_ACTIVE_vmem_pass"
+                    per[(f, row["Kernel_Name"].split("(")[0], row["Dispatch_Id"])][cn] += float(row["Counter_Value"])
     if not per:
         raise SystemExit(f"no dispatch of {pat} in {files}")
     # mean per dispatch of every kernel, then the kernels of one scoring launch added up (a mixed launch runs two)
@@ -70,6 +77,12 @@ def main():
                  # over the CUs, against the kernels' cycles
                  "l1_addr_busy": (launch["TA_BUSY_avr"] / cycles) if "TA_BUSY_avr" in launch else None,
                  "cycles": cycles, "wave_samples": wave_samples}
+        if "SQ_INSTS_VMEM_RD" in launch:
+            # vector-memory READ wave-instructions (gathers) of a launch; the same pass's own cycle count where it has one
+            vcyc = launch.get("GRBM_GUI_ACTIVE_vmem_pass", 0.0) / 8.0 or cycles
+            issue["vmem_rd_insts"] = launch["SQ_INSTS_VMEM_RD"]
+            issue["bound_unit_frac"] = launch["SQ_INSTS_VMEM_RD"] * 16.0 / (256.0 * vcyc)
+            issue["vmem_per_sample"] = launch["SQ_INSTS_VMEM_RD"] / wave_samples
     path = os.path.join(ROOT, "profiles", "score_traffic.json")
     try:
         rec = json.load(open(path))
@@ -97,6 +110,9 @@ def main():
         if issue:
             fh.write(f"issue: vector units busy {issue['valu_busy']:.3f} (four cycles per instruction), LDS busy {issue['lds_busy']}, "
                      f"L1 address path busy {issue['l1_addr_busy']}, vector instructions per wave-sample {issue['insts_per_sample']}\n")
+            if "bound_unit_frac" in issue:
+                fh.write(f"vector-memory read wave-instructions per launch {issue['vmem_rd_insts']:.6g} ({issue['vmem_per_sample']:.3f} per "
+                         f"wave-sample) x 16 cycles / (256 CUs x {issue['cycles']:.6g} cycles) = bound_unit_frac {issue['bound_unit_frac']:.3f}\n")
     print(open(summary).read())
 
 

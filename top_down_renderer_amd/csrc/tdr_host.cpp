@@ -126,6 +126,12 @@ struct tdr_filter {
   std::vector<float> gmm_means, gmm_covs;
   DevBuf<float> ml_dev;  // fields + mlState of the max-likelihood particle of the last update (tdr_k_save_ml_state)
   bool have_ml = false;
+  // meanLikelihood + computeMeanCov of the CURRENT particle set, as last read back: publishPoseEst asks for both in a row
+  // (src/top_down_render.cpp:333, 354), which is one kernel and one read-back here.  Everything that changes the set
+  // clears the flag (states_changed).
+  float mean_cov_host[24] = {0};
+  bool mean_cov_valid = false;
+  void states_changed() { mean_cov_valid = false; }
   hipStream_t stream = nullptr;
   tdr_score_ctx* score_ctx = nullptr;   // this filter's own span tuner (and the table's factors) for its scoring launches (tdr.h)
   // The reference's generator in parity mode: the host std::mt19937 `rng` and its continuation on the device, a
@@ -789,6 +795,7 @@ int tdr_filter_set_states(tdr_filter* f, const tdr_state* states, int64_t n) {
     HTRY(hipDeviceSynchronize());
   }
   f->n = n;
+  f->states_changed();
   f->maybe_uninit = false;
   for (int64_t i = 0; i < n; i++) f->maybe_uninit |= states[i].have_init == 0;
   if (f->fp.fixed_scale > 0) f->scale_frozen = true;
@@ -853,6 +860,7 @@ static bool rng_device_capable(const tdr_filter* f) { return f->rng_owned && f->
 // ParticleFilter::propagate (particle_filter.cpp:86-92)
 static int filter_propagate(tdr_filter* f, float tx, float ty, float omega, bool scale_freeze) {
   if (f->n == 0) return TDR_OK;
+  f->states_changed();
   const int64_t nl = f->nl();
   const float* z = nullptr;
   if (rng_device_capable(f)) {
@@ -958,6 +966,7 @@ int tdr_filter_update_geo(tdr_filter* f, const float* scan_imgs, const float* ge
     TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
     perm = f->perm.p;
   }
+  f->states_changed();   // (the init search writes headings)
   TTRY(f->ws.resize(tdr_score_geo_workspace_floats(ncls, nb, nr, n, n)));
   TTRY(tdr_k_score_polar_geo(&m->desc, &m->geo_desc, m->tab.p, f->scan_pk.p, f->geo_pk.p, (float)gs[0], (float)gs[1], nb, nr,
                              res, &f->fp, f->st.p, f->cap, n, n, perm, f->uniform_scale, f->maybe_uninit ? 1 : 0,
@@ -1020,6 +1029,7 @@ static int filter_score(tdr_filter* f, const float* scan_imgs, const tdr_rendere
     TTRY(tdr_k_locality_order(f->st.p, f->cap, n, m->desc.rows, m->desc.cols, f->perm.p, f->loc_tmp.p, f->stream));
     perm = f->perm.p;
   }
+  f->states_changed();   // (the init search writes headings)
   TTRY(f->ws.resize(tdr_score_workspace_floats(ncls, nb, nr, n, f->n)));
   if (f->maybe_uninit && !m->desc.rec16 && f->n >= tdr_config_rec16_min_particles(-1)) {
     // the search over this many particles pays for pre-split half records (filters on one map share the scratch: their
@@ -1071,6 +1081,7 @@ static int filter_resample(tdr_filter* f, int64_t n_target) {
     TTRY(tdr_k_save_ml_state(f->info.p, f->st.p, f->cap, 0, n, f->ml_dev.p, f->stream));
   }
   f->have_ml = true;
+  f->states_changed();
   std::swap(f->st.p, f->st_new.p);  // :187
   f->n = n_new;
   f->step++;
@@ -1115,10 +1126,16 @@ int tdr_filter_mean_cov(tdr_filter* f, int about_max, float state[4], float cov[
   float out[24];
   const float* gst = nullptr;
   int64_t gcap = 0;
-  TTRY(filter_global_states(f, &gst, &gcap));
+  // (a sharded filter's ranks make the same calls in the same order, so the cache is valid on all of them or on none:
+  // the all-gather inside filter_global_states stays collective)
+  if (about_max || !f->mean_cov_valid) TTRY(filter_global_states(f, &gst, &gcap));
   if (!about_max) {
-    TTRY(tdr_k_mean_cov(gst, gcap, f->n, nullptr, f->stats.p, f->stream));
-    HTRY(hipMemcpy(out, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
+    if (!f->mean_cov_valid) {
+      TTRY(tdr_k_mean_cov(gst, gcap, f->n, nullptr, f->stats.p, f->stream));
+      HTRY(hipMemcpy(f->mean_cov_host, f->stats.p, sizeof(out), hipMemcpyDeviceToHost));
+      f->mean_cov_valid = true;
+    }
+    std::memcpy(out, f->mean_cov_host, sizeof(out));
     if (state) std::memcpy(state, out, 4 * sizeof(float));
   } else {
     float ref[4] = {0, 0, 0, 0};
@@ -1141,6 +1158,7 @@ int tdr_filter_freeze_scale(tdr_filter* f) {
   int64_t gcap = 0;
   TTRY(filter_global_states(f, &gst, &gcap));
   TTRY(tdr_k_mean_cov(gst, gcap, f->n, nullptr, f->stats.p, f->stream));
+  f->states_changed();
   TTRY(tdr_k_set_scale(f->st.p, f->cap, f->nl(), f->stats.p + 20, f->stream));
   float gm = 0;
   HTRY(hipMemcpy(&gm, f->stats.p + 20, sizeof(float), hipMemcpyDeviceToHost));
@@ -1213,6 +1231,7 @@ int tdr_filter_update_map_labels(tdr_filter* f, const uint8_t* label_img, int im
   if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map_labels: null filter");
   const int ox = f->map->center_x, oy = f->map->center_y;
   TTRY(tdr_map_set_labels(f->map, label_img, img_h, img_w, flatten_lut, lut_size, ncls, resolution, center_x, center_y));
+  f->states_changed();
   if (f->n > 0) return tdr_k_shift_init(f->st.p, f->cap, f->nl(), (float)(center_x - ox), (float)(center_y - oy), f->stream);
   if (f->map->have_map) return tdr_filter_initialize_particles(f);  // :337-340
   return TDR_OK;
@@ -1224,6 +1243,7 @@ int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t*
   if (!f || !f->map) return failh(TDR_ERR_ARG, "filter_update_map: null filter");
   const int ox = f->map->center_x, oy = f->map->center_y;
   TTRY(tdr_map_set(f->map, class_maps, class_mask, ncls, rows, cols, resolution, center_x, center_y));
+  f->states_changed();
   if (f->n > 0) return tdr_k_shift_init(f->st.p, f->cap, f->nl(), (float)(center_x - ox), (float)(center_y - oy), f->stream);
   return tdr_filter_initialize_particles(f);  // :337-340
 }

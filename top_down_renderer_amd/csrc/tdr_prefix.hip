@@ -614,7 +614,12 @@ __global__ __launch_bounds__(PFXM_THREADS) void pfx_chunk_summary_kernel(const f
 #define PFXW_THREADS 512   // the walking workgroup: PFXW_THREADS x PFXW_K = one chunk
 #endif
 #define PFXW_K (PFXM_CHUNK / PFXW_THREADS)
-#define PFXW_HEAD 64   // leading elements the walk adds one by one (tunable: TDR_PFX_HEAD)
+#define PFXW_HEAD 64   // leading elements the walk adds one by one (tunable: tdr_config_tuning("prefix_head", n))
+static int g_pfx_head = PFXW_HEAD;
+extern "C" int tdr_config_prefix_head(int n) {   // < 0: query only
+  if (n >= 0) g_pfx_head = n < 1 ? 1 : (n > PFX_HEAD ? PFX_HEAD : n);
+  return g_pfx_head;
+}
 __device__ __forceinline__ void pfx_walk_chunk(const float* __restrict__ w, long long lo, int cnt,
                                                float* __restrict__ runmax, float* __restrict__ prefix_opt,
                                                float& r, float& carry, int head_len) {
@@ -1080,10 +1085,7 @@ __global__ __launch_bounds__(PFXW_THREADS) void chain_walk_kernel(ChainSrc s, in
   }
   if (threadIdx.x == 0) *total_out = r;
 }
-static int g_pfx_small = [] {
-  const char* e = getenv("TDR_PFX_SMALL");   // 0 = without the one-launch kernel (A/B and debugging)
-  return (e && atoi(e) == 0) ? 0 : 1;
-}();
+static int g_pfx_small = 1;   // 0 = without the one-launch kernel (A/B and debugging)
 extern "C" int tdr_config_prefix_small(int on) {   // < 0: query only
   if (on >= 0) g_pfx_small = on ? 1 : 0;
   return g_pfx_small;
@@ -1742,10 +1744,7 @@ __global__ __launch_bounds__(WAVES ? UWS_THREADS : PFXW_THREADS) void uw_small_k
   }
   UW_STAMP(9);
 }
-static int g_uw_waves = [] {
-  const char* e = getenv("TDR_UW_WAVES");   // 0 = the chains chunk by chunk on the whole workgroup (A/B and debugging)
-  return (e && atoi(e) == 0) ? 0 : 1;
-}();
+static int g_uw_waves = 1;   // 0 = the chains chunk by chunk on the whole workgroup (A/B and debugging)
 extern "C" int tdr_config_uw_waves(int on) {   // < 0: query only
   if (on >= 0) g_uw_waves = on ? 1 : 0;
   return g_uw_waves;
@@ -2053,11 +2052,7 @@ static int prefix_multi(const float* w, int64_t n, float* runmax_out, float* pre
     const int rc = pfx_small(w, (int64_t)c_first * PFXM_CHUNK, runmax_out, prefix_out, st, tail);
     if (rc) return rc;
   }
-  static const int head_len = [] {
-    const char* e = getenv("TDR_PFX_HEAD");
-    const int v = e ? atoi(e) : PFXW_HEAD;
-    return v < 1 ? 1 : (v > PFX_HEAD ? PFX_HEAD : v);
-  }();
+  const int head_len = tdr_config_prefix_head(-1);
   hipLaunchKernelGGL(pfx_walk_kernel, dim3(1), dim3(PFXW_THREADS), 0, st, w, n, ch, nch, runmax_out, prefix_out,
                      head_len, c_first, (const float*)tail);
   hipLaunchKernelGGL(pfx_chunk_fill_kernel, dim3(nch), dim3(PFXM_THREADS), 0, st, w, n, (const PfxChunk*)ch,

@@ -1594,10 +1594,7 @@ __global__ void init_fixup_kernel(const float* __restrict__ res_flag, int64_t n,
   if (p < n && res_flag[p] == 2.f) raw_w[p] = (float)(1. / (double)(3.402823466e+38f + regularization));
 }
 
-static int g_init_mfma = [] {
-  const char* e = getenv("TDR_INIT_MFMA");   // 0 = vector-unit search only (A/B and debugging)
-  return (e && atoi(e) == 0) ? 0 : 1;
-}();
+static int g_init_mfma = 1;   // 0 = vector-unit search only (A/B and debugging)
 static bool init_use_mfma() { return g_init_mfma != 0; }
 extern "C" int tdr_config_init_mfma(int on) {   // < 0: query only
   if (on >= 0) g_init_mfma = on ? 1 : 0;
@@ -1605,16 +1602,28 @@ extern "C" int tdr_config_init_mfma(int on) {   // < 0: query only
 }
 // the Cartesian kernel likes twice as many, shorter waves (A/B on MI355X, config 4: x1 183 ms, x2 179 ms, x4 177 ms)
 #define TDR_CART_WAVE_MUL 2
-static int64_t score_wave_target() {
-  static int64_t v = [] {
-    // tuning knob.  Many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms):
-    // workgroups of one ring chunk run together, so the concurrently touched part of the map is a thin annulus that
-    // L2 can hold, and the slow (scattered) batches no longer leave a long tail.
-    const char* e = getenv("TDR_SCORE_WAVES");
-    long t = e ? atol(e) : 0;
-    return (int64_t)(t > 0 ? t : 131072);
-  }();
-  return v;
+// Tuning knobs of the scoring launches (tdr_config_tuning, include/tdr.h) — defaults here, no environment variables: the
+// library reads nothing from the process environment.
+// score_waves: many short waves beat few long ones (A/B on MI355X, config 2: 16k waves 21.8 ms, 128k 15.2 ms): workgroups
+// of one ring chunk run together, so the concurrently touched part of the map is a thin annulus that L2 can hold, and
+// the slow (scattered) batches no longer leave a long tail.
+static int64_t g_score_waves = 131072;
+static int g_score_group = 0;   // 0: from the shapes (score_group_rings)
+static int g_su_group = 0;      // 0: from the shapes (tdr_score_workspace)
+static int g_init_ahead = 1;    // record loads the init search keeps in flight per wave (1..3)
+static int64_t score_wave_target() { return g_score_waves; }
+extern "C" int tdr_config_prefix_head(int);        // tdr_prefix.hip
+extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
+extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // value < 0: query only
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "score_waves") { if (value > 0) g_score_waves = value; return g_score_waves; }
+  if (n == "score_group") { if (value >= 0) g_score_group = (int)value; return g_score_group; }
+  if (n == "su_group") { if (value >= 0) g_su_group = (int)value; return g_su_group; }
+  if (n == "init_ahead") { if (value >= 1) g_init_ahead = (int)std::min<int64_t>(value, 3); return g_init_ahead; }
+  if (n == "prefix_head") return tdr_config_prefix_head((int)std::max<int64_t>(value, -1));
+  if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
+  return -1;
 }
 static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks, int target_mul = 1) {
   int64_t nbatches = cdiv(std::max<int64_t>(n, 1), 64);
@@ -1637,10 +1646,7 @@ __global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float sca
 // never the size of one launch or shard: the partition of a particle's score into partial sums is then the same in an
 // N-rank run as in the 1-rank run.  Aim: >= 2048 workgroups.  TDR_SCORE_GROUP overrides (tuning).
 static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
-  static const int forced = [] {
-    const char* e = getenv("TDR_SCORE_GROUP");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = g_score_group;
   const int64_t ring_bytes = std::max<int64_t>((int64_t)nb * rf * 4, 1);
   int g = (int)std::min<int64_t>(8, (32 * 1024) / ring_bytes);
   const int64_t chunks_wanted = cdiv(2048, cdiv(std::max<int64_t>(n_total, 1), 256));
@@ -1663,11 +1669,8 @@ extern "C" size_t tdr_map_rec16_bytes(int ncls, int rows, int cols) {
 // 0.35 ms, the price of searching ~2000 particles with 256 x 256 windows on the fly).  Filters below the threshold
 // ignore the scratch — the filter's TOTAL particle count decides (n_total, the same on every rank), so that the ranks of
 // a sharded filter take the kernel the one-rank filter takes and choose the same rotations where candidates tie.
-// TDR_INIT_HALF=0 turns the path off (A/B).
-static int64_t g_rec16_min = [] {
-  const char* e = getenv("TDR_INIT_HALF");
-  return (e && atoi(e) == 0) ? INT64_MAX : (int64_t)8192;
-}();
+// tdr_config_rec16_min_particles(INT64_MAX) turns the path off (A/B).
+static int64_t g_rec16_min = 8192;
 extern "C" int64_t tdr_config_rec16_min_particles(int64_t n) {   // < 0: query only
   if (n >= 0) g_rec16_min = n;
   return g_rec16_min;
@@ -1744,10 +1747,7 @@ static ScoreWs score_ws(int ncls, int nb, int nr, int64_t n, int64_t n_total) {
   w.su = tdr_su_shape_ok(nb, nr, w.group, n_total) && tdr_cmap_words(ncls) != 0;
   w.su_group = w.group;
   {
-    static const int forced = [] {
-      const char* e = getenv("TDR_SU_GROUP");
-      return e ? atoi(e) : 0;
-    }();
+    const int forced = g_su_group;
     // eight rings per group where that divides the image and still leaves thousands of workgroups: a sector's mask is
     // staged half as often (config 2: 3.50 against 3.56 ms; 16 rings: 3.69, the staged boxes grow)
     if (w.su && w.group == 4 && nr % 8 == 0 && cdiv(n_total, 256) * (nr / 8) >= 4096) w.su_group = 8;
@@ -1873,10 +1873,7 @@ static int check_map_addressing(const tdr_map_desc* map, int rf, const char* who
 }
 
 // The compact records are used whenever the map has them; tdr_config_compact(0) forces the dense ones (A/B, tests).
-static int g_use_compact = [] {
-  const char* e = getenv("TDR_COMPACT");
-  return e ? atoi(e) : 1;
-}();
+static int g_use_compact = 1;
 extern "C" int tdr_config_compact(int on) {   // < 0: query only
   if (on >= 0) g_use_compact = on ? 1 : 0;
   return g_use_compact;
@@ -1995,6 +1992,9 @@ extern "C" void tdr_score_ctx_destroy(tdr_score_ctx* c) {
 extern "C" float tdr_score_ctx_span(const tdr_score_ctx* c) {   // the span the context's tuner has settled on so far
   return c ? c->tuner.best : tdr_config_shift_uniform_span(-1.f);
 }
+extern "C" int64_t tdr_score_ctx_trial_calls(const tdr_score_ctx* c) {   // launches spent on trial spans so far
+  return c ? c->tuner.trial_calls : 0;
+}
 // closes the tuner's measurement on EVERY way out of a call
 struct TunerScope {
   tdr_score_ctx* c;
@@ -2082,11 +2082,7 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
       if (rf == 4) hipLaunchKernelGGL((half_records_kernel<4>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
       else hipLaunchKernelGGL((half_records_kernel<8>), hgrid, hblock, 0, s, rec4, ncells, unitw ? 1 : 0, *fp, map->ncls, r16);
       LAUNCH_CHECK("half_records");
-      static const int ahead = [] {
-        const char* e = getenv("TDR_INIT_AHEAD");   // tuning: record loads kept in flight per wave (1..3)
-        const int v = e ? atoi(e) : 1;
-        return v < 1 ? 1 : (v > 3 ? 3 : v);
-      }();
+      const int ahead = g_init_ahead;   // tuning: record loads kept in flight per wave (1..3)
       const int R = ahead + 1;
       const int img = init_half_image_rows(nb, R);
       const size_t ldsh = (size_t)4 * img * 16 + (size_t)4 * (nb + 2 * R) * 8;

@@ -291,10 +291,7 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-static int g_cart_skip = [] {
-  const char* e = getenv("TDR_CART_SKIP");
-  return e ? atoi(e) : 1;
-}();
+static int g_cart_skip = 1;
 extern "C" int tdr_config_cart_skip(int on) {   // < 0: query only
   if (on >= 0) g_cart_skip = on ? 1 : 0;
   return g_cart_skip;

@@ -42,11 +42,12 @@
 // segment 0 (rings 0..63, every direction) first, then segment 1's, ...: row m = segment * nb + direction.  The eight
 // gathers a wave has in flight are then neighbouring directions of ONE segment (config 2, uniform particles: 9.1 -> 8.4 ms;
 // with the offsets read from tab_ray the narrow rows cost more than that gains, so those launches keep the first order).
-// TDR_RAY_BM=0 keeps the first order everywhere (A/B).
-static const bool g_ray_bm = [] {
-  const char* e = getenv("TDR_RAY_BM");
-  return !e || atoi(e) != 0;
-}();
+// tdr_config_tuning("ray_block_major", 0) keeps the first order everywhere (A/B; same bits).
+static bool g_ray_bm = true;
+extern "C" int tdr_config_ray_block_major(int on) {   // < 0: query only
+  if (on >= 0) g_ray_bm = on != 0;
+  return g_ray_bm ? 1 : 0;
+}
 static inline bool ray_bm(const SuLaunch& L) { return g_ray_bm && L.fac != nullptr; }
 static inline int ray_gq(int nr, bool bm) { return bm ? 1 : (nr <= 64 ? 1 : (nr <= 128 ? 2 : 4)); }
 static inline int ray_blocks(int nr, bool bm) { return (int)cdiv(nr, 64 * ray_gq(nr, bm)); }

@@ -58,6 +58,7 @@ struct SpanTuner {
   float round_best = 16.f, best_ms = 3.0e38f;   // the fastest candidate of the round in progress, and its time
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool open = false, pending = false;
+  int64_t trial_calls = 0;            // launches that ran at a candidate span so far (diagnostics: tdr_score_ctx_trial_calls)
 };
 float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s);
 void tdr_su_span_end(SpanTuner* t, hipStream_t s);

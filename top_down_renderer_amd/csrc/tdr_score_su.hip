@@ -784,10 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // 0 = never, 1 = when it pays (default), 2 = whenever the shapes allow (tests: small filters, heavy padding)
-static int g_su_mode = [] {
-  const char* e = getenv("TDR_SHIFT_UNIFORM");
-  return e ? atoi(e) : 1;
-}();
+static int g_su_mode = 1;
 extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
   if (mode >= 0) g_su_mode = mode > 2 ? 2 : mode;
   return g_su_mode;
@@ -795,14 +792,11 @@ extern "C" int tdr_config_shift_uniform(int mode) {   // < 0: query only
 extern "C" size_t tdr_cmap_tile_words(int ncls, int rows, int cols);   // tdr_cmap.hip
 extern "C" size_t tdr_cmap_plane_offset_words(int ncls, int rows, int cols);
 extern "C" size_t tdr_cmap_plane_words(int ncls, int rows, int cols);
-// map cells the 64 locality neighbours of a "dense" particle may span: fixed (env TDR_SU_SPAN / the config call), or — the
-// default — tuned while running, starting from SU_SPAN_START
+// map cells the 64 locality neighbours of a "dense" particle may span: fixed (the config call), or — the default — tuned
+// while running, starting from SU_SPAN_START
 #define SU_SPAN_START 16.f
-static bool g_su_span_fixed = getenv("TDR_SU_SPAN") != nullptr;
-static float g_su_span = [] {
-  const char* e = getenv("TDR_SU_SPAN");
-  return e ? (float)atof(e) : SU_SPAN_START;
-}();
+static bool g_su_span_fixed = false;
+static float g_su_span = SU_SPAN_START;
 extern "C" float tdr_config_shift_uniform_span(float cells) {   // >= 0: fix it (0: every particle counts as dense);
   if (cells >= 0.f) { g_su_span = cells; g_su_span_fixed = true; }   // -1: query only; below -1.5: back to tuning
   else if (cells < -1.5f) { g_su_span = SU_SPAN_START; g_su_span_fixed = false; }
@@ -850,6 +844,7 @@ float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s) {
     t->round_best = t->best;
   }
   t->open = hipEventRecord(t->e0, s) == hipSuccess;
+  t->trial_calls++;
   return kSpanCand[t->phase];
 }
 void tdr_su_span_end(SpanTuner* t, hipStream_t s) {

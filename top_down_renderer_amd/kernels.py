@@ -27,6 +27,9 @@ class ScoreCtx:
     def span(self):
         return float(self.lib.tdr_score_ctx_span(self.handle))
 
+    def trial_calls(self):
+        return int(self.lib.tdr_score_ctx_trial_calls(self.handle))
+
     def __del__(self):
         try:
             if self.handle:
