@@ -31,8 +31,12 @@
 // Compiled with -mllvm -structurizecfg-skip-uniform-regions (build.py): the per-sample dispatch on the descriptor is a
 // tree of wave-uniform branches; left to the structuriser each leaf is followed by copies of all accumulators (phi
 // merges of its flow blocks: 128 v_mov_b64 in the loop), with uniform regions skipped the leaves are 3-4 instructions.
-// Memory operations of the loop are inline assembly with ONE explicit wait per step: the compiler's own placement
-// serialises the four record loads of a step as soon as one of them is conditional.
+// Memory operations: the hand-scheduled inner loop (tdr_score_su_asm.h, generated and statically checked by
+// tools/gen_su_asm.py) issues its loads and the waits for them inside ONE assembly text with a planned register file — the
+// compiler sees a single statement with declared outputs and clobbers.  Everything else in this file loads through plain
+// C++ (the compiler tracks the destination registers and places the waits): rounds 3-4 issued the C++ steps' loads through
+// separate inline-assembly statements with hand-counted s_waitcnt, which twice let the compiler move a copy between a load
+// and its wait ("fragile") — that pattern is gone.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <atomic>
@@ -314,6 +318,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
   typedef float tdr_v2f __attribute__((ext_vector_type(2)));
   const tdr_v2f offv = {off0, off1};
+  // plain, compiler-tracked loads: a word of the staged mask at an LDS byte address, bytes of the compact map at a byte offset
+  typedef const uint32_t __attribute__((address_space(3))) * tdr_lds_u;
+  auto lds_word = [](unsigned byte_addr) -> uint32_t { return *reinterpret_cast<tdr_lds_u>((uintptr_t)byte_addr); };
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  auto map_dword = [&](unsigned off) -> uint32_t { return *reinterpret_cast<const uint32_t*>(crecb + off); };
+  auto map_ushort = [&](unsigned off) -> uint32_t { return *reinterpret_cast<const uint16_t*>(crecb + off); };
   const bool weird = !(fabsf(off0) <= 1e9f) || !(fabsf(off1) <= 1e9f) || (!USCALE && !(fabsf(scale * a.res) <= 1e9f));
   auto field = [&](const uint32_t (&w)[CW], int k) -> uint32_t {   // distance k of a compact record (cmap_decode, one field)
     const uint32_t ww = w[k / 3];
@@ -402,8 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       code[u] = D[4 * u];
       // A ring the image does not have (SU_CODE_PAD) goes through the step like an EMPTY bin — su_prep gives it the offset of
       // the direction's last real ring, so its mask lookup stays inside the staged box — and is masked out of the known
-      // count below.  (Not by branching around the loads: another definition of their destination registers makes the
-      // compiler merge them with copies, and a copy between an inline-assembly load and its wait reads a stale register.)
+      // count below.
       pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;
       code[u] = code[u] == SU_CODE_PAD ? 0u : code[u];
       val[u] = D[4 * u + 1];
@@ -416,20 +425,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const int cw5 = ci >> 5;
       unsigned la;
       asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
-      asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
+      bits[u] = lds_word(la);
+      w[u] = 0;
+      offs[u] = 0;
       if (code[u] != 0) {   // wave-uniform: only a non-empty bin needs its record — one dword of it
         int t1, t2;
         const int cq = ci >> 2;
         asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(ckcol), "s"(ckc));
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
-      } else {
-        asm volatile("" : "=v"(w[u]), "=v"(offs[u]));   // not read
+        w[u] = map_dword(offs[u]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint32_t cd = code[u];
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           wr[0] = w[u];
 #pragma unroll
           for (int d = 1; d < CW; d++)
-            wr[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * d + offs[u]);
+            wr[d] = map_dword(offs[u] + 4u * d);
           full_bin(cd, val[u], wr, kmsk & 1, (int64_t)(j0 + jj + u) * nb + r);
         }
       }
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       code[u] = D[4 * u];
-      pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;   // (see cpp_step: masked, never branched around)
+      pad[u] = code[u] == SU_CODE_PAD ? 0u : 0xFFFFFFFFu;   // (see cpp_step)
       code[u] = code[u] == SU_CODE_PAD ? 0u : code[u];
       val[u] = D[4 * u + 1];
       const uint32_t pkc = D[4 * u + 2];
@@ -477,7 +484,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const int cw5 = ci >> 5;
       unsigned la;
       asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(la) : "v"(cw5), "v"(wa));
-      asm volatile("ds_read_b32 %0, %1" : "=v"(bits[u]) : "v"(la));
+      bits[u] = lds_word(la);
+      w[u] = 0;
       if (code[u] != 0) {   // wave-uniform
         int t1, t2;
         unsigned off;
@@ -485,13 +493,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(pkcol), "s"(pkc));
         asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t2) : "v"(ci), "v"(t1));
         asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ri), "v"(t2));
-        asm volatile("global_load_ushort %0, %1, %2" : "=v"(w[u]) : "v"(off), "s"(crec));
-      } else {
-        asm volatile("" : "=v"(w[u]));   // not read
+        w[u] = map_ushort(off);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]));
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int kmsk;   // 0 / -1: the cell's known bit
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
           asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(off) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
         }
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(w[4 * d + u]) : "v"(off), "s"(crec));
+        w[4 * d + u] = map_dword(off);   // (all 4 NS requests are issued before the first value is used below)
       }
       jx += 4;
       if (jx >= ((gn + 3) & ~3)) { jx = 0; ii++; }
@@ -553,8 +557,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const tdr_const_u D = dbase + ((int64_t)r * G + jx) * 4;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        // (the requests return in order: sample 4 d + u is there once all but the 4 NS - 1 - (4 d + u) behind it are)
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[4 * d + u]) : "n"(4 * NS - 1 - (4 * d + u)));
         const uint32_t ww = w[4 * d + u];
         const uint32_t cdr = D[4 * u];
         const uint32_t cd = cdr == SU_CODE_PAD ? 0u : cdr;   // a ring the image does not have: an empty bin that counts nothing
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             wr[0] = ww;
 #pragma unroll
             for (int q = 1; q < CW; q++)
-              wr[q] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + 4 * q + off);
+              wr[q] = map_dword(off + 4u * q);
             full_bin(cd, v, wr, (int)kb, (int64_t)(j0 + jx + u) * nb + r);
           }
         }
@@ -751,6 +753,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             mine[row * Wbw + wc] = wv;
             ev &= wv;
           }
+          // the wave reads what its lanes just wrote — through the assembly loop's ds_read as well: order the stores in front
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
           box_ok = 1;
           box_krow4 = Wbw * 4;
           box_kconst = (int)lbits_lds + wave * (SU_BOX_WORDS / 4) * 4 + (1 - wl - wrl * Wbw) * 4;
