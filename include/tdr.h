@@ -490,7 +490,9 @@ int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattere
  *   "init_ahead"       record loads in flight in the init search (1-3)
  *   "prefix_head"      leading addends the long running sum's walk adds one by one
  *   "ray_block_major"  0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
- *                      holds the table's factors (same bits) */
+ *                      holds the table's factors (same bits)
+ *   "cart_seg_rows"    window rows per segment of score_cart_su_kernel (a multiple of 4; 0: the Cartesian integer form's dense
+ *                      share goes through the plain kernel instead — same bits) */
 int64_t tdr_config_tuning(const char* name, int64_t value);
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);

@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Writes top_down_renderer_amd/csrc/tdr_score_cart_asm.h: the hand-scheduled gfx950 sample loop of
+score_cart_su_kernel (tdr_score_cart.hip) — the Cartesian integer form's dense kernel for maps with two-dword compact
+records (4-6 classes) — as inline-assembly text, in three variants: general / without the clamp of the coordinates into
+the map's guard ring / without clamp and known-mask lookups (every cell the wave can reach in the segment is known).
+LOADS AND THEIR WAITS LIVE INSIDE THIS ONE TEXT with a planned register file: the compiler sees a single statement with
+declared outputs and clobbers and never a load in flight (rounds 3-4 issued loads through separate inline-assembly
+statements with hand-counted waits; the compiler moved a copy between a load and its wait twice — DESIGN.md 5.1).
+
+    python3 tools/gen_cart_asm.py        (re-run after editing; the header is committed; tests/test_asm_guard.py checks both)
+
+One statement = one SEGMENT: `nblk` blocks of 4 window rows x the NCOL = 8 window columns of a column group, lane =
+particle.  A step = the 4 samples (rows i .. i + 3, column jc); the column loop is unrolled (the column terms AB[jc] of the
+rotation are eight operands computed once per column group), the row-block loop is a loop.
+Sample (i, j) of getLocalMap (src/top_down_map.cpp:367-389, 429-459):  p = (cs * y_i + AB_j) + centre, cell = round(p),
+with y_i = lo_r + float(i) * step_r (Eigen's LinSpaced, two roundings), cs = {cos, sin}(theta), AB_j = {-sin * x_j, cos * x_j}
+— the float operations of score_cart_kernel, in its order.
+
+Register plan (fixed registers, all named in the statement's clobber list):
+  v8..v15   sample u: v(8+2u) row -> ri, v(9+2u) column -> ci
+  v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
+  v20..v23  scratch;  v24..v27 sample u: the 2-byte cell of the bin's class plane
+  v32..v39  cs * y_(i+u), u = 0..3 (recomputed at every row block);  v40, v41 scratch of that
+  s48..s63 / s80..s95   the step's descriptors {code, count, plane constant, -} x 4 (cart_prep_kernel), even / odd columns:
+                        a step requests the next step's descriptors into the other set before it works on its own
+  s64 first row of the block, s65 row blocks left, s66 byte offset of (row block, column 0) in the descriptor array,
+  s67 offset being requested, s68..s75 byte offsets of the eight columns from column 0, s76 scratch
+Arithmetic: EXACT integer sums like the polar loop (tools/gen_su_asm.py): any order, any partition, any kernel gives the
+same bits.  Bins holding several classes are EMPTY to this loop (their descriptor code is 0 in the array it reads): the
+kernel adds their products from a per-chunk list afterwards; their known bit is counted here like an empty bin's.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_su_asm as su  # noqa: E402  (the register rules and their checker are shared)
+
+OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_cart_asm.h")
+NCOL = 8
+CLOBBER_V = range(8, 42)
+CLOBBER_S = range(48, 96)
+VARIANTS = (("", True, True), ("_NOCLAMP", False, True), ("_ALLKNOWN", False, False))
+
+
+def loop_text(clamp, mask):
+    L = []
+    a = L.append
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")               # drain whatever the compiler still has in flight (see gen_su_asm.py)
+    a("s_mov_b32 s64, %[i0]")
+    a("s_mov_b32 s65, %[nblk]")
+    a("s_mov_b32 s66, %[doff]")
+    a("s_mov_b32 s68, 0")
+    for jc in range(1, NCOL):
+        a(f"s_add_u32 s{68 + jc}, s{68 + jc - 1}, %[rows16]")   # column jc lies jc * rows * 16 bytes behind column 0
+    a("s_load_dwordx16 s[48:63], %[db], s66")
+    a(".Lct_blk%=:")
+    # cs * y_(i+u): y = lo_r + float(i + u) * step_r (LinSpaced: one product, one sum — no fused multiply-add)
+    for u in range(4):
+        a(f"s_add_u32 s76, s64, {u}")
+        a("v_cvt_f32_i32 v40, s76")
+        a("s_nop 0")
+        a("v_mul_f32 v40, v40, %[stepr]")
+        a("s_nop 0")
+        a("v_add_f32 v40, %[lor], v40")
+        a("s_nop 0")
+        a(f"v_pk_mul_f32 v[{32 + 2 * u}:{33 + 2 * u}], %[cs], v[40:41] op_sel_hi:[1,0]")   # {cos * y, sin * y}
+    if not mask:
+        a(f"v_add_u32 %[known], {4 * NCOL}, %[known]")   # every sample of the block is a known cell
+    a("s_waitcnt lgkmcnt(0)")                        # the descriptors of column 0
+    for jc in range(NCOL):
+        even = jc % 2 == 0
+        step(a, jc, clamp, mask, D=48 if even else 80, DN=80 if even else 48)
+    a("s_add_u32 s64, s64, 4")
+    a("s_add_u32 s66, s66, 64")
+    a("s_sub_u32 s65, s65, 1")
+    a("s_cmp_lg_u32 s65, 0")
+    a("s_cbranch_scc1 .Lct_blk%=")
+    a("s_waitcnt lgkmcnt(0)")                        # (the request for the block behind the last one)
+    return L
+
+
+def step(a, jc, clamp, mask, D, DN):
+    tag = f"c{jc}"
+    # the step behind this one: the next column of the block, or column 0 of the next block (its descriptors are the 64
+    # bytes behind this block's; behind the segment's last block that is the next segment's first — inside the array, the
+    # kernel never runs a group whose last block ends at the array's end without the pad behind it)
+    if jc + 1 < NCOL:
+        a(f"s_add_u32 s67, s66, s{68 + jc + 1}")
+    else:
+        a("s_add_u32 s67, s66, 64")
+    a(f"s_load_dwordx16 s[{DN}:{DN + 15}], %[db], s67")
+
+    def coords(us):
+        for u in us:
+            p = 8 + 2 * u
+            a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{32 + 2 * u}:{33 + 2 * u}], %[ab{jc}]")   # rotm * pts (:383-385)
+        if len(us) == 1:
+            a("s_nop 0")
+        for u in us:
+            p = 8 + 2 * u
+            a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[offv]")                    # + centre (:387-388)
+        if len(us) == 1:
+            a("s_nop 0")
+        if clamp:
+            for u in us:
+                p = 8 + 2 * u
+                a(f"v_med3_f32 v{p}, v{p}, %[rmax], -1.0")                               # clamp into the guard ring
+                a(f"v_med3_f32 v{p + 1}, v{p + 1}, %[cmax], -1.0")
+        for u in us:
+            p = 8 + 2 * u
+            a(f"v_pk_add_f32 v[{p}:{p + 1}], v[{p}:{p + 1}], %[half]")                    # round_half_away_clamped (:437)
+        if len(us) == 1:
+            a("s_nop 0")
+        for u in us:
+            p = 8 + 2 * u
+            a(f"v_cvt_flr_i32_f32 v{p}, v{p}")
+            a(f"v_cvt_flr_i32_f32 v{p + 1}, v{p + 1}")
+
+    if mask:
+        coords(range(4))
+        # word of the wave's staged known mask (LDS) of each cell: ri * krow4 + (ci >> 5) * 4 + kconst
+        for u in range(4):
+            a(f"v_mad_i32_i24 v{16 + u}, v{8 + 2 * u}, %[krow4], %[kconst]")
+        for u in range(4):
+            a(f"v_ashrrev_i32 v{20 + u}, 5, v{9 + 2 * u}")
+        for u in range(4):
+            a(f"v_lshl_add_u32 v{16 + u}, v{20 + u}, 2, v{16 + u}")
+        a("s_nop 0")
+        for u in range(4):
+            a(f"ds_read_b32 v{28 + u}, v{16 + u}")
+    # the 2-byte cell of the class's plane for every bin holding ONE class (plane_offset, tdr_score_dev.h)
+    for u in range(4):
+        code, ckc = D + 4 * u, D + 2 + 4 * u
+        a(f"s_cmp_eq_u32 s{code}, 0")
+        a(f"s_cbranch_scc1 .Lct_a{u}{tag}%=")
+        if not mask:
+            coords([u])     # (an empty bin of an all-known segment needs no cell at all)
+        a(f"v_ashrrev_i32 v{20 + u}, 3, v{9 + 2 * u}")
+        a("s_nop 0")
+        a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[pkcol], s{ckc}")
+        a("s_nop 0")
+        a(f"v_lshl_add_u32 v{20 + u}, v{9 + 2 * u}, 1, v{20 + u}")
+        a("s_nop 0")
+        a(f"v_lshl_add_u32 v{20 + u}, v{8 + 2 * u}, 4, v{20 + u}")
+        a("s_nop 0")
+        a(f"global_load_ushort v{24 + u}, v{20 + u}, %[crec]")     # (never into its own address register)
+        a(f".Lct_a{u}{tag}%=:")
+    # ---- everything requested above is waited for HERE, inside the text
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if mask:
+        for u in range(4):
+            a(f"v_bfe_i32 v{16 + u}, v{28 + u}, v{9 + 2 * u}, 1")                           # 0 / -1: the cell's known bit
+        a("v_add_u32 v20, v16, v17")
+        a("v_add_u32 v21, v18, v19")
+        a("s_nop 0")
+        a("v_add_u32 v20, v20, v21")
+        a("s_nop 0")
+        a("v_sub_u32 %[known], %[known], v20")
+    for u in range(4):
+        code, val = D + 4 * u, D + 1 + 4 * u
+        a(f"s_cmp_eq_u32 s{code}, 0")
+        a(f"s_cbranch_scc1 .Lct_b{u}{tag}%=")
+        if mask:
+            a(f"v_and_b32 v20, s{val}, v{16 + u}")                                           # the bin's count x known (:141-142)
+        a(f"v_and_b32 v21, 0xffc, v{24 + u}")                                                # the class's dictionary index * 4
+        if mask:
+            a("v_add_u32 %[norm], %[norm], v20")
+        else:
+            a(f"v_add_u32 %[norm], s{val}, %[norm]")
+        a("s_nop 0")
+        a("ds_read_b32 v21, v21")                                                            # the dictionary sits at LDS address 0
+        a("s_waitcnt lgkmcnt(0)")
+        # acc[class] += count * distance (state_particle.cpp:136-139) as integers: wave-uniform branches over the class
+        a(f"s_cmp_lt_u32 s{code}, 4")
+        a(f"s_cbranch_scc1 .Lct_k{u}lo{tag}%=")
+        a(f"s_cmp_lt_u32 s{code}, 5")
+        a(f"s_cbranch_scc1 .Lct_k{u}k3{tag}%=")
+        a(f"s_cmp_lt_u32 s{code}, 6")
+        a(f"s_cbranch_scc1 .Lct_k{u}k4{tag}%=")
+        a(f"v_mad_u64_u32 %[a5], vcc, s{val}, v21, %[a5]")
+        a(f"s_branch .Lct_b{u}{tag}%=")
+        a(f".Lct_k{u}k4{tag}%=:")
+        a(f"v_mad_u64_u32 %[a4], vcc, s{val}, v21, %[a4]")
+        a(f"s_branch .Lct_b{u}{tag}%=")
+        a(f".Lct_k{u}k3{tag}%=:")
+        a(f"v_mad_u64_u32 %[a3], vcc, s{val}, v21, %[a3]")
+        a(f"s_branch .Lct_b{u}{tag}%=")
+        a(f".Lct_k{u}lo{tag}%=:")
+        a(f"s_cmp_lt_u32 s{code}, 2")
+        a(f"s_cbranch_scc1 .Lct_k{u}k0{tag}%=")
+        a(f"s_cmp_lt_u32 s{code}, 3")
+        a(f"s_cbranch_scc1 .Lct_k{u}k1{tag}%=")
+        a(f"v_mad_u64_u32 %[a2], vcc, s{val}, v21, %[a2]")
+        a(f"s_branch .Lct_b{u}{tag}%=")
+        a(f".Lct_k{u}k1{tag}%=:")
+        a(f"v_mad_u64_u32 %[a1], vcc, s{val}, v21, %[a1]")
+        a(f"s_branch .Lct_b{u}{tag}%=")
+        a(f".Lct_k{u}k0{tag}%=:")
+        a(f"v_mad_u64_u32 %[a0], vcc, s{val}, v21, %[a0]")
+        a(f".Lct_b{u}{tag}%=:")
+
+
+def statement_operands():
+    return su.statement_operands("tdr_score_cart.hip", "CART_ASM_OPERANDS", "CART_ASM_CLOBBERS")
+
+
+def check_text(lines, outputs, inputs):
+    """The shared register rules (gen_su_asm.check_text) plus this loop's own: every load is waited for INSIDE the text — no
+    instruction reads a load's destination between the load and a wait that covers it, and the text ends with nothing in
+    flight.  (A linear pass over the text: the loop's back edge and its branches only skip instructions.)"""
+    import re
+    written = su.check_text(lines, outputs, inputs, CLOBBER_V, CLOBBER_S)
+    vm, lgkm = set(), set()                    # fixed destination registers of requests not yet waited for, by counter
+    for ln in lines:
+        if ln.endswith(":"):
+            continue
+        mn, _, rest = ln.partition(" ")
+        toks = [re.sub(r"\s+op_sel.*", "", t.strip()) for t in re.split(r",(?![^\[]*\])", rest)] if rest else []
+        if mn == "s_waitcnt":
+            if "vmcnt(0)" in rest:
+                vm.clear()
+            if "lgkmcnt(0)" in rest:
+                lgkm.clear()
+            continue
+        has_dest = not mn.startswith(su.NO_DEST)
+        sources = [r for t in toks[1 if has_dest else 0:] for r in su.regs_of(t)]
+        for r in sources:
+            assert r not in vm and r not in lgkm, f"reads the destination of a load before its wait: {ln}"
+        dest = set(su.regs_of(toks[0])) if has_dest and toks else set()
+        assert not (dest & (vm | lgkm)), f"overwrites the destination of a load in flight: {ln}"
+        if mn.startswith("global_load"):
+            vm |= dest
+        elif mn.startswith(("ds_read", "s_load")):
+            lgkm |= dest
+    assert not vm and not lgkm, "the text ends with a load in flight"
+    return written
+
+
+def check_all():
+    outputs, inputs = statement_operands()
+    n = 0
+    for _, clamp, mask in VARIANTS:
+        lines = loop_text(clamp, mask)
+        assert lines[0] == "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        written = check_text(lines, outputs, inputs)
+        assert written <= outputs
+        n += 1
+    return n
+
+
+def main():
+    check_all()
+    out = ["// tdr_score_cart_asm.h — GENERATED by tools/gen_cart_asm.py; do not edit.",
+           "// The sample loop of score_cart_su_kernel (tdr_score_cart.hip) for two-dword compact records (4-6 classes): see the",
+           "// generator for the register plan.  Loads and their waits are inside these texts.",
+           "#ifndef TDR_SCORE_CART_ASM_H_", "#define TDR_SCORE_CART_ASM_H_", "", f"#define CART_ASM_NCOL {NCOL}", ""]
+    for tag, clamp, mask in VARIANTS:
+        out.append(f"#define CART_ASM{tag} \\")
+        lines = loop_text(clamp, mask)
+        for i, ln in enumerate(lines):
+            out.append(f'  "{ln}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+        out.append("")
+    out.append("#define CART_ASM_CLOBBERS \\")
+    vregs = ", ".join(f'"v{i}"' for i in CLOBBER_V)
+    sregs = ", ".join(f'"s{i}"' for i in CLOBBER_S)
+    out.append(f"  {vregs}, \\")
+    out.append(f'  {sregs}, "vcc", "scc", "memory"')
+    out.append("#endif  // TDR_SCORE_CART_ASM_H_")
+    open(OUT, "w").write("\n".join(out) + "\n")
+    print(OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -222,11 +222,11 @@ CLOBBER_S = range(40, 96)
 NO_DEST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch_", "s_cmp_", "s_bitcmp")   # write nothing / SCC only
 
 
-def statement_operands():
-    """(outputs, inputs) named in SU_ASM_OPERANDS of the kernel source."""
+def statement_operands(source="tdr_score_su.hip", macro="SU_ASM_OPERANDS", clobbers="SU_ASM_CLOBBERS"):
+    """(outputs, inputs) named in the operand macro of the kernel source."""
     import re
-    src = open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su.hip")).read()
-    blk = src[src.index("#define SU_ASM_OPERANDS"):src.index(": SU_ASM_CLOBBERS")]
+    src = open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", source)).read()
+    blk = src[src.index("#define " + macro):src.index(": " + clobbers)]
     ops = re.findall(r'\[(\w+)\]\s*"([^"]+)"', blk)
     return {n for n, c in ops if c[0] in "+="}, {n for n, c in ops if c[0] not in "+="}
 
@@ -243,8 +243,10 @@ def regs_of(tok):
     return []
 
 
-def check_text(lines, outputs, inputs):
+def check_text(lines, outputs, inputs, clobber_v=None, clobber_s=None):
     import re
+    clobber_v = CLOBBER_V if clobber_v is None else clobber_v
+    clobber_s = CLOBBER_S if clobber_s is None else clobber_s
     assert lines[0] == "s_waitcnt vmcnt(0) lgkmcnt(0)", "the loop must begin by draining the loads in flight"
     named_written = set()
     for ln in lines:
@@ -263,7 +265,7 @@ def check_text(lines, outputs, inputs):
                     named_written.add(named.group(1))
                 continue
             for kind, i in regs_of(t):
-                ok = i in (CLOBBER_V if kind == "v" else CLOBBER_S)
+                ok = i in (clobber_v if kind == "v" else clobber_s)
                 assert ok, f"{'writes' if is_dest else 'reads'} {kind}{i}, which is outside the clobber list: {ln}"
     return named_written
 

@@ -1614,6 +1614,7 @@ static int g_init_ahead = 1;    // record loads the init search keeps in flight 
 static int64_t score_wave_target() { return g_score_waves; }
 extern "C" int tdr_config_prefix_head(int);        // tdr_prefix.hip
 extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
+extern "C" int tdr_config_cart_seg_rows(int);      // tdr_score_cart.hip
 extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // value < 0: query only
   if (!name) return -1;
   const std::string n(name);
@@ -1623,6 +1624,7 @@ extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // val
   if (n == "init_ahead") { if (value >= 1) g_init_ahead = (int)std::min<int64_t>(value, 3); return g_init_ahead; }
   if (n == "prefix_head") return tdr_config_prefix_head((int)std::max<int64_t>(value, -1));
   if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
+  if (n == "cart_seg_rows") return tdr_config_cart_seg_rows((int)std::max<int64_t>(value, -1));
   return -1;
 }
 static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks, int target_mul = 1) {
@@ -2424,7 +2426,7 @@ extern "C" int tdr_k_score_cart(const tdr_map_desc* map, const float* scan_pk, i
     fx.npad = io.npad; fx.order = io.slots; fx.counts = io.counts; fx.inexact = io.flags;
     fx.ipart = reinterpret_cast<const uint32_t*>(a.part);
     fx.dict_tail = reinterpret_cast<const uint32_t*>(map->dict) + 2 * TDR_CMAP_MAX_DICT;
-    fx.nchunks = a.nchunks; fx.ray_split = io.ray_split;
+    fx.nchunks = io.nchunks_dense; fx.ray_split = io.ray_split;
     hipLaunchKernelGGL(score_finalize_exact_kernel, dim3((unsigned)cdiv(io.npad, 64)), dim3(256), 0, s, fx);
     f.run_if = io.flags;
   }

@@ -53,6 +53,7 @@ struct CartIntOut {
   const int32_t* counts;   // {dense slots, scattered particles, both}
   const int32_t* flags;    // int_form_off
   int ray_split;
+  int nchunks_dense;       // chunk rows of partial sums a DENSE slot has (score_cart_su_kernel walks wider chunks)
   int64_t npad;            // slot capacity = stride of the integer partial sums
 };
 int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* desc_ws, int32_t* ws, float span,

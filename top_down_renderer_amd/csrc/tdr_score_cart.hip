@@ -35,10 +35,15 @@
 // pbase != 0 (the integer form's dense kernel): word [2] of a bin with ONE class is plane_offset's constant for the class's
 // plane instead (pbase + c * plane_bytes, a byte offset from crec) — 8 x 8-cell tiles of 2-byte cells: a wave whose
 // particles lie a few cells apart touches a third of the lines the 4 x 4-cell record tiles cost it (tdr_score_su.hip)
+// full_list != NULL (the descriptors score_cart_su_kernel reads): a bin holding SEVERAL classes gets code 0 — an empty bin to
+// the sample loop, which still counts its known bit — and goes on the list of its column chunk (chunks of cpc_su columns,
+// list_cap entries each) as row << 16 | column: the kernel adds those bins' products afterwards, in any order (exact sums).
 __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict__ scan_pk, int rows, int cols, int rf, int ncls,
                                                         int ckconst, const float* __restrict__ dict, int dict_n,
                                                         uint32_t* __restrict__ desc, int as_int, unsigned pbase,
-                                                        unsigned plane_bytes) {
+                                                        unsigned plane_bytes, uint32_t* __restrict__ full_list = nullptr,
+                                                        int32_t* __restrict__ full_cnt = nullptr, int cpc_su = 1,
+                                                        int64_t list_cap = 0) {
   bool bad = false;   // the dictionary is small: every workgroup checks it for itself
   for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
   const bool dict_bad = __syncthreads_or(bad);
@@ -68,7 +73,14 @@ __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict_
   };
   float val;
   uint32_t ckc, sh;
-  const uint32_t code = classify(t, val, ckc, sh);
+  uint32_t code = classify(t, val, ckc, sh);
+  if (full_list && code >= CART_CODE_FULL_ALL) {
+    const int j = (int)(t / rows), i = (int)(t - (int64_t)j * rows);   // scan_pk is [cols][rows][rf]
+    const int chunk = j / cpc_su;
+    full_list[(int64_t)chunk * list_cap + atomicAdd(&full_cnt[chunk], 1)] = ((uint32_t)i << 16) | (uint32_t)j;
+    code = 0;
+    val = 0.f;
+  }
   desc[4 * t] = code;
   desc[4 * t + 1] = as_int ? (uint32_t)val : __float_as_uint(val);
   desc[4 * t + 2] = ckc;
@@ -207,12 +219,13 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t2) : "v"(ci), "n"(CW == 1 ? 2 : (CW == 2 ? 3 : 4)), "v"(t1));
         asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(offs[u]) : "v"(ri), "n"(CW == 1 ? 4 : (CW == 2 ? 5 : 6)), "v"(t2));
       }
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(w[u]) : "v"(offs[u]), "s"(crec));
+      // a plain load: the compiler tracks the destination and places the waits (all NS requests are issued before the first
+      // value is used below).  (Rounds 3-4 issued these through inline assembly with hand-counted s_waitcnt; a register
+      // copy between a load and its wait gave wrong weights twice — DESIGN.md 5.1.)
+      w[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crec) + offs[u]);
     }
 #pragma unroll
     for (int u = 0; u < NS; u++) {
-      // (the requests return in order: sample u is there once all but the NS - 1 - u behind it are)
-      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[u]) : "n"(NS - 1 - u));
       const uint32_t cd = D[4 * u];
       if (cd == 0) {   // wave-uniform
         int kmsk;      // 0 / -1: the cell's known bit
@@ -287,6 +300,279 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
     for (int k = 0; k < ND; k++) o[(int64_t)k * a.npad] = (float)acc[k];
     o[(int64_t)(RF - 1) * a.npad] = norm;
     o[(int64_t)RF * a.npad] = (float)known;
+  }
+}
+
+
+// =========================================================================================================================
+// score_cart_su_kernel — the dense share of the Cartesian integer form for maps with two-dword compact records (4-6
+// classes): score_cart_skip_kernel<.., INT>'s sums, with the sample loop in GENERATED assembly (tdr_score_cart_asm.h,
+// tools/gen_cart_asm.py — loads and their waits inside one text, a planned register file, statically checked) and the
+// known mask STAGED IN LDS per wave:
+//   * lane = particle, grid.y = chunk of a.cpc window columns (a multiple of 8), walked in groups of 8 columns; a group in
+//     SEGMENTS of x.seg_rows window rows;
+//   * per (group, segment) a wave works out the box of map cells its 64 windows can reach (rounding is monotone and the
+//     window coordinates are monotone along both window axes: the four corners bound it), stages the known mask of that box
+//     in its own quarter of the LDS area — no workgroup barrier: a wave's LDS operations execute in order — and runs the
+//     loop variant the box allows: every cell known (an EMPTY scan bin, 84 % of config 4's, then costs no instruction at
+//     all) / every cell inside the map (no clamp) / general.  A box that does not fit the area (a large scale, particles
+//     far apart) takes the plain C++ steps with the mask gathered from global memory — compiler-tracked loads;
+//   * bins holding several classes are empty to the loop (cart_prep_kernel) and added from the chunk's list at the end.
+// Integer sums: exact, so the sums equal score_cart_skip_kernel<.., INT>'s and score_cart_ray_kernel's whatever the order
+// (tests/test_ray.py::test_cartesian_integer_form, tests/test_cart_su.py).
+#include "tdr_score_cart_asm.h"
+#define CART_SU_WBOX 1024   // LDS words of one wave's staged known mask (4 KB; a 32-row segment of config 4 needs ~200)
+
+struct CartSuArgs {
+  const uint32_t* full_list;   // [chunks][list_cap]: bins with several classes, row << 16 | column (cart_prep_kernel)
+  const int32_t* full_cnt;     // [chunks]
+  int64_t list_cap;
+  int seg_rows;                // window rows per segment (a multiple of 4)
+};
+struct CartSuLds {             // ONE object so that the dictionary sits at LDS address 0 (the assembly reads it there)
+  uint32_t dict[TDR_CMAP_MAX_DICT];
+  uint32_t bits[4][CART_SU_WBOX];
+};
+
+__global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuArgs x) {
+  constexpr int RF = 8, ND = 6, CW = 2;
+  __shared__ CartSuLds lds;
+  if (int_form_off(a.flags)) return;   // (uniform) the float form does this launch
+  for (int t = threadIdx.x; t < a.dict_n; t += 256) lds.dict[t] = a.dict_int[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nact = (int64_t)*a.count;
+  if ((int64_t)blockIdx.x * 256 >= nact) return;
+  const int64_t wbase = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (wbase >= nact) return;           // an idle wave (no barrier below this line)
+  const int64_t slot = wbase + lane;
+  int64_t p = a.order[slot];
+  const bool real = p >= 0;
+  if (p < 0) p = a.order[wbase];       // padding of the slot list: a wave's first slot never is
+  const float scale = a.st[TDR_ST_SCALE * a.cap + p];
+  const float cx = a.st[TDR_ST_DX * a.cap + p] * scale + a.st[TDR_ST_INIT_X * a.cap + p];
+  const float cy = a.st[TDR_ST_DY * a.cap + p] * scale + a.st[TDR_ST_INIT_Y * a.cap + p];
+  const float theta = a.st[TDR_ST_THETA * a.cap + p];
+  // the float operations of score_cart_kernel / score_cart_skip_kernel (src/top_down_map.cpp:367-389, 429-437)
+  const float off0 = cy / a.resolution, off1 = cx / a.resolution;
+  const float resq = (a.res * scale) / a.resolution;
+  const float c = tdr_libm::cosf_v(theta, a.libm_fma), sn = tdr_libm::sinf_v(theta, a.libm_fma);
+  const float ns = -sn;
+  typedef float tdr_v2f __attribute__((ext_vector_type(2)));
+  const tdr_v2f cs = {c, sn}, offv = {off0, off1};
+  const float lo_r = (float)((double)(-resq * (float)(a.rows - 1)) / 2.), hi_r = (float)((double)(resq * (float)(a.rows - 1)) / 2.);
+  const float lo_c = (float)((double)(-resq * (float)(a.cols - 1)) / 2.), hi_c = (float)((double)(resq * (float)(a.cols - 1)) / 2.);
+  const float step_r = a.rows == 1 ? 0.f : (hi_r - lo_r) / (float)(a.rows - 1);
+  const float step_c = a.cols == 1 ? 0.f : (hi_c - lo_c) / (float)(a.cols - 1);
+  const int r1 = a.rows == 1 ? 1 : a.rows - 1, c1 = a.cols == 1 ? 1 : a.cols - 1;
+  const float rmaxf = (float)a.map_rows, cmaxf = (float)a.map_cols;
+  const bool weird = !(fabsf(off0) <= 1e9f) || !(fabsf(off1) <= 1e9f) || !(fabsf(resq) <= 1e6f);
+
+  const int j0 = blockIdx.y * a.cpc, j1 = min(a.cols, j0 + a.cpc);
+  const uint32_t* __restrict__ crec = a.crec;
+  const char* __restrict__ crecb = reinterpret_cast<const char*>(a.crec);
+  const int ckcol = a.ctiles_r * 128 - 16 * CW, ckconst = a.ctiles_r * 128 + 128;   // cmap_offset
+  const int mrow = a.kmask_row, mconst = (int)a.kmask_off + a.kmask_row + 128;       // kmask_offset
+  const int pkcol = a.pkcol;
+  const uint32_t* __restrict__ kmask = reinterpret_cast<const uint32_t*>(crecb + a.kmask_off);
+  const int kcolw = a.kmask_row >> 2;   // words of one tile column of the mask
+  typedef const float __attribute__((address_space(4))) * tdr_const_f;
+  typedef const uint32_t __attribute__((address_space(4))) * tdr_const_u;
+  const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
+  const tdr_const_u descc = (tdr_const_u)a.desc;
+  const unsigned lds_base = (unsigned)(uintptr_t)&lds;
+  const unsigned my_bits_lds = (unsigned)(uintptr_t)&lds.bits[wave][0];
+
+  unsigned long long acc[ND];
+#pragma unroll
+  for (int k = 0; k < ND; k++) acc[k] = 0;
+  uint32_t inorm = 0, known = 0;
+
+  auto cell = [&](tdr_v2f cyi, tdr_v2f AB, int& ri, int& ci) {
+    tdr_v2f pv = cyi + AB;         // p0 = c * yi + (-s * xj), p1 = s * yi + c * xj
+    pv = pv + offv;
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;         // see round_half_away_clamped
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+  };
+  auto column_terms = [&](int j) -> tdr_v2f {
+    const float xj = cart_linspaced(j, c1, lo_c, hi_c, step_c);
+    return (tdr_v2f){ns * xj, c * xj};
+  };
+  auto add_class = [&](uint32_t cd, uint32_t v, uint32_t m) {   // acc[cd - 1] += v * m: a switch over a wave-uniform value
+    switch (cd) {
+#define CART_SU_CASE(K) \
+  case K + 1: asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[K]) : "s"(v), "v"(m) : "vcc"); break;
+      CART_SU_CASE(0) CART_SU_CASE(1) CART_SU_CASE(2) CART_SU_CASE(3) CART_SU_CASE(4) CART_SU_CASE(5)
+#undef CART_SU_CASE
+      default: break;
+    }
+  };
+  // NS samples of one window column in plain C++ (rows of cyi[], descriptors D): one compiler-tracked gather each — the
+  // mask word of an empty bin, the plane cell of a bin with one class — all requested before the first is used
+  auto samples = [&](auto ns_c, const tdr_v2f* cyi, tdr_v2f AB, tdr_const_u D) {
+    constexpr int NS = decltype(ns_c)::value;
+    uint32_t w[NS];
+    int cis[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      int ri, ci;
+      cell(cyi[u], AB, ri, ci);
+      cis[u] = ci;
+      if (D[4 * u] == 0) {   // wave-uniform
+        w[u] = *reinterpret_cast<const uint32_t*>(crecb + kmask_offset(ri, ci, mrow, mconst));
+      } else {
+        int t1, t2;
+        unsigned off;
+        const int cq = ci >> 3;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(cq), "v"(pkcol), "s"(D[4 * u + 2]));
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t2) : "v"(ci), "v"(t1));
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ri), "v"(t2));
+        w[u] = *reinterpret_cast<const uint16_t*>(crecb + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      const uint32_t cd = D[4 * u];
+      if (cd == 0) {   // wave-uniform
+        known += (w[u] >> (cis[u] & 31)) & 1u;
+      } else {
+        const uint32_t kb = w[u] >> 15;          // bit 15 of a plane's cell (tdr_cmap.hip)
+        known += kb;
+        const uint32_t v = D[4 * u + 1];
+        inorm += (0u - kb) & v;                  // the bin's count x known (state_particle.cpp:141-142)
+        add_class(cd, v, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds.dict) + (w[u] & 0xFFCu)));
+      }
+    }
+  };
+  // rows [ia, ib) x columns [ja, jb) in plain C++: blocks of 4 rows while they lie wholly below the last row, then row by row
+  // (LinSpaced selects `high` for its last element: cart_linspaced)
+  auto cpp_rows = [&](int ia, int ib, int ja, int jb) {
+    int i = ia;
+    for (; i + 4 <= ib && i + 4 <= a.rows - 1; i += 4) {
+      tdr_v2f cyi[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cyi[u] = cs * (lo_r + (float)(i + u) * step_r);
+      for (int j = ja; j < jb; j++) samples(std::integral_constant<int, 4>{}, cyi, column_terms(j), descc + ((int64_t)j * a.rows + i) * 4);
+    }
+    for (; i < ib; i++) {
+      const tdr_v2f cyi = cs * cart_linspaced(i, r1, lo_r, hi_r, step_r);
+      for (int j = ja; j < jb; j++) samples(std::integral_constant<int, 1>{}, &cyi, column_terms(j), descc + ((int64_t)j * a.rows + i) * 4);
+    }
+  };
+
+  // rows the assembly loop may take: whole blocks of 4 below the last row
+  const int iend = ((a.rows - 1) / 4) * 4;
+  const bool asm_ok = lds_base == 0 && (a.rows & 3) == 0 && x.seg_rows >= 4 && (x.seg_rows & 3) == 0;
+  const uint64_t half2 = 0x3EFFFFFF3EFFFFFFull;         // {0.49999997f, 0.49999997f}
+  const float rmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rmaxf)));
+  const float cmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cmaxf)));
+  const uint32_t rows16_s = __builtin_amdgcn_readfirstlane((uint32_t)a.rows * 16u);
+  for (int jg = j0; jg < j1; jg += CART_ASM_NCOL) {
+    if (!asm_ok || jg + CART_ASM_NCOL > j1) {   // (uniform) a partial group, or a shape the loop does not take
+      cpp_rows(0, a.rows, jg, min(j1, jg + CART_ASM_NCOL));
+      continue;
+    }
+    tdr_v2f ab[CART_ASM_NCOL];
+#pragma unroll
+    for (int jc = 0; jc < CART_ASM_NCOL; jc++) ab[jc] = column_terms(jg + jc);
+    for (int ia = 0; ia < iend; ia += x.seg_rows) {
+      const int ib = min(iend, ia + x.seg_rows);
+      // cells this lane's samples of the segment can fall on: the corners bound them (see the kernel's comment)
+      const tdr_v2f ya = cs * (lo_r + (float)ia * step_r), yb = cs * (lo_r + (float)(ib - 1) * step_r);
+      const tdr_v2f p00 = (ya + ab[0]) + offv, p01 = (ya + ab[CART_ASM_NCOL - 1]) + offv;
+      const tdr_v2f p10 = (yb + ab[0]) + offv, p11 = (yb + ab[CART_ASM_NCOL - 1]) + offv;
+      const float a0 = fminf(fminf(p00.x, p01.x), fminf(p10.x, p11.x)), b0 = fmaxf(fmaxf(p00.x, p01.x), fmaxf(p10.x, p11.x));
+      const float a1 = fminf(fminf(p00.y, p01.y), fminf(p10.y, p11.y)), b1 = fmaxf(fmaxf(p00.y, p01.y), fmaxf(p10.y, p11.y));
+      int rl = (int)fminf(fmaxf(floorf(a0) - 1.f, -1.f), rmaxf), rh = (int)fminf(fmaxf(ceilf(b0) + 1.f, -1.f), rmaxf);
+      int cl = (int)fminf(fmaxf(floorf(a1) - 1.f, -1.f), cmaxf), ch = (int)fminf(fmaxf(ceilf(b1) + 1.f, -1.f), cmaxf);
+      if (weird || !(a0 == a0) || !(b0 == b0) || !(a1 == a1) || !(b1 == b1)) { rl = -1; rh = a.map_rows; cl = -1; ch = a.map_cols; }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        rl = min(rl, __shfl_xor(rl, d)); rh = max(rh, __shfl_xor(rh, d));
+        cl = min(cl, __shfl_xor(cl, d)); ch = max(ch, __shfl_xor(ch, d));
+      }
+      const int wrl = __builtin_amdgcn_readfirstlane(rl), wrh = __builtin_amdgcn_readfirstlane(rh);
+      const int wcl = __builtin_amdgcn_readfirstlane(cl), wch = __builtin_amdgcn_readfirstlane(ch);
+      const int wl = (wcl >> 5) + 1, wh = (wch >> 5) + 1;   // mask words (a guard band of one word: kmask_offset)
+      const int Hw = wrh - wrl + 1, Wbw = wh - wl + 1;
+      if ((int64_t)Hw * Wbw > CART_SU_WBOX) {   // (wave-uniform) the box does not fit: the plain steps, the mask gathered
+        cpp_rows(ia, ib, jg, jg + CART_ASM_NCOL);
+        continue;
+      }
+      uint32_t ev = 0xFFFFFFFFu;
+      for (int wc = 0; wc < Wbw; wc++)       // (row fastest: consecutive lanes read consecutive words of one tile column)
+        for (int row = lane; row < Hw; row += 64) {
+          const uint32_t wv = kmask[(int64_t)(wl + wc) * kcolw + (wrl + row + 32)];
+          lds.bits[wave][row * Wbw + wc] = wv;
+          ev &= wv;
+        }
+      // the wave reads what its lanes just wrote, through the assembly's ds_read: order the stores in front
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int allknown = __builtin_amdgcn_readfirstlane(__all(ev == 0xFFFFFFFFu) ? 1 : 0);   // (cells outside the map are unknown)
+      const int inside = __builtin_amdgcn_readfirstlane((wrl >= 0 && wrh < a.map_rows && wcl >= 0 && wch < a.map_cols) ? 1 : 0);
+      const int krow4 = Wbw * 4;
+      const int kconst_s = __builtin_amdgcn_readfirstlane((int)my_bits_lds + (1 - wl - wrl * Wbw) * 4);
+      const uint32_t i0_s = __builtin_amdgcn_readfirstlane((uint32_t)ia);
+      const uint32_t nblk_s = __builtin_amdgcn_readfirstlane((uint32_t)((ib - ia) >> 2));
+      const uint32_t doff_s = __builtin_amdgcn_readfirstlane(((uint32_t)jg * (uint32_t)a.rows + (uint32_t)ia) * 16u);
+#define CART_ASM_OPERANDS                                                                                                  \
+      : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),   \
+        [norm] "+v"(inorm), [known] "+v"(known)                                                                             \
+      : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [ab3] "v"(ab[3]), [ab4] "v"(ab[4]), [ab5] "v"(ab[5]),         \
+        [ab6] "v"(ab[6]), [ab7] "v"(ab[7]), [offv] "v"(offv), [cs] "v"(cs), [lor] "v"(lo_r), [stepr] "v"(step_r),           \
+        [krow4] "v"(krow4), [pkcol] "v"(pkcol), [db] "s"(descc), [crec] "s"(crec), [rmax] "s"(rmax_s), [cmax] "s"(cmax_s),  \
+        [half] "s"(half2), [kconst] "s"(kconst_s), [i0] "s"(i0_s), [nblk] "s"(nblk_s), [doff] "s"(doff_s),                  \
+        [rows16] "s"(rows16_s)                                                                                              \
+      : CART_ASM_CLOBBERS
+      if (allknown) asm volatile(CART_ASM_ALLKNOWN CART_ASM_OPERANDS);
+      else if (inside) asm volatile(CART_ASM_NOCLAMP CART_ASM_OPERANDS);
+      else asm volatile(CART_ASM CART_ASM_OPERANDS);
+#undef CART_ASM_OPERANDS
+    }
+    cpp_rows(iend, a.rows, jg, jg + CART_ASM_NCOL);   // the last rows (LinSpaced's last element among them)
+  }
+  // bins holding several classes: the chunk's list (any order: the sums are exact); their known bit was counted above
+  {
+    const uint32_t* __restrict__ lst = x.full_list + (int64_t)blockIdx.y * x.list_cap;
+    const int nfull = __builtin_amdgcn_readfirstlane(x.full_cnt[blockIdx.y]);
+    for (int e = 0; e < nfull; e++) {
+      const uint32_t w = __builtin_amdgcn_readfirstlane(lst[e]);
+      const int i = (int)(w >> 16), j = (int)(w & 0xFFFFu);
+      int ri, ci;
+      cell(cs * cart_linspaced(i, r1, lo_r, hi_r, step_r), column_terms(j), ri, ci);
+      const unsigned off = cmap_offset<CW, 2>(ri, ci, ckcol, ckconst);
+      const uint2 rec = *reinterpret_cast<const uint2*>(crecb + off);
+      const uint32_t wr[2] = {rec.x, rec.y};
+      const uint32_t kb = rec.x & 1u;   // bit 0 of every dword of a narrow record is the known bit (tdr_cmap.hip)
+      const tdr_const_f S = scanc + ((int64_t)j * a.rows + i) * RF;
+      inorm += (0u - kb) & (uint32_t)S[RF - 1];
+#pragma unroll
+      for (int k = 0; k < ND; k++) {
+        const float sk = S[k];
+        if (sk != 0.f) {   // wave-uniform
+          const uint32_t ww = wr[k / 3];
+          const int sh = 10 * (k % 3);
+          const uint32_t boff = sh ? ((ww >> sh) & 0xFFCu) : (ww & 0xFFCu);
+          acc[k] += (unsigned long long)(uint32_t)sk *
+                    *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds.dict) + boff);
+        }
+      }
+    }
+  }
+  if (real) {   // [chunk][2 ncls + 2][npad] words, like score_polar_su_kernel
+    const int ncls = a.ncls;
+    uint32_t* o = reinterpret_cast<uint32_t*>(a.part) + (int64_t)blockIdx.y * (2 * ncls + 2) * a.npad + slot;
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      if (k < ncls) {
+        o[(int64_t)(2 * k) * a.npad] = (uint32_t)acc[k];
+        o[(int64_t)(2 * k + 1) * a.npad] = (uint32_t)(acc[k] >> 32);
+      }
+    o[(int64_t)(2 * ncls) * a.npad] = inorm;
+    o[(int64_t)(2 * ncls + 1) * a.npad] = known;
   }
 }
 
@@ -581,9 +867,23 @@ static inline int64_t cart_ray_desc_words(int rows, int cols) {
   return ((int64_t)rows * cart_ray_blocks(cols) * cart_ray_gq(cols) * 64 + 1) / 2 + 64;
 }
 static SuWs cart_order_ws(int64_t n) { return tdr_su_ws(1, 4, 4, std::max<int64_t>(n, 1)); }
+// score_cart_su_kernel's tables: its descriptors (bins with several classes as empty ones), their per-chunk lists (room for
+// every bin) and the lists' counters
+static inline int64_t cart_su_words(int rows, int cols) {
+  return tdr_cart_desc_words(rows, cols) + ((int64_t)rows * cols + 63) / 64 * 64 + ((int64_t)cols + 63) / 64 * 64;
+}
 int64_t tdr_cart_int_words(int rows, int cols, int64_t n) {
-  // [integer descriptors rows * cols * 4][ray descriptors][list rows * cols][ordering workspace]
-  return tdr_cart_desc_words(rows, cols) + cart_ray_desc_words(rows, cols) + (int64_t)rows * cols + 64 + cart_order_ws(n).total;
+  // [integer descriptors rows * cols * 4][ray descriptors][list rows * cols][ordering workspace][score_cart_su_kernel's tables]
+  return tdr_cart_desc_words(rows, cols) + cart_ray_desc_words(rows, cols) + (int64_t)rows * cols + 64 + cart_order_ws(n).total +
+         cart_su_words(rows, cols);
+}
+// rows of a segment of score_cart_su_kernel (a multiple of 4; tdr_config_tuning("cart_seg_rows", n)): the smaller the
+// segment, the smaller the box of cells a wave stages and the likelier it holds no unknown cell; the larger, the fewer
+// box computations.  Measured on config 4 (ms per step): see DESIGN.md 5.5
+static int g_cart_seg_rows = 32;
+extern "C" int tdr_config_cart_seg_rows(int n) {   // < 0: query only; 0: the assembly loop off (A/B: the plain kernel)
+  if (n >= 0) g_cart_seg_rows = n - n % 4;
+  return g_cart_seg_rows;
 }
 
 int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* desc_ws, int32_t* ws, float span, hipStream_t s,
@@ -623,6 +923,23 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
                      ints + 4);
   LAUNCH_CHECK("cart_ray_prep");
   const int32_t* flags = ints + 4;
+  // the dense share through score_cart_su_kernel (generated sample loop, staged mask) when the records are the two-dword
+  // ones: its own descriptors, the lists of bins with several classes per column chunk
+  const bool su_kernel = rf == 8 && tdr_has_kslot(map->ncls, rf) && map->cwords == 2 && g_cart_seg_rows >= 4 && (a.rows & 3) == 0 &&
+                         a.rows >= 8 && (int64_t)a.rows * a.cols * 16 < (int64_t)1 << 31;
+  const int cpc_su = (a.cpc + CART_ASM_NCOL - 1) / CART_ASM_NCOL * CART_ASM_NCOL;
+  const int nchunks_su = (int)cdiv(a.cols, cpc_su);   // <= a.nchunks: the partial sums' rows suffice
+  uint32_t* desc_su = reinterpret_cast<uint32_t*>(ows + W.total);
+  uint32_t* full_list = desc_su + tdr_cart_desc_words(a.rows, a.cols);
+  int32_t* full_cnt = reinterpret_cast<int32_t*>(full_list + ((int64_t)a.rows * a.cols + 63) / 64 * 64);
+  const int64_t list_cap = (int64_t)a.rows * cpc_su;
+  if (su_kernel) {
+    HIP_TRY(hipMemsetAsync(full_cnt, 0, sizeof(int32_t) * (size_t)nchunks_su, s));
+    hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
+                       map->ncls, ckconst, map->dict, map->dict_n, desc_su, 1, pbase, plane_bytes, full_list, full_cnt, cpc_su,
+                       list_cap);
+    LAUNCH_CHECK("cart_prep(su)");
+  }
   a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
   a.kmask_row = kmask_trows(map->rows) * 128;
   a.ncls = map->ncls;
@@ -662,6 +979,17 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
     d.flags = flags; d.run_if_int = 1;
     d.order = slots; d.count = counts; d.npad = npad_int;
     d.pkcol = plane_trows(map->rows) * 128 - 16;
+    out->nchunks_dense = a.nchunks;
+    if (su_kernel) {
+      CartSuArgs x;
+      x.full_list = full_list; x.full_cnt = full_cnt; x.list_cap = list_cap; x.seg_rows = g_cart_seg_rows;
+      d.desc = desc_su;
+      d.cpc = cpc_su;
+      d.nchunks = nchunks_su;
+      out->nchunks_dense = nchunks_su;
+      hipLaunchKernelGGL(score_cart_su_kernel, dim3((unsigned)cdiv(npad_int, 256), (unsigned)nchunks_su), dim3(256), 0, s, d, x);
+      LAUNCH_CHECK("score_cart_su");
+    } else {
     const dim3 grid((unsigned)cdiv(npad_int, 256), (unsigned)a.nchunks), block(256);
 #define TDR_LAUNCH_CART_INT(NV4)                                                                 \
   if (ks) hipLaunchKernelGGL((score_cart_skip_kernel<NV4, true, true>), grid, block, 0, s, d);    \
@@ -674,6 +1002,7 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
     }
 #undef TDR_LAUNCH_CART_INT
     LAUNCH_CHECK("score_cart_skip(int)");
+    }
   }
   // the float form, for a scan / map without an integer form (returns at once otherwise)
   {
