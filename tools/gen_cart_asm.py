@@ -21,10 +21,12 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
   v20..v23  scratch;  v24..v27 sample u: the 2-byte cell of the bin's class plane
   v32..v39  cs * y_(i+u), u = 0..3 (recomputed at every row block);  v40, v41 scratch of that
-  s48..s63 / s80..s95   the step's descriptors {code, count, plane constant, -} x 4 (cart_prep_kernel), even / odd columns:
-                        a step requests the next step's descriptors into the other set before it works on its own
-  s64 first row of the block, s65 row blocks left, s66 byte offset of (row block, column 0) in the descriptor array,
-  s67 offset being requested, s68..s75 byte offsets of the eight columns from column 0, s76 scratch
+  s48..s63 / s80..s95   the one-dword descriptors of columns 0-3 / 4-7 of the row block, 4 rows x 4 columns each
+                        (cart_prep_kernel's block layout: count in bits 0-23, class code in bits 24-26; a step's first
+                        descriptor: which of its four bins hold a class in bits 28-31; a block's first: bit 27 = any does).
+                        Half a block is ONE scalar load, requested half a block ahead into the other set
+  s64 first row of the block, s65 row blocks left, s66 byte offset of the block in the descriptor array,
+  s67 offset being requested, s76, s77 scratch
 Arithmetic: EXACT integer sums like the polar loop (tools/gen_su_asm.py): any order, any partition, any kernel gives the
 same bits.  Bins holding several classes are EMPTY to this loop (their descriptor code is 0 in the array it reads): the
 kernel adds their products from a per-chunk list afterwards; their known bit is counted here like an empty bin's.
@@ -50,11 +52,15 @@ def loop_text(clamp, mask):
     a("s_mov_b32 s64, %[i0]")
     a("s_mov_b32 s65, %[nblk]")
     a("s_mov_b32 s66, %[doff]")
-    a("s_mov_b32 s68, 0")
-    for jc in range(1, NCOL):
-        a(f"s_add_u32 s{68 + jc}, s{68 + jc - 1}, %[rows16]")   # column jc lies jc * rows * 16 bytes behind column 0
-    a("s_load_dwordx16 s[48:63], %[db], s66")
+    a("s_load_dwordx16 s[48:63], %[db], s66")        # the first half of the first block
     a(".Lct_blk%=:")
+    a("s_waitcnt lgkmcnt(0)")                        # set A: columns 0-3 of this block
+    if not mask:
+        a(f"v_add_u32 %[known], {4 * NCOL}, %[known]")   # every sample of the block is a known cell
+        a("s_bitcmp1_b32 s48, 27")                   # no bin of the block holds anything: nothing else to do for it
+        a("s_cbranch_scc0 .Lct_eblk%=")
+    a("s_add_u32 s67, s66, 64")
+    a("s_load_dwordx16 s[80:95], %[db], s67")        # set B: columns 4-7, requested behind everything this block waits for first
     # cs * y_(i+u): y = lo_r + float(i + u) * step_r (LinSpaced: one product, one sum — no fused multiply-add)
     for u in range(4):
         a(f"s_add_u32 s76, s64, {u}")
@@ -65,31 +71,37 @@ def loop_text(clamp, mask):
         a("v_add_f32 v40, %[lor], v40")
         a("s_nop 0")
         a(f"v_pk_mul_f32 v[{32 + 2 * u}:{33 + 2 * u}], %[cs], v[40:41] op_sel_hi:[1,0]")   # {cos * y, sin * y}
-    if not mask:
-        a(f"v_add_u32 %[known], {4 * NCOL}, %[known]")   # every sample of the block is a known cell
-    a("s_waitcnt lgkmcnt(0)")                        # the descriptors of column 0
     for jc in range(NCOL):
-        even = jc % 2 == 0
-        step(a, jc, clamp, mask, D=48 if even else 80, DN=80 if even else 48)
+        if jc == NCOL // 2:
+            a("s_waitcnt lgkmcnt(0)")                # set B (long since requested)
+            a("s_add_u32 s67, s66, 128")             # set A is free: the first half of the NEXT block (behind the segment's
+            a("s_load_dwordx16 s[48:63], %[db], s67")   # last block lies the group's next block: inside the array)
+        step(a, jc, clamp, mask, S=48 if jc < NCOL // 2 else 80)
+    a("s_add_u32 s66, s66, 128")
     a("s_add_u32 s64, s64, 4")
-    a("s_add_u32 s66, s66, 64")
     a("s_sub_u32 s65, s65, 1")
     a("s_cmp_lg_u32 s65, 0")
     a("s_cbranch_scc1 .Lct_blk%=")
+    if not mask:
+        a("s_branch .Lct_end%=")
+        a(".Lct_eblk%=:")                            # an empty block of an all-known segment: on to the next one
+        a("s_add_u32 s66, s66, 128")
+        a("s_load_dwordx16 s[48:63], %[db], s66")
+        a("s_add_u32 s64, s64, 4")
+        a("s_sub_u32 s65, s65, 1")
+        a("s_cmp_lg_u32 s65, 0")
+        a("s_cbranch_scc1 .Lct_blk%=")
+        a(".Lct_end%=:")
     a("s_waitcnt lgkmcnt(0)")                        # (the request for the block behind the last one)
     return L
 
 
-def step(a, jc, clamp, mask, D, DN):
+def step(a, jc, clamp, mask, S):
+    """One step = rows i .. i + 3 of column jc.  Its four descriptors are s(d0) .. s(d0 + 3), one dword each: count in bits
+    0-23, class code (1-6; 0 = nothing for the loop) in bits 24-26; the step's FIRST descriptor also carries, in bits 28-31,
+    which of the four bins hold a class (cart_prep_kernel)."""
     tag = f"c{jc}"
-    # the step behind this one: the next column of the block, or column 0 of the next block (its descriptors are the 64
-    # bytes behind this block's; behind the segment's last block that is the next segment's first — inside the array, the
-    # kernel never runs a group whose last block ends at the array's end without the pad behind it)
-    if jc + 1 < NCOL:
-        a(f"s_add_u32 s67, s66, s{68 + jc + 1}")
-    else:
-        a("s_add_u32 s67, s66, 64")
-    a(f"s_load_dwordx16 s[{DN}:{DN + 15}], %[db], s67")
+    d0 = S + 4 * (jc % (NCOL // 2))
 
     def coords(us):
         for u in us:
@@ -129,16 +141,21 @@ def step(a, jc, clamp, mask, D, DN):
         a("s_nop 0")
         for u in range(4):
             a(f"ds_read_b32 v{28 + u}, v{16 + u}")
+    # a step without any class: an all-known segment skips it altogether, the others only count their known bits
+    a(f"s_lshr_b32 s76, s{d0}, 28")
+    a(f"s_cbranch_scc0 .Lct_ae{tag}%=" if mask else f"s_cbranch_scc0 .Lct_be{tag}%=")
     # the 2-byte cell of the class's plane for every bin holding ONE class (plane_offset, tdr_score_dev.h)
     for u in range(4):
-        code, ckc = D + 4 * u, D + 2 + 4 * u
-        a(f"s_cmp_eq_u32 s{code}, 0")
-        a(f"s_cbranch_scc1 .Lct_a{u}{tag}%=")
+        a(f"s_bitcmp1_b32 s{d0}, {28 + u}")
+        a(f"s_cbranch_scc0 .Lct_a{u}{tag}%=")
         if not mask:
             coords([u])     # (an empty bin of an all-known segment needs no cell at all)
+        a(f"s_bfe_u32 s77, s{d0 + u}, 0x30018")                     # the class code: bits 24-26
+        a("s_mul_i32 s77, s77, %[pbytes]")                          # its plane's constant: pbase0 + code * plane bytes
+        a("s_add_u32 s77, s77, %[pbase0]")
         a(f"v_ashrrev_i32 v{20 + u}, 3, v{9 + 2 * u}")
         a("s_nop 0")
-        a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[pkcol], s{ckc}")
+        a(f"v_mad_i32_i24 v{20 + u}, v{20 + u}, %[pkcol], s77")
         a("s_nop 0")
         a(f"v_lshl_add_u32 v{20 + u}, v{9 + 2 * u}, 1, v{20 + u}")
         a("s_nop 0")
@@ -146,6 +163,8 @@ def step(a, jc, clamp, mask, D, DN):
         a("s_nop 0")
         a(f"global_load_ushort v{24 + u}, v{20 + u}, %[crec]")     # (never into its own address register)
         a(f".Lct_a{u}{tag}%=:")
+    if mask:
+        a(f".Lct_ae{tag}%=:")
     # ---- everything requested above is waited for HERE, inside the text
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     if mask:
@@ -157,48 +176,52 @@ def step(a, jc, clamp, mask, D, DN):
         a("v_add_u32 v20, v20, v21")
         a("s_nop 0")
         a("v_sub_u32 %[known], %[known], v20")
+        a(f"s_lshr_b32 s76, s{d0}, 28")
+        a(f"s_cbranch_scc0 .Lct_be{tag}%=")
     for u in range(4):
-        code, val = D + 4 * u, D + 1 + 4 * u
-        a(f"s_cmp_eq_u32 s{code}, 0")
-        a(f"s_cbranch_scc1 .Lct_b{u}{tag}%=")
+        a(f"s_bitcmp1_b32 s{d0}, {28 + u}")
+        a(f"s_cbranch_scc0 .Lct_b{u}{tag}%=")
+        a(f"s_and_b32 s77, s{d0 + u}, 0xffffff")                                             # the bin's count
         if mask:
-            a(f"v_and_b32 v20, s{val}, v{16 + u}")                                           # the bin's count x known (:141-142)
+            a(f"v_and_b32 v20, s77, v{16 + u}")                                              # count x known (:141-142)
         a(f"v_and_b32 v21, 0xffc, v{24 + u}")                                                # the class's dictionary index * 4
         if mask:
             a("v_add_u32 %[norm], %[norm], v20")
         else:
-            a(f"v_add_u32 %[norm], s{val}, %[norm]")
+            a("v_add_u32 %[norm], s77, %[norm]")
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                            # the dictionary sits at LDS address 0
+        a(f"s_bfe_u32 s76, s{d0 + u}, 0x30018")                                              # the class code
         a("s_waitcnt lgkmcnt(0)")
         # acc[class] += count * distance (state_particle.cpp:136-139) as integers: wave-uniform branches over the class
-        a(f"s_cmp_lt_u32 s{code}, 4")
+        a("s_cmp_lt_u32 s76, 4")
         a(f"s_cbranch_scc1 .Lct_k{u}lo{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 5")
+        a("s_cmp_lt_u32 s76, 5")
         a(f"s_cbranch_scc1 .Lct_k{u}k3{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 6")
+        a("s_cmp_lt_u32 s76, 6")
         a(f"s_cbranch_scc1 .Lct_k{u}k4{tag}%=")
-        a(f"v_mad_u64_u32 %[a5], vcc, s{val}, v21, %[a5]")
+        a("v_mad_u64_u32 %[a5], vcc, s77, v21, %[a5]")
         a(f"s_branch .Lct_b{u}{tag}%=")
         a(f".Lct_k{u}k4{tag}%=:")
-        a(f"v_mad_u64_u32 %[a4], vcc, s{val}, v21, %[a4]")
+        a("v_mad_u64_u32 %[a4], vcc, s77, v21, %[a4]")
         a(f"s_branch .Lct_b{u}{tag}%=")
         a(f".Lct_k{u}k3{tag}%=:")
-        a(f"v_mad_u64_u32 %[a3], vcc, s{val}, v21, %[a3]")
+        a("v_mad_u64_u32 %[a3], vcc, s77, v21, %[a3]")
         a(f"s_branch .Lct_b{u}{tag}%=")
         a(f".Lct_k{u}lo{tag}%=:")
-        a(f"s_cmp_lt_u32 s{code}, 2")
+        a("s_cmp_lt_u32 s76, 2")
         a(f"s_cbranch_scc1 .Lct_k{u}k0{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 3")
+        a("s_cmp_lt_u32 s76, 3")
         a(f"s_cbranch_scc1 .Lct_k{u}k1{tag}%=")
-        a(f"v_mad_u64_u32 %[a2], vcc, s{val}, v21, %[a2]")
+        a("v_mad_u64_u32 %[a2], vcc, s77, v21, %[a2]")
         a(f"s_branch .Lct_b{u}{tag}%=")
         a(f".Lct_k{u}k1{tag}%=:")
-        a(f"v_mad_u64_u32 %[a1], vcc, s{val}, v21, %[a1]")
+        a("v_mad_u64_u32 %[a1], vcc, s77, v21, %[a1]")
         a(f"s_branch .Lct_b{u}{tag}%=")
         a(f".Lct_k{u}k0{tag}%=:")
-        a(f"v_mad_u64_u32 %[a0], vcc, s{val}, v21, %[a0]")
+        a("v_mad_u64_u32 %[a0], vcc, s77, v21, %[a0]")
         a(f".Lct_b{u}{tag}%=:")
+    a(f".Lct_be{tag}%=:")
 
 
 def statement_operands():

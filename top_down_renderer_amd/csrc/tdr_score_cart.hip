@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict_
                                                         uint32_t* __restrict__ desc, int as_int, unsigned pbase,
                                                         unsigned plane_bytes, uint32_t* __restrict__ full_list = nullptr,
                                                         int32_t* __restrict__ full_cnt = nullptr, int cpc_su = 1,
-                                                        int64_t list_cap = 0) {
+                                                        int64_t list_cap = 0, uint32_t* __restrict__ bdesc = nullptr) {
   bool bad = false;   // the dictionary is small: every workgroup checks it for itself
   for (int k = threadIdx.x; k < dict_n; k += blockDim.x) bad |= !(fabsf(dict[k]) <= 3.402823466e+38f);
   const bool dict_bad = __syncthreads_or(bad);
@@ -80,6 +80,21 @@ __global__ __launch_bounds__(256) void cart_prep_kernel(const float* __restrict_
     full_list[(int64_t)chunk * list_cap + atomicAdd(&full_cnt[chunk], 1)] = ((uint32_t)i << 16) | (uint32_t)j;
     code = 0;
     val = 0.f;
+  }
+  if (bdesc) {
+    // The same bins once more in the BLOCK layout the generated loop streams (tools/gen_cart_asm.py): one dword per bin —
+    // count in bits 0-23, class code in bits 24-26 — at [(column group * row blocks + row block) * 32 + (column & 7) * 4 +
+    // (row & 3)], i.e. half a block (4 rows x 4 columns) is one 64-byte scalar load.  A step's first dword also says which
+    // of its four bins hold a class (bits 28-31), a block's first whether any of its 32 does (bit 27).  The array is zeroed
+    // before this kernel and only OR-ed into: the flags come from other threads.  (rows is a multiple of 4 here.)
+    const int j = (int)(t / rows), i = (int)(t - (int64_t)j * rows);
+    const int64_t blk = ((int64_t)(j >> 3) * (rows >> 2) + (i >> 2)) * 32;
+    const int jc = j & 7, u = i & 3;
+    if (code != 0) {
+      atomicOr(&bdesc[blk + jc * 4 + u], (code << 24) | ((uint32_t)val & 0xFFFFFFu));
+      atomicOr(&bdesc[blk + jc * 4], 1u << (28 + u));
+      atomicOr(&bdesc[blk], 1u << 27);
+    }
   }
   desc[4 * t] = code;
   desc[4 * t + 1] = as_int ? (uint32_t)val : __float_as_uint(val);
@@ -324,6 +339,8 @@ __global__ __launch_bounds__(256) void score_cart_skip_kernel(CartArgs a) {
 #define CART_SU_WBOX 1024   // LDS words of one wave's staged known mask (4 KB; a 32-row segment of config 4 needs ~200)
 
 struct CartSuArgs {
+  const uint32_t* bdesc;       // the descriptors in the block layout the generated loop streams (cart_prep_kernel)
+  unsigned pbase0, pbytes;     // plane_offset's constant for the plane of class code c: pbase0 + c * pbytes (a byte offset from crec)
   const uint32_t* full_list;   // [chunks][list_cap]: bins with several classes, row << 16 | column (cart_prep_kernel)
   const int32_t* full_cnt;     // [chunks]
   int64_t list_cap;
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuAr
   typedef const uint32_t __attribute__((address_space(4))) * tdr_const_u;
   const tdr_const_f scanc = (tdr_const_f)a.scan_pk;
   const tdr_const_u descc = (tdr_const_u)a.desc;
+  const tdr_const_u bdescc = (tdr_const_u)x.bdesc;
   const unsigned lds_base = (unsigned)(uintptr_t)&lds;
   const unsigned my_bits_lds = (unsigned)(uintptr_t)&lds.bits[wave][0];
 
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuAr
   const uint64_t half2 = 0x3EFFFFFF3EFFFFFFull;         // {0.49999997f, 0.49999997f}
   const float rmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rmaxf)));
   const float cmax_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(cmaxf)));
-  const uint32_t rows16_s = __builtin_amdgcn_readfirstlane((uint32_t)a.rows * 16u);
+  const uint32_t pbase0_s = __builtin_amdgcn_readfirstlane(x.pbase0), pbytes_s = __builtin_amdgcn_readfirstlane(x.pbytes);
   for (int jg = j0; jg < j1; jg += CART_ASM_NCOL) {
     if (!asm_ok || jg + CART_ASM_NCOL > j1) {   // (uniform) a partial group, or a shape the loop does not take
       cpp_rows(0, a.rows, jg, min(j1, jg + CART_ASM_NCOL));
@@ -517,15 +535,16 @@ __global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuAr
       const int kconst_s = __builtin_amdgcn_readfirstlane((int)my_bits_lds + (1 - wl - wrl * Wbw) * 4);
       const uint32_t i0_s = __builtin_amdgcn_readfirstlane((uint32_t)ia);
       const uint32_t nblk_s = __builtin_amdgcn_readfirstlane((uint32_t)((ib - ia) >> 2));
-      const uint32_t doff_s = __builtin_amdgcn_readfirstlane(((uint32_t)jg * (uint32_t)a.rows + (uint32_t)ia) * 16u);
+      // byte offset of block (column group jg / 8, row block ia / 4) in the block layout: 128 bytes a block
+      const uint32_t doff_s = __builtin_amdgcn_readfirstlane((((uint32_t)jg >> 3) * ((uint32_t)a.rows >> 2) + ((uint32_t)ia >> 2)) * 128u);
 #define CART_ASM_OPERANDS                                                                                                  \
       : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),   \
         [norm] "+v"(inorm), [known] "+v"(known)                                                                             \
       : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [ab3] "v"(ab[3]), [ab4] "v"(ab[4]), [ab5] "v"(ab[5]),         \
         [ab6] "v"(ab[6]), [ab7] "v"(ab[7]), [offv] "v"(offv), [cs] "v"(cs), [lor] "v"(lo_r), [stepr] "v"(step_r),           \
-        [krow4] "v"(krow4), [pkcol] "v"(pkcol), [db] "s"(descc), [crec] "s"(crec), [rmax] "s"(rmax_s), [cmax] "s"(cmax_s),  \
+        [krow4] "v"(krow4), [pkcol] "v"(pkcol), [db] "s"(bdescc), [crec] "s"(crec), [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), \
         [half] "s"(half2), [kconst] "s"(kconst_s), [i0] "s"(i0_s), [nblk] "s"(nblk_s), [doff] "s"(doff_s),                  \
-        [rows16] "s"(rows16_s)                                                                                              \
+        [pbase0] "s"(pbase0_s), [pbytes] "s"(pbytes_s)                                                                      \
       : CART_ASM_CLOBBERS
       if (allknown) asm volatile(CART_ASM_ALLKNOWN CART_ASM_OPERANDS);
       else if (inside) asm volatile(CART_ASM_NOCLAMP CART_ASM_OPERANDS);
@@ -869,8 +888,12 @@ static inline int64_t cart_ray_desc_words(int rows, int cols) {
 static SuWs cart_order_ws(int64_t n) { return tdr_su_ws(1, 4, 4, std::max<int64_t>(n, 1)); }
 // score_cart_su_kernel's tables: its descriptors (bins with several classes as empty ones), their per-chunk lists (room for
 // every bin) and the lists' counters
+static inline int64_t cart_bdesc_words(int rows, int cols) {   // block layout: whole groups of 8 columns + a block of pad
+  return (int64_t)((cols + 7) / 8) * ((rows + 3) / 4) * 32 + 64;
+}
 static inline int64_t cart_su_words(int rows, int cols) {
-  return tdr_cart_desc_words(rows, cols) + ((int64_t)rows * cols + 63) / 64 * 64 + ((int64_t)cols + 63) / 64 * 64;
+  return tdr_cart_desc_words(rows, cols) + ((int64_t)rows * cols + 63) / 64 * 64 + ((int64_t)cols + 63) / 64 * 64 +
+         cart_bdesc_words(rows, cols);
 }
 int64_t tdr_cart_int_words(int rows, int cols, int64_t n) {
   // [integer descriptors rows * cols * 4][ray descriptors][list rows * cols][ordering workspace][score_cart_su_kernel's tables]
@@ -932,12 +955,14 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
   uint32_t* desc_su = reinterpret_cast<uint32_t*>(ows + W.total);
   uint32_t* full_list = desc_su + tdr_cart_desc_words(a.rows, a.cols);
   int32_t* full_cnt = reinterpret_cast<int32_t*>(full_list + ((int64_t)a.rows * a.cols + 63) / 64 * 64);
+  uint32_t* bdesc = reinterpret_cast<uint32_t*>(full_cnt + ((int64_t)a.cols + 63) / 64 * 64);
   const int64_t list_cap = (int64_t)a.rows * cpc_su;
   if (su_kernel) {
     HIP_TRY(hipMemsetAsync(full_cnt, 0, sizeof(int32_t) * (size_t)nchunks_su, s));
+    HIP_TRY(hipMemsetAsync(bdesc, 0, sizeof(uint32_t) * (size_t)cart_bdesc_words(a.rows, a.cols), s));
     hipLaunchKernelGGL(cart_prep_kernel, dim3((unsigned)cdiv(nbins, 256)), dim3(256), 0, s, a.scan_pk, a.rows, a.cols, rf,
                        map->ncls, ckconst, map->dict, map->dict_n, desc_su, 1, pbase, plane_bytes, full_list, full_cnt, cpc_su,
-                       list_cap);
+                       list_cap, bdesc);
     LAUNCH_CHECK("cart_prep(su)");
   }
   a.kmask_off = (unsigned)(tdr_cmap_tile_words(map->ncls, map->rows, map->cols) * 4);
@@ -983,6 +1008,7 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
     if (su_kernel) {
       CartSuArgs x;
       x.full_list = full_list; x.full_cnt = full_cnt; x.list_cap = list_cap; x.seg_rows = g_cart_seg_rows;
+      x.bdesc = bdesc; x.pbytes = plane_bytes; x.pbase0 = pbase - plane_bytes;
       d.desc = desc_su;
       d.cpc = cpc_su;
       d.nchunks = nchunks_su;
