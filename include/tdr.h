@@ -439,7 +439,7 @@ int tdr_config_compact(int on);
  * compact records and class planes); < 0 only returns the mode.  Env TDR_SHIFT_UNIFORM sets the initial mode.
  * The span: a launch with a tdr_score_ctx TUNES it while the filter runs — from the 31st call of a shape on, 2, 8, 16, 24
  * and 40 cells are timed over two scoring calls each (HIP events on the caller's stream, polled, never waited for), the fastest is kept and the trial is
- * repeated every 4000 calls.  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) or env TDR_SU_SPAN fix
+ * repeated every 4000 calls.  Results never depend on it.  tdr_config_shift_uniform_span(cells >= 0) fixes
  * it for every caller; -1 only returns the configured span (16 by default: what a launch without a context uses); -2 goes
  * back to tuning. */
 int tdr_config_shift_uniform(int mode);
@@ -494,6 +494,12 @@ int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattere
  *   "cart_seg_rows"    window rows per segment of score_cart_su_kernel (a multiple of 4; 0: the Cartesian integer form's dense
  *                      share goes through the plain kernel instead — same bits) */
 int64_t tdr_config_tuning(const char* name, int64_t value);
+/* Device self-test of the scoring kernels: a tiny fixed problem (160 x 160 map, 6 classes, 512 particles) scored by every
+ * kernel the library has for it.  The integer-form kernels run generated, hand-scheduled assembly; their sums are exact, so
+ * score_polar_su_kernel == score_polar_ray_kernel and score_cart_su_kernel == score_cart_skip_kernel == score_cart_ray_kernel
+ * BIT FOR BIT, and both agree with the float kernels to rounding (3e-6).  TDR_OK, or an error whose message says which
+ * pair disagrees: a toolchain that miscompiles around the generated loops fails loudly here (smoke() calls it). */
+int tdr_selftest_score(void);
 /* Self-test hook: out[i] = the scoring loop's coordinate rounding of x[i] clamped to [-1, limit] (== roundf). */
 int tdr_k_selftest_round(const float* x, int64_t n, float limit, int32_t* out, void* stream);
 /* sinf / cosf on the device are the HOST libm's, bit for bit (csrc/tdr_sincosf.h: glibc >= 2.28's double-precision

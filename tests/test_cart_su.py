@@ -98,3 +98,12 @@ def test_generated_loop_equals_plain_kernel_ray_kernel_and_oracle(tdr, oracle, n
     err = np.abs(plain[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)
     assert err.max(initial=0.0) <= 1e-5, err.max()
     assert ok.sum() > len(st) // 2
+
+
+def test_device_selftest_of_the_scoring_kernels(tdr):
+    """tdr_selftest_score (include/tdr.h): the generated loops against the plain kernels on the library's own fixed problem."""
+    pkg, k = tdr
+    rc = k.lib.tdr_selftest_score()
+    assert rc == 0, k.lib.tdr_last_error().decode()
+    # the process-wide switches it sets are back where they were
+    assert k.lib.tdr_config_tuning(b"cart_seg_rows", -1) == 32

@@ -1248,4 +1248,155 @@ int tdr_filter_update_map(tdr_filter* f, const float* class_maps, const uint8_t*
   return tdr_filter_initialize_particles(f);  // :337-340
 }
 
+
+// ---- device self-test of the scoring kernels -------------------------------------------------------------------------------
+// The integer-form kernels run hand-scheduled, generated assembly (tdr_score_su_asm.h, tdr_score_cart_asm.h): a toolchain
+// change must fail LOUDLY, not shift weights.  A tiny fixed problem, scored every way the library can score it:
+//   polar      integer form, dense share through score_polar_su_kernel  ==  all particles through score_polar_ray_kernel
+//              (bit for bit: the sums are exact), and both against the float kernel score_polar_kernel (rounding: 3e-6)
+//   Cartesian  score_cart_su_kernel (generated loop)  ==  score_cart_skip_kernel<INT> (plain C++)  ==  score_cart_ray_kernel,
+//              and against the float kernel
+// Process-wide switches are set for the duration of the call and restored (one caller at a time, like the profile switch).
+namespace {
+struct SelftestRestore {
+  int mode;
+  float span;
+  bool span_fixed_before;
+  int64_t seg;
+  SelftestRestore() : mode(tdr_config_shift_uniform(-1)), span(tdr_config_shift_uniform_span(-1.f)), seg(tdr_config_tuning("cart_seg_rows", -1)) {}
+  ~SelftestRestore() {
+    tdr_config_shift_uniform(mode);
+    tdr_config_shift_uniform_span(-2.f);   // back to tuning (the default); a caller that had fixed a span sets it again
+    tdr_config_tuning("cart_seg_rows", seg);
+  }
+};
+}  // namespace
+int tdr_selftest_score(void) {
+  constexpr int NCLS = 6, SIZE = 160, NB = 64, NR = 32, CR = 32, CC = 24, N = 512;
+  SelftestRestore restore;
+  // a label image: bands of classes, a road grid (class 1), an unlabelled hole
+  std::vector<uint8_t> lab((size_t)SIZE * SIZE);
+  for (int y = 0; y < SIZE; y++)
+    for (int x = 0; x < SIZE; x++) {
+      int c = ((x / 13) + 2 * (y / 17)) % NCLS;
+      if (c == 1) c = 2;
+      if (x % 40 < 3 || y % 40 < 3) c = 1;
+      if (x >= 100 && x < 120 && y >= 30 && y < 52) c = 255;   // unknown
+      lab[(size_t)y * SIZE + x] = (uint8_t)c;
+    }
+  int32_t lut[256];
+  for (int i = 0; i < 256; i++) lut[i] = i < NCLS ? i : -1;
+  tdr_map* m = nullptr;
+  TTRY(tdr_map_create(&m));
+  struct MapGuard { tdr_map* m; ~MapGuard() { tdr_map_destroy(m); } } mg{m};
+  TTRY(tdr_map_set_labels(m, lab.data(), SIZE, SIZE, lut, 256, NCLS, 1.f, 0, 0));
+  TTRY(tdr_map_sample_pts_polar(m, NB, NR, (float)(2 * M_PI / NB)));
+  // scans: integer counts, mostly one class per bin, some bins with two, many empty
+  auto make_scan = [&](int rows, int cols, std::vector<float>& img) {
+    img.assign((size_t)NCLS * rows * cols, 0.f);
+    uint32_t h = 12345u;
+    for (int k = 0; k < rows * cols; k++) {
+      h = h * 1664525u + 1013904223u;
+      const uint32_t r = h >> 8;
+      if (r % 100 < 55) continue;
+      const int c = (int)((r >> 7) % NCLS);
+      img[(size_t)c * rows * cols + k] = (float)(1 + (r >> 11) % 5);
+      if (r % 100 > 96) img[(size_t)((c + 2) % NCLS) * rows * cols + k] = (float)(1 + (r >> 15) % 3);
+    }
+  };
+  std::vector<float> scan_p, scan_c;
+  make_scan(NB, NR, scan_p);
+  make_scan(CR, CC, scan_c);
+  // particles: a cluster inside the map (different headings), a few at the border and outside
+  std::vector<tdr_state> st(N);
+  {
+    uint32_t h = 777u;
+    auto u01 = [&]() { h = h * 1664525u + 1013904223u; return (float)(h >> 8) / 16777216.f; };
+    for (int p = 0; p < N; p++) {
+      tdr_state s{};
+      s.init_x_px = 70.f + 14.f * (u01() - 0.5f);
+      s.init_y_px = 85.f + 14.f * (u01() - 0.5f);
+      s.theta = 0.4f + 0.5f * (u01() - 0.5f);
+      s.scale = 1.f;
+      s.have_init = 1;
+      if (p % 61 == 0) { s.init_x_px = 2.f + 150.f * u01(); s.init_y_px = (p % 2) ? 1.f : 158.f; }
+      if (p == 3) { s.init_x_px = -40.f; s.init_y_px = 80.f; }
+      st[(size_t)p] = s;
+    }
+  }
+  tdr_filter_params fp{};
+  fp.pos_cov = 0.3f; fp.theta_cov = 0.03f; fp.regularization = 0.15f;
+  fp.fixed_scale = 1.f; fp.scale_log_min = -0.1f; fp.scale_log_max = 1.f;
+  fp.num_classes = NCLS;
+  for (int c = 0; c < 16; c++) fp.class_weights[c] = c < NCLS ? 1.f : 0.f;
+  tdr_filter* f = nullptr;
+  TTRY(tdr_filter_create(m, N, &fp, 1, &f));
+  struct FilterGuard { tdr_filter* f; ~FilterGuard() { tdr_filter_destroy(f); } } fg{f};
+  TTRY(tdr_filter_set_states(f, st.data(), N));
+  std::vector<float> got[6];
+  auto rel_ok = [](const std::vector<float>& a, const std::vector<float>& b, double tol, double* worst) {
+    *worst = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+      if (std::isnan(a[i]) != std::isnan(b[i])) return false;
+      if (std::isnan(a[i])) continue;
+      const double d = std::fabs((double)a[i] - (double)b[i]) / std::max(std::fabs((double)b[i]), 1e-30);
+      *worst = std::max(*worst, d);
+    }
+    return *worst <= tol;
+  };
+  auto same_bits = [](const std::vector<float>& a, const std::vector<float>& b) {
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0;
+  };
+  // ---- polar: float kernel, integer form (dense share), integer form with every particle ray-mapped
+  const struct { int mode; float span; } polar_runs[3] = {{0, 16.f}, {2, 16.f}, {2, 1e-6f}};
+  for (int r = 0; r < 3; r++) {
+    tdr_config_shift_uniform(polar_runs[r].mode);
+    tdr_config_shift_uniform_span(polar_runs[r].span);
+    TTRY(tdr_filter_compute_weights(f, scan_p.data(), nullptr, 1.f));
+    got[r].resize(N);
+    TTRY(tdr_filter_get_raw_weights(f, got[r].data(), N));
+  }
+  double worst = 0;
+  if (!same_bits(got[1], got[2]))
+    return failh(TDR_ERR_HIP, "selftest: score_polar_su_kernel and score_polar_ray_kernel disagree (exact integer sums must "
+                              "be identical): the generated loop does not survive this toolchain");
+  if (!rel_ok(got[1], got[0], 3e-6, &worst))
+    return failh(TDR_ERR_HIP, "selftest: the polar integer form is %.3g away from the float kernel", worst);
+  int finite = 0;
+  for (float w : got[1]) finite += std::isfinite(w) && w > 0.f;
+  if (finite < N / 2) return failh(TDR_ERR_HIP, "selftest: only %d of %d polar weights are finite", finite, N);
+  // ---- Cartesian: float kernel, plain integer kernel, generated loop (two segment lengths), ray-mapped
+  {
+    const int rf = tdr_rec_floats(NCLS);
+    DevBuf<float> img, pk, raw, ws;
+    TTRY(img.resize((size_t)NCLS * CR * CC));
+    TTRY(pk.resize((size_t)CR * CC * rf));
+    TTRY(raw.resize(N));
+    TTRY(ws.resize(tdr_score_cart_workspace_floats(NCLS, CR, CC, N, N)));
+    HTRY(hipMemcpyAsync(img.p, scan_c.data(), scan_c.size() * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    TTRY(tdr_k_pack_scan(img.p, NCLS, CR, CC, pk.p, f->stream));
+    const struct { int mode; float span; int seg; } cart_runs[5] = {{0, 16.f, 32}, {2, 0.f, 0}, {2, 0.f, 8}, {2, 0.f, 32}, {2, 1e-6f, 32}};
+    std::vector<float> c[5];
+    for (int r = 0; r < 5; r++) {
+      tdr_config_shift_uniform(cart_runs[r].mode);
+      tdr_config_shift_uniform_span(cart_runs[r].span);
+      tdr_config_tuning("cart_seg_rows", cart_runs[r].seg);
+      TTRY(tdr_k_score_cart(&m->desc, pk.p, CR, CC, 0.75f, &fp, f->st.p, f->cap, N, N, nullptr, raw.p, ws.p, f->stream));
+      c[r].resize(N);
+      HTRY(hipMemcpyAsync(c[r].data(), raw.p, N * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+      HTRY(hipStreamSynchronize(f->stream));
+    }
+    if (!same_bits(c[1], c[2]) || !same_bits(c[1], c[3]))
+      return failh(TDR_ERR_HIP, "selftest: score_cart_su_kernel (generated loop) and score_cart_skip_kernel disagree (exact "
+                                "integer sums must be identical): the generated loop does not survive this toolchain");
+    if (!same_bits(c[1], c[4])) return failh(TDR_ERR_HIP, "selftest: score_cart_ray_kernel disagrees with the dense kernels");
+    if (!rel_ok(c[1], c[0], 3e-6, &worst))
+      return failh(TDR_ERR_HIP, "selftest: the Cartesian integer form is %.3g away from the float kernel", worst);
+    finite = 0;
+    for (float w : c[1]) finite += std::isfinite(w) && w > 0.f;
+    if (finite < N / 2) return failh(TDR_ERR_HIP, "selftest: only %d of %d Cartesian weights are finite", finite, N);
+  }
+  return TDR_OK;
+}
+
 }  // extern "C"
