@@ -165,3 +165,59 @@ def test_the_pipe_draws_ahead_and_never_changes_the_stream(k):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     for h in (host, mirror):
         L.tdr_rng_destroy(h)
+
+
+# ---- jump-ahead: long calls fill stretches of the stream side by side (csrc/tdr_rng.hip: mt_jump_kernel) ---------------------
+def test_committed_jump_polynomials_are_the_generators_output(tmp_path):
+    """csrc/tdr_mt_jump.h is what tools/gen_mt_jump.py computes (characteristic polynomial by Berlekamp-Massey, t^J mod it
+    by square-and-multiply), and the generator's own check — the host restatement of the device's procedure jumps exactly
+    STRIDE and 2 STRIDE honest block steps — passes."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_mt_jump", os.path.join(root, "tools", "gen_mt_jump.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    g.OUT = str(tmp_path / "jump.h")
+    g.main()                                        # (runs self_check)
+    assert open(g.OUT).read() == open(os.path.join(root, "top_down_renderer_amd", "csrc", "tdr_mt_jump.h")).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,freeze,burn", [(16_000, False, 3), (20_000, True, 700), (100_003, False, 12345), (1_000_003, False, 99)])
+def test_stretches_reached_by_jump_ahead_give_the_serial_stream(k, n, freeze, burn):
+    """The same call with the raw stream walked by one wave and filled in stretches (their first blocks reached by jump-ahead
+    polynomials): normals, uniform and a following call bit for bit — and both are the host engine's (the test above)."""
+    import time
+    import torch
+    L = k.lib
+    before = L.tdr_config_tuning(b"mt_stretches", -1)
+    out, ms = {}, {}
+    try:
+        for mode in (0, 1):
+            L.tdr_config_tuning(b"mt_stretches", mode)
+            host = C.c_void_p(L.tdr_rng_create(C.c_uint32(4000 + n)))
+            for _ in range(burn):
+                L.tdr_rng_uniform_host(host)
+            state = k.rng_state_to_device(host)
+            z = k.zeros((n, 4))
+            k.rng_propagate_normals_dev(state, n, 0, n, freeze, z, n)     # (first use: allocations)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            z2 = k.zeros((n, 4))
+            k.rng_propagate_normals_dev(state, n, 0, n, freeze, z2, n)
+            torch.cuda.synchronize()
+            ms[mode] = (time.perf_counter() - t0) * 1e3
+            u = k.zeros((64,))
+            k.rng_uniform_dev(state, u)
+            out[mode] = (z.cpu().numpy().view(np.uint32), z2.cpu().numpy().view(np.uint32), float(u[0].item()))
+            if mode == 0 and n <= 100_003:
+                zh = _host_normals(L, host, n, freeze)
+                assert np.array_equal(out[0][0], zh.view(np.uint32))
+            L.tdr_rng_destroy(host)
+    finally:
+        L.tdr_config_tuning(b"mt_stretches", before)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+    print(f"n = {n}: one wave {ms[0]:.3f} ms, stretches {ms[1]:.3f} ms (whole call, incl. attempts / scan / normals)")

@@ -14,7 +14,7 @@ SRC = [os.path.join(PKG, "csrc", f) for f in
        ("tdr_core.hip", "tdr_map.hip", "tdr_raster.hip", "tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_score_cart.hip", "tdr_filter.hip", "tdr_rng.hip", "tdr_prefix.hip",
         "tdr_geo.hip", "tdr_cmap.hip", "tdr_active.hip", "tdr_host.cpp", "tdr_comm.cpp", "tdr_gmm.cpp", "tdr_png.cpp")]
 HDR = [os.path.join(ROOT, "include", "tdr.h")] + \
-      [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h", "tdr_score_su_asm.h", "tdr_score_cart.h", "tdr_score_cart_asm.h", "tdr_logf.h")]
+      [os.path.join(PKG, "csrc", f) for f in ("tdr_common.h", "tdr_sincosf.h", "tdr_atan2f.h", "tdr_score_su.h", "tdr_score_dev.h", "tdr_score_su_asm.h", "tdr_score_cart.h", "tdr_score_cart_asm.h", "tdr_logf.h", "tdr_mt_jump.h")]
 OUT = os.path.join(PKG, "libtdr_hip.so")
 OBJ_DIR = os.path.join(PKG, "_obj")
 STAMP = os.path.join(PKG, "libtdr_hip.toolchain.txt")

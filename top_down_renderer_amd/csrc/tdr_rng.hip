@@ -10,9 +10,14 @@
 // object has nothing saved, so the stream of a propagate call is nothing but attempts, and particle p owns the accepted
 // attempts 3p (theta: y), 3p + 1 (dx: y, dy: the saved x), 3p + 2 (scale: y) — 2p, 2p + 1 with the scale frozen.  That
 // makes the stream parallel:
-//   mt_fill_kernel      the generator's untempered state blocks, one after the other (the only serial part: one wave,
-//                       a block of 624 words in four LDS round trips — 192 elements of a block depend on nothing younger
+//   mt_fill_kernel      the generator's untempered state blocks, one after the other (one wave per STRETCH of blocks: a
+//                       block of 624 words in four LDS round trips — 192 elements of a block depend on nothing younger
 //                       than 227 elements);
+//   mt_jump_kernel      a long call (more than MT_JUMP_STRIDE blocks) is cut into stretches whose first blocks are reached
+//                       by JUMPING AHEAD — the recurrence is linear over GF(2): the state J words on is g(A) s with
+//                       g = t^J mod the characteristic polynomial, constants of the generator (tdr_mt_jump.h, computed by
+//                       tools/gen_mt_jump.py) — in ceil(log2 stretches) rounds of doubling; then the stretches fill side
+//                       by side.  A million particles' 13 500 blocks: 4.7 ms on one wave, ~0.4 ms this way;
 //   mt_attempt_kernel   every attempt of the budget: tempering, the two canonical floats, accepted or not;
 //   rocPRIM             exclusive scan of the accepted flags = the rank of every accepted attempt;
 //   mt_normal_kernel    accepted attempt of rank a -> particle a / 3 (or a / 2), with glibc's logf restated (tdr_logf.h) and
@@ -31,6 +36,7 @@
 
 #include "tdr_common.h"
 #include "tdr_logf.h"
+#include "tdr_mt_jump.h"
 
 #define MT_N 624
 #define MT_M 397
@@ -84,17 +90,85 @@ __device__ __forceinline__ void mt_twist(uint32_t* x, int lane, uint32_t* __rest
   mt_twist_batch<9, 1>(x, lane, out);   // elements 576 .. 623 (and 16 lanes of padding)
 }
 
-// raw [nblocks][624]: block 0 = the state as it is, block b = the state b twists later (untempered words)
-__global__ __launch_bounds__(64) void mt_fill_kernel(const uint32_t* __restrict__ state, int nblocks, uint32_t* __restrict__ raw) {
+// raw [nblocks][624]: block 0 = the state as it is, block b = the state b twists later (untempered words).
+// One wave per stretch of `stride` blocks: stretch w starts from `state` (w == 0) or from the block a jump left at
+// raw[w * stride] (mt_jump_kernel) and fills the blocks behind it up to the next stretch's first / to nblocks.
+__global__ __launch_bounds__(64) void mt_fill_kernel(const uint32_t* __restrict__ state, int nblocks, int stride,
+                                                     uint32_t* __restrict__ raw) {
   __shared__ uint32_t x[MT_X];
   const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * stride;
+  const uint32_t* __restrict__ from = blockIdx.x == 0 ? state : raw + b0 * MT_N;
   for (int k = lane; k < MT_N; k += 64) {
-    const uint32_t v = state[k];
+    const uint32_t v = from[k];
     x[k] = v;
-    raw[k] = v;
+    if (blockIdx.x == 0) raw[k] = v;
   }
   __syncthreads();
-  for (int b = 1; b < nblocks; b++) mt_twist(x, lane, raw + (int64_t)b * MT_N);
+  const int64_t b1 = min((int64_t)nblocks, b0 + stride);
+  for (int64_t b = b0 + 1; b < b1; b++) mt_twist(x, lane, raw + b * MT_N);
+}
+
+// One jump: the block at the start of stretch k -> the block at the start of stretch k + 2^level, i.e. MT_JUMP_STRIDE * 2^level
+// blocks further down the stream, without walking there.  With A the generator's one-word step and g = t^J mod its
+// characteristic polynomial split as g(t) = sum_j t^(624 j) r_j(t) (tdr_mt_jump.h), the target is sum_j B^j (r_j(A) s), B = A^624
+// = the block step: r_j(A) s is the XOR of the 624-word windows [i, i + 624) of (block || next block) over the set bits i of
+// r_j — 16 waves, two chunks j each, a lane ten output words — and the sum over j is Horner's rule in B, 31 block steps by one
+// wave.  A window's first word carries garbage in its low 31 bits (the generator's state has 19937 bits: only the top bit of
+// its first word belongs to it); they are restored at the end from x[J + 623] = x[J + 396] ^ T(top(x[J - 1]) | low(x[J])).
+// Stretch 0's first block is the state itself.
+__global__ __launch_bounds__(1024) void mt_jump_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ raw, int level) {
+  __shared__ uint32_t stream[2 * MT_N + 64];   // block || next block (+ padding read by lanes without an output word)
+  __shared__ uint32_t xs[MT_X];
+  __shared__ uint32_t R[MT_JUMP_CHUNKS][MT_N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = blockIdx.x;
+  const uint32_t* __restrict__ src = k == 0 ? state : raw + (int64_t)k * MT_JUMP_STRIDE * MT_N;
+  uint32_t* __restrict__ dst = raw + (int64_t)(k + (1 << level)) * MT_JUMP_STRIDE * MT_N;
+  for (int i = tid; i < MT_X; i += 1024) xs[i] = i < MT_N ? src[i] : 0u;
+  for (int i = tid; i < 2 * MT_N + 64; i += 1024) stream[i] = i < MT_N ? src[i] : 0u;
+  __syncthreads();
+  if (wave == 0) mt_twist(xs, lane, nullptr);
+  __syncthreads();
+  for (int i = tid; i < MT_N; i += 1024) stream[MT_N + i] = xs[i];
+  __syncthreads();
+  for (int j = wave; j < MT_JUMP_CHUNKS; j += 16) {
+    uint32_t acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) acc[t] = 0;
+    for (int wd = 0; wd < 20; wd++) {
+      uint32_t bits = __builtin_amdgcn_readfirstlane(MT_JUMP[level][j][wd]);
+      while (bits) {   // (wave-uniform)
+        const int i = 32 * wd + __builtin_ctz(bits);
+        bits &= bits - 1;
+#pragma unroll
+        for (int t = 0; t < 10; t++) acc[t] ^= stream[i + lane + 64 * t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; t++)
+      if (lane + 64 * t < MT_N) R[j][lane + 64 * t] = acc[t];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  for (int p = lane; p < MT_X; p += 64) xs[p] = p < MT_N ? R[MT_JUMP_CHUNKS - 1][p] : 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int j = MT_JUMP_CHUNKS - 2; j >= 0; j--) {
+    mt_twist(xs, lane, nullptr);
+    for (int p = lane; p < MT_N; p += 64) xs[p] ^= R[j][p];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    const uint32_t v = xs[MT_N - 1] ^ xs[MT_M - 1];
+    const uint32_t lsb = v >> 31;
+    const uint32_t y = ((v ^ (lsb ? 0x9908b0dfu : 0u)) << 1) | lsb;
+    xs[0] = (xs[0] & 0x80000000u) | (y & 0x7fffffffu);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int p = lane; p < MT_N; p += 64) dst[p] = xs[p];
 }
 
 struct MtAttempt {
@@ -182,6 +256,12 @@ __global__ __launch_bounds__(64) void mt_uniform_kernel(uint32_t* __restrict__ s
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
+// 0: every call's raw stream on one wave (A/B, tests); 1 (default): long calls in stretches (tdr_config_tuning("mt_stretches"))
+static int g_mt_stretches = 1;
+extern "C" int tdr_config_mt_stretches(int on) {   // < 0: query only
+  if (on >= 0) g_mt_stretches = on ? 1 : 0;
+  return g_mt_stretches;
+}
 // attempts a call may look at: the expected 3.82 per particle-normal... (acceptance pi / 4) plus 5 % and ten standard
 // deviations: running out has probability ~1e-23 (and is reported, never silent)
 static int64_t mt_attempt_budget(int64_t need) {
@@ -232,7 +312,20 @@ extern "C" int tdr_k_rng_propagate_normals(uint32_t* state, int64_t n, int64_t l
   uint32_t* rank = reinterpret_cast<uint32_t*>(base + W.off_rank);
   uint32_t* consumed = reinterpret_cast<uint32_t*>(base + W.off_consumed);
   HIP_TRY(hipMemsetAsync(consumed, 0xFF, 4, s));
-  hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)state, (int)W.nblocks, raw);
+  // the raw stream: one wave walks it, or — a long call — stretches of MT_JUMP_STRIDE blocks side by side, their first blocks
+  // reached by jumping ahead in rounds of doubling (round m: the 2^m stretch starts there are, each 2^m stretches further)
+  const int64_t nstretch = cdiv(W.nblocks, (int64_t)MT_JUMP_STRIDE);
+  if (g_mt_stretches && nstretch > 1 && nstretch <= ((int64_t)1 << MT_JUMP_LEVELS)) {
+    for (int m = 0; ((int64_t)1 << m) < nstretch; m++) {
+      const int64_t have = (int64_t)1 << m, jumps = std::min(have, nstretch - have);
+      hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)jumps), dim3(1024), 0, s, (const uint32_t*)state, raw, m);
+      LAUNCH_CHECK("mt_jump");
+    }
+    hipLaunchKernelGGL(mt_fill_kernel, dim3((unsigned)nstretch), dim3(64), 0, s, (const uint32_t*)state, (int)W.nblocks,
+                       MT_JUMP_STRIDE, raw);
+  } else {
+    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)state, (int)W.nblocks, (int)W.nblocks, raw);
+  }
   LAUNCH_CHECK("mt_fill");
   const unsigned blocks = (unsigned)cdiv(W.nattempts, 256);
   hipLaunchKernelGGL(mt_attempt_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)raw, (const uint32_t*)state,

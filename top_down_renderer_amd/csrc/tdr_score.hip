@@ -1615,6 +1615,7 @@ static int64_t score_wave_target() { return g_score_waves; }
 extern "C" int tdr_config_prefix_head(int);        // tdr_prefix.hip
 extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
 extern "C" int tdr_config_cart_seg_rows(int);      // tdr_score_cart.hip
+extern "C" int tdr_config_mt_stretches(int);       // tdr_rng.hip
 extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // value < 0: query only
   if (!name) return -1;
   const std::string n(name);
@@ -1625,6 +1626,7 @@ extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // val
   if (n == "prefix_head") return tdr_config_prefix_head((int)std::max<int64_t>(value, -1));
   if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
   if (n == "cart_seg_rows") return tdr_config_cart_seg_rows((int)std::max<int64_t>(value, -1));
+  if (n == "mt_stretches") return tdr_config_mt_stretches((int)std::max<int64_t>(value, -1));
   return -1;
 }
 static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks, int target_mul = 1) {
