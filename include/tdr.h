@@ -491,6 +491,8 @@ int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattere
  *   "prefix_head"      leading addends the long running sum's walk adds one by one
  *   "ray_block_major"  0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
  *                      holds the table's factors (same bits)
+ *   "su_wave_span"     map cells a wave's own 64 same-heading particles may spread over before the wave is re-routed from the
+ *                      shift-uniform kernel to the ray-mapped kernel (0, the default: never — measured, it does not pay) — same bits either way
  *   "mt_stretches"     0: the reference's random stream is always generated by one wave; 1 (default): calls of more than 128
  *                      state blocks fill stretches side by side, reached by jump-ahead (csrc/tdr_rng.hip) — the same words
  *   "cart_seg_rows"    window rows per segment of score_cart_su_kernel (a multiple of 4; 0: the Cartesian integer form's dense

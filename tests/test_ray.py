@@ -162,10 +162,16 @@ def test_weights_do_not_depend_on_the_order_of_the_additions(tdr, oracle, ncls, 
         assert np.array_equal(a, run(3.0, perm=shuffled), equal_nan=True)
         assert np.array_equal(a, run(ALL_RAY, 2, perm=None), equal_nan=True)
         assert np.array_equal(a, run(5.0, ctx=k.score_ctx_create()), equal_nan=True)
+        # the re-routing pass (tdr_config_tuning("su_wave_span"): waves whose own particles spread too far go to the ray-mapped
+        # kernel after all; off by default — measured, it does not pay): some, then every wave re-routed
+        for cells in (6, 1):
+            k.lib.tdr_config_tuning(b"su_wave_span", cells)
+            assert np.array_equal(a, run(40.0), equal_nan=True), f"waves wider than {cells} cells re-routed"
     finally:
         k.lib.tdr_config_shift_uniform(before)
         k.lib.tdr_config_shift_uniform_span(-2.0)
         k.lib.tdr_config_ray_split(0)
+        k.lib.tdr_config_tuning(b"su_wave_span", 0)
     assert np.array_equal(np.isnan(a), np.isnan(ref))
     ok = ~np.isnan(ref)
     err = np.abs(a[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)

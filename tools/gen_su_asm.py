@@ -31,6 +31,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su_asm.h")
+EXPERIMENT_LDS_GATHER = False   # tools/exp_lds_gather.sh
 
 
 def loop_text(uscale, clamp, mask=True):
@@ -141,7 +142,14 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a(f"v_lshl_add_u32 v{20 + u}, v{8 + 2 * u}, 4, v{20 + u}")
         a("s_nop 0")
         # (never into its own address register: a load that is replayed reads its address again)
-        a(f"global_load_ushort v{24 + u}, v{20 + u}, %[crec]")
+        if EXPERIMENT_LDS_GATHER:
+            # TIMING EXPERIMENT ONLY (wrong results): what the loop would cost if the class-plane cell came out of LDS instead
+            # of a 64-lane global gather — an upper bound on what staging the planes in LDS could gain
+            a(f"v_and_b32 v{20 + u}, 0x3ffe, v{20 + u}")
+            a("s_nop 0")
+            a(f"ds_read_u16 v{24 + u}, v{20 + u}")
+        else:
+            a(f"global_load_ushort v{24 + u}, v{20 + u}, %[crec]")
         a(f".Lsu_a{u}{tag}%=:")
     # ---- phase B
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -282,6 +290,8 @@ def check_all():
 
 
 def main():
+    global EXPERIMENT_LDS_GATHER
+    EXPERIMENT_LDS_GATHER = "--experiment-lds-gather" in __import__("sys").argv
     check_all()
     out = ["// tdr_score_su_asm.h — GENERATED by tools/gen_su_asm.py; do not edit.",
            "// The inner loop of score_polar_su_kernel for two-dword compact records (4-6 classes), see the generator for the",

@@ -406,12 +406,19 @@ extern "C" int tdr_k_selftest_logf(const float* x, int64_t n, float* out, void* 
 // way (tests/test_rng.py replays call sequences against the host engine).
 // (device-to-device moves of a state are kernels, not runtime copies: a runtime copy between event waits of two streams
 // cost the caller's stream ~0.3 ms per step whenever it also did host-to-device copies of its own)
-__global__ void mt_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+// err (optional): a word of pinned HOST memory the pipe looks at before every call — a state whose error word
+// (state[MT_N + 1]: mt_advance_kernel ran out of its attempt budget) is set raises it, so a filter that never hands its
+// stream back to the host still hears about it at its next call instead of continuing with stale normals
+__global__ void mt_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n, uint32_t* __restrict__ err) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) dst[k] = src[k];
+  if (k < n) {
+    const uint32_t v = src[k];
+    if (dst) dst[k] = v;
+    if (err && k == MT_N + 1 && v != 0) *err = v;
+  }
 }
-static int mt_copy(const void* src, void* dst, int words, hipStream_t s) {
-  hipLaunchKernelGGL(mt_copy_kernel, dim3((unsigned)cdiv(words, 256)), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, words);
+static int mt_copy(const void* src, void* dst, int words, hipStream_t s, uint32_t* err = nullptr) {
+  hipLaunchKernelGGL(mt_copy_kernel, dim3((unsigned)cdiv(words, 256)), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, words, err);
   LAUNCH_CHECK("mt_copy");
   return TDR_OK;
 }
@@ -431,7 +438,14 @@ struct tdr_rng_pipe {
   int64_t spec_n = 0, spec_lo = 0, spec_hi = 0;
   int spec_freeze = 0;
   int misses = 0;                   // consecutive calls the draw-ahead did not fit: it pauses after two
+  uint32_t* err_host = nullptr;     // pinned, device-visible: raised by the device when a call ran out of its attempt budget
 };
+static int pipe_check(const tdr_rng_pipe* p, const char* who) {
+  if (p->err_host && *(volatile const uint32_t*)p->err_host)
+    return fail(TDR_ERR_HIP, "%s: an earlier call of the device generator ran out of its attempt budget — the stream is "
+                             "stopped where it stood (probability ~1e-23 per call: more likely a damaged state)", who);
+  return TDR_OK;
+}
 extern "C" int tdr_rng_pipe_create(int64_t n_max, tdr_rng_pipe** out) {
   if (!out || n_max < 1) return fail(TDR_ERR_ARG, "rng_pipe_create: bad arguments");
   *out = nullptr;
@@ -446,6 +460,8 @@ extern "C" int tdr_rng_pipe_create(int64_t n_max, tdr_rng_pipe** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&p->state, sizeof(uint32_t) * TDR_RNG_STATE_WORDS);
   if (e == hipSuccess) e = hipMalloc((void**)&p->spec_state, sizeof(uint32_t) * TDR_RNG_STATE_WORDS * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&p->shift, sizeof(float) * 32);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->err_host, sizeof(uint32_t), hipHostMallocMapped);
+  if (e == hipSuccess) *p->err_host = 0;
   for (int k = 0; k < 2 && e == hipSuccess; k++) {
     e = hipMalloc((void**)&p->z[k], sizeof(float) * 4 * (size_t)n_max);
     if (e == hipSuccess) e = hipMalloc(&p->ws[k], wsb);
@@ -463,6 +479,7 @@ extern "C" void tdr_rng_pipe_destroy(tdr_rng_pipe* p) {
   for (hipEvent_t ev : {p->ev_fork, p->ev_uniform, p->ev_all})
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(p->state); (void)hipFree(p->spec_state); (void)hipFree(p->shift);
+  if (p->err_host) (void)hipHostFree(p->err_host);
   for (int k = 0; k < 2; k++) { (void)hipFree(p->z[k]); (void)hipFree(p->ws[k]); }
   delete p;
 }
@@ -501,6 +518,7 @@ extern "C" int tdr_rng_pipe_from_host(tdr_rng_pipe* p, void* host_rng, void* str
   HIP_TRY(hipStreamSynchronize(s));
   p->on_device = true;
   p->misses = 0;
+  if (p->err_host) *p->err_host = 0;   // a fresh state from the host engine
   return TDR_OK;
 }
 // ... and back on the host engine (synchronises)
@@ -523,12 +541,13 @@ extern "C" int tdr_rng_pipe_normals(tdr_rng_pipe* p, int64_t n, int64_t lo, int6
   if (!p || !z4_out) return fail(TDR_ERR_ARG, "rng_pipe_normals: null pointer");
   if (!p->on_device) return fail(TDR_ERR_ARG, "rng_pipe_normals: the stream is on the host (tdr_rng_pipe_from_host)");
   if (n < 1 || n > p->n_max || lo < 0 || hi > n || lo > hi) return fail(TDR_ERR_ARG, "rng_pipe_normals: bad range");
+  if (int rc = pipe_check(p, "rng_pipe_normals")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int fr = scale_freeze ? 1 : 0;
   if (p->spec == 2 && p->spec_n == n && p->spec_lo == lo && p->spec_hi == hi && p->spec_freeze == fr) {
     // drawn ahead: adopt its values and the state behind them
     HIP_TRY(hipStreamWaitEvent(s, p->ev_all, 0));
-    if (int rc = mt_copy(p->spec_state, p->state, TDR_RNG_STATE_WORDS, s)) return rc;
+    if (int rc = mt_copy(p->spec_state, p->state, TDR_RNG_STATE_WORDS, s, p->err_host)) return rc;
     p->cur = 1 - p->cur;
     p->spec = 0;
     p->misses = 0;
@@ -537,6 +556,7 @@ extern "C" int tdr_rng_pipe_normals(tdr_rng_pipe* p, int64_t n, int64_t lo, int6
     else if (p->misses) p->misses--;   // (a call that had nothing to compare with: the pattern gets another chance)
     if (int rc = pipe_drop(p, s)) return rc;
     if (int rc = tdr_k_rng_propagate_normals(p->state, n, lo, hi, fr, p->z[p->cur], p->ws[p->cur], s)) return rc;
+    if (int rc = mt_copy(p->state, nullptr, TDR_RNG_STATE_WORDS, s, p->err_host)) return rc;   // (only looks at the error word)
   }
   *z4_out = p->z[p->cur];
   return pipe_draw_ahead(p, n, lo, hi, fr, s);
@@ -545,6 +565,7 @@ extern "C" int tdr_rng_pipe_normals(tdr_rng_pipe* p, int64_t n, int64_t lo, int6
 extern "C" int tdr_rng_pipe_uniform(tdr_rng_pipe* p, const float** shift_out, void* stream) {
   if (!p || !shift_out) return fail(TDR_ERR_ARG, "rng_pipe_uniform: null pointer");
   if (!p->on_device) return fail(TDR_ERR_ARG, "rng_pipe_uniform: the stream is on the host (tdr_rng_pipe_from_host)");
+  if (int rc = pipe_check(p, "rng_pipe_uniform")) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (p->spec == 1) {   // drawn ahead
     HIP_TRY(hipStreamWaitEvent(s, p->ev_uniform, 0));

@@ -1616,6 +1616,7 @@ extern "C" int tdr_config_prefix_head(int);        // tdr_prefix.hip
 extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
 extern "C" int tdr_config_cart_seg_rows(int);      // tdr_score_cart.hip
 extern "C" int tdr_config_mt_stretches(int);       // tdr_rng.hip
+extern "C" int tdr_config_su_wave_span(int);       // tdr_score_su.hip
 extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // value < 0: query only
   if (!name) return -1;
   const std::string n(name);
@@ -1627,6 +1628,7 @@ extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // val
   if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
   if (n == "cart_seg_rows") return tdr_config_cart_seg_rows((int)std::max<int64_t>(value, -1));
   if (n == "mt_stretches") return tdr_config_mt_stretches((int)std::max<int64_t>(value, -1));
+  if (n == "su_wave_span") return tdr_config_su_wave_span((int)std::max<int64_t>(value, -1));
   return -1;
 }
 static void choose_chunks(int64_t n, int nr, int& rpc, int& nchunks, int target_mul = 1) {
@@ -2170,6 +2172,7 @@ extern "C" int tdr_k_score_polar_ctx(const tdr_map_desc* map, const float* tab, 
     L.group = W.su_group; L.nchunks = W.su_nchunks; L.npad = W.npad_part; L.part = a.part;
     L.fac = ctx && ctx->fac && ctx->fac_nb == nb && ctx->fac_nr == nr ? ctx->fac : nullptr;
     L.uscale = uniform_scale;
+    L.wave_span = tdr_su_wave_span();
     L.ray_split = tdr_ray_splits(nb, nr, n, tdr_ray_block_major(L));
     L.ws = reinterpret_cast<int32_t*>(workspace + W.off_su);
     TunerScope tuner_scope(ctx, s);   // (closes the tuner's measurement on every way out)

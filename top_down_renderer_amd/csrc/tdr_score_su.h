@@ -11,9 +11,11 @@ bool tdr_su_shape_ok(int nb, int nr, int group, int64_t n_total);
 // The path's share of the scoring workspace, in 4-byte words, carved in this order (each part 256-byte aligned):
 struct SuWs {
   int64_t tab_su, desc, bbox, keys_in, keys_out, vals_in, vals_out, ints, slots, sort_tmp, ray_tab, ray_desc, ray_multi, ray_rad, total;
-  // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3][n_multi][inexact][mass bound]  (int_form_off)
+  int64_t slots2, wave_tmp;   // the re-routing pass (su_wave_far_kernel ...): a second slot list, four ints per wave
+  // ints: [cnt nb + 1][start nb + 1][slot_start nb + 1][counts 3][n_multi][inexact][mass bound][table is not its factors]
+  //       [the counts before the re-routing pass 3]  (int_form_off)
 };
-#define TDR_SU_TAIL_INTS 7        // the words of `ints` behind the three per-key tables
+#define TDR_SU_TAIL_INTS 10       // the words of `ints` behind the three per-key tables
 #define TDR_RAY_MAX_SPLIT 8       // waves a particle's window may be split over (tdr_ray_splits): chunk rows of `part`
 SuWs tdr_su_ws(int nb, int nr, int group, int64_t n);
 
@@ -35,6 +37,8 @@ struct SuLaunch {
   float uscale;              // the caller's uniform scale (<= 0: none)
   int32_t* ws;               // tdr_su_ws(...).total words
   float span;                // map cells the 64 locality neighbours of a dense particle may span (tdr_su_span_begin)
+  float wave_span = 0.f;     // > 0: a wave of the heading-bin order whose OWN 64 particles spread over more cells than this goes
+                             // to the ray-mapped kernel after all (su_wave_far_kernel; tdr_config_tuning("su_wave_span"))
 };
 // ordering passes + descriptors (everything but the scoring kernels).  slots_out: the slot list — the dense particles
 // by heading bin, every bin padded to whole waves (-1), then the sparse particles in the caller's order (su_key_kernel);
@@ -62,6 +66,7 @@ struct SpanTuner {
 };
 float tdr_su_span_begin(SpanTuner* t, int64_t shape, hipStream_t s);
 void tdr_su_span_end(SpanTuner* t, hipStream_t s);
+float tdr_su_wave_span();   // tdr_config_tuning("su_wave_span")
 // the shift-uniform kernel over the heading bins' slots
 int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s);
 // the ray-mapped kernel (tdr_score_ray.hip): whether the map carries what it reads (class planes, integer dictionary

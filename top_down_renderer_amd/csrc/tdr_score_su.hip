@@ -261,6 +261,107 @@ __global__ __launch_bounds__(256) void su_scatter_kernel(const uint32_t* __restr
   slots[slot_start[k] + ((int)t - start[k])] = vals[t];
 }
 
+// ---- re-routing by the wave's own box ---------------------------------------------------------------------------------------
+// su_key_kernel calls a particle dense when its 64 neighbours in the ALL-heading locality order lie close together.  The
+// shift-uniform kernel's waves, though, hold 64 neighbours of ONE heading bin: where the headings are many and the cloud is
+// wide (config 5: 8 clusters x 40 headings, 780 particles per cluster and heading over ~25 000 cells) those lie tens of cells
+// apart, the wave's windows do not fit its quarter of the mask staging area, and the wave takes the kernel's far path — one
+// gather per SAMPLE, a quarter of config 5's wave-sectors in round 4.  Such a wave is what the ray-mapped kernel is for: this
+// pass, behind the heading-bin order, moves every wave whose own particles spread over more than `wave_span` cells to the
+// scattered share (three small kernels; the sums are exact integers: whichever kernel scores a particle, the bits agree).
+__global__ __launch_bounds__(256) void su_wave_far_kernel(const float* __restrict__ st, int64_t cap, const int32_t* __restrict__ slots,
+                                                          const int32_t* __restrict__ counts, float wave_span,
+                                                          int32_t* __restrict__ keep, int32_t* __restrict__ moved) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), base = w * 64;
+  if (base >= (int64_t)counts[0]) return;
+  const int32_t p = slots[base + lane];
+  float x0 = 3.0e38f, x1 = -3.0e38f, y0 = 3.0e38f, y1 = -3.0e38f;
+  if (p >= 0) {
+    const float sc = st[TDR_ST_SCALE * cap + p];
+    const float x = st[TDR_ST_DX * cap + p] * sc + st[TDR_ST_INIT_X * cap + p];
+    const float y = st[TDR_ST_DY * cap + p] * sc + st[TDR_ST_INIT_Y * cap + p];
+    x0 = x1 = x;
+    y0 = y1 = y;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
+    y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+  }
+  const int nvalid = __popcll(__ballot(p >= 0));
+  // (a NaN centre makes the comparison false: the wave stays — the kernel's own checks deal with it)
+  const bool far = (x1 - x0 > wave_span) || (y1 - y0 > wave_span);
+  if (lane == 0) {
+    keep[w] = far ? 0 : 1;
+    moved[w] = far ? nvalid : 0;
+  }
+}
+// One workgroup: exclusive sums of the kept waves (x 64 slots) and of the moved particles; the new counts
+__global__ __launch_bounds__(256) void su_compact_offsets_kernel(int32_t* __restrict__ keep, int32_t* __restrict__ moved,
+                                                                 int32_t* __restrict__ counts, int32_t* __restrict__ old_counts) {
+  __shared__ int sa[256], sb[256];
+  const int c0 = counts[0], c1 = counts[1], c2 = counts[2];
+  const int nw = c0 >> 6;
+  int carry_a = 0, carry_b = 0;
+  for (int base = 0; base < nw; base += 256) {
+    const int w = base + threadIdx.x;
+    const int a = w < nw ? keep[w] : 0, b = w < nw ? moved[w] : 0;
+    sa[threadIdx.x] = a;
+    sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {   // Hillis-Steele inclusive scan
+      const int va = threadIdx.x >= d ? sa[threadIdx.x - d] : 0;
+      const int vb = threadIdx.x >= d ? sb[threadIdx.x - d] : 0;
+      __syncthreads();
+      sa[threadIdx.x] += va;
+      sb[threadIdx.x] += vb;
+      __syncthreads();
+    }
+    if (w < nw) {
+      // keep[w]: the wave's new first slot, or -1; moved[w]: the rank of its first particle among the moved ones
+      keep[w] = a ? (carry_a + sa[threadIdx.x] - a) * 64 : -1;
+      moved[w] = carry_b + sb[threadIdx.x] - b;
+    }
+    carry_a += sa[255];
+    carry_b += sb[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    old_counts[0] = c0; old_counts[1] = c1; old_counts[2] = c2;
+    counts[0] = carry_a * 64;
+    counts[1] = c1 + carry_b;
+    counts[2] = carry_a * 64 + c1 + carry_b;
+  }
+}
+// slot t of the old list -> its place in the new one: kept waves close ranks, then the old scattered share, then the moved
+__global__ __launch_bounds__(256) void su_compact_scatter_kernel(const int32_t* __restrict__ slots, const int32_t* __restrict__ keep,
+                                                                 const int32_t* __restrict__ moved,
+                                                                 const int32_t* __restrict__ counts,
+                                                                 const int32_t* __restrict__ old_counts, int32_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int oc0 = old_counts[0], oc1 = old_counts[1];
+  if (t >= (int64_t)oc0 + oc1) return;
+  const int32_t p = slots[t];
+  if (t >= oc0) {   // the old scattered share, in its order
+    out[(int64_t)counts[0] + (t - oc0)] = p;
+    return;
+  }
+  const int64_t w = t >> 6;   // (a wave of this kernel is a wave of the list: blocks of 256 slots)
+  const int32_t k = keep[w];
+  const uint64_t valid = __ballot(p >= 0);
+  if (k >= 0) {
+    out[(int64_t)k + (t & 63)] = p;
+  } else if (p >= 0) {
+    const int rank = __popcll(valid & (((uint64_t)1 << (t & 63)) - 1));
+    out[(int64_t)counts[0] + oc1 + moved[w] + rank] = p;
+  }
+}
+__global__ void su_copy_slots_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ counts, int32_t* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (int64_t)counts[2]) dst[t] = src[t];
+}
+
 // LDS of the scoring kernel, ONE object so that the dictionary sits at LDS address 0 (the assembly loop reads it there)
 struct SuLds {
   uint32_t dict[TDR_CMAP_MAX_DICT];   // integer dictionary
@@ -857,6 +958,16 @@ void tdr_su_span_end(SpanTuner* t, hipStream_t s) {
   t->open = false;
   t->pending = hipEventRecord(t->e1, s) == hipSuccess;
 }
+// cells a wave's own 64 particles may spread over before the wave is re-routed to the ray-mapped kernel (0: never — the
+// default: MEASURED, AND IT DOES NOT PAY.  MI355X, ms per step at 0 / 24 / 32 / 40 / 56 cells: config 5 14.40 / 16.16 / 15.19 /
+// 14.87 / 14.31, config 2 4.67 / 6.58 / 5.69 / 5.67 / 5.34 — a particle on the shift-uniform kernel's far path costs ~68 ns, on
+// the ray-mapped kernel ~80 ns: the waves this moves are cheaper where they are.  DESIGN.md 5.1.)
+static float g_su_wave_span = 0.f;
+extern "C" int tdr_config_su_wave_span(int cells) {   // < 0: query only
+  if (cells >= 0) g_su_wave_span = (float)cells;
+  return (int)g_su_wave_span;
+}
+float tdr_su_wave_span() { return g_su_wave_span; }
 static std::atomic<int64_t> g_su_launches{0};   // diagnostics only
 extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches.load(); }
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
@@ -893,6 +1004,8 @@ SuWs tdr_su_ws(int nb, int nr, int group, int64_t n) {
   w.vals_out = take(n);
   w.ints = take(3 * ((int64_t)nb + 1) + TDR_SU_TAIL_INTS);   // [cnt][start][slot_start] nb + 1 each, [counts 3][n_multi][inexact][mass bound][table is not its factors]
   w.slots = take(su_npad(n, nb));
+  w.slots2 = take(su_npad(n, nb));
+  w.wave_tmp = take(2 * (su_npad(n, nb) / 64 + 1));
   w.sort_tmp = take((int64_t)((su_sort_tmp_bytes(n) + 3) / 4));
   const int64_t T = tdr_ray_padded_samples(nb, nr);
   w.ray_tab = take(2 * T);                     // tdr_score_ray.hip: sample offsets and 16-bit scan descriptors in ray order,
@@ -933,6 +1046,22 @@ int tdr_su_order(const SuLaunch& L, const SuWs& W, hipStream_t s, const int32_t*
   hipLaunchKernelGGL(su_scatter_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const uint32_t*)keys_out,
                      (const int32_t*)vals_out, n, (const int*)start, (const int*)slot_start, slots);
   LAUNCH_CHECK("su_scatter");
+  if (L.wave_span > 0.f && L.nb > 1) {   // waves whose own particles lie far apart: to the scattered share after all
+    int32_t* slots2 = base + W.slots2;
+    int32_t* keep = base + W.wave_tmp;
+    int32_t* moved = keep + (L.npad / 64 + 1);
+    int32_t* old_counts = counts + 7;   // (ints: TDR_SU_TAIL_INTS)
+    const int64_t nwaves = L.npad / 64;
+    hipLaunchKernelGGL(su_wave_far_kernel, dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, s, L.st, L.cap, (const int32_t*)slots,
+                       (const int32_t*)counts, L.wave_span, keep, moved);
+    hipLaunchKernelGGL(su_compact_offsets_kernel, dim3(1), dim3(256), 0, s, keep, moved, counts, old_counts);
+    hipLaunchKernelGGL(su_compact_scatter_kernel, dim3((unsigned)cdiv(L.npad, 256)), dim3(256), 0, s, (const int32_t*)slots,
+                       (const int32_t*)keep, (const int32_t*)moved, (const int32_t*)counts, (const int32_t*)old_counts, slots2);
+    // padding slots of kept waves travel with them; nothing reads behind counts[2]
+    hipLaunchKernelGGL(su_copy_slots_kernel, dim3((unsigned)cdiv(L.npad, 256)), dim3(256), 0, s, (const int32_t*)slots2,
+                       (const int32_t*)counts, slots);
+    LAUNCH_CHECK("su_reroute");
+  }
   *slots_out = slots;
   *counts_out = counts;
   return TDR_OK;
