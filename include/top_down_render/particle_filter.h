@@ -8,8 +8,10 @@
 //   * the mixture behind the adaptive particle count (:151-157, 245-318) is fitted on demand by computeGMM() with a
 //     deterministic EM (csrc/tdr_gmm.cpp) instead of cv::ml::EM in a detached thread; getGMM() returns it;
 //     setAdaptiveCount(true) feeds it into update() like :151-157, setTargetCount(n) overrides;
-//   * visualize(cv::Mat&) (:373-423) is drawing code and not rebuilt: the call forwards a host snapshot of the
-//     particle set to a hook the host may set (setVisualizer), and is a no-op otherwise;
+//   * visualize(cv::Mat&) (:373-423) works on a host snapshot of the particle set: a hook the host sets (setVisualizer)
+//     gets it; without a hook and with OpenCV present (TDR_HAVE_OPENCV) the default drawing of particle_viz.h — particles
+//     as red arrows, the mixture as blue ellipses, the best particle as a blue arrow, like the reference — runs; without
+//     either the call is a no-op (there is nothing to draw with);
 //   * top_down_geo is accepted and ignored like in the reference's score, whose geometric block is commented out
 //     (src/state_particle.cpp:145-152); setGeometricCost(true) switches that block on.
 #ifndef PARTICLE_FILTER_H_
@@ -168,7 +170,9 @@ class ParticleFilter {
   typedef void (*Visualizer)(cv::Mat& img, const Snapshot& snap, void* user);
   void setVisualizer(Visualizer fn, void* user = nullptr) { visualizer_ = fn; visualizer_user_ = user; }
   void visualize(cv::Mat& img) {
+#ifndef TDR_HAVE_OPENCV
     if (!visualizer_) return;
+#endif
     Snapshot snap;
     snap.particles = states();
     getGMM(snap.gmm_means, snap.gmm_covs);
@@ -177,8 +181,14 @@ class ParticleFilter {
       snap.have_best = true;
       for (int i = 0; i < 4; i++) snap.best[i] = s[i];
     }
-    visualizer_(img, snap, visualizer_user_);
+    if (visualizer_) visualizer_(img, snap, visualizer_user_);
+#ifdef TDR_HAVE_OPENCV
+    else drawSnapshot(img, snap);   // include/top_down_render/particle_viz.h
+#endif
   }
+#ifdef TDR_HAVE_OPENCV
+  static void drawSnapshot(cv::Mat& img, const Snapshot& snap);   // the default drawing (particle_viz.h)
+#endif
 
   // --- beyond the reference's surface -------------------------------------------------------------------------------
   void setTargetCount(int n) { target_count_ = n; }  // explicit adaptive particle count; < 0 keeps N
@@ -234,5 +244,9 @@ class ParticleFilter {
   FilterParams params_;
   tdr_filter* f_ = nullptr;
 };
+
+#ifdef TDR_HAVE_OPENCV
+#include "top_down_render/particle_viz.h"
+#endif
 
 #endif  // PARTICLE_FILTER_H_

@@ -271,3 +271,18 @@ def test_facade_session_matches_oracle(session_exe, oracle):
     geo = np.stack([rd("out_geo_render.bin", np.float32), rd("out_geo_render1.bin", np.float32)])
     pts4 = np.ascontiguousarray(sc.pts[:, :4])
     assert np.array_equal(geo, oracle.raster_geo_polar(pts4, len(pts4), 1, cfg.res, cfg.ang_res, cfg.nb, cfg.nr))
+
+
+def test_default_drawing_of_visualize_compiles_and_draws_with_an_opencv_stand_in():
+    """ParticleFilter::visualize without a hook draws like the reference (src/particle_filter.cpp:373-423) when OpenCV is
+    present (include/top_down_render/particle_viz.h).  This image has no OpenCV: tests/cpp/viz_compile.cpp builds the drawing
+    against a minimal stand-in that records the primitives (tests/cpp/opencv_stub — test infrastructure only) and checks
+    them on a hand-made snapshot; no GPU involved."""
+    from top_down_renderer_amd import build
+    build.build()
+    exe = os.path.join(tempfile.mkdtemp(prefix="tdr_facade_"), "viz_compile")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "opencv_stub"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "viz_compile.cpp"), "-o", exe,
+                    "-L", PKG, "-ltdr_hip", f"-Wl,-rpath,{PKG}"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "as expected" in r.stdout, r.stdout + r.stderr
