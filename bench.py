@@ -181,6 +181,20 @@ def cpu_baseline(sc, cfg, n_sample, threads):
                       f"the reference)" + first}
 
 
+def variant_shares(v, polar):
+    """Which loop variant the dense kernel's wave-sectors (polar) / wave-segments (Cartesian) ran during the timed steps
+    (tdr_profile_variants): shares of the total."""
+    if polar:
+        names = ("wg_box_all_known", "wg_box_inside", "wg_box_general", "wave_box_all_known", "wave_box_inside",
+                 "wave_box_general", "far_path")
+        vals = v[:7]
+    else:
+        names = ("all_known", "inside", "general", "plain_steps")
+        vals = v[8:12]
+    tot = sum(vals)
+    return {n: (x / tot if tot else None) for n, x in zip(names, vals)} | {"units": tot}
+
+
 def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
@@ -351,6 +365,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # which loop variant the dense kernel's waves run: two more steps with the device counters on (they cost an atomic per
+    # wave-sector, so never inside the timed region)
+    vstats = (C.c_int64 * 16)()
+    k.lib.tdr_profile_enable(2)
+    for _ in range(2):
+        step()
+    barrier()
+    k.lib.tdr_profile_variants(vstats)
+    k.lib.tdr_profile_enable(0)
+
     shares = None
     if rank == 0 and cfg.polar:
         # the launch's two kernels on their own: one more scoring call on the particle set every timed step starts from
@@ -450,6 +474,7 @@ def main():
                                  "A polar launch runs two kernels one after the other — score_polar_su_kernel for the dense "
                                  "particles, score_polar_ray_kernel for the scattered ones, both bound by the L1 address path "
                                  "(cache lines per gather) — and `avg_launch_ms` spans both (DESIGN.md 5.1)",
+                         "variants": variant_shares(list(vstats), cfg.polar),
                          "avg_launch_ms": avg_ms, "launches": launches.value,
                          # polar configs: the dense / scattered split of the mixed launch this filter's tuner settled on
                          "tuner": ({"span_cells": f.score_ctx.span(), "trials_in_timed_region": trials_timed,

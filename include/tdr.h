@@ -479,6 +479,11 @@ int tdr_profile_score_ms(double* total_ms, int64_t* launches);
  * ray-mapped kernel over the scattered ones — and the number of scattered particles (synchronises).  Measurement state is
  * process-wide like the switch itself: one measuring thread. */
 int tdr_profile_shares(double* dense_ms, double* scattered_ms, int64_t* scattered_particles);
+/* With tdr_profile_enable(2) — never inside a timed region: an atomic per wave-sector slows the kernels — the dense kernels count which loop variant each wave-sector (polar) / wave-segment (Cartesian) ran; reads
+ * and resets the 16 counters (synchronises): [0..2] score_polar_su_kernel with the workgroup's staged box — every cell known /
+ * every cell inside the map / general; [3..5] the same with the wave's own box; [6] its far path; [8..10]
+ * score_cart_su_kernel — all known / inside / general; [11] its plain steps (a box that did not fit). */
+int tdr_profile_variants(int64_t out[16]);
 
 /* The library reads NOTHING from the process environment: behaviour switches are these calls (and the tdr_config_* calls
  * above), process-wide, meant for A/B measurements, tests and debugging — results never depend on them unless stated.

@@ -109,6 +109,7 @@ SIGNATURES = {
     "tdr_score_ctx_trial_calls": (_i64, [_vp]),
     "tdr_config_tuning": (_i64, [C.c_char_p, _i64]),
     "tdr_selftest_score": (_i, []),
+    "tdr_profile_variants": (_i, [C.POINTER(_i64)]),
     "tdr_score_ctx_set_polar_factors": (_i, [_vp, _vp, _i, _i]),
     "tdr_polar_factors_host": (_i, [_i, _i, _f, _f, _vp]),
     "tdr_k_score_polar_ctx": (_i, [C.POINTER(MapDescC), _vp, _vp, _i, _i, _f, C.POINTER(FilterParamsC), _vp, _i64, _i64,

@@ -73,4 +73,6 @@ int tdr_chain_total(const float* raw, const float* mean_dev, int kind, int64_t n
 int tdr_uw_small(const float* raw, const float* last_dist, int64_t n, float* w, float* info, hipStream_t st);
 // a record with a spare slot (ncls + 2 <= rf) carries `known` twice: slot rf-2 pairs with a constant 1 of the scan record
 __host__ __device__ inline bool tdr_has_kslot(int ncls, int rf) { return ncls + 2 <= rf; }
+// diagnostics: 16 device counters while tdr_profile_enable(1) is in force, else NULL (tdr_score.hip, tdr_profile_variants)
+uint32_t* tdr_profile_stats_ptr();
 #endif  // TDR_COMMON_H_

@@ -1831,8 +1831,32 @@ struct ShareProfScope {
     if (stop) (void)hipEventRecord(stop, s);
   }
 };
+// ... and which loop VARIANT the dense kernels' waves ran, counted on the device while profiling is on (16 counters, see
+// tdr_profile_variants in tdr.h): what fraction of the wave-sectors / wave-segments found every reachable cell known.
+static uint32_t* g_variant_stats = nullptr;
+static bool g_prof_variants = false;   // tdr_profile_enable(2): the counters cost the kernels an atomic per wave-sector
+uint32_t* tdr_profile_stats_ptr() {   // NULL unless the variant counters are on (the kernels then count nothing)
+  if (!g_prof_on || !g_prof_variants) return nullptr;
+  if (!g_variant_stats) {
+    if (hipMalloc((void**)&g_variant_stats, 16 * sizeof(uint32_t)) != hipSuccess) { g_variant_stats = nullptr; return nullptr; }
+    (void)hipMemset(g_variant_stats, 0, 16 * sizeof(uint32_t));
+  }
+  return g_variant_stats;
+}
+extern "C" int tdr_profile_variants(int64_t out[16]) {   // reads and resets (synchronises)
+  if (!out) return fail(TDR_ERR_ARG, "profile_variants: null pointer");
+  for (int k = 0; k < 16; k++) out[k] = 0;
+  if (!g_variant_stats) return TDR_OK;
+  uint32_t h[16];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h, g_variant_stats, sizeof(h), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(g_variant_stats, 0, sizeof(h)));
+  for (int k = 0; k < 16; k++) out[k] = h[k];
+  return TDR_OK;
+}
 extern "C" int tdr_profile_enable(int on) {
   g_prof_on = on != 0;
+  g_prof_variants = on == 2;
   g_prof_used = 0;
   g_share_valid = false;
   return TDR_OK;

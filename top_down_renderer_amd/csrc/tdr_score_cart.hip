@@ -345,13 +345,15 @@ struct CartSuArgs {
   const int32_t* full_cnt;     // [chunks]
   int64_t list_cap;
   int seg_rows;                // window rows per segment (a multiple of 4)
+  uint32_t* stats;             // NULL, or (profiling) counters of the variants the wave-segments ran: tdr_profile_variants
 };
 struct CartSuLds {             // ONE object so that the dictionary sits at LDS address 0 (the assembly reads it there)
   uint32_t dict[TDR_CMAP_MAX_DICT];
   uint32_t bits[4][CART_SU_WBOX];
 };
 
-__global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuArgs x) {
+// (five waves per SIMD: the kernel sits at 96-97 registers, and 4 waves instead of 5 cost it 12 % — 16.4 against 18.3 ms at config 4)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void score_cart_su_kernel(CartArgs a, CartSuArgs x) {
   constexpr int RF = 8, ND = 6, CW = 2;
   __shared__ CartSuLds lds;
   if (int_form_off(a.flags)) return;   // (uniform) the float form does this launch
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuAr
       const int wl = (wcl >> 5) + 1, wh = (wch >> 5) + 1;   // mask words (a guard band of one word: kmask_offset)
       const int Hw = wrh - wrl + 1, Wbw = wh - wl + 1;
       if ((int64_t)Hw * Wbw > CART_SU_WBOX) {   // (wave-uniform) the box does not fit: the plain steps, the mask gathered
+        if (x.stats && lane == 0) atomicAdd(&x.stats[11], 1u);
         cpp_rows(ia, ib, jg, jg + CART_ASM_NCOL);
         continue;
       }
@@ -546,6 +549,7 @@ __global__ __launch_bounds__(256) void score_cart_su_kernel(CartArgs a, CartSuAr
         [half] "s"(half2), [kconst] "s"(kconst_s), [i0] "s"(i0_s), [nblk] "s"(nblk_s), [doff] "s"(doff_s),                  \
         [pbase0] "s"(pbase0_s), [pbytes] "s"(pbytes_s)                                                                      \
       : CART_ASM_CLOBBERS
+      if (x.stats && lane == 0) atomicAdd(&x.stats[allknown ? 8 : (inside ? 9 : 10)], 1u);   // [8..10] all known / inside / general, [11] plain steps
       if (allknown) asm volatile(CART_ASM_ALLKNOWN CART_ASM_OPERANDS);
       else if (inside) asm volatile(CART_ASM_NOCLAMP CART_ASM_OPERANDS);
       else asm volatile(CART_ASM CART_ASM_OPERANDS);
@@ -1009,6 +1013,7 @@ int tdr_cart_int_launch(CartArgs a, const tdr_map_desc* map, int rf, uint32_t* d
       CartSuArgs x;
       x.full_list = full_list; x.full_cnt = full_cnt; x.list_cap = list_cap; x.seg_rows = g_cart_seg_rows;
       x.bdesc = bdesc; x.pbytes = plane_bytes; x.pbase0 = pbase - plane_bytes;
+      x.stats = tdr_profile_stats_ptr();
       d.desc = desc_su;
       d.cpc = cpc_su;
       d.nchunks = nchunks_su;

@@ -77,6 +77,7 @@ struct SuArgs {
   int group, nchunks, ncls;
   int64_t npad;            // stride of `part`
   uint32_t* part;          // [nchunks][2 ncls + 2][npad]: class k's integer sum as {low, high} words, normalisation, known count
+  uint32_t* stats;         // NULL, or (profiling) counters of the variants the wave-sectors ran: tdr_profile_variants
 };
 
 // Scan descriptor of a bin, four dwords:
@@ -870,6 +871,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       box_allknown = __builtin_amdgcn_readfirstlane(box_allknown);
       box_krow4 = __builtin_amdgcn_readfirstlane(box_krow4);
       box_kconst = __builtin_amdgcn_readfirstlane(box_kconst);
+      if (a.stats && lane == 0)   // [0..2] the workgroup's box: all known / inside / general; [3..5] the wave's own; [6] far
+        atomicAdd(&a.stats[!box_ok ? 6 : ((fits ? 0 : 3) + (box_allknown ? 0 : (box_inside ? 1 : 2)))], 1u);
       if (box_ok) run_sector(i0, i1, box_krow4, box_kconst, box_inside != 0, box_allknown != 0);
       else far_sector(i0, i1);
     }
@@ -1108,6 +1111,7 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   u.nb = L.nb; u.nr = L.nr; u.res = L.res; u.st = L.st; u.cap = L.cap;
   u.slots = base + W.slots; u.nslots = nslots;
   u.group = L.group; u.nchunks = L.nchunks; u.ncls = map->ncls; u.npad = L.npad; u.part = reinterpret_cast<uint32_t*>(L.part);
+  u.stats = tdr_profile_stats_ptr();
   const dim3 grid((unsigned)cdiv(L.npad, 256), (unsigned)L.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, L.rf), us = L.uniform_scale;
 #define TDR_LAUNCH_SU(NV4)                                                                         \
