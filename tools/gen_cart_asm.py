@@ -21,6 +21,8 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
   v20..v23  scratch;  v24..v27 sample u: the 2-byte cell of the bin's class plane
   v32..v39  cs * y_(i+u), u = 0..3 (recomputed at every row block);  v40, v41 scratch of that
+  v42..v53  the six 64-bit class accumulators: the statement's a0..a5 operands are TIED to these registers ("+{v[42:43]}" ...),
+            the loop addresses them relative to v[40:41] through the GPR index (M0)
   s48..s63 / s80..s95   the one-dword descriptors of columns 0-3 / 4-7 of the row block, 4 rows x 4 columns each
                         (cart_prep_kernel's block layout: count in bits 0-23, class code in bits 24-26; a step's first
                         descriptor: which of its four bins hold a class in bits 28-31; a block's first: bit 27 = any does).
@@ -41,6 +43,7 @@ import gen_su_asm as su  # noqa: E402  (the register rules and their checker are
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_cart_asm.h")
 NCOL = 8
 CLOBBER_V = range(8, 42)
+ACC_V = range(42, 54)     # the accumulators: operands of the statement tied to these registers (not clobbers)
 CLOBBER_S = range(48, 96)
 VARIANTS = (("", True, True), ("_NOCLAMP", False, True), ("_ALLKNOWN", False, False))
 
@@ -193,33 +196,14 @@ def step(a, jc, clamp, mask, S):
         a("ds_read_b32 v21, v21")                                                            # the dictionary sits at LDS address 0
         a(f"s_bfe_u32 s76, s{d0 + u}, 0x30018")                                              # the class code
         a("s_waitcnt lgkmcnt(0)")
-        # acc[class] += count * distance (state_particle.cpp:136-139) as integers: wave-uniform branches over the class
-        a("s_cmp_lt_u32 s76, 4")
-        a(f"s_cbranch_scc1 .Lct_k{u}lo{tag}%=")
-        a("s_cmp_lt_u32 s76, 5")
-        a(f"s_cbranch_scc1 .Lct_k{u}k3{tag}%=")
-        a("s_cmp_lt_u32 s76, 6")
-        a(f"s_cbranch_scc1 .Lct_k{u}k4{tag}%=")
-        a("v_mad_u64_u32 %[a5], vcc, s77, v21, %[a5]")
-        a(f"s_branch .Lct_b{u}{tag}%=")
-        a(f".Lct_k{u}k4{tag}%=:")
-        a("v_mad_u64_u32 %[a4], vcc, s77, v21, %[a4]")
-        a(f"s_branch .Lct_b{u}{tag}%=")
-        a(f".Lct_k{u}k3{tag}%=:")
-        a("v_mad_u64_u32 %[a3], vcc, s77, v21, %[a3]")
-        a(f"s_branch .Lct_b{u}{tag}%=")
-        a(f".Lct_k{u}lo{tag}%=:")
-        a("s_cmp_lt_u32 s76, 2")
-        a(f"s_cbranch_scc1 .Lct_k{u}k0{tag}%=")
-        a("s_cmp_lt_u32 s76, 3")
-        a(f"s_cbranch_scc1 .Lct_k{u}k1{tag}%=")
-        a("v_mad_u64_u32 %[a2], vcc, s77, v21, %[a2]")
-        a(f"s_branch .Lct_b{u}{tag}%=")
-        a(f".Lct_k{u}k1{tag}%=:")
-        a("v_mad_u64_u32 %[a1], vcc, s77, v21, %[a1]")
-        a(f"s_branch .Lct_b{u}{tag}%=")
-        a(f".Lct_k{u}k0{tag}%=:")
-        a("v_mad_u64_u32 %[a0], vcc, s77, v21, %[a0]")
+        # acc[class] += count * distance (state_particle.cpp:136-139) as integers.  The six 64-bit accumulators sit in FIXED
+        # registers v[42:53] (the statement's operands are tied to them) and the class picks its pair by VGPR-relative
+        # indexing: destination and addend of the multiply-add are v[40:41] + 2 * code (tools/gpr_idx_probe.hip checks the
+        # mode on gfx950) — three scalar instructions and no branch where a tree of compares and branches stood
+        a("s_lshl_b32 s76, s76, 1")
+        a("s_set_gpr_idx_on s76, 0xc")                                                       # SRC2 | DST relative
+        a("v_mad_u64_u32 v[40:41], vcc, s77, v21, v[40:41]")
+        a("s_set_gpr_idx_off")
         a(f".Lct_b{u}{tag}%=:")
     a(f".Lct_be{tag}%=:")
 
@@ -235,6 +219,15 @@ def check_text(lines, outputs, inputs):
     import re
     written = su.check_text(lines, outputs, inputs, CLOBBER_V, CLOBBER_S)
     vm, lgkm = set(), set()                    # fixed destination registers of requests not yet waited for, by counter
+    # VGPR-relative indexing: exactly one instruction between an `on` and its `off` — the accumulate, whose destination and
+    # addend are the pair below the accumulators (v[40:41] + 2 * code reaches v[42:53], the registers a0..a5 are tied to)
+    for k, ln in enumerate(lines):
+        if ln.startswith("s_set_gpr_idx_on"):
+            assert ln == "s_set_gpr_idx_on s76, 0xc", ln
+            assert lines[k + 1] == "v_mad_u64_u32 v[40:41], vcc, s77, v21, v[40:41]" and lines[k + 2] == "s_set_gpr_idx_off", \
+                f"only the accumulate may run under the GPR index: {lines[k + 1]}"
+            assert lines[k - 1] == "s_lshl_b32 s76, s76, 1", "the index is twice the class code"
+    assert ACC_V.start == max(CLOBBER_V) + 1, "the accumulators sit right behind the clobbered registers"
     for ln in lines:
         if ln.endswith(":"):
             continue
@@ -288,7 +281,7 @@ def main():
     vregs = ", ".join(f'"v{i}"' for i in CLOBBER_V)
     sregs = ", ".join(f'"s{i}"' for i in CLOBBER_S)
     out.append(f"  {vregs}, \\")
-    out.append(f'  {sregs}, "vcc", "scc", "memory"')
+    out.append(f'  {sregs}, "vcc", "scc", "m0", "memory"')
     out.append("#endif  // TDR_SCORE_CART_ASM_H_")
     open(OUT, "w").write("\n".join(out) + "\n")
     print(OUT)

@@ -541,8 +541,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
       // byte offset of block (column group jg / 8, row block ia / 4) in the block layout: 128 bytes a block
       const uint32_t doff_s = __builtin_amdgcn_readfirstlane((((uint32_t)jg >> 3) * ((uint32_t)a.rows >> 2) + ((uint32_t)ia >> 2)) * 128u);
 #define CART_ASM_OPERANDS                                                                                                  \
-      : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),   \
-        [norm] "+v"(inorm), [known] "+v"(known)                                                                             \
+      /* the accumulators are TIED to v[42:53]: the loop reaches them by VGPR-relative indexing (tools/gen_cart_asm.py) */       \
+      : [a0] "+{v[42:43]}"(acc[0]), [a1] "+{v[44:45]}"(acc[1]), [a2] "+{v[46:47]}"(acc[2]), [a3] "+{v[48:49]}"(acc[3]),      \
+        [a4] "+{v[50:51]}"(acc[4]), [a5] "+{v[52:53]}"(acc[5]), [norm] "+v"(inorm), [known] "+v"(known)                       \
       : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [ab3] "v"(ab[3]), [ab4] "v"(ab[4]), [ab5] "v"(ab[5]),         \
         [ab6] "v"(ab[6]), [ab7] "v"(ab[7]), [offv] "v"(offv), [cs] "v"(cs), [lor] "v"(lo_r), [stepr] "v"(step_r),           \
         [krow4] "v"(krow4), [pkcol] "v"(pkcol), [db] "s"(bdescc), [crec] "s"(crec), [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), \
