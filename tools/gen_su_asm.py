@@ -11,8 +11,9 @@ Register plan (fixed registers, all named in the statement's clobber list):
   v16..v19  sample u: mask word address -> 0 / -1 known;  v28..v31 sample u: mask word
   v20..v23  scratch
   v24..v27  sample u: the 2-byte cell of the bin's class plane
-  (the accumulators of classes 0..5 — 64-bit integers, see below — , the normalisation and the known count are operands
-   of the statement: the register allocator places them)
+  v32..v43  the accumulators of classes 0..5 — 64-bit integers, see below: the statement's a0..a5 operands are TIED to these
+            registers ("+{v[32:33]}" ...) and the loop reaches them relative to v[30:31] through the GPR index (M0)
+  (the normalisation and the known count are operands of the statement: the register allocator places them)
   s40..s47 / s72..s79   the step's sample offsets {tx, ty} x 4           (even / odd steps: the loop body exists twice and
   s48..s63 / s80..s95   the step's descriptors {code, value, plane constant, flag} x 4 (su_prep_kernel)   requests the next
                         step's scalars into the other set before it works on its own)
@@ -178,33 +179,14 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                # the dictionary sits at LDS address 0
         a("s_waitcnt lgkmcnt(0)")
-        # acc[class] += count * distance (state_particle.cpp:136-139), as integers: a tree of wave-uniform branches over the class
-        a(f"s_cmp_lt_u32 s{code}, 4")
-        a(f"s_cbranch_scc1 .Lsu_c{u}lo{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 5")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k3{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 6")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k4{tag}%=")
-        a(f"v_mad_u64_u32 %[a5], vcc, s{val}, v21, %[a5]")
-        a(f"s_branch .Lsu_b{u}{tag}%=")
-        a(f".Lsu_c{u}k4{tag}%=:")
-        a(f"v_mad_u64_u32 %[a4], vcc, s{val}, v21, %[a4]")
-        a(f"s_branch .Lsu_b{u}{tag}%=")
-        a(f".Lsu_c{u}k3{tag}%=:")
-        a(f"v_mad_u64_u32 %[a3], vcc, s{val}, v21, %[a3]")
-        a(f"s_branch .Lsu_b{u}{tag}%=")
-        a(f".Lsu_c{u}lo{tag}%=:")
-        a(f"s_cmp_lt_u32 s{code}, 2")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k0{tag}%=")
-        a(f"s_cmp_lt_u32 s{code}, 3")
-        a(f"s_cbranch_scc1 .Lsu_c{u}k1{tag}%=")
-        a(f"v_mad_u64_u32 %[a2], vcc, s{val}, v21, %[a2]")
-        a(f"s_branch .Lsu_b{u}{tag}%=")
-        a(f".Lsu_c{u}k1{tag}%=:")
-        a(f"v_mad_u64_u32 %[a1], vcc, s{val}, v21, %[a1]")
-        a(f"s_branch .Lsu_b{u}{tag}%=")
-        a(f".Lsu_c{u}k0{tag}%=:")
-        a(f"v_mad_u64_u32 %[a0], vcc, s{val}, v21, %[a0]")
+        # acc[class] += count * distance (state_particle.cpp:136-139), as integers.  The six 64-bit accumulators sit in FIXED
+        # registers v[32:43] (the statement's a0..a5 operands are tied to them) and the class picks its pair by VGPR-relative
+        # indexing: destination and addend are v[30:31] + 2 * code (tools/gpr_idx_probe.hip checks the mode on gfx950) — three
+        # scalar instructions and no branch where a tree of compares and branches stood (round 5)
+        a(f"s_lshl_b32 s64, s{code}, 1")
+        a("s_set_gpr_idx_on s64, 0xc")                                                       # SRC2 | DST relative
+        a(f"v_mad_u64_u32 v[30:31], vcc, s{val}, v21, v[30:31]")
+        a("s_set_gpr_idx_off")
         a(f".Lsu_b{u}{tag}%=:")
     # ---- next step
     a("s_mov_b32 s65, s69")
@@ -257,6 +239,13 @@ def check_text(lines, outputs, inputs, clobber_v=None, clobber_s=None):
     clobber_s = CLOBBER_S if clobber_s is None else clobber_s
     assert lines[0] == "s_waitcnt vmcnt(0) lgkmcnt(0)", "the loop must begin by draining the loads in flight"
     named_written = set()
+    # VGPR-relative indexing: exactly one instruction between an `on` and its `off` — the accumulate, whose destination and
+    # addend name the pair below the accumulators (+ 2 * class code reaches the registers a0..a5 are tied to)
+    for k, ln in enumerate(lines):
+        if ln.startswith("s_set_gpr_idx_on"):
+            assert re.fullmatch(r"s_set_gpr_idx_on s\d+, 0xc", ln), ln
+            assert re.fullmatch(r"v_mad_u64_u32 (v\[\d+:\d+\]), vcc, s\d+, v21, \1", lines[k + 1]) and \
+                lines[k + 2] == "s_set_gpr_idx_off", f"only the accumulate may run under the GPR index: {lines[k + 1]}"
     for ln in lines:
         if ln.endswith(":"):
             continue
@@ -308,7 +297,7 @@ def main():
     vregs = ", ".join(f'"v{i}"' for i in CLOBBER_V)
     sregs = ", ".join(f'"s{i}"' for i in CLOBBER_S)
     out.append(f"  {vregs}, \\")
-    out.append(f'  {sregs}, "vcc", "memory"')
+    out.append(f'  {sregs}, "vcc", "m0", "memory"')
     out.append("#endif  // TDR_SCORE_SU_ASM_H_")
     open(OUT, "w").write("\n".join(out) + "\n")
     print(OUT)

@@ -739,8 +739,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const uint64_t res2 = (uint64_t)__float_as_uint(a.res) * 0x100000001ull;   // {res, res} in an SGPR pair
         while (nleft != 0xFFFFFFFFu) {
 #define SU_ASM_OPERANDS                                                                                               \
-          : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),   /* 64-bit */ \
-            [a5] "+v"(acc[ND > 5 ? 5 : 0]), [norm] "+v"(norm), [known] "+v"(known), [toff] "+v"(toff), [doff] "+v"(doff), \
+          /* the accumulators (64-bit) are TIED to v[32:43]: the loop reaches them by VGPR-relative indexing */                \
+          : [a0] "+{v[32:33]}"(acc[0]), [a1] "+{v[34:35]}"(acc[1]), [a2] "+{v[36:37]}"(acc[2]), [a3] "+{v[38:39]}"(acc[3]),    \
+            [a4] "+{v[40:41]}"(acc[4]), [a5] "+{v[42:43]}"(acc[ND > 5 ? 5 : 0]), [norm] "+v"(norm), [known] "+v"(known),       \
+            [toff] "+v"(toff), [doff] "+v"(doff),                                                                             \
             [nleft] "+v"(nleft), [wleft] "+v"(wleft)                                                                   \
           : [offv] "v"(offv), [krow4] "v"(krow4), [pkcol] "v"(pkcol), [tb] "s"(tbase), [db] "s"(dbase),              \
             [rmax] "s"(rmax_s), [cmax] "s"(cmax_s), [half] "s"(half2), [kconst] "s"(kconst_s), [crec] "s"(crec),           \
