@@ -522,13 +522,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
         cpp_rows(ia, ib, jg, jg + CART_ASM_NCOL);
         continue;
       }
+      // (the all-known test looks at the box's own columns only: the bits of its first and last word that lie outside the
+      // box count as known — a word is 32 cells wide, a 32-row segment's box about as many)
+      const uint32_t edge_lo = (1u << (wcl & 31)) - 1u, edge_hi = ~((2u << (wch & 31)) - 1u);
       uint32_t ev = 0xFFFFFFFFu;
-      for (int wc = 0; wc < Wbw; wc++)       // (row fastest: consecutive lanes read consecutive words of one tile column)
+      for (int wc = 0; wc < Wbw; wc++) {     // (row fastest: consecutive lanes read consecutive words of one tile column)
+        const uint32_t outside = (wc == 0 ? edge_lo : 0u) | (wc == Wbw - 1 ? edge_hi : 0u);
         for (int row = lane; row < Hw; row += 64) {
           const uint32_t wv = kmask[(int64_t)(wl + wc) * kcolw + (wrl + row + 32)];
           lds.bits[wave][row * Wbw + wc] = wv;
-          ev &= wv;
+          ev &= wv | outside;
         }
+      }
       // the wave reads what its lanes just wrote, through the assembly's ds_read: order the stores in front
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
