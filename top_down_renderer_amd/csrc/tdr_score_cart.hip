@@ -787,6 +787,29 @@ __global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
   };
   auto row_term = [&](int i) -> tdr_v2f { return cs * cart_linspaced(i, r1, lo_r, hi_r, step_r); };
+  // The column terms {-sin * x_j, cos * x_j} of the lane's columns: a lane meets the same GQ * blocks columns in every
+  // window row, so for windows of up to two blocks (512 columns) they are computed ONCE (2 GQ register pairs) instead of
+  // in every step — seven of the step's forty vector instructions.  A column the window does not have gets a term that
+  // throws its cell off the map: the guard cell is unknown and its descriptor is empty, so it counts nothing.
+  // (GQ == 4 only — windows of 129 .. 512 columns, config 4's: the narrower instantiations would pay for the registers with
+  // a wave per SIMD)
+  constexpr int NT = GQ == 4 ? 2 * GQ : 1;
+  const bool tab = GQ == 4 && a.blocks <= 2;   // (uniform)
+  tdr_v2f ABt[NT];
+#pragma unroll
+  for (int k = 0; k < (GQ == 4 ? NT : 0); k++) {
+    const int j = k * 64 + lane;
+    const float xj = cart_linspaced(j, c1, lo_c, hi_c, step_c);
+    ABt[k] = (tab && j < a.cols) ? (tdr_v2f){ns * xj, c * xj} : (tdr_v2f){1.0e30f, 1.0e30f};
+  }
+  auto cell_tab = [&](tdr_v2f cyi, tdr_v2f AB, int& ri, int& ci) {
+    tdr_v2f pv = cyi + AB;
+    pv = pv + offv;
+    tdr_v2f qv = {__builtin_amdgcn_fmed3f(pv.x, -1.f, rmaxf), __builtin_amdgcn_fmed3f(pv.y, -1.f, cmaxf)};
+    qv = qv + 0.49999997f;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ri) : "v"(qv.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ci) : "v"(qv.y));
+  };
 
   // rows of steps: m = window row * blocks + block; this wave's share
   const int rows_all = a.rows * a.blocks, per = (rows_all + a.nsplit - 1) / a.nsplit;
@@ -795,23 +818,30 @@ __global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
   constexpr int U = 8 / GQ;
   typedef uint16_t desc_t __attribute__((ext_vector_type(GQ)));
   const desc_t* __restrict__ descv = reinterpret_cast<const desc_t*>(a.desc_ray);
-  auto rows_step = [&](auto cnt_c, int m) {
+  auto rows_step = [&](auto cnt_c, auto tab_c, int m) {
     constexpr int N = decltype(cnt_c)::value;
+    constexpr bool TAB = decltype(tab_c)::value;
     desc_t dd[N];
 #pragma unroll
     for (int u = 0; u < N; u++) dd[u] = descv[(int64_t)(m + u) * 64 + lane];
     uint32_t v[N * GQ], shb[N * GQ], cnt[N * GQ], acc_at[N * GQ], ok[N * GQ];
 #pragma unroll
     for (int u = 0; u < N; u++) {
-      const int i = (m + u) / a.blocks, b = (m + u) - i * a.blocks;   // (wave-uniform)
+      // (wave-uniform; with the table there are at most two blocks: no division)
+      const int i = TAB ? (a.blocks == 2 ? (m + u) >> 1 : m + u) : (m + u) / a.blocks, b = (m + u) - i * a.blocks;
       const tdr_v2f cyi = row_term(i);
 #pragma unroll
       for (int g = 0; g < GQ; g++) {
         const int sidx = u * GQ + g;
         const int j = (b * GQ + g) * 64 + lane;
         int ri, ci;
-        cell(cyi, j, ri, ci);
-        ok[sidx] = j < a.cols ? 1u : 0u;   // a column the window does not have counts nothing
+        if constexpr (TAB) {
+          cell_tab(cyi, b ? ABt[(GQ + g) % NT] : ABt[g % NT], ri, ci);
+          ok[sidx] = 1u;                     // (a column the window does not have fell on the guard cell: unknown)
+        } else {
+          cell(cyi, j, ri, ci);
+          ok[sidx] = j < a.cols ? 1u : 0u;   // a column the window does not have counts nothing
+        }
         const uint32_t d = dd[u][g];
         cnt[sidx] = d & 0xFFFu;
         const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
@@ -836,8 +866,16 @@ __global__ __launch_bounds__(256) void score_cart_ray_kernel(CartRayArgs a) {
     }
   };
   int m = m0;
-  for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, m);
-  for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, m);
+  if constexpr (GQ == 4) {
+    if (tab) {
+      for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, std::true_type{}, m);
+      for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, std::true_type{}, m);
+    }
+  }
+  {
+    for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, std::false_type{}, m);
+    for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, std::false_type{}, m);
+  }
   {   // the list: bins with several classes (or one large count)
     const int nm = *a.n_list, mper = (nm + a.nsplit - 1) / a.nsplit;
     const int e1 = min(nm, (part_id + 1) * mper);
