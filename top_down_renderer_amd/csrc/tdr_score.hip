@@ -1650,7 +1650,7 @@ __global__ void utab_kernel(const float* __restrict__ tab, int64_t n2, float sca
 // (the group's scan rows must fit the LDS budget; 32 KB keeps four workgroups per CU; at most 8 rings; whole steps of
 // TDR_SCORE_U) and from the TOTAL particle count of the filter — n_total, the same on every rank of a sharded filter,
 // never the size of one launch or shard: the partition of a particle's score into partial sums is then the same in an
-// N-rank run as in the 1-rank run.  Aim: >= 2048 workgroups.  TDR_SCORE_GROUP overrides (tuning).
+// N-rank run as in the 1-rank run.  Aim: >= 2048 workgroups.  tdr_config_tuning("score_group", g) overrides (tuning).
 static int score_group_rings(int nb, int nr, int rf, int64_t n_total) {
   const int forced = g_score_group;
   const int64_t ring_bytes = std::max<int64_t>((int64_t)nb * rf * 4, 1);
