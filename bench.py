@@ -199,7 +199,7 @@ def kernel_source_hash():
     """Hash of the sources the scoring kernels are built from: a traffic record made with other sources is stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_cmap.hip", "tdr_score_su.h", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
+    for f in ("tdr_score.hip", "tdr_score_su.hip", "tdr_score_ray.hip", "tdr_cmap.hip", "tdr_score_su.h", "tdr_score_su_asm.h", "tdr_score_cart.hip", "tdr_score_cart.h", "tdr_score_cart_asm.h", "tdr_score_dev.h", "tdr_common.h", "tdr_sincosf.h"):
         h.update(open(os.path.join(ROOT, "top_down_renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -397,7 +397,7 @@ def main():
     if rank == 0:
         P = cfg.nb * cfg.nr
         b_pu = P * (4 * cfg.ncls + 1) + 64
-        kname = "score_cart"   # score_cart_skip_kernel (tdr_score_cart.hip) or the general score_cart_kernel
+        kname = "score_cart"   # score_cart_su_kernel + score_cart_ray_kernel (tdr_score_cart.hip), or the float form score_cart_kernel
         if cfg.polar:
             kname = "score_polar"   # score_polar_su_kernel + score_polar_ray_kernel (the integer form), or score_polar_kernel (the float form)
         n_local = per_gpu

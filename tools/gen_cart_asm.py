@@ -28,7 +28,7 @@ Register plan (fixed registers, all named in the statement's clobber list):
                         descriptor: which of its four bins hold a class in bits 28-31; a block's first: bit 27 = any does).
                         Half a block is ONE scalar load, requested half a block ahead into the other set
   s64 first row of the block, s65 row blocks left, s66 byte offset of the block in the descriptor array,
-  s67 offset being requested, s76, s77 scratch
+  s67 offset being requested, s76, s77 scratch, s68 the all-known variant's normalisation (wave-uniform)
 Arithmetic: EXACT integer sums like the polar loop (tools/gen_su_asm.py): any order, any partition, any kernel gives the
 same bits.  Bins holding several classes are EMPTY to this loop (their descriptor code is 0 in the array it reads): the
 kernel adds their products from a per-chunk list afterwards; their known bit is counted here like an empty bin's.
@@ -56,6 +56,8 @@ def loop_text(clamp, mask):
     a("s_mov_b32 s65, %[nblk]")
     a("s_mov_b32 s66, %[doff]")
     a("s_load_dwordx16 s[48:63], %[db], s66")        # the first half of the first block
+    if not mask:
+        a("s_mov_b32 s68, 0")
     a(".Lct_blk%=:")
     a("s_waitcnt lgkmcnt(0)")                        # set A: columns 0-3 of this block
     if not mask:
@@ -96,7 +98,9 @@ def loop_text(clamp, mask):
         a("s_cbranch_scc1 .Lct_blk%=")
         a(".Lct_end%=:")
     a("s_waitcnt lgkmcnt(0)")                        # (the request for the block behind the last one)
-    return L
+    if not mask:
+        a("v_add_u32 %[norm], s68, %[norm]")
+    return [x for x in L if su.PAD or x != "s_nop 0"]
 
 
 def step(a, jc, clamp, mask, S):
@@ -190,8 +194,8 @@ def step(a, jc, clamp, mask, S):
         a(f"v_and_b32 v21, 0xffc, v{24 + u}")                                                # the class's dictionary index * 4
         if mask:
             a("v_add_u32 %[norm], %[norm], v20")
-        else:
-            a("v_add_u32 %[norm], s77, %[norm]")
+        else:   # every cell known: the normalisation is the same for every lane — summed in s68, added at the exit
+            a("s_add_u32 s68, s68, s77")
         a("s_nop 0")
         a("ds_read_b32 v21, v21")                                                            # the dictionary sits at LDS address 0
         a(f"s_bfe_u32 s76, s{d0 + u}, 0x30018")                                              # the class code

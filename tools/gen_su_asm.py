@@ -25,14 +25,17 @@ replaces (tools/valu_cost.hip) — and does not depend on the order of the addit
 the same bits.
 Cost model behind the schedule (tools/valu_cost.hip, tools/ta_cost.hip; per CU): scalar instructions issue 1 per cycle,
 plain VOP2 2 cycles per SIMD, VOP3 / packed / conversions 4, a 64-lane gather >= 16 cycles of the L1 address path.
-Dependent vector instructions are kept at least one instruction apart (s_nop 0 where nothing else fits), as hipcc's own
-hazard padding does after VOP3 producers.
+Rounds 3-4 kept dependent vector instructions one instruction apart with s_nop 0; the hardware interlocks those
+dependencies, and without the padding (13 of a step's ~100 instructions) every configuration runs the same or 1 % faster
+(config 2 4.645 / 4.631 ms, config 4 15.57 / 15.36): `--pad` regenerates the padded text for A/B.
 """
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "top_down_renderer_amd", "csrc", "tdr_score_su_asm.h")
 EXPERIMENT_LDS_GATHER = False   # tools/exp_lds_gather.sh
+PAD = "--pad" in sys.argv   # A/B: an s_nop 0 between dependent vector instructions, as rounds 3-4 had it (measured: no difference)
 
 
 def loop_text(uscale, clamp, mask=True):
@@ -50,6 +53,9 @@ def loop_text(uscale, clamp, mask=True):
     a("v_readfirstlane_b32 s68, %[wleft]")
     a("s_load_dwordx8 s[40:47], %[tb], s65")
     a("s_load_dwordx16 s[48:63], %[db], s66")
+    if not mask:
+        a("s_mov_b32 s96, 0")                        # the steps' counts (see phase B)
+        a("s_mov_b32 s97, s67")                      # steps left at entry: every finished step is four more known samples
     a("s_waitcnt lgkmcnt(0)")
     # The loop body exists twice: the offsets / descriptors of step k + 1 are requested (into the other register set) before
     # step k is worked on, so their scalar-cache latency hides behind it
@@ -57,11 +63,16 @@ def loop_text(uscale, clamp, mask=True):
     step(a, uscale, clamp, mask, T=72, D=80, TN=40, DN=48, tag="o", nxt="e")
     a(".Lsu_out%=:")
     a("s_waitcnt lgkmcnt(0)")                        # (a request for the step behind the last one may still be in flight)
+    if not mask:
+        a("s_sub_u32 s97, s97, s67")                 # steps done (s67 = 0xFFFFFFFF after the last one: the difference still counts it)
+        a("s_lshl_b32 s97, s97, 2")
+        a("v_add_u32 %[norm], s96, %[norm]")
+        a("v_add_u32 %[known], s97, %[known]")
     a("v_mov_b32 %[toff], s65")
     a("v_mov_b32 %[doff], s66")
     a("v_mov_b32 %[nleft], s67")
     a("v_mov_b32 %[wleft], s68")
-    return L
+    return [x for x in L if PAD or x != "s_nop 0"]
 
 
 def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
@@ -163,8 +174,7 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a("v_add_u32 v20, v20, v21")
         a("s_nop 0")
         a("v_sub_u32 %[known], %[known], v20")
-    else:   # every cell the sector can reach is known: four more known samples, nothing to look up
-        a("v_add_u32 %[known], 4, %[known]")
+    # (every cell the sector can reach known: four more known samples per step, counted at the exit)
     for u in range(4):
         code, val = D + 4 * u, D + 1 + 4 * u
         a(f"s_cmp_eq_u32 s{code}, 0")
@@ -174,15 +184,17 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
         a(f"v_and_b32 v21, 0xffc, v{24 + u}")                                    # the class's dictionary index * 4
         if mask:
             a("v_add_u32 %[norm], %[norm], v20")
-        else:
-            a(f"v_add_u32 %[norm], s{val}, %[norm]")
-        a("s_nop 0")
+        else:   # every cell known: the normalisation is the same for every lane — summed in a scalar, added at the exit
+            a(f"s_add_u32 s96, s96, s{val}")
         a("ds_read_b32 v21, v21")                                                # the dictionary sits at LDS address 0
         a("s_waitcnt lgkmcnt(0)")
         # acc[class] += count * distance (state_particle.cpp:136-139), as integers.  The six 64-bit accumulators sit in FIXED
         # registers v[32:43] (the statement's a0..a5 operands are tied to them) and the class picks its pair by VGPR-relative
         # indexing: destination and addend are v[30:31] + 2 * code (tools/gpr_idx_probe.hip checks the mode on gfx950) — three
-        # scalar instructions and no branch where a tree of compares and branches stood (round 5)
+        # scalar instructions and no branch where a tree of compares and branches stood (round 5).
+        # (Tried in round 5: all four bins' dictionary reads in flight together and their products without a branch — an empty
+        # bin has a count of zero — so that a step waits for the LDS once: 2.93 against 2.83 ms; the extra reads and
+        # multiply-adds cost more than the waits.)
         a(f"s_lshl_b32 s64, s{code}, 1")
         a("s_set_gpr_idx_on s64, 0xc")                                                       # SRC2 | DST relative
         a(f"v_mad_u64_u32 v[30:31], vcc, s{val}, v21, v[30:31]")
@@ -208,7 +220,7 @@ def step(a, uscale, clamp, mask, T, D, TN, DN, tag, nxt):
 #   3. every fixed register an instruction READS is inside the clobber list too (nothing outside the plan is touched), and
 #      the named inputs are never written.
 CLOBBER_V = range(8, 32)
-CLOBBER_S = range(40, 96)
+CLOBBER_S = range(40, 98)
 NO_DEST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch_", "s_cmp_", "s_bitcmp")   # write nothing / SCC only
 
 
@@ -244,7 +256,7 @@ def check_text(lines, outputs, inputs, clobber_v=None, clobber_s=None):
     for k, ln in enumerate(lines):
         if ln.startswith("s_set_gpr_idx_on"):
             assert re.fullmatch(r"s_set_gpr_idx_on s\d+, 0xc", ln), ln
-            assert re.fullmatch(r"v_mad_u64_u32 (v\[\d+:\d+\]), vcc, s\d+, v21, \1", lines[k + 1]) and \
+            assert re.fullmatch(r"v_mad_u64_u32 (v\[\d+:\d+\]), vcc, s\d+, v\d+, \1", lines[k + 1]) and \
                 lines[k + 2] == "s_set_gpr_idx_off", f"only the accumulate may run under the GPR index: {lines[k + 1]}"
     for ln in lines:
         if ln.endswith(":"):

@@ -1617,6 +1617,7 @@ extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
 extern "C" int tdr_config_cart_seg_rows(int);      // tdr_score_cart.hip
 extern "C" int tdr_config_mt_stretches(int);       // tdr_rng.hip
 extern "C" int tdr_config_su_wave_span(int);       // tdr_score_su.hip
+extern "C" int tdr_config_su_lds_pad(int);
 extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // value < 0: query only
   if (!name) return -1;
   const std::string n(name);
@@ -1628,6 +1629,7 @@ extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // val
   if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
   if (n == "cart_seg_rows") return tdr_config_cart_seg_rows((int)std::max<int64_t>(value, -1));
   if (n == "mt_stretches") return tdr_config_mt_stretches((int)std::max<int64_t>(value, -1));
+  if (n == "su_lds_pad") return tdr_config_su_lds_pad((int)std::max<int64_t>(value, -1));
   if (n == "su_wave_span") return tdr_config_su_wave_span((int)std::max<int64_t>(value, -1));
   return -1;
 }

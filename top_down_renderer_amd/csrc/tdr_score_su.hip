@@ -973,6 +973,11 @@ extern "C" int tdr_config_su_wave_span(int cells) {   // < 0: query only
   return (int)g_su_wave_span;
 }
 float tdr_su_wave_span() { return g_su_wave_span; }
+static int g_su_lds_pad = 0;   // EXPERIMENT: dynamic LDS bytes per workgroup (limits the waves per SIMD without touching the code)
+extern "C" int tdr_config_su_lds_pad(int bytes) {
+  if (bytes >= 0) g_su_lds_pad = bytes;
+  return g_su_lds_pad;
+}
 static std::atomic<int64_t> g_su_launches{0};   // diagnostics only
 extern "C" int64_t tdr_shift_uniform_launches(void) { return g_su_launches.load(); }
 // Padding costs up to 63 idle lanes per heading bin: the order pays once a bin holds a few waves on average.
@@ -1117,10 +1122,10 @@ int tdr_su_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
   const dim3 grid((unsigned)cdiv(L.npad, 256), (unsigned)L.nchunks), block(256);
   const bool ks = tdr_has_kslot(map->ncls, L.rf), us = L.uniform_scale;
 #define TDR_LAUNCH_SU(NV4)                                                                         \
-  if (ks && us) hipLaunchKernelGGL((score_polar_su_kernel<NV4, true, true>), grid, block, 0, s, u);  \
-  else if (ks) hipLaunchKernelGGL((score_polar_su_kernel<NV4, true, false>), grid, block, 0, s, u);  \
-  else if (us) hipLaunchKernelGGL((score_polar_su_kernel<NV4, false, true>), grid, block, 0, s, u);  \
-  else hipLaunchKernelGGL((score_polar_su_kernel<NV4, false, false>), grid, block, 0, s, u);
+  if (ks && us) hipLaunchKernelGGL((score_polar_su_kernel<NV4, true, true>), grid, block, g_su_lds_pad, s, u);  \
+  else if (ks) hipLaunchKernelGGL((score_polar_su_kernel<NV4, true, false>), grid, block, g_su_lds_pad, s, u);  \
+  else if (us) hipLaunchKernelGGL((score_polar_su_kernel<NV4, false, true>), grid, block, g_su_lds_pad, s, u);  \
+  else hipLaunchKernelGGL((score_polar_su_kernel<NV4, false, false>), grid, block, g_su_lds_pad, s, u);
   switch (L.rf / 4) {
     case 1: TDR_LAUNCH_SU(1) break;
     case 2: TDR_LAUNCH_SU(2) break;
