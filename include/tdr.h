@@ -501,7 +501,9 @@ int tdr_profile_variants(int64_t out[16]);
  *   "mt_stretches"     0: the reference's random stream is always generated by one wave; 1 (default): calls of more than 128
  *                      state blocks fill stretches side by side, reached by jump-ahead (csrc/tdr_rng.hip) — the same words
  *   "cart_seg_rows"    window rows per segment of score_cart_su_kernel (a multiple of 4; 0: the Cartesian integer form's dense
- *                      share goes through the plain kernel instead — same bits) */
+ *                      share goes through the plain kernel instead — same bits)
+ *   "su_lds_pad"       bytes of dynamic LDS added to a workgroup of score_polar_su_kernel: fewer workgroups fit a CU — an
+ *                      occupancy sweep without touching the code object (0, the default; same bits) */
 int64_t tdr_config_tuning(const char* name, int64_t value);
 /* Device self-test of the scoring kernels: a tiny fixed problem (160 x 160 map, 6 classes, 512 particles) scored by every
  * kernel the library has for it.  The integer-form kernels run generated, hand-scheduled assembly; their sums are exact, so
