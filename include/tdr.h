@@ -496,6 +496,11 @@ int tdr_profile_variants(int64_t out[16]);
  *   "prefix_head"      leading addends the long running sum's walk adds one by one
  *   "ray_block_major"  0: the ray-mapped kernel keeps its first row order (direction-major) also when the caller's context
  *                      holds the table's factors (same bits)
+ *   "ray_patch"        0: the ray-mapped kernel walks 64 rings of ONE direction per step also where the patch order applies (a
+ *                      context with the table's factors, a direction count that is a multiple of 16, at most 256): 1 (default) =
+ *                      4 directions x 16 rings per step, a lane's four descriptors of a unit in one load (same bits)
+ *   "ray_borrow"       0: an empty scan bin of the ray-mapped kernel reads its known bit from the coarse mask plane; 1 (default):
+ *                      from the class plane its nearest non-empty neighbour of four rings reads anyway (same bits)
  *   "su_wave_span"     map cells a wave's own 64 same-heading particles may spread over before the wave is re-routed from the
  *                      shift-uniform kernel to the ray-mapped kernel (0, the default: never — measured, it does not pay) — same bits either way
  *   "mt_stretches"     0: the reference's random stream is always generated by one wave; 1 (default): calls of more than 128

@@ -179,13 +179,16 @@ def test_weights_do_not_depend_on_the_order_of_the_additions(tdr, oracle, ncls, 
 
 
 @pytest.mark.parametrize("nb,nr,scale_fixed", [(64, 32, True), (100, 100, True), (40, 200, False), (12, 300, True),
-                                               (9, 530, False)])
+                                               (9, 530, False), (32, 130, False), (256, 40, True), (48, 70, True)])
 def test_offsets_multiplied_out_of_the_tables_factors(tdr, oracle, nb, nr, scale_fixed):
     """A context that holds the table's factors (tdr_polar_factors_host): the ray-mapped kernel multiplies a direction's
     pair with a ring's radius itself instead of reading the product — the same float products (checked here on the host,
     and by the kernel's preparation on the device), so the same bits as the kernel that reads the table; one, two and four
     rings per lane, one block and several.  With factors that are NOT the table's (another angular resolution) the
-    preparation notices and the table is read: the same bits again."""
+    preparation notices and the table is read: the same bits again.  Direction counts that are multiples of 16 take the
+    PATCH order (a step = 4 directions x 16 rings, a lane's four descriptors of a unit in one load, radii per ring block;
+    ragged ring counts pad the last block) — switched off and on here, like the borrowed class planes of empty bins
+    (tdr_config_tuning "ray_patch" / "ray_borrow"): the same bits every way."""
     import torch
     pkg, k = tdr
     sc = _scene(ncls=5, nb=nb, nr=nr, size=400, n=1200, seed=5300 + nr, pts=9000)
@@ -222,9 +225,15 @@ def test_offsets_multiplied_out_of_the_tables_factors(tdr, oracle, nb, nr, scale
         k.lib.tdr_config_shift_uniform(2)
         a = run(ALL_RAY, 1, None)
         assert not (a == -7.0).any()
-        for split in (1, 2, 8):
-            assert np.array_equal(a, run(ALL_RAY, split, ctx), equal_nan=True), f"factors, {split} waves per particle"
-        assert np.array_equal(a, run(3.0, 0, ctx), equal_nan=True)
+        for patch, borrow in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            k.lib.tdr_config_tuning(b"ray_patch", patch)
+            k.lib.tdr_config_tuning(b"ray_borrow", borrow)
+            for split in (1, 2, 8):
+                assert np.array_equal(a, run(ALL_RAY, split, ctx), equal_nan=True), \
+                    f"factors, {split} waves per particle, patch order {patch}, borrowed planes {borrow}"
+            assert np.array_equal(a, run(3.0, 0, ctx), equal_nan=True)
+        k.lib.tdr_config_tuning(b"ray_patch", 1)
+        k.lib.tdr_config_tuning(b"ray_borrow", 1)
         other = np.empty(2 * nb + nr, np.float32)
         rc = k.lib.tdr_polar_factors_host(nb, nr, C.c_float(cfg.ang_res * 1.01), C.c_float(1.0), other.ctypes.data_as(C.c_void_p))
         assert rc == 0
@@ -235,6 +244,8 @@ def test_offsets_multiplied_out_of_the_tables_factors(tdr, oracle, nb, nr, scale
         k.lib.tdr_config_shift_uniform(before)
         k.lib.tdr_config_shift_uniform_span(-2.0)
         k.lib.tdr_config_ray_split(0)
+        k.lib.tdr_config_tuning(b"ray_patch", 1)
+        k.lib.tdr_config_tuning(b"ray_borrow", 1)
     ref = oracle.compute_weights(oracle.OracleMap(sc.class_maps, sc.class_mask, 1.0), oracle.polar_table(nb, nr, cfg.ang_res),
                                  nb, nr, scan, cfg.res, oracle.make_params(cfg.ncls, **params), st.copy())
     assert np.array_equal(np.isnan(a), np.isnan(ref))

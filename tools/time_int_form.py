@@ -7,7 +7,8 @@ splits between the two kernels (GPU box only):
     all ray      every particle through the ray-mapped kernel (with and without the factors)
     float        the float kernel (tdr_config_shift_uniform(0))
 Usage: python3 tools/time_int_form.py [config] [quick] [only=<distribution>] [ray|su]
-   ray / su: only the all-ray / all-shift-uniform launch, three times (counter passes: tools/pmc_ray_bound.sh)"""
+   ray / su: only the all-ray / all-shift-uniform launch, three times (counter passes: tools/pmc_ray_bound.sh)
+   rayctx [patch=0|1]: the all-ray launch with a caller context (block-major / patch order)"""
 import os
 import sys
 import time
@@ -78,6 +79,14 @@ def main():
                 lib.tdr_config_ray_split(0)
                 continue
             print(f"{sname:14s} span 16 +ctx: {timed(6, ctx=ctx):6.2f}   one stream: {timed(6):6.2f}", flush=True)
+            lib.tdr_config_shift_uniform_span(-2.0)
+            continue
+        if "rayctx" in sys.argv:   # every particle through the ray-mapped kernel, the caller's context holding the table's factors
+            for a_ in sys.argv:
+                if a_.startswith("patch="):
+                    lib.tdr_config_tuning(b"ray_patch", int(a_[6:]))
+            lib.tdr_config_shift_uniform_span(1e-6)
+            print(f"{sname:14s} all ray +ctx (ray_patch {lib.tdr_config_tuning(b'ray_patch', -1)}): {timed(4, ctx=ctx):6.2f}", flush=True)
             lib.tdr_config_shift_uniform_span(-2.0)
             continue
         if "ray" in sys.argv or "su" in sys.argv:

@@ -1614,6 +1614,8 @@ static int g_init_ahead = 1;    // record loads the init search keeps in flight 
 static int64_t score_wave_target() { return g_score_waves; }
 extern "C" int tdr_config_prefix_head(int);        // tdr_prefix.hip
 extern "C" int tdr_config_ray_block_major(int);    // tdr_score_ray.hip
+extern "C" int tdr_config_ray_patch(int);
+extern "C" int tdr_config_ray_borrow(int);
 extern "C" int tdr_config_cart_seg_rows(int);      // tdr_score_cart.hip
 extern "C" int tdr_config_mt_stretches(int);       // tdr_rng.hip
 extern "C" int tdr_config_su_wave_span(int);       // tdr_score_su.hip
@@ -1626,6 +1628,8 @@ extern "C" int64_t tdr_config_tuning(const char* name, int64_t value) {   // val
   if (n == "su_group") { if (value >= 0) g_su_group = (int)value; return g_su_group; }
   if (n == "init_ahead") { if (value >= 1) g_init_ahead = (int)std::min<int64_t>(value, 3); return g_init_ahead; }
   if (n == "prefix_head") return tdr_config_prefix_head((int)std::max<int64_t>(value, -1));
+  if (n == "ray_borrow") return tdr_config_ray_borrow((int)std::max<int64_t>(value, -1));
+  if (n == "ray_patch") return tdr_config_ray_patch((int)std::max<int64_t>(value, -1));
   if (n == "ray_block_major") return tdr_config_ray_block_major((int)std::max<int64_t>(value, -1));
   if (n == "cart_seg_rows") return tdr_config_cart_seg_rows((int)std::max<int64_t>(value, -1));
   if (n == "mt_stretches") return tdr_config_mt_stretches((int)std::max<int64_t>(value, -1));

@@ -43,12 +43,42 @@
 // gathers a wave has in flight are then neighbouring directions of ONE segment (config 2, uniform particles: 9.1 -> 8.4 ms;
 // with the offsets read from tab_ray the narrow rows cost more than that gains, so those launches keep the first order).
 // tdr_config_tuning("ray_block_major", 0) keeps the first order everywhere (A/B; same bits).
+// PATCH order (round 5; block-major launches whose direction count is a multiple of 16 and at most RAY_PATCH_MAX_NB).
+// Counters of the block-major ray order (100 000 uniform particles, profiles/r05_pmc_ray_patch_v1.txt): the L1 address path
+// 0.87 busy at 38 cycles per step — for THREE vector memory instructions a step (the gather, the 2-byte descriptors, the
+// radii), each at least 16 cycles there (four lanes a cycle, whatever a lane fetches).  So the step should cost ONE and a
+// quarter:
+//   * a UNIT is 16 scan rows x 16 rings = four steps; a lane's four 16-bit descriptors of a unit lie side by side: ONE 8-byte
+//     load per unit.  That needs the unit aligned in the descriptor array whatever the particle's heading: units are groups of 16
+//     SCAN rows, the window direction of scan row r is (r - shift) mod nb — the window is a full circle, any rotation of the
+//     grouping walks all of it;
+//   * a step's 64 lanes are 4 neighbouring directions x 16 consecutive rings — a PATCH of the window, not a ray (fewer tiles);
+//     the four directions' {cos, sin} pairs are no longer uniform over the wave: they come out of LDS (the factors' direction
+//     table, 8 bytes a direction), the lane's radius depends on the ring block only: four registers per 64-ring segment;
+//   * order: segment of 64 rings -> group of 16 scan rows -> the segment's four ring blocks -> the unit's four steps, so that
+//     what a wave has just fetched is the sector next to the one it fetches now.
+// Lane l = direction (l >> 4) of the step's four, ring (l & 15) of the block.  tdr_config_tuning("ray_patch", 0): the ray order
+// (A/B; same bits).
+#define RAY_PR 16             // rings of a patch
+#define RAY_PG 16             // scan rows of a unit (four steps of four directions)
+#define RAY_PATCH_MAX_NB 256
+static bool g_ray_borrow = true;   // empty bins borrow a neighbour's class plane for their known bit (ray_prep_kernel)
+extern "C" int tdr_config_ray_borrow(int on) {   // < 0: query only
+  if (on >= 0) g_ray_borrow = on != 0;
+  return g_ray_borrow ? 1 : 0;
+}
+static bool g_ray_patch = true;
+extern "C" int tdr_config_ray_patch(int on) {   // < 0: query only
+  if (on >= 0) g_ray_patch = on != 0;
+  return g_ray_patch ? 1 : 0;
+}
 static bool g_ray_bm = true;
 extern "C" int tdr_config_ray_block_major(int on) {   // < 0: query only
   if (on >= 0) g_ray_bm = on != 0;
   return g_ray_bm ? 1 : 0;
 }
 static inline bool ray_bm(const SuLaunch& L) { return g_ray_bm && L.fac != nullptr; }
+static inline bool ray_patch(const SuLaunch& L) { return ray_bm(L) && g_ray_patch && L.nb % RAY_PG == 0 && L.nb <= RAY_PATCH_MAX_NB; }
 static inline int ray_gq(int nr, bool bm) { return bm ? 1 : (nr <= 64 ? 1 : (nr <= 128 ? 2 : 4)); }
 static inline int ray_blocks(int nr, bool bm) { return (int)cdiv(nr, 64 * ray_gq(nr, bm)); }
 // (the first order pads to whole blocks of GQ steps: never less than the block-major order needs)
@@ -71,7 +101,7 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
                                                        uint16_t* __restrict__ desc_ray, uint32_t* __restrict__ list,
                                                        int32_t* __restrict__ n_list, int32_t* __restrict__ inexact,
                                                        const float* __restrict__ fac, float uscale, float res,
-                                                       float* __restrict__ rad_ray, int bm) {
+                                                       float* __restrict__ rad_ray, int bm, int patch, int borrow) {
   const int rpad = blocks * gq * 64;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0 && dict_tail[1] != 1u) atomicOr(inexact, 1);
@@ -90,6 +120,10 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
   if (!live) return;
   const int g = j >> 6, l = j & 63, b = g / gq;
   const int64_t at = bm ? ((int64_t)b * nb + i) * 64 + l : (((int64_t)i * blocks + b) * 64 + l) * gq + (g - b * gq);
+  // patch order (descriptors only; the offsets keep the block-major order): unit (ring block j / 16, scan-row group i / 16),
+  // lane (i & 3) * 16 + (j & 15), step (i & 15) >> 2 — a lane's four steps side by side
+  int64_t at_d = at;
+  if (patch) at_d = ((((int64_t)(j / RAY_PR) * (nb / RAY_PG) + i / RAY_PG) * 64 + (i & 3) * RAY_PR + (j % RAY_PR)) << 2) + ((i % RAY_PG) >> 2);
   float tx = -1.0e30f, ty = -1.0e30f;
   uint32_t d = 0;
   if (fac && i == 0) rad_ray[((int64_t)b * 64 + l) * gq + (g - b * gq)] = real ? fac[2 * nb + j] : 1.0e30f;
@@ -121,9 +155,31 @@ __global__ __launch_bounds__(256) void ray_prep_kernel(const float* __restrict__
     else if (nz == 1 && r[first] < 4096.f) d = (uint32_t)r[first] | ((uint32_t)(first + 1) << 12);
     else if (nz >= 1) list[atomicAdd(n_list, 1)] = ((uint32_t)i << 16) | (uint32_t)j;   // (any order: the sums are exact)
   }
+  // An EMPTY bin (and one that went on the list) needs its cell's known bit and nothing else — and every class plane carries that
+  // bit (bit 15 of a cell).  Four consecutive lanes of a gather — four consecutive rings of one scan row, in every order above —
+  // are served together by the L1's address path, at a cost per distinct LINE among them: an empty bin between two bins of
+  // class c that reads the coarse mask plane is a line of its own, one that reads class c's plane with a count of zero rides
+  // along.  So an empty bin borrows the class of the nearest non-empty bin of its aligned group of four rings (none: code 0,
+  // the mask plane, one line for the four); the product with a zero count adds nothing (round 5).
+  {
+    const uint32_t own = d >> 12;
+    const int ql = threadIdx.x & 3;
+    uint32_t c4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) c4[q] = __shfl(own, (threadIdx.x & 60) + q, 64);   // (threads of a group: the same scan row i, rings 4 q' .. 4 q' + 3)
+    if (borrow && own == 0) {
+      uint32_t pick = 0;
+#pragma unroll
+      for (int dist = 3; dist >= 1; dist--) {   // the nearest wins (written last)
+        if (ql + dist < 4 && c4[(ql + dist) & 3]) pick = c4[(ql + dist) & 3];
+        if (ql - dist >= 0 && c4[(ql - dist) & 3]) pick = c4[(ql - dist) & 3];
+      }
+      d = pick << 12;
+    }
+  }
   tab_ray[2 * at] = tx;
   tab_ray[2 * at + 1] = ty;
-  desc_ray[at] = (uint16_t)d;
+  desc_ray[at_d] = (uint16_t)d;
 }
 
 struct RayArgs {
@@ -162,13 +218,17 @@ struct RayArgs {
 // (ray_prep_kernel checked that), and 16 bytes per lane and row less through the texture path.
 // lacc [4 waves][ncls + 1][64 lanes]: a lane's sums per class (slot 0: no class); lut, per class code: {plane constant,
 // column shift, known-bit index, accumulator}
-template <int GQ, bool USCALE, bool FAC, bool BM>
-__device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* lacc, uint32_t* ldict, uint4* lut) {
+// PATCH (with BM): the patch order (see the top of the file); ldir: the directions' pairs in LDS
+template <int GQ, bool USCALE, bool FAC, bool BM, bool PATCH>
+__device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* lacc, uint32_t* ldict, uint4* lut, float2* ldir) {
   static_assert(!BM || GQ == 1, "block-major: one step per row");
+  static_assert(!PATCH || BM, "the patch order is a block-major order");
   const int nsparse = a.counts[1];
   if ((int64_t)blockIdx.x * 4 >= (int64_t)nsparse * a.nsplit) return;   // whole workgroup idle (uniform)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int t = threadIdx.x; t < a.dict_n; t += 256) ldict[t] = a.dict_int[t];
+  if constexpr (PATCH && FAC)
+    for (int t = threadIdx.x; t < a.nb; t += 256) ldir[t] = reinterpret_cast<const float2*>(a.fac)[t];
   const unsigned pconst = (unsigned)(a.pkcol + 16) + 128u;   // plane_offset's constant without the plane's own offset
   if (threadIdx.x < 16) {
     const int code = threadIdx.x;
@@ -239,6 +299,29 @@ __device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* l
   const bool one_block = a.blocks == 1;
   rad_t rad0 = {};
   if constexpr (FAC) rad0 = radv[lane];   // (block 0's; the only block of a window of up to 256 rings)
+  // one sample, first half: everything that depends on the bin's class out of the table, the cell's address, the gather
+  auto issue = [&](uint32_t d, int ri, int ci, uint32_t& v, uint32_t& shb, uint32_t& cnt, uint32_t& acc_at) {
+    cnt = d & 0xFFFu;
+    // one 16-byte LDS read: everything that depends on the bin's class
+    const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
+    const int rr = ri >> (int)e.y, cc = ci >> (int)e.y;  // a mask cell spans 4 x 4 map cells
+    const unsigned off = plane_offset(rr, cc, a.pkcol, (int)e.x);
+    // bit of `known`: 15 in a class cell, (row & 3) * 4 + (column & 3) in a mask cell
+    shb = ((((uint32_t)ri & 3u) << 2) | ((uint32_t)ci & 3u)) | e.z;
+    acc_at = e.w;
+    v = *reinterpret_cast<const uint16_t*>(crecb + off);
+  };
+  // ... second half: the known bit, the normalisation, the product into the lane's accumulator of the class
+  auto consume = [&](uint32_t v, uint32_t shb, uint32_t cnt, uint32_t acc_at) {
+    uint32_t kbit;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(v), "v"(shb));
+    known += kbit;
+    norm = __umul24(cnt, kbit) + norm;                  // state_particle.cpp:141-142
+    const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + (v & 0xFFCu));
+    const unsigned long long prod = (unsigned long long)cnt * D;   // :136-139, as integers (0 for an empty bin)
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(my) + acc_at);
+    __hip_atomic_fetch_add(acc, prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u64; the lane's own slot
+  };
   auto rows_step = [&](auto cnt_c, int m) {
     constexpr int N = decltype(cnt_c)::value;
     desc_t dd[N];
@@ -279,32 +362,77 @@ __device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* l
         int ri, ci;
         if constexpr (FAC) cell_fac(dir[u], rr_[u][g], ri, ci);
         else cell(tt[u][2 * g], tt[u][2 * g + 1], ri, ci);
-        const uint32_t d = dd[u][g];
-        cnt[s] = d & 0xFFFu;
-        // one 16-byte LDS read: everything that depends on the bin's class
-        const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + ((d >> 8) & 0xF0u));
-        const int rr = ri >> (int)e.y, cc = ci >> (int)e.y;  // a mask cell spans 4 x 4 map cells
-        const unsigned off = plane_offset(rr, cc, a.pkcol, (int)e.x);
-        // bit of `known`: 15 in a class cell, (row & 3) * 4 + (column & 3) in a mask cell
-        shb[s] = ((((uint32_t)ri & 3u) << 2) | ((uint32_t)ci & 3u)) | e.z;
-        acc_at[s] = e.w;
-        v[s] = *reinterpret_cast<const uint16_t*>(crecb + off);
+        issue(dd[u][g], ri, ci, v[s], shb[s], cnt[s], acc_at[s]);
       }
 #pragma unroll
-    for (int s = 0; s < N * GQ; s++) {
-      uint32_t kbit;
-      asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(v[s]), "v"(shb[s]));
-      known += kbit;
-      norm = __umul24(cnt[s], kbit) + norm;                  // state_particle.cpp:141-142
-      const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldict) + (v[s] & 0xFFCu));
-      const unsigned long long prod = (unsigned long long)cnt[s] * D;   // :136-139, as integers (0 for an empty bin)
-      unsigned long long* const acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(my) + acc_at[s]);
-      __hip_atomic_fetch_add(acc, prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u64; the lane's own slot
-    }
+    for (int s = 0; s < N * GQ; s++) consume(v[s], shb[s], cnt[s], acc_at[s]);
   };
-  int m = m0;
-  for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, m);
-  for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, m);
+  if constexpr (PATCH) {
+    // the patch order (top of the file): a wave takes a contiguous share of the SECTORS (segment of 64 rings, group of 16 scan
+    // rows); a sector = the segment's four ring blocks = four units of four steps; two units' gathers are in flight together
+    const int ngroups = a.nb / RAY_PG, sectors_all = a.blocks * ngroups;
+    const int sper = (sectors_all + a.nsplit - 1) / a.nsplit;
+    const int s0 = part_id * sper, s1 = min(sectors_all, s0 + sper);
+    const int pl_d = lane >> 4, pl_r = lane & (RAY_PR - 1);
+    const uint2* __restrict__ descq = reinterpret_cast<const uint2*>(a.desc_ray);
+    float rad4[4] = {0.f, 0.f, 0.f, 0.f};
+    int cur_seg = -1;
+    int seg = s0 / ngroups, pg = s0 - seg * ngroups;
+    for (int sc = s0; sc < s1; sc++) {
+      if (seg != cur_seg) {   // (wave-uniform) the lane's radii of the segment's four ring blocks
+        cur_seg = seg;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const int j = (seg * 4 + qq) * RAY_PR + pl_r;
+          rad4[qq] = j < a.nr ? a.fac[2 * a.nb + j] : 1.0e30f;   // (a ring the image does not have: its cell leaves the map)
+        }
+      }
+      // the window directions of the sector's four steps: scan row 16 pg + 4 k + (lane >> 4) meets direction (row - shift) mod nb
+      int wi[4];
+      tdr_v2f wdir[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int i = pg * RAY_PG + 4 * k + pl_d - shift;
+        i += i < 0 ? a.nb : 0;
+        wi[k] = i;
+        if constexpr (FAC) {
+          const float2 dv = ldir[i];
+          wdir[k] = (tdr_v2f){dv.x, dv.y};
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        uint2 dd[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) dd[u] = descq[((int64_t)(seg * 4 + 2 * h + u) * ngroups + pg) * 64 + lane];
+        uint32_t v[8], shb[8], cnt[8], acc_at[8];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int ri, ci;
+            if constexpr (FAC) {
+              cell_fac(wdir[k], rad4[2 * h + u], ri, ci);
+            } else {   // (the table is not its factors' products: its own entries, in its own order)
+              const int j = min((seg * 4 + 2 * h + u) * RAY_PR + pl_r, a.nr - 1);
+              const int64_t kk = (int64_t)j * a.nb + wi[k];
+              if ((seg * 4 + 2 * h + u) * RAY_PR + pl_r < a.nr) cell(a.tab[2 * kk], a.tab[2 * kk + 1], ri, ci);
+              else cell(-1.0e30f, -1.0e30f, ri, ci);
+            }
+            const uint32_t w = k < 2 ? dd[u].x : dd[u].y;
+            issue((k & 1) ? (w >> 16) : (w & 0xFFFFu), ri, ci, v[u * 4 + k], shb[u * 4 + k], cnt[u * 4 + k], acc_at[u * 4 + k]);
+          }
+#pragma unroll
+        for (int t = 0; t < 8; t++) consume(v[t], shb[t], cnt[t], acc_at[t]);
+      }
+      pg++;
+      if (pg == ngroups) { pg = 0; seg++; }
+    }
+  } else {
+    int m = m0;
+    for (; m + U <= m1; m += U) rows_step(std::integral_constant<int, U>{}, m);
+    for (; m < m1; m++) rows_step(std::integral_constant<int, 1>{}, m);
+  }
 
   // the list: bins that hold several classes (or one large count).  The loop above saw them as empty bins — their cell's
   // known bit is counted — ; here every class present meets its plane, and the bin's count enters the normalisation.
@@ -354,15 +482,16 @@ __device__ __forceinline__ void ray_body(const RayArgs& a, unsigned long long* l
     o[(int64_t)(2 * a.ncls + 1) * a.npad] = known;
   }
 }
-template <int GQ, bool USCALE, bool BM = false>
+template <int GQ, bool USCALE, bool BM = false, bool PATCH = false>
 __global__ __launch_bounds__(256) void score_polar_ray_kernel(RayArgs a) {
   extern __shared__ unsigned long long lacc[];
   __shared__ uint32_t ldict[TDR_CMAP_MAX_DICT];
   __shared__ uint4 lut[16];
+  __shared__ float2 ldir[PATCH ? RAY_PATCH_MAX_NB : 1];
   if (int_form_off(a.inexact)) return;
   // with factors that ARE the table's (ray_prep_kernel's check; uniform over the launch) the offsets are multiplied out
-  if (a.fac && a.inexact[2] == 0) ray_body<GQ, USCALE, true, BM>(a, lacc, ldict, lut);
-  else ray_body<GQ, USCALE, false, BM>(a, lacc, ldict, lut);
+  if (a.fac && a.inexact[2] == 0) ray_body<GQ, USCALE, true, BM, PATCH>(a, lacc, ldict, lut, ldir);
+  else ray_body<GQ, USCALE, false, BM, PATCH>(a, lacc, ldict, lut, ldir);
 }
 
 
@@ -405,7 +534,8 @@ int tdr_ray_prepare(const SuLaunch& L, const SuWs& W, hipStream_t s) {
                      L.map->ncls, gq, blocks, reinterpret_cast<const uint32_t*>(L.map->dict) + 2 * TDR_CMAP_MAX_DICT,
                      reinterpret_cast<float*>(base + W.ray_tab), reinterpret_cast<uint16_t*>(base + W.ray_desc),
                      reinterpret_cast<uint32_t*>(base + W.ray_multi), ints + 3, ints + 4, L.fac,
-                     L.uniform_scale ? L.uscale : 0.f, L.res, reinterpret_cast<float*>(base + W.ray_rad), bm ? 1 : 0);
+                     L.uniform_scale ? L.uscale : 0.f, L.res, reinterpret_cast<float*>(base + W.ray_rad), bm ? 1 : 0,
+                     ray_patch(L) ? 1 : 0, g_ray_borrow ? 1 : 0);
   LAUNCH_CHECK("ray_prep");
   return TDR_OK;
 }
@@ -446,7 +576,10 @@ int tdr_ray_score(const SuLaunch& L, const SuWs& W, hipStream_t s) {
 #define TDR_LAUNCH_RAY(GQ)                                                                            \
   if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<GQ, true>), grid, block, lds, s, r); \
   else hipLaunchKernelGGL((score_polar_ray_kernel<GQ, false>), grid, block, lds, s, r);
-  if (ray_bm(L)) {
+  if (ray_patch(L)) {
+    if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<1, true, true, true>), grid, block, lds, s, r);
+    else hipLaunchKernelGGL((score_polar_ray_kernel<1, false, true, true>), grid, block, lds, s, r);
+  } else if (ray_bm(L)) {
     if (L.uniform_scale) hipLaunchKernelGGL((score_polar_ray_kernel<1, true, true>), grid, block, lds, s, r);
     else hipLaunchKernelGGL((score_polar_ray_kernel<1, false, true>), grid, block, lds, s, r);
   } else switch (ray_gq(L.nr, false)) {
