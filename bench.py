@@ -404,7 +404,8 @@ def main():
                 k.locality_order(f.st, nl, m.rows, m.cols, f.perm)
             k.lib.tdr_profile_enable(1)
             k.score(m.dev, r.last_scan()[1], float(cfg.res), f.fp_c, f.st, nl, f.raw_w,
-                    perm=f.perm if f.locality_every else None, uniform_scale=f._uniform_scale, n_total=n_global)
+                    perm=f.perm if f.locality_every else None, uniform_scale=f._uniform_scale, n_total=n_global,
+                    ctx=k.score_ctx_create())   # (a context like the filter's: the table's factors, the configured span)
             d_ms, s_ms, s_n = C.c_double(0), C.c_double(0), C.c_int64(0)
             if k.lib.tdr_profile_shares(C.byref(d_ms), C.byref(s_ms), C.byref(s_n)) == 0:
                 shares = {"dense_ms": d_ms.value, "dense_particles": nl - int(s_n.value), "dense_kernel": "score_polar_su_kernel",
