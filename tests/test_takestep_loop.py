@@ -244,3 +244,120 @@ def test_take_step_loop_with_a_moving_range_scale_matches_oracle(loop_exe, oracl
     print(f"loop ok: res {res_seen[0]:.2f} .. {min(res_seen):.2f}/{max(res_seen):.2f}, froze at {froze_at}, converged at {conv_at}, "
           f"{mism_total} resample indices differed over {STEPS} steps")
 
+
+
+# ---- the Python form of the same class (top_down_renderer_amd/top_down_render_core.py) --------------------------------
+@pytest.fixture(scope="module")
+def tdr():
+    import torch
+    import top_down_renderer_amd as pkg
+    from top_down_renderer_amd.kernels import HipKernels
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return pkg, HipKernels()
+
+
+class _StubFilter:
+    """What publishPoseEst asks of a filter, with the answers given."""
+
+    def __init__(self, cov, scale, n, ml_scale, frozen):
+        self.cov, self.scale_, self.n, self.ml, self.frozen, self.froze_called = np.asarray(cov, np.float32), scale, n, ml_scale, frozen, 0
+
+    def computeMeanCov(self):
+        return self.cov
+
+    def scale(self):
+        return 1.0 if self.froze_called and self.scale_ < 0 else self.scale_   # (a freeze makes the scale known)
+
+    def numParticles(self):
+        return self.n
+
+    def meanLikelihood(self):
+        return np.asarray([0, 0, 0, self.ml], np.float32)
+
+    def isScaleFrozen(self):
+        return bool(self.frozen)
+
+    def freezeScale(self):
+        self.froze_called += 1
+
+
+def test_python_core_publish_pose_est_equals_the_oracles(oracle):
+    """TopDownRenderCore.publishPoseEst (Python) against orc_publish_pose_est / _gate over a sweep of covariances, scales and
+    range scales: the same range-scale trajectory bit for bit, the same freeze and convergence decisions."""
+    from top_down_renderer_amd.top_down_render_core import CoreConfig, TopDownRenderCore
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    core = TopDownRenderCore(CoreConfig(range_scale_min=RS_MIN, range_scale_max=RS_MAX, target_uncertainty_m=2.5))
+    ns = oracle.NodeState(RS_MAX, RS_MIN, RS_MAX, 2.5, 0)
+    for k in range(400):
+        cov = np.zeros((4, 4), np.float32)
+        cov[0, 0], cov[1, 1] = rng.choice([0.0, 3.0, 6.2, 6.3, 39.0, 41.0, 100.0], 2)
+        cov[2, 2] = rng.choice([0.1, 0.4, 0.5, 0.6])
+        cov[3, 3] = rng.choice([0.0029, 0.0031, 0.5])
+        scale = float(rng.choice([-1.0, 0.5, 1.0, 2.0]))
+        n = int(rng.choice([0, 10]))
+        ml = float(rng.choice([1.0, 1.1]))
+        frozen = int(rng.integers(0, 2))
+        if k % 50 == 0:   # restart both sides somewhere else
+            start = float(np.float32(rng.uniform(RS_MIN, RS_MAX)))
+            core.current_range_scale_ = np.float32(start)
+            core.is_converged_ = False
+            ns = oracle.NodeState(start, RS_MIN, RS_MAX, 2.5, 0)
+        stub = _StubFilter(cov, scale, n, ml, frozen)
+        core.filter_ = stub
+        e = core.publishPoseEst()
+        c16 = np.ascontiguousarray(cov.reshape(16))
+        freeze = L.orc_publish_pose_est(C.byref(ns), oracle._p(c16), C.c_float(scale), C.c_int(n), C.c_float(ml), C.c_int(frozen))
+        if n >= 1:
+            sc_now = 1.0 if (freeze and scale < 0) else scale
+            L.orc_publish_pose_est_gate(C.byref(ns), oracle._p(c16), C.c_float(np.float32(scale) * np.float32(scale)), C.c_float(sc_now))
+        assert np.float32(e.range_scale) == np.float32(ns.current_range_scale), k
+        assert e.froze_scale == bool(freeze) and stub.froze_called == int(bool(freeze)), k
+        assert e.converged == bool(ns.is_converged), k
+        assert (e.ml_state is None) == (n < 1)
+
+
+@pytest.mark.gpu
+def test_python_core_take_step_loop_matches_oracle(tdr, oracle):
+    """The Python TopDownRenderCore over the HIP path, 12 steps with `res` moving on every step, against the oracle's loop
+    stepping from the same particle set (teacher-forced resample indices, like the C++ test above)."""
+    from top_down_renderer_amd.top_down_render_core import CoreConfig, TopDownRenderCore
+    pkg, k = tdr
+    sc, cfg, st = _scenario()
+    n, steps = len(st), 12
+    m = pkg.TopDownMapPolar(pkg.Params(resolution=cfg.map_resolution), sc.class_maps, sc.class_mask, kernels=k)
+    core = TopDownRenderCore(CoreConfig(particle_count=n, range_scale_min=RS_MIN, range_scale_max=RS_MAX, target_uncertainty_m=TARGET,
+                                        theta_bins=cfg.nb, range_bins=cfg.nr, seed=SEED), kernels=k)
+    core.initialize(m, pkg.FilterParams(fixed_scale=-1.0), sc.lut, init_particles=False)
+    core.filter_.set_states(st)
+    loop = _oracle_loop(oracle, sc, cfg, st)
+    fields = ("init_x_px", "init_y_px", "dx_m", "dy_m", "theta", "scale")
+    res_seen, froze_at = [], None
+    for s in range(steps):
+        res_now = core.currentRangeScale()
+        e = core.takeStep(sc.pts, MOTION[:2], MOTION[2])
+        assert e is not None and core.lastRes() == res_now
+        raw = core.filter_.raw_weights()[:n]
+        idx = core.filter_.resample_indices()[:n]
+        got = core.filter_.get_states()
+        o = loop.step(sc.pts, *MOTION, force_idx=idx)
+        assert np.float32(o["res"]) == np.float32(res_now), f"step {s}"
+        res_seen.append(res_now)
+        for name in fields:
+            if name == "scale" and o["froze"]:
+                assert np.allclose(got[name], loop.states[name], rtol=2e-6)
+            else:
+                assert np.array_equal(got[name], loop.states[name]), f"step {s}: {name}"
+        assert np.array_equal(np.isnan(raw), np.isnan(o["raw"]))
+        ok = ~np.isnan(o["raw"])
+        same = raw[ok] == o["raw"][ok]
+        rel = np.where(same, 0.0, np.abs(raw[ok] - o["raw"][ok]) / np.maximum(np.abs(o["raw"][ok]), 1e-30))
+        assert rel.max() < 1e-5, f"step {s}: raw weights off by {rel.max():.2e}"
+        assert np.float32(e.range_scale) == np.float32(o["range_scale"]), f"step {s}"
+        assert e.froze_scale == o["froze"] and e.converged == o["converged"], f"step {s}"
+        if o["froze"]:
+            froze_at = s
+            loop.states["scale"] = got["scale"]
+    assert all(a != b for a, b in zip(res_seen, res_seen[1:]))
+    assert froze_at is not None

@@ -8,6 +8,7 @@ from .particle_filter import FilterParams, ParticleFilter  # noqa: F401
 from .scan_renderer import ScanRenderer, ScanRendererPolar  # noqa: F401
 from .synth import STATE_DTYPE  # noqa: F401
 from .top_down_map import Params, TopDownMap, TopDownMapPolar  # noqa: F401
+from .top_down_render_core import CoreConfig, PoseEst, TopDownRenderCore  # noqa: F401
 
 __all__ = ["ActiveLocalizer", "FilterParams", "ParticleFilter", "ScanRenderer", "ScanRendererPolar", "Params", "TopDownMap",
-           "TopDownMapPolar", "STATE_DTYPE"]
+           "TopDownMapPolar", "STATE_DTYPE", "CoreConfig", "PoseEst", "TopDownRenderCore"]
