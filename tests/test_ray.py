@@ -179,7 +179,8 @@ def test_weights_do_not_depend_on_the_order_of_the_additions(tdr, oracle, ncls, 
 
 
 @pytest.mark.parametrize("nb,nr,scale_fixed", [(64, 32, True), (100, 100, True), (40, 200, False), (12, 300, True),
-                                               (9, 530, False), (32, 130, False), (256, 40, True), (48, 70, True)])
+                                               (9, 530, False), (32, 130, False), (256, 40, True), (48, 70, True), (16, 300, True), (96, 17, False),
+                                               (240, 64, True), (128, 129, False)])
 def test_offsets_multiplied_out_of_the_tables_factors(tdr, oracle, nb, nr, scale_fixed):
     """A context that holds the table's factors (tdr_polar_factors_host): the ray-mapped kernel multiplies a direction's
     pair with a ring's radius itself instead of reading the product — the same float products (checked here on the host,
